@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: candidate-pose distance evaluations per second.
+
+Workload (BASELINE.json `metric` / north_star): CoreSLAM Monte-Carlo search on a 2048^2 HoleMap with a
+1080-ray scan, --cands candidate poses per GPU per step (default 16384 = BASELINE.json configs[1]/[2]).
+One "step" = one full search over this rank's shard of the flat candidate list: candidate transform
+(pose + jitter -> px,py,c,s with device trig), K1 batched distance over all rays, K1r partial-sum +
+arg-min reduce; with N > 1 GPUs the per-rank packed (distance << 32 | index) keys are min-all-reduced
+over RCCL (one 8-byte all-reduce per step).  All inputs (map, scan, jitter list) are resident in HBM
+before the timed region.  Weak scaling: per-GPU candidates are fixed as N grows.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=2048, help="HoleMap side in pixels")
+    ap.add_argument("--rays", type=int, default=1080)
+    ap.add_argument("--cands", type=int, default=16384, help="candidate poses per GPU per step")
+    ap.add_argument("--map-updates", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket K1 with HIP events")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import slam.net_amd.capi as capi
+    import slam.net_amd.coreslam as cs
+    import slam.net_amd.sim as sim
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    # ---- synthetic world: default field, 30 mapping updates, scan 31 -----------------------
+    ctx = cs.Context(local)
+    dev = cs.CoreSlamDevice(ctx, 40.0, a.size, max(a.size // 4, 1))
+    segs = sim.default_field()
+    rng = sim.PCG32(1234)
+    traj = sim.trajectory(a.map_updates + 1)
+    for p in traj[:-1]:
+        _, xy = sim.make_scan(segs, p, a.rays, rng)
+        dev.set_scan(xy)
+        dev.update_holemap(p, 0.6, 50)
+    true_pose = traj[-1]
+    _, xy = sim.make_scan(segs, true_pose, a.rays, rng)
+    assert xy.shape[0] == a.rays, "every ray must hit (closed field)"
+    base = (true_pose + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
+    K_total = a.cands * world                          # flat candidates, index 0 = un-jittered pose
+    offs = sim.gaussian_offsets(K_total - 1, 0.1, math.radians(10.0), seed=42)
+    dev.set_scan(xy)
+    dev.set_offsets(offs)
+    first, count = rank * a.cands, a.cands
+
+    key = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    ext = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", local))
+
+    def step():
+        dev.search_shard_async(base, first, count, key.data_ptr())
+        if world > 1:
+            with torch.cuda.stream(ext):
+                dist.all_reduce(key, op=dist.ReduceOp.MIN)
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    sync_all()
+    if not a.no_kernel_timing:
+        ctx.timing_reset()
+        ctx.timing_enable(1 << capi.K_CS_DISTANCE)
+    if world > 1:
+        dist.barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    if world > 1:
+        dist.barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    k1_ms, k1_n = (0.0, 0)
+    if not a.no_kernel_timing:
+        k1_ms, k1_n = ctx.timing_get(capi.K_CS_DISTANCE)
+        ctx.timing_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_key = int(key.item())
+
+    if rank == 0:
+        evals = float(K_total) * a.steps
+        value = evals / elapsed
+        bytes_per_eval = 2 * a.rays + 16                     # BASELINE.md sec.3 / SURVEY.md sec.8d
+        roof = None
+        if k1_n > 0:
+            avg_s = (k1_ms / k1_n) * 1e-3
+            achieved = a.cands * bytes_per_eval / avg_s / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "k1_distance", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
+                    "bytes_per_launch": a.cands * bytes_per_eval}
+        out = {
+            "metric": "candidate-pose distance evals/sec on 2048^2 map, 1080-ray scan, 1/2/4/8 GPU",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 transform + u16 gather / integer sum", "data": "synthetic",
+            "config": {"workload": "CoreSLAM Monte-Carlo distance search, %dx%d HoleMap, %d rays, %d candidates/GPU/step"
+                                   % (a.size, a.size, a.rays, a.cands),
+                       "map": a.size, "rays": a.rays, "candidates_per_gpu": a.cands, "candidates_total": K_total,
+                       "collective": "rccl all_reduce(min, 8 B)/step" if world > 1 else "none",
+                       "best_index": final_key & 0xFFFFFFFF, "best_distance": final_key >> 32},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs, final_key)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    dev.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, dev, xy, base, offs, gpu_key):
+    """The reference's ParallelWorker-structured CPU search (oracle/cpu_baseline.c, kind = "port": the C#
+    reference cannot run here) on the SAME map / scan / candidates, bounded to ~a.cpu_seconds of CPU work."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    oc.set_trig_mode(oc.TRIG_DET)
+    pix = dev.holemap_download()
+    T = os.cpu_count() or 1
+    n = offs.shape[0]
+    iters = max(n // T, 1)
+    secs, evals, bi, bd = oc.cpu_baseline_search(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, 1)
+    rate = evals / secs
+    scans = max(int(a.cpu_seconds * rate / evals) - 1, 1)
+    secs2, evals2, bi, bd = oc.cpu_baseline_search(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, scans)
+    # parity spot-check on the full candidate list of the GPU step (single oracle pass, ~0.1 s)
+    rbi, _, rbd, _ = oc.search(pix, dev.hole_size, dev.hole_scale, xy, base, offs)
+    same = bool(((rbd << 32) | rbi) == gpu_key)
+    return {"value": evals2 / secs2, "unit": "evals/s", "cores": T, "kind": "port",
+            "sample": "%d scans x %d threads x (%d jitters + base) on the same map/scan/candidates, %.1f s"
+                      % (scans, T, iters, secs2),
+            "argmin_matches_gpu": same}
+
+
+if __name__ == "__main__":
+    main()

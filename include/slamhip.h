@@ -1,0 +1,286 @@
+/*
+ * slamhip.h -- C-ABI of libslamhip.so: the MI355X-native CoreSLAM / HectorSLAM hot path.
+ *
+ * This is the drop-in boundary for mikkleini/slam.net.  The reference is 100 % managed C# with no
+ * FFI seam of its own: its hot path is private methods of CoreSLAMProcessor and
+ * ScanMatcher/OccGridMap.  The entry points below are what a P/Invoke shim behind the unchanged public
+ * C# API (CoreSLAMProcessor / HoleMap / ObstacleMap / ScanMatcher / OccGridMap / MapRepMultiMap /
+ * HectorSLAMProcessor) binds; each one cites the reference member it replaces
+ * (paths relative to the reference repo).  INTEGRATION.md shows the C# [DllImport] stubs.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, blittable structs only; no callbacks, no exceptions.
+ *   - every function returns int32 status: 0 = SLAMHIP_OK, < 0 = error; slamhip_last_error() returns
+ *     a thread-local message.  Degenerate *data* (empty scan, robot outside the map, no point in
+ *     bounds ...) is a silent no-op exactly as in the reference; negative status is reserved for
+ *     API misuse and HIP / RCCL failures.
+ *   - host pointers are only read/written during the call (pin with `fixed` / GCHandle); the
+ *     library copies in/out and never retains them.  Device memory lives behind opaque handles.
+ *   - a handle is single-caller (like the reference objects: ParallelWorker.Work is "blocking,
+ *     non-reentrant", BaseSLAM/ParallelWorker.cs:95); different handles may be used from different
+ *     threads.  Calls block until the result is on the host unless the name ends in _async.
+ *   - float poses are (x [m], y [m], theta [rad]) = System.Numerics.Vector3; points are
+ *     System.Numerics.Vector2 (8 B); LogOddsCell is {int32 UpdateIndex; float Value} (8 B).
+ *   - there is no CPU fallback: every compute entry point launches HIP kernels on gfx950.
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMHIP_OK            0
+#define SLAMHIP_ERR_INVALID  (-1)   /* bad argument / API misuse */
+#define SLAMHIP_ERR_HIP      (-2)   /* HIP runtime failure (message in slamhip_last_error) */
+#define SLAMHIP_ERR_NOMEM    (-3)
+#define SLAMHIP_ERR_STATE    (-4)   /* call order violated (e.g. search before set_scan) */
+#define SLAMHIP_ERR_RCCL     (-5)
+
+typedef struct slamhip_ctx    slamhip_ctx;     /* one GPU + one HIP stream */
+typedef struct slamhip_cs     slamhip_cs;      /* CoreSLAM device state: HoleMap + ObstacleMap + scan + candidates */
+typedef struct slamhip_csproc slamhip_csproc;  /* CoreSLAMProcessor state machine on top of slamhip_cs */
+typedef struct slamhip_hs     slamhip_hs;      /* HectorSLAM MapRepMultiMap pyramid + ScanMatcher */
+typedef struct slamhip_hsproc slamhip_hsproc;  /* HectorSLAMProcessor state machine on top of slamhip_hs */
+typedef struct slamhip_group  slamhip_group;   /* N GPUs in one process + RCCL communicator */
+
+/* {int UpdateIndex; float Value} -- HectorSLAM/Map/LogOddsCell.cs:16-21 */
+typedef struct { int32_t update_index; float value; } slamhip_cell;
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / context
+ * ---------------------------------------------------------------------------------------------- */
+const char *slamhip_version(void);
+const char *slamhip_last_error(void);
+int32_t slamhip_device_count(int32_t *out_count);
+
+/* Replaces `new ParallelWorker(numThreads)` (BaseSLAM/ParallelWorker.cs:34-56): the execution resource
+ * the hot path runs on.  One context = one GPU ordinal + one non-blocking HIP stream. */
+int32_t slamhip_ctx_create(int32_t device_ordinal, slamhip_ctx **out);
+int32_t slamhip_ctx_destroy(slamhip_ctx *ctx);                     /* ParallelWorker.Dispose :122-139 */
+int32_t slamhip_ctx_synchronize(slamhip_ctx *ctx);
+int32_t slamhip_ctx_device(slamhip_ctx *ctx, int32_t *out_ordinal);
+void   *slamhip_ctx_stream(slamhip_ctx *ctx);                      /* hipStream_t, for interop (RCCL / torch) */
+
+/* Kernel timing (the reference only has Stopwatch EMAs, HectorSLAMProcessor.cs:92-96,111-115).
+ * When enabled, each kernel class is bracketed by HIP events on the context's stream. */
+enum {
+    SLAMHIP_K_CS_PREP = 0,      /* candidate transform (pose + offset -> px,py,c,s) */
+    SLAMHIP_K_CS_DISTANCE = 1,  /* K1 batched distance (dominant kernel) */
+    SLAMHIP_K_CS_REDUCE = 2,    /* K1r partial-sum + arg-min reduce */
+    SLAMHIP_K_CS_HOLEMAP = 3,   /* K2 */
+    SLAMHIP_K_CS_OBSTACLE = 4,  /* K3 */
+    SLAMHIP_K_HS_MATCH = 5,     /* K4 */
+    SLAMHIP_K_HS_UPDATE = 6,    /* K5 */
+    SLAMHIP_K_COUNT = 7
+};
+/* mask: bit k enables kernel class k (e.g. 1 << SLAMHIP_K_CS_DISTANCE); 0 = off; -1 = all classes */
+int32_t slamhip_ctx_timing_enable(slamhip_ctx *ctx, int32_t mask);
+int32_t slamhip_ctx_timing_reset(slamhip_ctx *ctx);
+/* total milliseconds and launch count accumulated for one kernel class since the last reset
+ * (synchronises the stream) */
+int32_t slamhip_ctx_timing_get(slamhip_ctx *ctx, int32_t which, double *out_ms, int64_t *out_launches);
+
+/* ------------------------------------------------------------------------------------------------
+ * CoreSLAM, operator level
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces `new HoleMap(holeMapSize, physicalMapSize)`, `new ObstacleMap(obstacleMapSize, ...)` and
+ * the noHitMap (CoreSLAM/CoreSLAMProcessor.cs:131-133; HoleMap.cs:17-22; ObstacleMap.cs:17-22).
+ * Scale = sizePixels / sizeMeters in binary32.  Maps are created in the Reset() state. */
+int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical_map_size, int32_t hole_map_size,
+                          int32_t obstacle_map_size, slamhip_cs **out);
+int32_t slamhip_cs_destroy(slamhip_cs *cs);
+int32_t slamhip_cs_info(slamhip_cs *cs, int32_t *hole_size, float *hole_scale, int32_t *obst_size, float *obst_scale);
+
+/* CoreSLAMProcessor.Reset map part (:169-170): HoleMap := 32750, ObstacleMap := unmapped_obstacle_hits */
+int32_t slamhip_cs_reset(slamhip_cs *cs, int32_t unmapped_obstacle_hits);
+
+/* HoleMap.Pixels (HoleMap.cs:27): ushort[Size*Size] row-major.  n_pixels must equal Size*Size. */
+int32_t slamhip_cs_holemap_upload(slamhip_cs *cs, const uint16_t *pixels, size_t n_pixels);
+int32_t slamhip_cs_holemap_download(slamhip_cs *cs, uint16_t *pixels, size_t n_pixels);
+/* HoleMap.GetPackedPixels (HoleMap.cs:44-55): 4-bit packing done on the device; n_bytes = Size*Size/2 */
+int32_t slamhip_cs_holemap_download_packed(slamhip_cs *cs, uint8_t *packed, size_t n_bytes);
+/* ObstacleMap.Pixels (ObstacleMap.cs:31): sbyte[Size,Size], [y,x] row-major */
+int32_t slamhip_cs_obstaclemap_upload(slamhip_cs *cs, const int8_t *pixels, size_t n_pixels);
+int32_t slamhip_cs_obstaclemap_download(slamhip_cs *cs, int8_t *pixels, size_t n_pixels);
+
+/* The ScanCloud of the current Update (output of ScanSegmentsToCloud, CoreSLAMProcessor.cs:187-207):
+ * n_points robot-frame points (x,y).  Kept on the device for the search and both map updates. */
+int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t n_points);
+
+/* CalculateDistance (CoreSLAMProcessor.cs:215-259) for K candidates in one batched kernel.
+ * pxcs is K x 4: px = x*Scale+0.5f, py = y*Scale+0.5f, c = cos(theta)*Scale, s = sin(theta)*Scale
+ * (:232-235) computed by the caller, so the CRT trig stays on the host and every distance is
+ * bit-exact with the reference for the same (px,py,c,s).  out_dist (K, may be NULL) receives every
+ * distance; the arg-min uses the reference tie-break (first strictly smaller, :644,:700). */
+int32_t slamhip_cs_distance_pxcs(slamhip_cs *cs, const float *pxcs, int32_t K, int32_t *out_dist,
+                                 int32_t *out_best_index, int32_t *out_best_dist);
+/* Same from poses (K x 3: x,y,theta); (px,py,c,s) are formed on the device with the deterministic
+ * correctly-rounded float sin/cos (csrc/det_trig.h). */
+int32_t slamhip_cs_distance_poses(slamhip_cs *cs, const float *poses, int32_t K, int32_t *out_dist,
+                                  int32_t *out_best_index, int32_t *out_best_dist);
+
+/* The pre-drawn jitter list: replaces FillRandomQueues + the Redzen samplers
+ * (CoreSLAMProcessor.cs:136-137,:599-612).  offs is n x 3 (dx, dy, dtheta) in the reference draw order
+ * X, Y, theta (:635-637), flat thread-major: entry t*iterations+i is thread t's i-th draw.
+ * Like the reference's background refill (:692) this is off the search's critical path. */
+int32_t slamhip_cs_set_offsets(slamhip_cs *cs, const float *offs, int32_t n);
+/* Device-side generation: counter-based Philox4x32-10 + Box-Muller keyed by
+ * (seed, stream, index), so a shard of the list has the same values on every GPU. */
+int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta,
+                                    uint64_t seed, uint64_t stream);
+int32_t slamhip_cs_offsets_download(slamhip_cs *cs, float *offs, int32_t n);
+
+/* ParallelMonteCarloSearch / SingleMonteCarloSearch (CoreSLAMProcessor.cs:624-710) over the flat
+ * candidate list: candidate 0 = search_pose itself (:626-628), candidate k = search_pose + offs[k-1].
+ * Returns the winning pose, its distance and its flat index. */
+int32_t slamhip_cs_search(slamhip_cs *cs, const float search_pose[3], float out_pose[3],
+                          int32_t *out_dist, int32_t *out_index);
+/* Shard of the same search: only flat candidates [first, first+count) are evaluated.  The result is
+ * the packed key (uint64(distance) << 32) | flat_index; min over shards == the full search
+ * (cross-thread arg-min :695-705; cross-GPU: one RCCL min all-reduce of this key). */
+int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float search_pose[3], int32_t first, int32_t count,
+                                uint64_t *out_key);
+/* Asynchronous form: enqueues on the context's stream and writes the key to DEVICE memory d_out_key
+ * (8 bytes, e.g. a torch tensor fed to an RCCL all-reduce on the same stream). */
+int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float search_pose[3], int32_t first,
+                                      int32_t count, uint64_t *d_out_key);
+/* Recompute the winner's pose from a (possibly all-reduced) key: search_pose + offs[index-1]. */
+int32_t slamhip_cs_pose_from_key(slamhip_cs *cs, const float search_pose[3], uint64_t key,
+                                 float out_pose[3], int32_t *out_dist, int32_t *out_index);
+
+/* UpdateHoleMap + DrawLaserRayOnHoleMap + ClipRay (CoreSLAMProcessor.cs:320-443,:496-534) with the
+ * current scan.  Bit-exact uint16 result including the ray-order dependence of the blend (:431). */
+int32_t slamhip_cs_update_holemap(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality);
+int32_t slamhip_cs_update_holemap_pxcs(slamhip_cs *cs, const float pxcs[4], float hole_width, int32_t quality);
+/* UpdateObstacleMap + DrawLaserRayOnObstacleMap (:456-490,:540-593) */
+int32_t slamhip_cs_update_obstaclemap(slamhip_cs *cs, const float pose[3], int32_t max_obstacle_hits);
+int32_t slamhip_cs_update_obstaclemap_pxcs(slamhip_cs *cs, const float pxcs[4], int32_t max_obstacle_hits);
+/* number of pixels blended by the last HoleMap update (4 algorithmic bytes each) */
+int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out_pixels);
+
+/* Fused configuration C3 (device boundary at CoreSLAMProcessor.cs:732,:750,:751): search, NormalizeAngle
+ * (:746) and both map updates in one call; the winning pose never leaves the device between them. */
+int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float search_pose[3], float hole_width,
+                                     int32_t quality, int32_t max_obstacle_hits, float out_pose[3],
+                                     int32_t *out_dist, int32_t *out_index);
+
+/* ------------------------------------------------------------------------------------------------
+ * CoreSLAM, processor level (host-side orchestration in C++, mirrors the public C# class)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* new CoreSLAMProcessor(physicalMapSize, holeMapSize, obstacleMapSize, startPose, sigmaXY, sigmaTheta,
+ * iterationsPerThread, numSearchThreads)  (CoreSLAMProcessor.cs:119-162).  The candidate list has
+ * max(numSearchThreads,1) * iterationsPerThread jitters; it is device-generated from (seed, scan number)
+ * unless slamhip_csproc_set_offsets pins it. */
+int32_t slamhip_csproc_create(slamhip_ctx *ctx, float physical_map_size, int32_t hole_map_size,
+                              int32_t obstacle_map_size, const float start_pose[3], float sigma_xy,
+                              float sigma_theta, int32_t iterations_per_thread, int32_t num_search_threads,
+                              slamhip_csproc **out);
+int32_t slamhip_csproc_destroy(slamhip_csproc *p);                 /* Dispose :757-773 */
+int32_t slamhip_csproc_reset(slamhip_csproc *p);                   /* Reset :167-175 */
+/* Update(List<ScanSegment>) (:717-752).  Segment i has pose seg_poses[3i..3i+2] and rays
+ * [seg_start[i], seg_start[i+1]) of (angle, radius) pairs (BaseSLAM/ScanSegment.cs, Ray.cs). */
+int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_poses, const int32_t *seg_start,
+                              int32_t n_segments, const float *rays);
+int32_t slamhip_csproc_get_pose(slamhip_csproc *p, float out_pose[3]);                /* Pose :106 */
+/* Quality :80, HoleWidth :85, PositionSearchBeginning :90, UnmappedObstacleHits :96, MaxObstacleHits :101 */
+int32_t slamhip_csproc_set_params(slamhip_csproc *p, int32_t quality, float hole_width,
+                                  int32_t position_search_beginning, int32_t unmapped_obstacle_hits,
+                                  int32_t max_obstacle_hits);
+int32_t slamhip_csproc_set_seed(slamhip_csproc *p, uint64_t seed);
+/* pin the jitter list used by the next searching Update (parity tests feed the oracle the same list) */
+int32_t slamhip_csproc_set_offsets(slamhip_csproc *p, const float *offs, int32_t n);
+/* the underlying operator-level object (HoleMap / ObstacleMap properties :45,:50) */
+int32_t slamhip_csproc_cs(slamhip_csproc *p, slamhip_cs **out_cs);
+
+/* ------------------------------------------------------------------------------------------------
+ * HectorSLAM, operator level
+ * ---------------------------------------------------------------------------------------------- */
+
+/* new MapRepMultiMap(mapResolution, mapSize, numDepth, Vector2.Zero) (HectorSLAM/Main/MapRepMultiMap.cs:40-58;
+ * OccGridMap ctor Map/OccGridMap.cs:35-48; GridMap ctor Map/GridMap.cs:33-51): level i has
+ * (w >> i, h >> i) cells of cell_length * 2^i metres; levels are independent maps. */
+int32_t slamhip_hs_create(slamhip_ctx *ctx, float cell_length, int32_t width, int32_t height, int32_t levels,
+                          slamhip_hs **out);
+int32_t slamhip_hs_destroy(slamhip_hs *hs);
+int32_t slamhip_hs_reset(slamhip_hs *hs);                                   /* MapRepMultiMap.Reset :63-66 */
+int32_t slamhip_hs_level_info(slamhip_hs *hs, int32_t level, int32_t *width, int32_t *height, float *cell_length);
+/* SetUpdateFactorFree / SetUpdateFactorOccupied (:83-95; OccGridMap.cs:58-79) */
+int32_t slamhip_hs_set_factors(slamhip_hs *hs, float update_free_factor, float update_occupied_factor);
+/* OccGridMap.EstimateIterations per level (OccGridMap.cs:53; default 3) */
+int32_t slamhip_hs_set_iterations(slamhip_hs *hs, const int32_t *iterations_per_level);
+/* mapArray of one level (GridMap.cs:13): n_cells = width*height LogOddsCell structs */
+int32_t slamhip_hs_cells_upload(slamhip_hs *hs, int32_t level, const slamhip_cell *cells, size_t n_cells);
+int32_t slamhip_hs_cells_download(slamhip_hs *hs, int32_t level, slamhip_cell *cells, size_t n_cells);
+/* GridMap.GetBitmapData (GridMap.cs:104-115) computed on the device */
+int32_t slamhip_hs_bitmap_download(slamhip_hs *hs, int32_t level, uint8_t *out, size_t n_cells);
+/* OccGridMap.GetCachedProbability (OccGridMap.cs:97-107) for a list of cell indices */
+int32_t slamhip_hs_probability(slamhip_hs *hs, int32_t level, const int32_t *indices, int32_t n, float *out);
+
+/* The ScanCloud handed to MatchData / UpdateByScan: points + scan.Pose.xy (ScanCloud.cs:15-20) */
+int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t n_points, const float scan_origin[2]);
+
+/* ScanMatcher.MatchData(MapRepMultiMap, scan, hintPose) (HectorSLAM/Matcher/ScanMatcher.cs:41-54):
+ * all levels x iterations in ONE persistent launch, 3x3 solve on the device. */
+int32_t slamhip_hs_match(slamhip_hs *hs, const float hint_pose[3], float out_pose[3]);
+/* ScanMatcher.MatchData(OccGridMap, scan, hintPose) (:64-84) on one level */
+int32_t slamhip_hs_match_level(slamhip_hs *hs, int32_t level, const float hint_pose[3], int32_t iterations,
+                               float out_pose[3]);
+/* B independent hints against the same scan and maps in one launch (throughput form) */
+int32_t slamhip_hs_match_batch(slamhip_hs *hs, const float *hint_poses, int32_t B, float *out_poses);
+/* GetCompleteHessianDerivs (:135-204) at a map-coordinate pose: H row-major 3x3, dTr 3 */
+int32_t slamhip_hs_hessian(slamhip_hs *hs, int32_t level, const float pose_map[3], float H[9], float dTr[3]);
+
+/* MapRepMultiMap.UpdateByScan -> OccGridMap.UpdateByScan on every level (MapRepMultiMap.cs:73-77;
+ * OccGridMap.cs:114-239), all levels in one launch sequence. */
+int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float robot_pose_world[3]);
+
+/* ------------------------------------------------------------------------------------------------
+ * HectorSLAM, processor level
+ * ---------------------------------------------------------------------------------------------- */
+/* new HectorSLAMProcessor(mapResolution, mapSize, startPose, numDepth, numThreads) (Main/HectorSLAMProcessor.cs:66-77) */
+int32_t slamhip_hsproc_create(slamhip_ctx *ctx, float map_resolution, int32_t width, int32_t height,
+                              const float start_pose[3], int32_t num_depth, slamhip_hsproc **out);
+int32_t slamhip_hsproc_destroy(slamhip_hsproc *p);
+int32_t slamhip_hsproc_reset(slamhip_hsproc *p);                                        /* :131-138 */
+/* Update(scan, poseHintWorld, mapWithoutMatching) (:86-126); *out_map_updated = return value */
+int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int32_t n_points, const float scan_origin[2],
+                              const float pose_hint_world[3], int32_t map_without_matching,
+                              int32_t *out_map_updated);
+int32_t slamhip_hsproc_get(slamhip_hsproc *p, float match_pose[3], float last_map_update_pose[3],
+                           float *match_timing_ms, float *update_timing_ms);            /* :31-46 */
+/* MinDistanceDiffForMapUpdate :51, MinAngleDiffForMapUpdate :56 */
+int32_t slamhip_hsproc_set_thresholds(slamhip_hsproc *p, float min_distance_diff, float min_angle_diff);
+int32_t slamhip_hsproc_hs(slamhip_hsproc *p, slamhip_hs **out_hs);                       /* MapRep :26 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU (new; no reference counterpart: the reference's only parallelism is ParallelWorker threads)
+ * ---------------------------------------------------------------------------------------------- */
+/* One process, n GPUs: a context + CoreSLAM replica per device and one RCCL communicator. */
+int32_t slamhip_group_create(const int32_t *device_ordinals, int32_t n, float physical_map_size,
+                             int32_t hole_map_size, int32_t obstacle_map_size, slamhip_group **out);
+int32_t slamhip_group_destroy(slamhip_group *g);
+int32_t slamhip_group_size(slamhip_group *g, int32_t *out_n);
+int32_t slamhip_group_cs(slamhip_group *g, int32_t rank, slamhip_cs **out_cs);
+/* broadcast-by-replication helpers: apply the same call to every replica */
+int32_t slamhip_group_reset(slamhip_group *g, int32_t unmapped_obstacle_hits);
+int32_t slamhip_group_holemap_upload(slamhip_group *g, const uint16_t *pixels, size_t n_pixels);
+int32_t slamhip_group_set_scan(slamhip_group *g, const float *xy, int32_t n_points);
+int32_t slamhip_group_set_offsets(slamhip_group *g, const float *offs, int32_t n);
+/* Candidates block-sharded over the GPUs, one ncclAllReduce(min, uint64, count 1) of the packed key
+ * over xGMI, winner pose recomputed locally. */
+int32_t slamhip_group_search(slamhip_group *g, const float search_pose[3], float out_pose[3],
+                             int32_t *out_dist, int32_t *out_index);
+/* replicas apply the identical deterministic update (integer-exact kernels keep them bit-identical) */
+int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float hole_width, int32_t quality,
+                                  int32_t max_obstacle_hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

@@ -15,7 +15,10 @@
  *       skipped in the HoleMap update instead of drawing the x64-specific garbage line;
  *   D2  Math.Abs(int.MinValue) / int.MinValue / -1 (OverflowException in C#) skip the ray;
  *   D3  a blend whose ptr leaves the pixel array (IndexOutOfRangeException in C#) is skipped
- *       and counted in oracle_cs_oob_blends.
+ *       and counted in oracle_cs_oob_blends (unreachable once D4 holds; kept as a guard);
+ *   D4  a ray whose CLIPPED endpoint is still outside the map -- reachable only through int32
+ *       overflow of the products in ClipRay (:329,:340) for endpoints hundreds of metres away,
+ *       where C# would walk off the array and throw -- is skipped.
  */
 #include "oracle.h"
 #include <math.h>
@@ -166,6 +169,7 @@ int oracle_cs_draw_ray_holemap(uint16_t *pixels, int size, int x1, int y1, int x
     int x2c = x2, y2c = y2;                                                       /* :361-362 */
     if (!oracle_cs_clip_ray(size, &x2c, &y2c, x1, y1)) return -1;                 /* :365 */
     if (!oracle_cs_clip_ray(size, &y2c, &x2c, y1, x1)) return -1;                 /* :366 */
+    if (x2c < 0 || x2c >= size || y2c < 0 || y2c >= size) return -1;              /* D4 */
 
     int32_t ddx = wsub(x2, x1), ddy = wsub(y2, y1);
     int32_t ddxc = wsub(x2c, x1), ddyc = wsub(y2c, y1);

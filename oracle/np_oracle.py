@@ -175,6 +175,8 @@ def ray_fragments(size, x1, y1, x2, y2, xp, yp, value=TS_OBSTACLE):
     ok, y2c, x2c = clip_ray(size, y2c, x2c, y1, x1)                  # :366
     if not ok:
         return None
+    if not (0 <= x2c < size and 0 <= y2c < size):                    # deviation D4 (oracle.h / coreslam_oracle.c)
+        return None
     ddx, ddy, ddxc, ddyc = wrap32(x2 - x1), wrap32(y2 - y1), wrap32(x2c - x1), wrap32(y2c - y1)
     if INT_MIN in (ddx, ddy, ddxc, ddyc):
         return None

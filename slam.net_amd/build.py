@@ -1,0 +1,72 @@
+"""hipcc build recipe for libslamhip.so (gfx950 only, in-tree so the .so travels with gpurun snapshots).
+
+Flags that are part of the numerical contract:
+  -ffp-contract=off   the reference's pixel coordinates are separate binary32 mul/add roundings
+                      (CoreSLAMProcessor.cs:240-241); an FMA would change map cells
+  no fast-math; IEEE divide / sqrt (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libslamhip.so")
+SOURCES = ["context.hip", "distance.hip", "holemap.hip", "obstacle.hip", "coreslam.hip", "processor.hip",
+           "hector.hip", "group.hip"]
+HEADERS = ["common.h", "cs_internal.h", "det_trig.h", "m3x2.h", os.path.join("..", "..", "include", "slamhip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libslamhip cannot be built (there is no CPU fallback)")
+
+
+def stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return OUT
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        spath = os.path.join(CSRC, src)
+        hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
+                and os.path.getmtime(obj) > hdr_t and os.path.getmtime(obj) > os.path.getmtime(os.path.abspath(__file__))):
+            continue
+        cmd = [cc] + FLAGS + ["-c", spath, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lpthread"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,54 @@
+// common.h -- shared declarations for libslamhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <limits.h>
+#include "../../include/slamhip.h"
+
+void slamhip_set_error(const char *fmt, ...);
+
+#define SH_FAIL(code, ...) do { slamhip_set_error(__VA_ARGS__); return (code); } while (0)
+#define SH_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+        slamhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        return SLAMHIP_ERR_HIP; } } while (0)
+#define SH_CHECK_ARG(cond) do { if (!(cond)) { slamhip_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+        return SLAMHIP_ERR_INVALID; } } while (0)
+#define SH_TRY(expr) do { int32_t r_ = (expr); if (r_ != SLAMHIP_OK) return r_; } while (0)
+
+struct slamhip_ctx {
+    int device;
+    hipStream_t stream;
+    int num_cus;
+    // timing
+    uint32_t timing;          // bit mask of timed kernel classes
+    struct TimedLaunch { hipEvent_t a, b; int which; };
+    TimedLaunch *pending; int n_pending, cap_pending;
+    hipEvent_t *pool; int n_pool, cap_pool;     // recycled events
+    double ms[SLAMHIP_K_COUNT]; int64_t launches[SLAMHIP_K_COUNT];
+};
+
+// RAII-ish helper: brackets a kernel class with events when timing is on.
+struct sh_timer {
+    slamhip_ctx *ctx; int which; hipEvent_t a;
+    sh_timer(slamhip_ctx *c, int w);
+    ~sh_timer();
+};
+int32_t sh_timing_collect(slamhip_ctx *ctx);
+
+static inline int sh_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// C# (int)float on x64 (cvttss2si): truncate toward zero, NaN / out-of-range -> INT_MIN.
+__host__ __device__ static inline int32_t sh_f2i(float f)
+{
+    if (!(f > -2147483904.0f && f < 2147483648.0f)) return INT32_MIN;
+    return (int32_t)f;
+}
+// C# unchecked int arithmetic
+__host__ __device__ static inline int32_t sh_wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__host__ __device__ static inline int32_t sh_wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__host__ __device__ static inline int32_t sh_wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+__host__ __device__ static inline int32_t sh_sign(int32_t a) { return (a > 0) - (a < 0); }
+__host__ __device__ static inline int32_t sh_abs(int32_t a) { return a < 0 ? sh_wsub(0, a) : a; }

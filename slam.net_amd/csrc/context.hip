@@ -1,0 +1,153 @@
+// context.hip -- library / context entry points of include/slamhip.h (gfx950 only).
+#include "common.h"
+#include <stdlib.h>
+
+static thread_local char g_err[512] = "";
+
+void slamhip_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *slamhip_version(void) { return "slamhip 0.1.0 (gfx950, HIP)"; }
+extern "C" const char *slamhip_last_error(void) { return g_err; }
+
+extern "C" int32_t slamhip_device_count(int32_t *out)
+{
+    SH_CHECK_ARG(out);
+    int n = 0;
+    SH_HIP(hipGetDeviceCount(&n));
+    *out = n;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_create(int32_t device, slamhip_ctx **out)
+{
+    SH_CHECK_ARG(out);
+    int n = 0;
+    SH_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) SH_FAIL(SLAMHIP_ERR_INVALID, "device ordinal %d out of range (have %d)", device, n);
+    SH_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SH_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        SH_FAIL(SLAMHIP_ERR_INVALID, "device %d is %s; libslamhip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    slamhip_ctx *c = (slamhip_ctx *)calloc(1, sizeof(slamhip_ctx));
+    if (!c) SH_FAIL(SLAMHIP_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { free(c); SH_FAIL(SLAMHIP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    *out = c;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_destroy(slamhip_ctx *c)
+{
+    if (!c) return SLAMHIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->n_pending; i++) { (void)hipEventDestroy(c->pending[i].a); (void)hipEventDestroy(c->pending[i].b); }
+    for (int i = 0; i < c->n_pool; i++) (void)hipEventDestroy(c->pool[i]);
+    free(c->pending); free(c->pool);
+    (void)hipStreamDestroy(c->stream);
+    free(c);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_synchronize(slamhip_ctx *c)
+{
+    SH_CHECK_ARG(c);
+    SH_HIP(hipStreamSynchronize(c->stream));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_device(slamhip_ctx *c, int32_t *out)
+{
+    SH_CHECK_ARG(c && out);
+    *out = c->device;
+    return SLAMHIP_OK;
+}
+
+extern "C" void *slamhip_ctx_stream(slamhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---- timing ------------------------------------------------------------------------------------
+static hipEvent_t ev_get(slamhip_ctx *c)
+{
+    if (c->n_pool > 0) return c->pool[--c->n_pool];
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+static void ev_put(slamhip_ctx *c, hipEvent_t e)
+{
+    if (c->n_pool == c->cap_pool) {
+        c->cap_pool = c->cap_pool ? c->cap_pool * 2 : 64;
+        c->pool = (hipEvent_t *)realloc(c->pool, sizeof(hipEvent_t) * c->cap_pool);
+    }
+    c->pool[c->n_pool++] = e;
+}
+
+sh_timer::sh_timer(slamhip_ctx *c, int w) : ctx(c), which(w), a(nullptr)
+{
+    if (!(ctx->timing & (1u << which))) return;
+    a = ev_get(ctx);
+    if (a) (void)hipEventRecord(a, ctx->stream);
+}
+sh_timer::~sh_timer()
+{
+    if (!a) return;
+    hipEvent_t b = ev_get(ctx);
+    if (!b) { ev_put(ctx, a); return; }
+    (void)hipEventRecord(b, ctx->stream);
+    if (ctx->n_pending == ctx->cap_pending) {
+        ctx->cap_pending = ctx->cap_pending ? ctx->cap_pending * 2 : 256;
+        ctx->pending = (slamhip_ctx::TimedLaunch *)realloc(ctx->pending, sizeof(slamhip_ctx::TimedLaunch) * ctx->cap_pending);
+    }
+    ctx->pending[ctx->n_pending++] = { a, b, which };
+}
+
+int32_t sh_timing_collect(slamhip_ctx *c)
+{
+    SH_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->n_pending; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->pending[i].a, c->pending[i].b) == hipSuccess) {
+            c->ms[c->pending[i].which] += ms;
+            c->launches[c->pending[i].which] += 1;
+        }
+        ev_put(c, c->pending[i].a);
+        ev_put(c, c->pending[i].b);
+    }
+    c->n_pending = 0;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_timing_enable(slamhip_ctx *c, int32_t mask)
+{
+    SH_CHECK_ARG(c);
+    if (c->timing) SH_TRY(sh_timing_collect(c));
+    c->timing = (uint32_t)mask;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_timing_reset(slamhip_ctx *c)
+{
+    SH_CHECK_ARG(c);
+    SH_TRY(sh_timing_collect(c));
+    memset(c->ms, 0, sizeof(c->ms));
+    memset(c->launches, 0, sizeof(c->launches));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_timing_get(slamhip_ctx *c, int32_t which, double *out_ms, int64_t *out_launches)
+{
+    SH_CHECK_ARG(c && which >= 0 && which < SLAMHIP_K_COUNT);
+    SH_TRY(sh_timing_collect(c));
+    if (out_ms) *out_ms = c->ms[which];
+    if (out_launches) *out_launches = c->launches[which];
+    return SLAMHIP_OK;
+}

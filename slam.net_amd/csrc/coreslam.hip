@@ -1,0 +1,557 @@
+// coreslam.hip -- CoreSLAM operator-level entry points of include/slamhip.h (gfx950 only).
+#include "cs_internal.h"
+#include "det_trig.h"
+#include <algorithm>
+#include <numeric>
+#include <math.h>
+#include <stdlib.h>
+
+// ---- small kernels ------------------------------------------------------------------------------------
+__global__ void k_fill_u16(uint16_t *p, size_t n, uint16_t v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// HoleMap.GetPackedPixels (HoleMap.cs:44-55)
+__global__ void k_pack_holemap(const uint16_t *__restrict__ pix, uint8_t *__restrict__ out, size_t n_bytes)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bytes) return;
+    out[i] = (uint8_t)(((pix[i * 2] >> 12) << 4) | (pix[i * 2 + 1] >> 12));      // :51
+}
+
+// evaluation list: ev_idx[j] (or first + j) is a flat candidate index; flat 0 is the un-jittered pose
+__global__ void k_gather_offsets(const float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first,
+                                 int count, float *__restrict__ ev_off, int *__restrict__ ev_idx_out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const int flat = ev_idx_in ? ev_idx_in[j] : first + j;
+    float ox = 0.f, oy = 0.f, ot = 0.f;
+    if (flat > 0) { ox = offs_flat[3 * (flat - 1)]; oy = offs_flat[3 * (flat - 1) + 1]; ot = offs_flat[3 * (flat - 1) + 2]; }
+    ev_off[3 * j] = ox; ev_off[3 * j + 1] = oy; ev_off[3 * j + 2] = ot;
+    if (ev_idx_out) ev_idx_out[j] = flat;
+}
+
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3")
+__device__ static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// Device replacement for FillRandomQueues (CoreSLAMProcessor.cs:599-612): jitter i is a pure function of
+// (seed, stream, i).  dx,dy ~ N(0, sigma_xy) by Box-Muller; dtheta is STRATIFIED: the i-th of n equal-
+// probability strata of N(0, sigma_theta), so the flat list is already sorted by theta (no sort on the
+// search path) while every dtheta is still N(0, sigma_theta) distributed.
+__global__ void k_generate_offsets(float *__restrict__ offs_flat, int n, float sigma_xy, float sigma_theta,
+                                   uint64_t seed, uint64_t stream)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c[4] = { (uint32_t)i, 0u, (uint32_t)stream, (uint32_t)(stream >> 32) };
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530718f * u2, &sn, &cs);
+    const float q = ((float)i + u3) / (float)n;
+    offs_flat[3 * i + 0] = sigma_xy * rad * cs;
+    offs_flat[3 * i + 1] = sigma_xy * rad * sn;
+    offs_flat[3 * i + 2] = sigma_theta * normcdfinvf(q);
+}
+
+// winner pose from the packed key: search_pose + offs[index-1] (:635-637), theta normalised (:746)
+__global__ void k_best_pose(const unsigned long long *__restrict__ key, const float *__restrict__ offs_flat,
+                            float bx, float by, float bth, float *__restrict__ out_pose)
+{
+    const uint32_t flat = (uint32_t)(*key);
+    float x = bx, y = by, th = bth;
+    if (flat > 0) { x = bx + offs_flat[3 * (flat - 1)]; y = by + offs_flat[3 * (flat - 1) + 1]; th = bth + offs_flat[3 * (flat - 1) + 2]; }
+    out_pose[0] = x; out_pose[1] = y; out_pose[2] = sh_normalize_angle(th);
+    out_pose[3] = th;     // un-normalised, as MonteCarloSearch returns it
+}
+
+// ---- lifecycle -------------------------------------------------------------------------------------------
+extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
+{
+    if (!cs) return SLAMHIP_OK;
+    (void)hipSetDevice(cs->ctx->device);
+    (void)hipStreamSynchronize(cs->ctx->stream);
+    (void)hipFree(cs->d_hole); (void)hipFree(cs->d_obst);
+    (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start);
+    (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
+    (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
+    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose);
+    if (cs->h_key) (void)hipHostFree(cs->h_key);
+    cs_holemap_free(cs);
+    cs_obstacle_free(cs);
+    delete cs;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t hole_size, int32_t obst_size, slamhip_cs **out)
+{
+    SH_CHECK_ARG(ctx && out);
+    SH_CHECK_ARG(hole_size >= 2 && hole_size <= 32768 && obst_size >= 1 && obst_size <= 32768);
+    SH_CHECK_ARG(physical > 0.0f);
+    SH_HIP(hipSetDevice(ctx->device));
+    slamhip_cs *cs = new slamhip_cs();
+    cs->ctx = ctx;
+    cs->physical = physical;
+    cs->hs = hole_size; cs->hscale = (float)hole_size / physical;          // HoleMap.cs:19-20
+    cs->os = obst_size; cs->oscale = (float)obst_size / physical;          // ObstacleMap.cs:19-20
+    cs->shard_first = cs->shard_count = -1;
+    int32_t rc = SLAMHIP_OK;
+    do {
+        if (hipMalloc(&cs->d_hole, sizeof(uint16_t) * (size_t)hole_size * hole_size) != hipSuccess ||
+            hipMalloc(&cs->d_obst, (size_t)obst_size * obst_size) != hipSuccess ||
+            hipMalloc(&cs->d_key, sizeof(uint64_t)) != hipSuccess ||
+            hipMalloc(&cs->d_best_pose, sizeof(float) * 4) != hipSuccess ||
+            hipHostMalloc(&cs->h_key, 64) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
+        if ((rc = cs_holemap_alloc(cs)) != SLAMHIP_OK) break;
+        if ((rc = cs_obstacle_alloc(cs)) != SLAMHIP_OK) break;
+        if ((rc = slamhip_cs_reset(cs, -5)) != SLAMHIP_OK) break;          // CoreSLAMProcessor.cs:96,:140
+    } while (0);
+    if (rc != SLAMHIP_OK) { slamhip_cs_destroy(cs); return rc; }
+    *out = cs;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_info(slamhip_cs *cs, int32_t *hs, float *hscale, int32_t *os, float *oscale)
+{
+    SH_CHECK_ARG(cs);
+    if (hs) *hs = cs->hs;
+    if (hscale) *hscale = cs->hscale;
+    if (os) *os = cs->os;
+    if (oscale) *oscale = cs->oscale;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_reset(slamhip_cs *cs, int32_t unmapped)
+{
+    SH_CHECK_ARG(cs);
+    SH_CHECK_ARG(unmapped >= -128 && unmapped <= 127);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    const size_t n = (size_t)cs->hs * cs->hs;
+    hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, cs->ctx->stream, cs->d_hole, n,
+                       (uint16_t)((0 + 65500) / 2));                       // :169 (TS_OBSTACLE + TS_NO_OBSTACLE) / 2
+    SH_HIP(hipMemsetAsync(cs->d_obst, (int)(uint8_t)(int8_t)unmapped, (size_t)cs->os * cs->os, cs->ctx->stream)); // :170
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    return SLAMHIP_OK;
+}
+
+// ---- map transfer ---------------------------------------------------------------------------------------
+extern "C" int32_t slamhip_cs_holemap_upload(slamhip_cs *cs, const uint16_t *pix, size_t n)
+{
+    SH_CHECK_ARG(cs && pix && n == (size_t)cs->hs * cs->hs);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_HIP(hipMemcpyAsync(cs->d_hole, pix, n * sizeof(uint16_t), hipMemcpyHostToDevice, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    return SLAMHIP_OK;
+}
+extern "C" int32_t slamhip_cs_holemap_download(slamhip_cs *cs, uint16_t *pix, size_t n)
+{
+    SH_CHECK_ARG(cs && pix && n == (size_t)cs->hs * cs->hs);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_HIP(hipMemcpyAsync(pix, cs->d_hole, n * sizeof(uint16_t), hipMemcpyDeviceToHost, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    return SLAMHIP_OK;
+}
+extern "C" int32_t slamhip_cs_holemap_download_packed(slamhip_cs *cs, uint8_t *packed, size_t n_bytes)
+{
+    SH_CHECK_ARG(cs && packed && n_bytes == ((size_t)cs->hs * cs->hs) / 2);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    uint8_t *d = nullptr;
+    SH_HIP(hipMalloc(&d, n_bytes));
+    hipLaunchKernelGGL(k_pack_holemap, dim3((unsigned)((n_bytes + 255) / 256)), dim3(256), 0, cs->ctx->stream, cs->d_hole, d, n_bytes);
+    hipError_t e = hipMemcpyAsync(packed, d, n_bytes, hipMemcpyDeviceToHost, cs->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(cs->ctx->stream);
+    (void)hipFree(d);
+    SH_HIP(e);
+    return SLAMHIP_OK;
+}
+extern "C" int32_t slamhip_cs_obstaclemap_upload(slamhip_cs *cs, const int8_t *pix, size_t n)
+{
+    SH_CHECK_ARG(cs && pix && n == (size_t)cs->os * cs->os);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_HIP(hipMemcpyAsync(cs->d_obst, pix, n, hipMemcpyHostToDevice, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    return SLAMHIP_OK;
+}
+extern "C" int32_t slamhip_cs_obstaclemap_download(slamhip_cs *cs, int8_t *pix, size_t n)
+{
+    SH_CHECK_ARG(cs && pix && n == (size_t)cs->os * cs->os);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_HIP(hipMemcpyAsync(pix, cs->d_obst, n, hipMemcpyDeviceToHost, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    return SLAMHIP_OK;
+}
+
+// ---- scan --------------------------------------------------------------------------------------------------
+static inline uint32_t part1by1(uint32_t x)
+{
+    x &= 0x0000ffff;
+    x = (x ^ (x << 8)) & 0x00ff00ff;
+    x = (x ^ (x << 4)) & 0x0f0f0f0f;
+    x = (x ^ (x << 2)) & 0x33333333;
+    x = (x ^ (x << 1)) & 0x55555555;
+    return x;
+}
+
+extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t n)
+{
+    SH_CHECK_ARG(cs && n >= 0 && (xy || n == 0));
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    cs->n_points = n;
+    cs->n_rb = 0;
+    if (n == 0) return SLAMHIP_OK;
+    if (n > cs->cap_points) {
+        (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start);
+        cs->d_pts = cs->d_pts_sorted = nullptr; cs->d_rb_start = nullptr; cs->cap_points = 0;
+        const int cap = n + n / 4 + 64;
+        SH_HIP(hipMalloc(&cs->d_pts, sizeof(float2) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_pts_sorted, sizeof(float2) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_rb_start, sizeof(int) * (size_t)(cap + 2)));
+        cs->cap_points = cap;
+    }
+    // K1 sums integers, so it may visit the rays in any order: sort them along a Z-order curve at
+    // 64-pixel granularity so that a ray block's end points stay close together in the map (the rigid
+    // candidate transform preserves distances), then cut the sorted list into blocks of <= CS_RB_MAX.
+    bool sane = true;
+    std::vector<uint64_t> keys((size_t)n);
+    const float cell = 64.0f / cs->hscale;          // metres per 64 px
+    for (int i = 0; i < n; i++) {
+        const float X = xy[2 * i], Y = xy[2 * i + 1];
+        if (!(fabsf(X) < 1.0e9f) || !(fabsf(Y) < 1.0e9f)) sane = false;
+        float gx = X / cell + 32768.0f, gy = Y / cell + 32768.0f;
+        uint32_t ux = gx > 0.0f ? (gx < 65535.0f ? (uint32_t)gx : 65535u) : 0u;
+        uint32_t uy = gy > 0.0f ? (gy < 65535.0f ? (uint32_t)gy : 65535u) : 0u;
+        keys[i] = ((uint64_t)(part1by1(ux) | (part1by1(uy) << 1)) << 32) | (uint32_t)i;
+    }
+    std::sort(keys.begin(), keys.end());
+    std::vector<float> sorted((size_t)n * 2);
+    std::vector<int> rb;
+    rb.push_back(0);
+    int cur = 0;
+    uint32_t cur_cell = (uint32_t)(keys[0] >> 32) >> 4;     // 4x4 cells (256 px) per coarse bucket
+    for (int j = 0; j < n; j++) {
+        const int i = (int)(uint32_t)keys[j];
+        sorted[2 * j] = xy[2 * i]; sorted[2 * j + 1] = xy[2 * i + 1];
+        const uint32_t cb = (uint32_t)(keys[j] >> 32) >> 4;
+        if (cur == CS_RB_MAX || (cb != cur_cell && cur > 0)) { rb.push_back(j); cur = 0; }
+        cur_cell = cb;
+        cur++;
+    }
+    rb.push_back(n);
+    cs->n_rb = (int)rb.size() - 1;
+    cs->pts_sane = sane;
+    SH_HIP(hipMemcpyAsync(cs->d_pts, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, cs->ctx->stream));
+    SH_HIP(hipMemcpyAsync(cs->d_pts_sorted, sorted.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, cs->ctx->stream));
+    SH_HIP(hipMemcpyAsync(cs->d_rb_start, rb.data(), sizeof(int) * rb.size(), hipMemcpyHostToDevice, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));     // host staging buffers die here
+    return SLAMHIP_OK;
+}
+
+// ---- distance ---------------------------------------------------------------------------------------------
+static int32_t finish_distance(slamhip_cs *cs, int K, int32_t *out_dist, int32_t *out_best_index, int32_t *out_best_dist)
+{
+    slamhip_ctx *ctx = cs->ctx;
+    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_dist) SH_HIP(hipMemcpyAsync(out_dist, cs->d_dist, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+    SH_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t key = *cs->h_key;
+    if (out_best_index) *out_best_index = (int32_t)(uint32_t)key;
+    if (out_best_dist) *out_best_dist = (int32_t)(uint32_t)(key >> 32);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_distance_pxcs(slamhip_cs *cs, const float *pxcs, int32_t K, int32_t *out_dist,
+                                            int32_t *out_best_index, int32_t *out_best_dist)
+{
+    SH_CHECK_ARG(cs && pxcs && K > 0);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
+    SH_TRY(cs_alloc_candidates(cs, K));
+    bool sane = true;
+    for (size_t i = 0; i < (size_t)K * 4; i++) if (!(fabsf(pxcs[i]) < 1.0e9f)) { sane = false; break; }
+    cs->shard_first = cs->shard_count = -1;        // evaluation buffers no longer hold the offset shard
+    SH_HIP(hipMemcpyAsync(cs->d_pxcs, pxcs, sizeof(float) * 4 * (size_t)K, hipMemcpyHostToDevice, cs->ctx->stream));
+    int *saved = cs->d_ev_idx; cs->d_ev_idx = nullptr;          // identity: evaluation order == flat order
+    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane);
+    cs->d_ev_idx = saved;
+    SH_TRY(rc);
+    return finish_distance(cs, K, out_dist, out_best_index, out_best_dist);
+}
+
+extern "C" int32_t slamhip_cs_distance_poses(slamhip_cs *cs, const float *poses, int32_t K, int32_t *out_dist,
+                                             int32_t *out_best_index, int32_t *out_best_dist)
+{
+    SH_CHECK_ARG(cs && poses && K > 0);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
+    SH_TRY(cs_alloc_candidates(cs, K));
+    bool sane = true;
+    for (size_t i = 0; i < (size_t)K * 3; i++) if (!(fabsf(poses[i]) < 1.0e6f)) { sane = false; break; }
+    cs->shard_first = cs->shard_count = -1;
+    // stage the poses in d_ev_off (same 3-float layout)
+    SH_HIP(hipMemcpyAsync(cs->d_ev_off, poses, sizeof(float) * 3 * (size_t)K, hipMemcpyHostToDevice, cs->ctx->stream));
+    cs_launch_prep_poses(cs, cs->d_ev_off, K);
+    int *saved = cs->d_ev_idx; cs->d_ev_idx = nullptr;
+    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane);
+    cs->d_ev_idx = saved;
+    SH_TRY(rc);
+    return finish_distance(cs, K, out_dist, out_best_index, out_best_dist);
+}
+
+// ---- offsets ------------------------------------------------------------------------------------------------
+static int32_t ensure_offsets_capacity(slamhip_cs *cs, int n)
+{
+    SH_TRY(cs_alloc_candidates(cs, n + 1));
+    // d_offs_flat is sized with the candidate buffers
+    static_assert(sizeof(float) == 4, "float");
+    if (cs->d_offs_flat) { (void)hipFree(cs->d_offs_flat); cs->d_offs_flat = nullptr; }
+    SH_HIP(hipMalloc(&cs->d_offs_flat, sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_set_offsets(slamhip_cs *cs, const float *offs, int32_t n)
+{
+    SH_CHECK_ARG(cs && n >= 0 && (offs || n == 0));
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    SH_TRY(ensure_offsets_capacity(cs, n));
+    cs->n_offs = n;
+    cs->h_offs.assign(offs, offs + (size_t)n * 3);
+    cs->offs_on_device_sorted = false;
+    cs->shard_first = cs->shard_count = -1;
+    if (n > 0) SH_HIP(hipMemcpy(cs->d_offs_flat, offs, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta,
+                                               uint64_t seed, uint64_t stream)
+{
+    SH_CHECK_ARG(cs && n >= 0);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (n != cs->n_offs || !cs->d_offs_flat) {
+        SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+        SH_TRY(ensure_offsets_capacity(cs, n));
+    }
+    cs->n_offs = n;
+    cs->h_offs.clear();
+    cs->offs_on_device_sorted = true;
+    cs->shard_first = cs->shard_count = -1;
+    if (n > 0)
+        hipLaunchKernelGGL(k_generate_offsets, dim3(sh_div_up(n, 256)), dim3(256), 0, cs->ctx->stream,
+                           cs->d_offs_flat, n, sigma_xy, sigma_theta, seed, stream);
+    SH_HIP(hipGetLastError());
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_offsets_download(slamhip_cs *cs, float *offs, int32_t n)
+{
+    SH_CHECK_ARG(cs && offs && n == cs->n_offs);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (n > 0) {
+        SH_HIP(hipMemcpyAsync(offs, cs->d_offs_flat, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, cs->ctx->stream));
+        SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    }
+    return SLAMHIP_OK;
+}
+
+static int32_t host_offsets(slamhip_cs *cs)
+{
+    if (cs->h_offs.size() == (size_t)cs->n_offs * 3) return SLAMHIP_OK;
+    cs->h_offs.resize((size_t)cs->n_offs * 3);
+    if (cs->n_offs > 0) {
+        SH_HIP(hipMemcpyAsync(cs->h_offs.data(), cs->d_offs_flat, sizeof(float) * 3 * (size_t)cs->n_offs,
+                              hipMemcpyDeviceToHost, cs->ctx->stream));
+        SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    }
+    return SLAMHIP_OK;
+}
+
+// materialise the theta-sorted evaluation list of flat candidates [first, first+count)
+static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
+{
+    if (cs->shard_first == first && cs->shard_count == count) return SLAMHIP_OK;
+    slamhip_ctx *ctx = cs->ctx;
+    if (cs->offs_on_device_sorted) {
+        hipLaunchKernelGGL(k_gather_offsets, dim3(sh_div_up(count, 256)), dim3(256), 0, ctx->stream,
+                           cs->d_offs_flat, (const int *)nullptr, first, count, cs->d_ev_off, cs->d_ev_idx);
+    } else {
+        // theta = search_pose.Z + dtheta and float addition is monotone, so sorting by dtheta sorts by theta
+        std::vector<int> perm((size_t)count);
+        std::iota(perm.begin(), perm.end(), first);
+        const float *o = cs->h_offs.data();
+        std::stable_sort(perm.begin(), perm.end(), [o](int a, int b) {
+            const float ta = a > 0 ? o[3 * (size_t)(a - 1) + 2] : 0.0f, tb = b > 0 ? o[3 * (size_t)(b - 1) + 2] : 0.0f;
+            return ta < tb;
+        });
+        SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_gather_offsets, dim3(sh_div_up(count, 256)), dim3(256), 0, ctx->stream,
+                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, cs->d_ev_off, (int *)nullptr);
+        SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
+    }
+    SH_HIP(hipGetLastError());
+    cs->shard_first = first; cs->shard_count = count;
+    return SLAMHIP_OK;
+}
+
+static int32_t search_enqueue(slamhip_cs *cs, const float pose[3], int first, int count)
+{
+    SH_CHECK_ARG(cs && pose);
+    SH_CHECK_ARG(first >= 0 && count > 0 && first + count <= cs->n_offs + 1);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
+    SH_TRY(ensure_shard(cs, first, count));
+    const bool sane = fabsf(pose[0]) < 1.0e6f && fabsf(pose[1]) < 1.0e6f && fabsf(pose[2]) < 1.0e4f;
+    cs_launch_prep_offsets(cs, count, pose);
+    return cs_launch_distance(cs, count, false, sane);
+}
+
+extern "C" int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count,
+                                                 uint64_t *d_out_key)
+{
+    SH_CHECK_ARG(d_out_key);
+    SH_TRY(search_enqueue(cs, pose, first, count));
+    SH_HIP(hipMemcpyAsync(d_out_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToDevice, cs->ctx->stream));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count, uint64_t *out_key)
+{
+    SH_CHECK_ARG(out_key);
+    SH_TRY(search_enqueue(cs, pose, first, count));
+    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    *out_key = *cs->h_key;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_pose_from_key(slamhip_cs *cs, const float pose[3], uint64_t key, float out_pose[3],
+                                            int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(cs && pose);
+    const uint32_t flat = (uint32_t)key;
+    SH_CHECK_ARG(flat <= (uint32_t)cs->n_offs);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_TRY(host_offsets(cs));
+    if (out_pose) {
+        out_pose[0] = pose[0]; out_pose[1] = pose[1]; out_pose[2] = pose[2];       // :626
+        if (flat > 0) {
+            const float *o = cs->h_offs.data() + 3 * (size_t)(flat - 1);
+            out_pose[0] = pose[0] + o[0];                                          // :635
+            out_pose[1] = pose[1] + o[1];                                          // :636
+            out_pose[2] = pose[2] + o[2];                                          // :637
+        }
+    }
+    if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);
+    if (out_index) *out_index = (int32_t)flat;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_search(slamhip_cs *cs, const float pose[3], float out_pose[3], int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(cs);
+    uint64_t key = 0;
+    SH_TRY(slamhip_cs_search_shard(cs, pose, 0, cs->n_offs + 1, &key));
+    return slamhip_cs_pose_from_key(cs, pose, key, out_pose, out_dist, out_index);
+}
+
+// ---- map updates ---------------------------------------------------------------------------------------------
+static float4 pxcs_from_pose(const float pose[3], float scale)
+{
+    float s, c;
+    sh_det_sincosf(pose[2], &s, &c);
+    float4 q;
+    q.x = pose[0] * scale + 0.5f;
+    q.y = pose[1] * scale + 0.5f;
+    q.z = c * scale;
+    q.w = s * scale;
+    return q;
+}
+
+static int32_t finish_holemap(slamhip_cs *cs)
+{
+    int *h = (int *)cs->h_key;
+    SH_HIP(hipMemcpyAsync(h + 4, cs->d_k2_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    cs->last_hole_pixels = h[4 + 2];
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_update_holemap_pxcs(slamhip_cs *cs, const float pxcs[4], float hole_width, int32_t quality)
+{
+    SH_CHECK_ARG(cs && pxcs && quality >= 0 && quality <= 256);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    cs->last_hole_pixels = 0;
+    if (cs->n_points <= 0) return SLAMHIP_OK;
+    SH_TRY(cs_launch_holemap_update(cs, nullptr, make_float4(pxcs[0], pxcs[1], pxcs[2], pxcs[3]), hole_width, quality));
+    return finish_holemap(cs);
+}
+
+extern "C" int32_t slamhip_cs_update_holemap(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality)
+{
+    SH_CHECK_ARG(cs && pose);
+    const float4 q = pxcs_from_pose(pose, cs->hscale);                      // :499-502
+    const float a[4] = { q.x, q.y, q.z, q.w };
+    return slamhip_cs_update_holemap_pxcs(cs, a, hole_width, quality);
+}
+
+extern "C" int32_t slamhip_cs_update_obstaclemap_pxcs(slamhip_cs *cs, const float pxcs[4], int32_t max_hits)
+{
+    SH_CHECK_ARG(cs && pxcs && max_hits >= -128 && max_hits <= 127);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (cs->n_points <= 0) return SLAMHIP_OK;
+    SH_TRY(cs_launch_obstacle_update(cs, nullptr, make_float4(pxcs[0], pxcs[1], pxcs[2], pxcs[3]), max_hits));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_update_obstaclemap(slamhip_cs *cs, const float pose[3], int32_t max_hits)
+{
+    SH_CHECK_ARG(cs && pose);
+    const float4 q = pxcs_from_pose(pose, cs->oscale);                      // :545-548
+    const float a[4] = { q.x, q.y, q.z, q.w };
+    return slamhip_cs_update_obstaclemap_pxcs(cs, a, max_hits);
+}
+
+extern "C" int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out)
+{
+    SH_CHECK_ARG(cs && out);
+    *out = cs->last_hole_pixels;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality,
+                                                int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(cs && pose);
+    SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
+    slamhip_ctx *ctx = cs->ctx;
+    SH_TRY(search_enqueue(cs, pose, 0, cs->n_offs + 1));                    // :732
+    hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
+                       cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);   // :746-747
+    SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality));   // :750
+    SH_TRY(cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits));             // :751
+    float *hp = (float *)(cs->h_key + 4);
+    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SH_HIP(hipMemcpyAsync(hp, cs->d_best_pose, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SH_TRY(finish_holemap(cs));
+    const uint64_t key = *cs->h_key;
+    if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
+    if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);
+    if (out_index) *out_index = (int32_t)(uint32_t)key;
+    return SLAMHIP_OK;
+}

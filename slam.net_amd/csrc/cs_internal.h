@@ -1,0 +1,74 @@
+// cs_internal.h -- device state of the CoreSLAM operator object (slamhip_cs).
+#pragma once
+#include "common.h"
+#include <vector>
+
+// Rays are grouped into blocks of at most CS_RB_MAX consecutive (spatially sorted) points; one
+// workgroup of the distance kernel handles (candidate group) x (ray block) and emits one packed
+// partial per candidate: (in-bounds count << 21) | pixel sum   (32 * 65535 < 2^21).
+#define CS_RB_MAX 32
+#define CS_PART_SUM_BITS 21
+#define CS_PART_SUM_MASK ((1u << CS_PART_SUM_BITS) - 1u)
+
+struct cs_ray;      // K2 per-ray table entry (holemap.hip)
+
+struct slamhip_cs {
+    slamhip_ctx *ctx;
+    float physical;
+    int hs; float hscale;         // HoleMap Size / Scale      (HoleMap.cs:19-20)
+    int os; float oscale;         // ObstacleMap Size / Scale  (ObstacleMap.cs:19-20)
+    uint16_t *d_hole;             // ushort[hs*hs] row-major   (HoleMap.cs:27)
+    int8_t *d_obst;               // sbyte[os,os] [y,x]        (ObstacleMap.cs:31)
+
+    // ---- scan -------------------------------------------------------------------------------
+    int n_points, cap_points;
+    float2 *d_pts;                // original order: K2/K3 are ray-order dependent
+    float2 *d_pts_sorted;         // spatially sorted copy for K1 (integer sum: any order is exact)
+    int n_rb;                     // ray blocks over d_pts_sorted
+    int *d_rb_start;              // [n_rb + 1]
+    bool pts_sane;                // all |coords| < 1e9: fast kernels need no NaN/overflow handling
+
+    // ---- candidates ---------------------------------------------------------------------------
+    int n_offs;                   // jitters in the flat list; flat candidate count = n_offs + 1
+    std::vector<float> h_offs;    // host copy (n_offs x 3) for shard sorting / pose_from_key
+    bool offs_on_device_sorted;   // generated on the device: flat list already theta-sorted
+    float *d_offs_flat;           // [n_offs x 3] flat order
+    int shard_first, shard_count; // evaluation list currently materialised
+    float *d_ev_off;              // [cap_cand x 3] offsets in evaluation (theta-sorted) order
+    int *d_ev_idx;                // [cap_cand] evaluation position -> flat index
+    int cap_cand;
+    float4 *d_pxcs;               // [cap_cand] (px,py,c,s) in evaluation order
+    uint32_t *d_partial; size_t cap_partial;   // [n_rb][count]
+    int32_t *d_dist;              // [cap_cand] per-candidate distances in FLAT order (optional output)
+    uint64_t *d_key;              // packed (dist << 32 | flat index) arg-min
+    uint64_t *h_key;              // pinned
+    float *d_grp_bounds; int cap_grp;          // per candidate group: min/max of px,py,c,s (8 floats)
+    float *d_best_pose;           // winner's pose (theta normalised), device-resident for the fused path
+
+    // ---- K2 HoleMap update scratch ---------------------------------------------------------------
+    uint32_t *d_h_cnt;            // [hs*hs] fragments per pixel this scan (kept zero between calls)
+    int32_t *d_h_vmin, *d_h_vmax; // [hs*hs] min / max pixval per pixel this scan
+    cs_ray *d_rays; int cap_rays;
+    int *d_chunk_ray, *d_chunk_x0; int cap_chunks;   // fragment chunks: (ray, first step)
+    int *d_k2_counters;           // [0] n_chunks, [1] n_conflict_pixels, [2] total fragments (blended pixels)
+    int *d_conflict_pix; int cap_conflict;
+    int64_t last_hole_pixels;
+
+    // ---- K3 ObstacleMap update scratch ---------------------------------------------------------------
+    uint32_t *d_o_hits;           // [os*os] endpoint hits this scan
+    uint8_t *d_o_nohit;           // [os*os] noHitMap (CoreSLAMProcessor.cs:26,:133)
+};
+
+// distance.hip
+int32_t cs_alloc_candidates(slamhip_cs *cs, int count);
+int32_t cs_launch_distance(slamhip_cs *cs, int count, bool want_dist, bool cand_sane);
+void    cs_launch_prep_offsets(slamhip_cs *cs, int count, const float pose[3]);
+void    cs_launch_prep_poses(slamhip_cs *cs, const float *d_poses, int count);
+// holemap.hip
+int32_t cs_holemap_alloc(slamhip_cs *cs);
+void    cs_holemap_free(slamhip_cs *cs);
+int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float hole_width, int quality);
+// obstacle.hip
+int32_t cs_obstacle_alloc(slamhip_cs *cs);
+void    cs_obstacle_free(slamhip_cs *cs);
+int32_t cs_launch_obstacle_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, int max_hits);

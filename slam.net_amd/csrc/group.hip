@@ -1,0 +1,175 @@
+// group.hip -- single-process multi-GPU CoreSLAM search: candidates block-sharded over the GPUs, one RCCL
+// min all-reduce of the packed (distance << 32 | flat index) key over xGMI per scan.
+//
+// New design with no reference counterpart (the reference's only parallelism is ParallelWorker threads,
+// BaseSLAM/ParallelWorker.cs:15-141): the cross-thread arg-min of CoreSLAMProcessor.cs:695-705 becomes
+// ncclAllReduce(min, uint64, count = 1).  The 8-byte message makes the collective latency-bound; every rank
+// then holds the winning key and recomputes the winning pose locally, and map updates are replicated
+// (bit-exact integer kernels keep the replicas identical).
+// RCCL is resolved with dlopen at group creation so that single-GPU users of libslamhip never load it
+// (and a host process that already loaded its own librccl, e.g. PyTorch, shares that copy).
+#include "cs_internal.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <vector>
+
+struct rccl_api {
+    void *lib;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+
+static int32_t load_rccl(rccl_api *api)
+{
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    api->lib = nullptr;
+    for (const char *nm : names) { api->lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (api->lib) break; }
+    if (!api->lib) SH_FAIL(SLAMHIP_ERR_RCCL, "cannot load librccl: %s", dlerror());
+#define SH_SYM(field, name) do { *(void **)(&api->field) = dlsym(api->lib, name); \
+        if (!api->field) SH_FAIL(SLAMHIP_ERR_RCCL, "librccl lacks %s", name); } while (0)
+    SH_SYM(CommInitAll, "ncclCommInitAll");
+    SH_SYM(CommDestroy, "ncclCommDestroy");
+    SH_SYM(AllReduce, "ncclAllReduce");
+    SH_SYM(GroupStart, "ncclGroupStart");
+    SH_SYM(GroupEnd, "ncclGroupEnd");
+    SH_SYM(GetErrorString, "ncclGetErrorString");
+#undef SH_SYM
+    return SLAMHIP_OK;
+}
+
+#define SH_NCCL(g, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+        slamhip_set_error("%s failed: %s", #expr, (g)->api.GetErrorString(r_)); return SLAMHIP_ERR_RCCL; } } while (0)
+
+struct slamhip_group {
+    int n;
+    rccl_api api;
+    std::vector<slamhip_ctx *> ctx;
+    std::vector<slamhip_cs *> cs;
+    std::vector<ncclComm_t> comm;
+    std::vector<uint64_t *> d_key;
+    int n_offs;
+};
+
+extern "C" int32_t slamhip_group_destroy(slamhip_group *g)
+{
+    if (!g) return SLAMHIP_OK;
+    for (int r = 0; r < (int)g->comm.size(); r++) if (g->comm[r]) g->api.CommDestroy(g->comm[r]);
+    for (int r = 0; r < (int)g->cs.size(); r++) {
+        if (g->d_key.size() > (size_t)r && g->d_key[r]) { (void)hipSetDevice(g->ctx[r]->device); (void)hipFree(g->d_key[r]); }
+        slamhip_cs_destroy(g->cs[r]);
+    }
+    for (auto c : g->ctx) slamhip_ctx_destroy(c);
+    if (g->api.lib) dlclose(g->api.lib);
+    delete g;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_create(const int32_t *devices, int32_t n, float physical, int32_t hole_size, int32_t obst_size,
+                                        slamhip_group **out)
+{
+    SH_CHECK_ARG(devices && n >= 1 && n <= 64 && out);
+    slamhip_group *g = new slamhip_group();
+    g->n = n; g->n_offs = 0;
+    int32_t rc = load_rccl(&g->api);
+    for (int r = 0; r < n && rc == SLAMHIP_OK; r++) {
+        slamhip_ctx *c = nullptr; slamhip_cs *cs = nullptr; uint64_t *dk = nullptr;
+        rc = slamhip_ctx_create(devices[r], &c);
+        if (rc == SLAMHIP_OK) { g->ctx.push_back(c); rc = slamhip_cs_create(c, physical, hole_size, obst_size, &cs); }
+        if (rc == SLAMHIP_OK) { g->cs.push_back(cs); if (hipMalloc(&dk, sizeof(uint64_t)) != hipSuccess) { slamhip_set_error("hipMalloc failed"); rc = SLAMHIP_ERR_NOMEM; } }
+        if (rc == SLAMHIP_OK) g->d_key.push_back(dk);
+    }
+    if (rc == SLAMHIP_OK) {
+        g->comm.assign((size_t)n, nullptr);
+        std::vector<int> devs(devices, devices + n);
+        ncclResult_t r_ = g->api.CommInitAll(g->comm.data(), n, devs.data());
+        if (r_ != ncclSuccess) { slamhip_set_error("ncclCommInitAll failed: %s", g->api.GetErrorString(r_)); rc = SLAMHIP_ERR_RCCL; }
+    }
+    if (rc != SLAMHIP_OK) { slamhip_group_destroy(g); return rc; }
+    *out = g;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_size(slamhip_group *g, int32_t *out)
+{
+    SH_CHECK_ARG(g && out);
+    *out = g->n;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_cs(slamhip_group *g, int32_t rank, slamhip_cs **out)
+{
+    SH_CHECK_ARG(g && out && rank >= 0 && rank < g->n);
+    *out = g->cs[rank];
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_reset(slamhip_group *g, int32_t unmapped)
+{
+    SH_CHECK_ARG(g);
+    for (int r = 0; r < g->n; r++) SH_TRY(slamhip_cs_reset(g->cs[r], unmapped));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_holemap_upload(slamhip_group *g, const uint16_t *pix, size_t n)
+{
+    SH_CHECK_ARG(g);
+    for (int r = 0; r < g->n; r++) SH_TRY(slamhip_cs_holemap_upload(g->cs[r], pix, n));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_set_scan(slamhip_group *g, const float *xy, int32_t n)
+{
+    SH_CHECK_ARG(g);
+    for (int r = 0; r < g->n; r++) SH_TRY(slamhip_cs_set_scan(g->cs[r], xy, n));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_set_offsets(slamhip_group *g, const float *offs, int32_t n)
+{
+    SH_CHECK_ARG(g);
+    for (int r = 0; r < g->n; r++) SH_TRY(slamhip_cs_set_offsets(g->cs[r], offs, n));
+    g->n_offs = n;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_group_search(slamhip_group *g, const float pose[3], float out_pose[3], int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(g && pose);
+    const int K = g->n_offs + 1;                 // flat candidates, 0 = un-jittered pose
+    // contiguous blocks keep the flat (thread-major) indices, so the packed-key min reproduces the
+    // reference tie-break across GPUs exactly as across threads (:695-705)
+    for (int r = 0; r < g->n; r++) {
+        const int first = (int)((long long)K * r / g->n), last = (int)((long long)K * (r + 1) / g->n);
+        SH_HIP(hipSetDevice(g->ctx[r]->device));
+        if (last > first) {
+            SH_TRY(slamhip_cs_search_shard_async(g->cs[r], pose, first, last - first, g->d_key[r]));
+        } else {
+            SH_HIP(hipMemsetAsync(g->d_key[r], 0xFF, sizeof(uint64_t), g->ctx[r]->stream));
+        }
+    }
+    SH_NCCL(g, g->api.GroupStart());
+    for (int r = 0; r < g->n; r++) {
+        ncclResult_t r_ = g->api.AllReduce(g->d_key[r], g->d_key[r], 1, ncclUint64, ncclMin, g->comm[r], g->ctx[r]->stream);
+        if (r_ != ncclSuccess) { g->api.GroupEnd(); slamhip_set_error("ncclAllReduce failed: %s", g->api.GetErrorString(r_)); return SLAMHIP_ERR_RCCL; }
+    }
+    SH_NCCL(g, g->api.GroupEnd());
+    uint64_t key = 0;
+    SH_HIP(hipSetDevice(g->ctx[0]->device));
+    SH_HIP(hipMemcpyAsync(&key, g->d_key[0], sizeof(uint64_t), hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    for (int r = 0; r < g->n; r++) { SH_HIP(hipSetDevice(g->ctx[r]->device)); SH_HIP(hipStreamSynchronize(g->ctx[r]->stream)); }
+    return slamhip_cs_pose_from_key(g->cs[0], pose, key, out_pose, out_dist, out_index);
+}
+
+extern "C" int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float hole_width, int32_t quality, int32_t max_hits)
+{
+    SH_CHECK_ARG(g && pose);
+    for (int r = 0; r < g->n; r++) {
+        SH_TRY(slamhip_cs_update_holemap(g->cs[r], pose, hole_width, quality));
+        SH_TRY(slamhip_cs_update_obstaclemap(g->cs[r], pose, max_hits));
+    }
+    return SLAMHIP_OK;
+}

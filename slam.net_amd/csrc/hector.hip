@@ -1,0 +1,696 @@
+// hector.hip -- K4 (Gauss-Newton scan matcher) and K5 (log-odds grid update) + HectorSLAM entry points.
+//
+// K4 replaces ScanMatcher.MatchData / EstimateTransformationLogLh / GetCompleteHessianDerivs /
+// InterpMapValueWithDerivatives (HectorSLAM/Matcher/ScanMatcher.cs:41-249): all pyramid levels and all
+// iterations of one match run in ONE persistent workgroup (the reference fans out to ParallelWorker
+// threads once per iteration, :154); the nine sums are accumulated per lane in fp32, reduced across the
+// workgroup in fp64 and the 3x3 system is solved on the device with the BCL's cofactor formulas.
+// Occupancy probabilities are computed on the fly as exp(v)/(exp(v)+1) (OccGridMap.cs:97-107) instead of
+// through the reference's lazily filled cache.  Float parity target: pose within 1e-4 m / 1e-4 rad (H6).
+//
+// K5 replaces OccGridMap.UpdateByScan and friends (HectorSLAM/Map/OccGridMap.cs:114-239) for every level of
+// the pyramid (MapRepMultiMap.cs:73-77).  The once-per-scan guards make a cell's new value depend only on
+// (a) whether it is touched as free, (b) whether it is an end point, and (c) whether the first free touch
+// precedes the first end-point touch in ray order.  Pass 1 walks every ray and records
+// atomicMin(2*ray + isOcc) plus an end-point flag per cell; pass 2 re-walks, elects one fragment per cell
+// and replays the at most two state transitions literally -- bit-exact fp32 cell values.
+#include "common.h"
+#include "m3x2.h"
+#include <vector>
+#include <chrono>
+#include <stdlib.h>
+
+#define HS_MAX_LEVELS 8
+#define HS_NONE 0xFFFFFFFFu
+
+struct hs_level {
+    int w, h; float cell, stm;             // MapProperties: Dimensions, CellLength, ScaleToMap (MapProperties.cs:22-32)
+    sh_m3x2 map_t_world, world_t_map;      // GridMap.cs:46-47
+    float *d_value; int32_t *d_upd;        // LogOddsCell SoA (GridMap.cs:13)
+    uint32_t *d_minkey; uint8_t *d_occ;    // K5 per-scan scratch (kept clean between calls)
+    int curr_update_index;                 // OccGridMap.cs:20
+    int iterations;                        // EstimateIterations (OccGridMap.cs:53)
+};
+
+struct hs_level_dev {                      // what the kernels need, by value
+    int w, h; float cell, stm;
+    sh_m3x2 map_t_world, world_t_map;
+    const float *value;
+    int iterations;
+};
+
+struct slamhip_hs {
+    slamhip_ctx *ctx;
+    int n_levels;
+    hs_level lv[HS_MAX_LEVELS];
+    float odds_free, odds_occ, lo_free, lo_occ;          // OccGridMap.cs:24-27
+    int n_points, cap_points;
+    float2 *d_pts; float origin[2];
+    float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
+};
+
+struct hs_levels_arg { hs_level_dev lv[HS_MAX_LEVELS]; int n; };
+
+// ---- K4 device code ------------------------------------------------------------------------------------------
+// OccGridMap.GetCachedProbability (:97-107)
+__device__ static inline float hs_prob(const float *__restrict__ value, int idx)
+{
+    const float odds = expf(value[idx]);                                   // :101
+    return odds / (odds + 1.0f);                                           // :102
+}
+
+// InterpMapValueWithDerivatives (ScanMatcher.cs:211-249)
+__device__ static inline void hs_interp(const hs_level_dev &L, float cx, float cy, float &P, float &gx, float &gy)
+{
+    const float limx = (float)L.w - 2.0f, limy = (float)L.h - 2.0f;       // MapProperties.cs:42
+    if (!(cx == cx) || !(cy == cy) || cx < 0.0f || cx > limx || cy < 0.0f || cy > limy) {   // MapProperties.cs:83-87
+        P = gx = gy = 0.0f;                                                // :216-219
+        return;
+    }
+    const int ix = (int)floorf(cx), iy = (int)floorf(cy);                  // :222
+    const float fx = cx - (float)ix, fy = cy - (float)iy;                  // :225
+    const int idx = iy * L.w + ix;                                         // :227
+    const float i0 = hs_prob(L.value, idx), i1 = hs_prob(L.value, idx + 1);            // :230-231
+    const float i2 = hs_prob(L.value, idx + L.w), i3 = hs_prob(L.value, idx + L.w + 1);// :232-233
+    const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;            // :235-239
+    const float xi = 1.0f - fx, yi = 1.0f - fy;                            // :241-242
+    P = ((i0 * xi + i1 * fx) * yi) + ((i2 * xi + i3 * fx) * fy);           // :245-246
+    gx = -((dx1 * xi) + (dx2 * fx));                                       // :247
+    gy = -((dy1 * yi) + (dy2 * fy));                                       // :248
+}
+
+// GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) broadcast in sums[].
+// order: dTr.x, dTr.y, dTr.z, H11, H22, H33, H12, H13, H23
+__device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__restrict__ pts, int n, const float pose[3],
+                                        double *red /* [nwaves*9] LDS */, float sums[9])
+{
+    const sh_m3x2 t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]),
+                                              sh_m3x2_translation(pose[0] * L.cell, pose[1] * L.cell)),
+                                  sh_m3x2_scale(L.stm));                   // :139-142
+    float s, c;
+    sh_det_sincosf(pose[2], &s, &c);
+    const float sinRot = s * L.stm, cosRot = c * L.stm;                    // :145-146
+    float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float2 p = pts[i];
+        float mx, my, P, gx, gy;
+        sh_v2_transform(p.x, p.y, t, &mx, &my);                            // :161
+        hs_interp(L, mx, my, P, gx, gy);                                   // :162
+        const float fun = 1.0f - P;                                        // :164
+        const float rot = ((-sinRot * p.x - cosRot * p.y) * gx + (cosRot * p.x - sinRot * p.y) * gy);   // :169-170
+        acc[0] += gx * fun;  acc[1] += gy * fun;  acc[2] += rot * fun;     // :166,:167,:172
+        acc[3] += gx * gx;   acc[4] += gy * gy;   acc[5] += rot * rot;     // :174-176
+        acc[6] += gx * gy;   acc[7] += gx * rot;  acc[8] += gy * rot;      // :178-180
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = 0; k < 9; k++) {
+        double v = (double)acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wid * 9 + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double v = 0.0;
+        for (int w = 0; w < nw; w++) v += red[w * 9 + threadIdx.x];
+        red[threadIdx.x] = v;                  // wave 0's own slots: safe, every read of them is by this thread
+    }
+    __syncthreads();
+    for (int k = 0; k < 9; k++) sums[k] = (float)red[k];
+    __syncthreads();
+}
+
+// EstimateTransformationLogLh (:93-125) applied by every thread identically (uniform registers)
+__device__ static inline void hs_step(const float sums[9], float est[3])
+{
+    const float H[9] = { sums[3], sums[6], sums[7],  sums[6], sums[4], sums[8],  sums[7], sums[8], sums[5] };  // :198-200
+    if (H[0] != 0.0f && H[4] != 0.0f) {                                    // :97
+        float R[9];
+        if (!sh_invert_h(H, R)) return;                                    // :99-103
+        const float d0 = sums[0], d1 = sums[1], d2 = sums[2];
+        float sx = (d0 * R[0]) + (d1 * R[3]) + (d2 * R[6]) + 0.0f;         // :105 Vector3.Transform(dTr, iH)
+        float sy = (d0 * R[1]) + (d1 * R[4]) + (d2 * R[7]) + 0.0f;
+        float sz = (d0 * R[2]) + (d1 * R[5]) + (d2 * R[8]) + 0.0f;
+        if (sz > 0.2f) sz = 0.2f;                                          // :107-111
+        else if (sz < -0.2f) sz = -0.2f;                                   // :113-117
+        est[0] += sx; est[1] += sy; est[2] += sz;                          // :119
+    }
+}
+
+// MatchData(MapRepMultiMap) (:41-54): one workgroup per hint; levels coarse -> fine.
+// only_level >= 0 restricts to one level with `iters_override` iterations (MatchData(OccGridMap), :64-84).
+__global__ void __launch_bounds__(256)
+k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float *__restrict__ out,
+         int only_level, int iters_override)
+{
+    __shared__ double red[4 * 9];
+    const int b = blockIdx.x;
+    float est_w[3] = { hints[3 * b], hints[3 * b + 1], hints[3 * b + 2] };  // :43
+    if (n > 0) {                                                           // :66 (else: hint returned, :83)
+        const int l_hi = only_level >= 0 ? only_level : A.n - 1;
+        const int l_lo = only_level >= 0 ? only_level : 0;
+        for (int l = l_hi; l >= l_lo; l--) {                               // :47
+            const hs_level_dev &L = A.lv[l];
+            float est[3];
+            sh_v2_transform(est_w[0], est_w[1], L.map_t_world, &est[0], &est[1]);   // :68 GetMapCoordsPose
+            est[2] = est_w[2];
+            const int iters = only_level >= 0 ? iters_override : L.iterations;
+            for (int it = 0; it < iters; it++) {                           // :70-73
+                float sums[9];
+                hs_hessian_block(L, pts, n, est, red, sums);
+                hs_step(sums, est);
+            }
+            est[2] = sh_normalize_angle(est[2]);                           // :76
+            sh_v2_transform(est[0], est[1], L.world_t_map, &est_w[0], &est_w[1]);   // :79 GetWorldCoordsPose
+            est_w[2] = est[2];
+        }
+    }
+    if (threadIdx.x == 0) { out[3 * b] = est_w[0]; out[3 * b + 1] = est_w[1]; out[3 * b + 2] = est_w[2]; }
+}
+
+__global__ void __launch_bounds__(256)
+k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, const float *__restrict__ pose_in,
+           float *__restrict__ out12)
+{
+    __shared__ double red[4 * 9];
+    float pose[3] = { pose_in[0], pose_in[1], pose_in[2] };
+    float sums[9];
+    hs_hessian_block(A.lv[level], pts, n, pose, red, sums);
+    if (threadIdx.x == 0) {
+        out12[0] = sums[3]; out12[1] = sums[6]; out12[2] = sums[7];
+        out12[3] = sums[6]; out12[4] = sums[4]; out12[5] = sums[8];
+        out12[6] = sums[7]; out12[7] = sums[8]; out12[8] = sums[5];
+        out12[9] = sums[0]; out12[10] = sums[1]; out12[11] = sums[2];
+    }
+}
+
+// ---- K5 device code --------------------------------------------------------------------------------------------
+struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; uint32_t *minkey; uint8_t *occ; int mark_free, mark_occ; };
+struct k5_arg { k5_level lv[HS_MAX_LEVELS]; int n; };
+
+// UpdateByScan (:126-141) + UpdateLineBresenhami (:155-190) + Bresenham2D (:220-239) for one ray on one
+// level; calls f(cell_index, is_occ) for every cell the reference would touch, in its order.
+template <typename F>
+__device__ static inline void k5_walk(const k5_level &L, float ox, float oy, float2 p, F f)
+{
+    float bxf, byf, exf, eyf;
+    sh_v2_transform(ox, oy, L.t, &bxf, &byf);                              // :126
+    sh_v2_transform(p.x, p.y, L.t, &exf, &eyf);                            // :133
+    const int bx = sh_f2i(rintf(bxf)), by = sh_f2i(rintf(byf));            // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
+    const int ex = sh_f2i(rintf(exf)), ey = sh_f2i(rintf(eyf));            // :134
+    if (bx == ex && by == ey) return;                                      // :137
+    if (!(bx >= 0 && by >= 0 && bx < L.w && by < L.h) || !(ex >= 0 && ey >= 0 && ex < L.w && ey < L.h)) return;   // :158-161
+    const int dx = ex - bx, dy = ey - by;
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    const int odx = sh_sign(dx), ody = sh_sign(dy) * L.w;                  // :169-170
+    int offset = by * L.w + bx;                                            // :172
+    int da, db, err, oa, ob;
+    if (adx >= ady) { da = adx; db = ady; err = adx / 2; oa = odx; ob = ody; }      // :175-179
+    else            { da = ady; db = adx; err = ady / 2; oa = ody; ob = odx; }      // :180-185
+    f(offset, 0);                                                          // :222
+    for (int i = 0; i < da - 1; ++i) {                                     // :224-226
+        offset += oa;
+        err += db;
+        if (err >= da) { offset += ob; err -= da; }                        // :231-235
+        f(offset, 0);                                                      // :237
+    }
+    f(ey * L.w + ex, 1);                                                   // :187-189
+}
+
+__global__ void __launch_bounds__(256)
+k5_mark(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const k5_level &L = A.lv[blockIdx.y];
+    k5_walk(L, ox, oy, pts[i], [&](int cell, int is_occ) {
+        atomicMin(&L.minkey[cell], 2u * (uint32_t)i + (uint32_t)is_occ);
+        if (is_occ) L.occ[cell] = 1;
+    });
+}
+
+__global__ void __launch_bounds__(256)
+k5_resolve(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, float lo_free, float lo_occ)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const k5_level &L = A.lv[blockIdx.y];
+    k5_walk(L, ox, oy, pts[i], [&](int cell, int) {
+        const uint32_t k = atomicExch(&L.minkey[cell], HS_NONE);          // elect one fragment per cell
+        if (k == HS_NONE) return;
+        const bool has_occ = L.occ[cell] != 0;
+        L.occ[cell] = 0;
+        float v = L.value[cell];
+        int u = L.upd[cell];
+        if ((k & 1u) == 0u) {                                              // first touch in ray order is "free"
+            if (u < L.mark_free) { v += lo_free; u = L.mark_free; }        // BresenhamCellFree :192-199
+        }
+        if (has_occ && u < L.mark_occ) {                                   // BresenhamCellOcc :201-218
+            if (u == L.mark_free) v -= lo_free;                            // :206-209
+            if (v < 50.0f) v += lo_occ;                                    // :211-214
+            u = L.mark_occ;                                                // :216
+        }
+        L.value[cell] = v;
+        L.upd[cell] = u;
+    });
+}
+
+__global__ void k5_fill_cells(float *value, int32_t *upd, uint32_t *minkey, uint8_t *occ, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { value[i] = 0.0f; upd[i] = -1; minkey[i] = HS_NONE; occ[i] = 0; }   // LogOddsCell.Reset :38-42
+}
+
+__global__ void k5_pack_cells(const float *value, const int32_t *upd, slamhip_cell *out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[i].update_index = upd[i]; out[i].value = value[i]; }
+}
+__global__ void k5_unpack_cells(const slamhip_cell *in, float *value, int32_t *upd, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { upd[i] = in[i].update_index; value[i] = in[i].value; }
+}
+// GridMap.GetBitmapData (GridMap.cs:104-115)
+__global__ void k5_bitmap(const float *value, uint8_t *out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = value[i];
+    const int sgn = (v > 0.0f) - (v < 0.0f);
+    out[i] = (uint8_t)(127 - sgn * 127);                                   // :111
+}
+__global__ void k5_probability(const float *value, const int32_t *idx, int n, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hs_prob(value, idx[i]);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static float prob_to_logodds(float prob) { const float odds = prob / (1.0f - prob); return logf(odds); }   // OccGridMap.cs:86-90
+
+static hs_levels_arg levels_arg(slamhip_hs *hs)
+{
+    hs_levels_arg A;
+    memset(&A, 0, sizeof(A));
+    A.n = hs->n_levels;
+    for (int l = 0; l < hs->n_levels; l++) {
+        const hs_level &L = hs->lv[l];
+        A.lv[l].w = L.w; A.lv[l].h = L.h; A.lv[l].cell = L.cell; A.lv[l].stm = L.stm;
+        A.lv[l].map_t_world = L.map_t_world; A.lv[l].world_t_map = L.world_t_map;
+        A.lv[l].value = L.d_value; A.lv[l].iterations = L.iterations;
+    }
+    return A;
+}
+
+extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
+{
+    if (!hs) return SLAMHIP_OK;
+    (void)hipSetDevice(hs->ctx->device);
+    (void)hipStreamSynchronize(hs->ctx->stream);
+    for (int l = 0; l < hs->n_levels; l++) {
+        (void)hipFree(hs->lv[l].d_value); (void)hipFree(hs->lv[l].d_upd);
+        (void)hipFree(hs->lv[l].d_minkey); (void)hipFree(hs->lv[l].d_occ);
+    }
+    (void)hipFree(hs->d_pts); (void)hipFree(hs->d_io);
+    if (hs->h_io) (void)hipHostFree(hs->h_io);
+    free(hs);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_reset(slamhip_hs *hs)
+{
+    SH_CHECK_ARG(hs);
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    for (int l = 0; l < hs->n_levels; l++) {
+        hs_level &L = hs->lv[l];
+        hipLaunchKernelGGL(k5_fill_cells, dim3(1024), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, L.d_minkey, L.d_occ,
+                           (size_t)L.w * L.h);                             // GridMap.Reset :56-62
+        L.curr_update_index = 0;                                           // OccGridMap.Reset :244-252
+    }
+    SH_HIP(hipStreamSynchronize(hs->ctx->stream));
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_create(slamhip_ctx *ctx, float cell_length, int32_t w, int32_t h, int32_t levels, slamhip_hs **out)
+{
+    SH_CHECK_ARG(ctx && out && levels >= 1 && levels <= HS_MAX_LEVELS && cell_length > 0.0f);
+    SH_CHECK_ARG(w >= 2 && h >= 2 && w <= 32768 && h <= 32768 && (w >> (levels - 1)) >= 2 && (h >> (levels - 1)) >= 2);
+    SH_HIP(hipSetDevice(ctx->device));
+    slamhip_hs *hs = (slamhip_hs *)calloc(1, sizeof(slamhip_hs));
+    if (!hs) SH_FAIL(SLAMHIP_ERR_NOMEM, "out of host memory");
+    hs->ctx = ctx;
+    hs->n_levels = levels;
+    hs->odds_occ = 0.9f; hs->odds_free = 0.4f;                            // OccGridMap.cs:24-25
+    hs->lo_free = prob_to_logodds(hs->odds_free);                         // :46
+    hs->lo_occ = prob_to_logodds(hs->odds_occ);                           // :47
+    float res = cell_length;
+    int32_t rc = SLAMHIP_OK;
+    for (int l = 0; l < levels && rc == SLAMHIP_OK; l++) {                // MapRepMultiMap.cs:49-57
+        hs_level &L = hs->lv[l];
+        L.w = w; L.h = h; L.cell = res; L.stm = 1.0f / res;               // MapProperties.cs:32
+        L.iterations = 3;                                                 // OccGridMap.cs:53
+        L.map_t_world = sh_m3x2_mul(sh_m3x2_scale(L.stm), sh_m3x2_translation(0.0f, 0.0f));   // GridMap.cs:46 (offset = 0)
+        if (!sh_m3x2_invert(L.map_t_world, &L.world_t_map)) { slamhip_set_error("Map to world matrix is not invertible"); rc = SLAMHIP_ERR_INVALID; break; }  // :47-50
+        const size_t n = (size_t)w * h;
+        if (hipMalloc(&L.d_value, sizeof(float) * n) != hipSuccess || hipMalloc(&L.d_upd, sizeof(int32_t) * n) != hipSuccess ||
+            hipMalloc(&L.d_minkey, sizeof(uint32_t) * n) != hipSuccess || hipMalloc(&L.d_occ, n) != hipSuccess) {
+            slamhip_set_error("device allocation failed (level %d)", l); rc = SLAMHIP_ERR_NOMEM; break;
+        }
+        w /= 2; h /= 2;                                                   // :55
+        res *= 2.0f;                                                      // :56
+    }
+    if (rc == SLAMHIP_OK) {
+        hs->cap_io = 4096;
+        if (hipMalloc(&hs->d_io, sizeof(float) * hs->cap_io) != hipSuccess || hipHostMalloc(&hs->h_io, sizeof(float) * hs->cap_io) != hipSuccess) {
+            slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM;
+        }
+    }
+    if (rc == SLAMHIP_OK) rc = slamhip_hs_reset(hs);
+    if (rc != SLAMHIP_OK) { slamhip_hs_destroy(hs); return rc; }
+    *out = hs;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_level_info(slamhip_hs *hs, int32_t level, int32_t *w, int32_t *h, float *cell)
+{
+    SH_CHECK_ARG(hs && level >= 0 && level < hs->n_levels);
+    if (w) *w = hs->lv[level].w;
+    if (h) *h = hs->lv[level].h;
+    if (cell) *cell = hs->lv[level].cell;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_set_factors(slamhip_hs *hs, float free_f, float occ_f)
+{
+    SH_CHECK_ARG(hs);
+    hs->odds_free = free_f; hs->lo_free = prob_to_logodds(free_f);        // OccGridMap.cs:58-66
+    hs->odds_occ = occ_f;   hs->lo_occ = prob_to_logodds(occ_f);          // :71-79
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_set_iterations(slamhip_hs *hs, const int32_t *it)
+{
+    SH_CHECK_ARG(hs && it);
+    for (int l = 0; l < hs->n_levels; l++) { SH_CHECK_ARG(it[l] >= 0 && it[l] <= 1000); hs->lv[l].iterations = it[l]; }
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_cells_upload(slamhip_hs *hs, int32_t level, const slamhip_cell *cells, size_t n)
+{
+    SH_CHECK_ARG(hs && cells && level >= 0 && level < hs->n_levels);
+    hs_level &L = hs->lv[level];
+    SH_CHECK_ARG(n == (size_t)L.w * L.h);
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    slamhip_cell *d = nullptr;
+    SH_HIP(hipMalloc(&d, sizeof(slamhip_cell) * n));
+    hipError_t e = hipMemcpyAsync(d, cells, sizeof(slamhip_cell) * n, hipMemcpyHostToDevice, hs->ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k5_unpack_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, d, L.d_value, L.d_upd, n);
+        e = hipStreamSynchronize(hs->ctx->stream);
+    }
+    (void)hipFree(d);
+    SH_HIP(e);
+    // keep the once-per-scan guards meaningful: the next scan's marks must exceed every stored index
+    int mx = -1;
+    for (size_t i = 0; i < n; i++) if (cells[i].update_index > mx) mx = cells[i].update_index;
+    if (mx >= 0) {                      // marks of scan k are 3k+1 / 3k+2 (OccGridMap.cs:116-117,:144)
+        const int need = (mx / 3 + 1) * 3;
+        if (need > L.curr_update_index) L.curr_update_index = need;
+    }
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_cells_download(slamhip_hs *hs, int32_t level, slamhip_cell *cells, size_t n)
+{
+    SH_CHECK_ARG(hs && cells && level >= 0 && level < hs->n_levels);
+    hs_level &L = hs->lv[level];
+    SH_CHECK_ARG(n == (size_t)L.w * L.h);
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    slamhip_cell *d = nullptr;
+    SH_HIP(hipMalloc(&d, sizeof(slamhip_cell) * n));
+    hipLaunchKernelGGL(k5_pack_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, d, n);
+    hipError_t e = hipMemcpyAsync(cells, d, sizeof(slamhip_cell) * n, hipMemcpyDeviceToHost, hs->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
+    (void)hipFree(d);
+    SH_HIP(e);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_bitmap_download(slamhip_hs *hs, int32_t level, uint8_t *out, size_t n)
+{
+    SH_CHECK_ARG(hs && out && level >= 0 && level < hs->n_levels);
+    hs_level &L = hs->lv[level];
+    SH_CHECK_ARG(n == (size_t)L.w * L.h);
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    uint8_t *d = nullptr;
+    SH_HIP(hipMalloc(&d, n));
+    hipLaunchKernelGGL(k5_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, L.d_value, d, n);
+    hipError_t e = hipMemcpyAsync(out, d, n, hipMemcpyDeviceToHost, hs->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
+    (void)hipFree(d);
+    SH_HIP(e);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_probability(slamhip_hs *hs, int32_t level, const int32_t *indices, int32_t n, float *out)
+{
+    SH_CHECK_ARG(hs && indices && out && n > 0 && level >= 0 && level < hs->n_levels);
+    hs_level &L = hs->lv[level];
+    for (int i = 0; i < n; i++) SH_CHECK_ARG(indices[i] >= 0 && (size_t)indices[i] < (size_t)L.w * L.h);
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    int32_t *di = nullptr; float *dout = nullptr;
+    SH_HIP(hipMalloc(&di, sizeof(int32_t) * n));
+    hipError_t e = hipMalloc(&dout, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(di, indices, sizeof(int32_t) * n, hipMemcpyHostToDevice, hs->ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k5_probability, dim3(sh_div_up(n, 256)), dim3(256), 0, hs->ctx->stream, L.d_value, di, n, dout);
+        e = hipMemcpyAsync(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost, hs->ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
+    (void)hipFree(di); (void)hipFree(dout);
+    SH_HIP(e);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t n, const float origin[2])
+{
+    SH_CHECK_ARG(hs && n >= 0 && (xy || n == 0));
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    hs->n_points = n;
+    hs->origin[0] = origin ? origin[0] : 0.0f;
+    hs->origin[1] = origin ? origin[1] : 0.0f;
+    if (n == 0) return SLAMHIP_OK;
+    if (n > hs->cap_points) {
+        (void)hipFree(hs->d_pts); hs->d_pts = nullptr; hs->cap_points = 0;
+        SH_HIP(hipMalloc(&hs->d_pts, sizeof(float2) * (size_t)(n + n / 4 + 64)));
+        hs->cap_points = n + n / 4 + 64;
+    }
+    SH_HIP(hipMemcpyAsync(hs->d_pts, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, hs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(hs->ctx->stream));
+    return SLAMHIP_OK;
+}
+
+static int32_t ensure_io(slamhip_hs *hs, int floats)
+{
+    if (floats <= hs->cap_io) return SLAMHIP_OK;
+    (void)hipFree(hs->d_io); (void)hipHostFree(hs->h_io);
+    hs->d_io = nullptr; hs->h_io = nullptr; hs->cap_io = 0;
+    SH_HIP(hipMalloc(&hs->d_io, sizeof(float) * (size_t)floats * 2));
+    SH_HIP(hipHostMalloc(&hs->h_io, sizeof(float) * (size_t)floats * 2));
+    hs->cap_io = floats * 2;
+    return SLAMHIP_OK;
+}
+
+static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, int only_level, int iters)
+{
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    slamhip_ctx *ctx = hs->ctx;
+    SH_TRY(ensure_io(hs, 6 * B));
+    float *d_in = hs->d_io, *d_out = hs->d_io + 3 * (size_t)B;
+    memcpy(hs->h_io, hints, sizeof(float) * 3 * (size_t)B);
+    SH_HIP(hipMemcpyAsync(d_in, hs->h_io, sizeof(float) * 3 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+    {
+        sh_timer t(ctx, SLAMHIP_K_HS_MATCH);
+        hipLaunchKernelGGL(k4_match, dim3(B), dim3(256), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
+                           (const float *)d_in, d_out, only_level, iters);
+    }
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipMemcpyAsync(hs->h_io + 3 * (size_t)B, d_out, sizeof(float) * 3 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+    SH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, hs->h_io + 3 * (size_t)B, sizeof(float) * 3 * (size_t)B);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_match(slamhip_hs *hs, const float hint[3], float out[3])
+{
+    SH_CHECK_ARG(hs && hint && out);
+    return run_match(hs, hint, 1, out, -1, 0);
+}
+
+extern "C" int32_t slamhip_hs_match_level(slamhip_hs *hs, int32_t level, const float hint[3], int32_t iterations, float out[3])
+{
+    SH_CHECK_ARG(hs && hint && out && level >= 0 && level < hs->n_levels && iterations >= 0);
+    return run_match(hs, hint, 1, out, level, iterations);
+}
+
+extern "C" int32_t slamhip_hs_match_batch(slamhip_hs *hs, const float *hints, int32_t B, float *out)
+{
+    SH_CHECK_ARG(hs && hints && out && B > 0);
+    return run_match(hs, hints, B, out, -1, 0);
+}
+
+extern "C" int32_t slamhip_hs_hessian(slamhip_hs *hs, int32_t level, const float pose_map[3], float H[9], float dTr[3])
+{
+    SH_CHECK_ARG(hs && pose_map && H && dTr && level >= 0 && level < hs->n_levels);
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    slamhip_ctx *ctx = hs->ctx;
+    SH_TRY(ensure_io(hs, 32));
+    memcpy(hs->h_io, pose_map, sizeof(float) * 3);
+    SH_HIP(hipMemcpyAsync(hs->d_io, hs->h_io, sizeof(float) * 3, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k4_hessian, dim3(1), dim3(256), 0, ctx->stream, levels_arg(hs), level, hs->d_pts, hs->n_points,
+                       (const float *)hs->d_io, hs->d_io + 16);
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipMemcpyAsync(hs->h_io + 16, hs->d_io + 16, sizeof(float) * 12, hipMemcpyDeviceToHost, ctx->stream));
+    SH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(H, hs->h_io + 16, sizeof(float) * 9);
+    memcpy(dTr, hs->h_io + 25, sizeof(float) * 3);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3])
+{
+    SH_CHECK_ARG(hs && pose);
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    slamhip_ctx *ctx = hs->ctx;
+    const int n = hs->n_points;
+    k5_arg A;
+    memset(&A, 0, sizeof(A));
+    A.n = hs->n_levels;
+    for (int l = 0; l < hs->n_levels; l++) {
+        hs_level &L = hs->lv[l];
+        A.lv[l].w = L.w; A.lv[l].h = L.h;
+        A.lv[l].t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]), sh_m3x2_translation(pose[0], pose[1])),
+                                sh_m3x2_scale(L.stm));                    // OccGridMap.cs:120-123
+        A.lv[l].value = L.d_value; A.lv[l].upd = L.d_upd; A.lv[l].minkey = L.d_minkey; A.lv[l].occ = L.d_occ;
+        A.lv[l].mark_free = L.curr_update_index + 1;                      // :116
+        A.lv[l].mark_occ = L.curr_update_index + 2;                       // :117
+    }
+    if (n > 0) {
+        sh_timer t(ctx, SLAMHIP_K_HS_UPDATE);
+        const dim3 grid(sh_div_up(n, 256), hs->n_levels);                 // all levels in one launch (MapRepMultiMap.cs:76)
+        hipLaunchKernelGGL(k5_mark, grid, dim3(256), 0, ctx->stream, A, hs->d_pts, n, hs->origin[0], hs->origin[1]);
+        hipLaunchKernelGGL(k5_resolve, grid, dim3(256), 0, ctx->stream, A, hs->d_pts, n, hs->origin[0], hs->origin[1],
+                           hs->lo_free, hs->lo_occ);
+    }
+    SH_HIP(hipGetLastError());
+    for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144
+    SH_HIP(hipStreamSynchronize(ctx->stream));
+    return SLAMHIP_OK;
+}
+
+// ---- HectorSLAMProcessor (Main/HectorSLAMProcessor.cs) ---------------------------------------------------------------
+struct slamhip_hsproc {
+    slamhip_hs *hs;
+    float start_pose[3], match_pose[3], last_update_pose[3];
+    float match_timing, update_timing;
+    float min_dist, min_angle;
+};
+
+static const float F_MIN = -3.40282347e+38f;       // float.MinValue
+
+extern "C" int32_t slamhip_hsproc_create(slamhip_ctx *ctx, float res, int32_t w, int32_t h, const float start[3], int32_t depth,
+                                         slamhip_hsproc **out)
+{
+    SH_CHECK_ARG(ctx && start && out);
+    slamhip_hs *hs = nullptr;
+    SH_TRY(slamhip_hs_create(ctx, res, w, h, depth, &hs));                // :71
+    slamhip_hsproc *p = (slamhip_hsproc *)calloc(1, sizeof(*p));
+    if (!p) { slamhip_hs_destroy(hs); SH_FAIL(SLAMHIP_ERR_NOMEM, "out of host memory"); }
+    p->hs = hs;
+    memcpy(p->start_pose, start, sizeof(float) * 3);
+    memcpy(p->match_pose, start, sizeof(float) * 3);                      // :75
+    p->last_update_pose[0] = p->last_update_pose[1] = p->last_update_pose[2] = F_MIN;   // :76
+    p->min_dist = 0.3f; p->min_angle = 0.13f;                             // :51,:56
+    *out = p;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hsproc_destroy(slamhip_hsproc *p)
+{
+    if (!p) return SLAMHIP_OK;
+    slamhip_hs_destroy(p->hs);
+    free(p);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hsproc_reset(slamhip_hsproc *p)
+{
+    SH_CHECK_ARG(p);
+    SH_TRY(slamhip_hs_reset(p->hs));                                      // :133
+    memcpy(p->match_pose, p->start_pose, sizeof(float) * 3);              // :136
+    p->last_update_pose[0] = p->last_update_pose[1] = p->last_update_pose[2] = F_MIN;   // :137
+    return SLAMHIP_OK;
+}
+
+static float deg_diff(float a, float b)                                   // MathEx.DegDiff (BaseSLAM/MathEx.cs:69-73)
+{
+    float d = ((a - b) + 180.0f) / 360.0f;
+    return ((d - floorf(d)) * 360.0f) - 180.0f;
+}
+
+extern "C" int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int32_t n, const float origin[2],
+                                         const float hint[3], int32_t map_without_matching, int32_t *out_updated)
+{
+    SH_CHECK_ARG(p && hint);
+    SH_TRY(slamhip_hs_set_scan(p->hs, xy, n, origin));
+    if (!map_without_matching) {                                          // :89
+        auto t0 = std::chrono::steady_clock::now();
+        float m[3];
+        SH_TRY(slamhip_hs_match(p->hs, hint, m));                         // :93
+        memcpy(p->match_pose, m, sizeof(m));
+        const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        p->match_timing = (3.0f * p->match_timing + ms) / 4.0f;           // :96
+    } else {
+        memcpy(p->match_pose, hint, sizeof(float) * 3);                   // :100
+    }
+    const float ddx = p->match_pose[0] - p->last_update_pose[0], ddy = p->match_pose[1] - p->last_update_pose[1];
+    const float dist2 = ddx * ddx + ddy * ddy;                            // Vector2.DistanceSquared :107
+    int updated = 0;
+    if (dist2 > p->min_dist * p->min_dist ||
+        deg_diff(p->match_pose[2], p->last_update_pose[2]) > p->min_angle ||   // :108 (radians through DegDiff, as the reference does)
+        map_without_matching) {                                           // :109
+        auto t0 = std::chrono::steady_clock::now();
+        SH_TRY(slamhip_hs_update_by_scan(p->hs, p->match_pose));          // :112
+        const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        p->update_timing = (3.0f * p->update_timing + ms) / 4.0f;         // :115
+        memcpy(p->last_update_pose, p->match_pose, sizeof(float) * 3);    // :118
+        updated = 1;                                                      // :122
+    }
+    if (out_updated) *out_updated = updated;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hsproc_get(slamhip_hsproc *p, float match_pose[3], float last[3], float *mt, float *ut)
+{
+    SH_CHECK_ARG(p);
+    if (match_pose) memcpy(match_pose, p->match_pose, sizeof(float) * 3);
+    if (last) memcpy(last, p->last_update_pose, sizeof(float) * 3);
+    if (mt) *mt = p->match_timing;
+    if (ut) *ut = p->update_timing;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hsproc_set_thresholds(slamhip_hsproc *p, float min_dist, float min_angle)
+{
+    SH_CHECK_ARG(p);
+    p->min_dist = min_dist; p->min_angle = min_angle;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hsproc_hs(slamhip_hsproc *p, slamhip_hs **out)
+{
+    SH_CHECK_ARG(p && out);
+    *out = p->hs;
+    return SLAMHIP_OK;
+}

@@ -1,0 +1,212 @@
+"""GPU parity tests for the HectorSLAM hot path (K4 matcher, K5 grid update) vs the CPU oracle.
+Grid cells (fp32 log-odds + update indices) must be bit-exact; matcher outputs are floating point
+whose summation order differs from the reference's thread chunks, so poses are compared within the
+north-star tolerance of 1e-4 m / 1e-4 rad."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POS_TOL = 1e-4      # metres
+ANG_TOL = 1e-4      # radians
+
+
+@pytest.fixture(scope="module")
+def hs_mod():
+    import slam.net_amd.hector as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(hs_mod):
+    c = hs_mod.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def det(oc):
+    oc.set_trig_mode(oc.TRIG_DET)
+    yield oc
+    oc.set_trig_mode(oc.TRIG_LIBM)
+
+
+def cells_equal(got, ref_cells):
+    return (got["update_index"] == ref_cells["update_index"]).all() and (got["value"] == ref_cells["value"]).all()
+
+
+def test_grid_golden(hs_mod, ctx):
+    g = np.load(os.path.join(GOLD, "hs_grid_200_r180.npz"))
+    side = int(g["side"])
+    rep = hs_mod.MapRepMultiMap(float(g["cell"]), (side, side), 1, ctx=ctx)
+    for i in range(g["xy"].shape[0]):
+        rep.UpdateByScan(hs_mod.ScanCloud(g["xy"][i]), g["poses"][i])
+    cells = rep.Maps[0].GetCells()
+    assert (cells["update_index"] == g["upd"]).all()
+    assert (cells["value"] == g["value"]).all()
+    rep.set_scan(hs_mod.ScanCloud(g["match_xy"]))
+    H, d = rep.Maps[0].Hessian(g["est_map"])
+    for Hk, dk in (("H1", "d1"), ("H4", "d4")):
+        assert np.allclose(H, g[Hk], rtol=1e-4, atol=1e-4) and np.allclose(d, g[dk], rtol=1e-4, atol=1e-3)
+    rep.close()
+
+
+@pytest.mark.parametrize("side,cell,levels,R", [(400, 0.1, 4, 400), (2048, 40.0 / 2048, 3, 1080), (301, 0.13, 2, 360)])
+def test_grid_update_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R):
+    oc = det
+    segs = sim.default_field()
+    rep = hs_mod.MapRepMultiMap(cell, (side, side), levels, ctx=ctx)
+    ref = oc.make_pyramid(cell, side, side, levels)
+    for l in range(levels):
+        assert rep.Maps[l].Dimensions == (ref[l].w, ref[l].h)
+        assert rep.Maps[l].CellLength == ref[l].cell_len
+    rng = sim.PCG32(side)
+    for it in range(6):
+        p = np.array([20 + 0.25 * it, 20 - 0.1 * it, 0.15 * it], np.float32)
+        rays, xy = sim.make_scan(segs, p, R, rng)
+        rep.UpdateByScan(hs_mod.ScanCloud(xy), p)
+        for l in range(levels):
+            ref[l].update_by_scan(xy, p)
+    for l in range(levels):
+        got = rep.Maps[l].GetCells()
+        assert cells_equal(got, ref[l].cells), l
+        assert (rep.Maps[l].GetBitmapData() == ref[l].bitmap()).all()
+    # probabilities (expf on the device vs libm expf: <= 1 ulp)
+    idx = np.flatnonzero(ref[0].cells["value"] != 0)[:500].astype(np.int32)
+    pg = rep.Maps[0].GetCachedProbability(idx)
+    pr = np.array([ref[0].prob(i) for i in idx], np.float32)
+    assert np.allclose(pg, pr, rtol=0, atol=2e-7)
+    # scan origin offset, factors, degenerate points, upload/download round trip
+    rep.SetUpdateFactorFree(0.3); rep.SetUpdateFactorOccupied(0.8)
+    for g in ref:
+        g.set_factors(0.3, 0.8)
+    xy = np.array([[0.0, 0.0], [0.01, 0.0], [500.0, 0.0], [np.nan, 1.0], [3.0, 4.0], [3.0, 4.0], [-6.0, 2.5]], np.float32)
+    rep.UpdateByScan(hs_mod.ScanCloud(xy, (0.5, -0.25, 0.0)), [20.0, 20.0, 0.7])
+    for l in range(levels):
+        ref[l].update_by_scan(xy, [20.0, 20.0, 0.7], origin=(0.5, -0.25))
+        assert cells_equal(rep.Maps[l].GetCells(), ref[l].cells), l
+    cells = rep.Maps[levels - 1].GetCells().copy()
+    rep.Reset()
+    assert (rep.Maps[0].GetCells()["value"] == 0).all() and (rep.Maps[0].GetCells()["update_index"] == -1).all()
+    rep.Maps[levels - 1].SetCells(cells)
+    assert cells_equal(rep.Maps[levels - 1].GetCells(), cells)
+    rep.close()
+
+
+def test_grid_update_order_dependence(hs_mod, ctx, det):
+    """Free-then-occupied vs occupied-then-free within one scan (OccGridMap.cs:192-218)."""
+    oc = det
+    for xy in (np.array([[8.0, 0.0], [5.0, 0.0]], np.float32), np.array([[5.0, 0.0], [8.0, 0.0]], np.float32)):
+        rep = hs_mod.MapRepMultiMap(1.0, (32, 32), 1, ctx=ctx)
+        ref = oc.Grid(1.0, 32, 32)
+        c0 = ref.cells.copy(); c0["value"] = np.linspace(-3, 3, 1024).astype(np.float32)
+        ref.cells[:] = c0
+        rep.Maps[0].SetCells(c0)
+        for _ in range(3):
+            rep.UpdateByScan(hs_mod.ScanCloud(xy), [10.0, 10.0, 0.0])
+            ref.update_by_scan(xy, [10.0, 10.0, 0.0])
+            assert cells_equal(rep.Maps[0].GetCells(), ref.cells)
+        rep.close()
+
+
+def build_pair(hs_mod, ctx, oc, sim, side, cell, levels, R, n_scans):
+    segs = sim.default_field()
+    rep = hs_mod.MapRepMultiMap(cell, (side, side), levels, ctx=ctx)
+    ref = oc.make_pyramid(cell, side, side, levels)
+    rng = sim.PCG32(3)
+    for it in range(n_scans):
+        p = np.array([20 + 0.05 * it, 20 + 0.02 * it, 0.01 * it], np.float32)
+        rays, xy = sim.make_scan(segs, p, R, rng)
+        rep.UpdateByScan(hs_mod.ScanCloud(xy), p)
+        for g in ref:
+            g.update_by_scan(xy, p)
+    return rep, ref, segs, rng
+
+
+@pytest.mark.parametrize("side,cell,levels,R,iters", [(400, 0.1, 4, 400, [7, 4, 4, 4]), (2048, 40.0 / 2048, 3, 1080, [3, 3, 3])])
+def test_match_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R, iters):
+    oc = det
+    rep, ref, segs, rng = build_pair(hs_mod, ctx, oc, sim, side, cell, levels, R, 12)
+    for l, it in enumerate(iters):
+        rep.Maps[l].EstimateIterations = it
+    matcher = hs_mod.ScanMatcher(4)
+    true_pose = np.array([20.6, 20.25, 0.12], np.float32)
+    rays, xy = sim.make_scan(segs, true_pose, R, rng)
+    scan = hs_mod.ScanCloud(xy)
+    hints = [true_pose + np.array(d, np.float32) for d in ((0, 0, 0), (0.1, -0.08, 0.03), (-0.15, 0.1, -0.05), (0.02, 0.3, 0.0))]
+    for hint in hints:
+        got = matcher.MatchData(rep, scan, hint)
+        for T in (1, 4):
+            want = oc.match_pyramid(ref, xy, hint, iters, n_threads=T)
+            assert abs(got[0] - want[0]) < POS_TOL and abs(got[1] - want[1]) < POS_TOL, (hint, T, got, want)
+            assert abs(math.remainder(float(got[2]) - float(want[2]), 2 * math.pi)) < ANG_TOL, (hint, T, got, want)
+    # H / dTr at a fixed map pose (single level API) within fp32 summation noise
+    rep.set_scan(scan)
+    est_map = ref[0].map_pose(hints[1])
+    H, d = rep.Maps[0].Hessian(est_map)
+    Hr, dr = ref[0].hessian(xy, est_map, 1)
+    assert np.allclose(H, Hr, rtol=2e-4, atol=1e-3) and np.allclose(d, dr, rtol=2e-4, atol=1e-2)
+    # MatchData(OccGridMap) on one level (:64-84)
+    got = matcher.MatchData(rep.Maps[1], scan, hints[1])
+    want = ref[1].match(xy, hints[1], iters[1], 1)
+    assert np.allclose(got[:2], want[:2], atol=POS_TOL) and abs(got[2] - want[2]) < ANG_TOL
+    # batched hints == single-hint launches (same kernel, one workgroup per hint)
+    batch = matcher.MatchDataBatch(rep, scan, np.stack(hints * 8))
+    for i, hint in enumerate(hints * 8):
+        assert (batch[i] == matcher.MatchData(rep, scan, hint)).all()
+    # empty scan returns the hint (:82-83); a hint far outside the map leaves the estimate unchanged (:97,:124)
+    assert (matcher.MatchData(rep, hs_mod.ScanCloud(np.zeros((0, 2), np.float32)), hints[1]) == hints[1]).all()
+    far = np.array([500.0, 500.0, 0.3], np.float32)
+    got = matcher.MatchData(rep, scan, far)
+    want = oc.match_pyramid(ref, xy, far, iters, 1)
+    assert np.allclose(got, want, atol=1e-3)
+    rep.close()
+
+
+def test_hector_processor_gating(hs_mod, ctx, det, sim):
+    """HectorSLAMProcessor.Update (:86-126): map-without-matching, distance / angle thresholds, DegDiff quirk."""
+    oc = det
+    segs = sim.default_field()
+    start = np.array([20.0, 20.0, 0.0], np.float32)
+    proc = hs_mod.HectorSLAMProcessor(0.1, (400, 400), start, 3, 4, ctx=ctx)
+    proc.MinDistanceDiffForMapUpdate = 0.4                              # Simulation/MainWindow.xaml.cs:78-79
+    proc.MinAngleDiffForMapUpdate = math.radians(8)
+    ref = oc.make_pyramid(0.1, 400, 400, 3)
+    rng = sim.PCG32(8)
+    pose = start.copy()
+    assert (proc.LastMapUpdatePose < -3e38).all()
+    last = None
+    for loop in range(16):
+        true_pose = np.array([20 + 0.06 * loop, 20 + 0.01 * loop, 0.004 * loop], np.float32)
+        rays, xy = sim.make_scan(segs, true_pose, 400, rng)
+        scan = hs_mod.ScanCloud(xy)
+        hint = proc.MatchPose if loop else start
+        map_only = loop < 10                                            # MainWindow.xaml.cs:179
+        updated = proc.Update(scan, hint, map_only)
+        if map_only:
+            want = np.asarray(hint, np.float32)
+        else:
+            want = oc.match_pyramid(ref, xy, hint, [3, 3, 3], 1)
+        got = proc.MatchPose
+        assert np.allclose(got, want, atol=POS_TOL), loop
+        d2 = np.inf if last is None else float((got[0] - last[0]) ** 2 + (got[1] - last[1]) ** 2)
+        ang = -np.inf if last is None else oc.deg_diff(float(got[2]), float(last[2]))
+        expect = bool(map_only or d2 > 0.4 ** 2 or ang > math.radians(8))
+        assert updated == expect, (loop, d2, ang)
+        if updated:
+            for g in ref:
+                g.update_by_scan(xy, got)
+            last = got.copy()
+            assert (proc.LastMapUpdatePose == got).all()
+        if map_only:
+            for l in range(3):
+                c = proc.MapRep.Maps[l].GetCells()
+                assert (c["update_index"] == ref[l].cells["update_index"]).all() and (c["value"] == ref[l].cells["value"]).all()
+    assert proc.MatchTiming > 0 and proc.UpdateTiming > 0
+    proc.Reset()
+    assert (proc.MatchPose == start).all() and (proc.MapRep.Maps[0].GetCells()["value"] == 0).all()
+    proc.Dispose()
