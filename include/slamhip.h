@@ -163,6 +163,11 @@ int32_t slamhip_cs_update_obstaclemap_pxcs(slamhip_cs *cs, const float pxcs[4], 
 /* number of pixels blended by the last HoleMap update (4 algorithmic bytes each) */
 int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out_pixels);
 
+/* Diagnostics: with the environment variable SLAMHIP_K1_VERIFY=1 the distance kernel checks every end
+ * point against the LDS tile box it derived by interval arithmetic and counts violations (always 0 when
+ * the box reasoning holds; the parity tests assert it).  Returns the count accumulated so far. */
+int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out_failures);
+
 /* Fused configuration C3 (device boundary at CoreSLAMProcessor.cs:732,:750,:751): search, NormalizeAngle
  * (:746) and both map updates in one call; the winning pose never leaves the device between them. */
 int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float search_pose[3], float hole_width,

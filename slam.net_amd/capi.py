@@ -88,6 +88,7 @@ def _declare(L):
         "slamhip_cs_update_obstaclemap_pxcs": (i32, [vp, fp, i32]),
         "slamhip_cs_last_holemap_pixels": (i32, [vp, P(i64)]),
         "slamhip_cs_search_and_update": (i32, [vp, fp, f, i32, i32, fp, ip, ip]),
+        "slamhip_cs_selfcheck_failures": (i32, [vp, P(C.c_uint32)]),
         "slamhip_csproc_create": (i32, [vp, f, i32, i32, fp, f, f, i32, i32, vpp]),
         "slamhip_csproc_destroy": (i32, [vp]),
         "slamhip_csproc_reset": (i32, [vp]),

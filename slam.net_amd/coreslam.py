@@ -198,6 +198,12 @@ class CoreSlamDevice:
         capi.call("slamhip_cs_last_holemap_pixels", self._h, C.byref(v))
         return v.value
 
+    @property
+    def selfcheck_failures(self):
+        v = C.c_uint32()
+        capi.call("slamhip_cs_selfcheck_failures", self._h, C.byref(v))
+        return v.value
+
     def search_and_update(self, search_pose, hole_width=0.6, quality=50, max_hits=10):
         sp = capi.f32(search_pose)
         pose = np.empty(3, np.float32); d, i = C.c_int32(), C.c_int32()

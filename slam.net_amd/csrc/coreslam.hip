@@ -91,7 +91,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start);
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
-    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose);
+    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose); (void)hipFree(cs->d_verify);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
     cs_holemap_free(cs);
     cs_obstacle_free(cs);
@@ -117,7 +117,9 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
             hipMalloc(&cs->d_obst, (size_t)obst_size * obst_size) != hipSuccess ||
             hipMalloc(&cs->d_key, sizeof(uint64_t)) != hipSuccess ||
             hipMalloc(&cs->d_best_pose, sizeof(float) * 4) != hipSuccess ||
+            hipMalloc(&cs->d_verify, sizeof(unsigned int) * 4) != hipSuccess ||
             hipHostMalloc(&cs->h_key, 64) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
+        if (hipMemset(cs->d_verify, 0, sizeof(unsigned int) * 4) != hipSuccess) { slamhip_set_error("hipMemset failed"); rc = SLAMHIP_ERR_HIP; break; }
         if ((rc = cs_holemap_alloc(cs)) != SLAMHIP_OK) break;
         if ((rc = cs_obstacle_alloc(cs)) != SLAMHIP_OK) break;
         if ((rc = slamhip_cs_reset(cs, -5)) != SLAMHIP_OK) break;          // CoreSLAMProcessor.cs:96,:140
@@ -243,13 +245,18 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     std::vector<int> rb;
     rb.push_back(0);
     int cur = 0;
-    uint32_t cur_cell = (uint32_t)(keys[0] >> 32) >> 4;     // 4x4 cells (256 px) per coarse bucket
+    float bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+    const float ext = CS_RB_EXTENT_PX / cs->hscale;            // block extent limit in metres
     for (int j = 0; j < n; j++) {
         const int i = (int)(uint32_t)keys[j];
-        sorted[2 * j] = xy[2 * i]; sorted[2 * j + 1] = xy[2 * i + 1];
-        const uint32_t cb = (uint32_t)(keys[j] >> 32) >> 4;
-        if (cur == CS_RB_MAX || (cb != cur_cell && cur > 0)) { rb.push_back(j); cur = 0; }
-        cur_cell = cb;
+        const float X = xy[2 * i], Y = xy[2 * i + 1];
+        sorted[2 * j] = X; sorted[2 * j + 1] = Y;
+        if (cur > 0) {
+            const float nx0 = fminf(bx0, X), nx1 = fmaxf(bx1, X), ny0 = fminf(by0, Y), ny1 = fmaxf(by1, Y);
+            if (cur == CS_RB_MAX || !(nx1 - nx0 <= ext) || !(ny1 - ny0 <= ext)) { rb.push_back(j); cur = 0; }
+            else { bx0 = nx0; bx1 = nx1; by0 = ny0; by1 = ny1; }
+        }
+        if (cur == 0) { bx0 = bx1 = X; by0 = by1 = Y; }
         cur++;
     }
     rb.push_back(n);
@@ -287,7 +294,8 @@ extern "C" int32_t slamhip_cs_distance_pxcs(slamhip_cs *cs, const float *pxcs, i
     cs->shard_first = cs->shard_count = -1;        // evaluation buffers no longer hold the offset shard
     SH_HIP(hipMemcpyAsync(cs->d_pxcs, pxcs, sizeof(float) * 4 * (size_t)K, hipMemcpyHostToDevice, cs->ctx->stream));
     int *saved = cs->d_ev_idx; cs->d_ev_idx = nullptr;          // identity: evaluation order == flat order
-    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane);
+    cs_launch_arm_key(cs, cs->d_key);
+    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane, cs->d_key);
     cs->d_ev_idx = saved;
     SH_TRY(rc);
     return finish_distance(cs, K, out_dist, out_best_index, out_best_dist);
@@ -305,9 +313,9 @@ extern "C" int32_t slamhip_cs_distance_poses(slamhip_cs *cs, const float *poses,
     cs->shard_first = cs->shard_count = -1;
     // stage the poses in d_ev_off (same 3-float layout)
     SH_HIP(hipMemcpyAsync(cs->d_ev_off, poses, sizeof(float) * 3 * (size_t)K, hipMemcpyHostToDevice, cs->ctx->stream));
-    cs_launch_prep_poses(cs, cs->d_ev_off, K);
+    cs_launch_prep_poses(cs, cs->d_ev_off, K, cs->d_key);
     int *saved = cs->d_ev_idx; cs->d_ev_idx = nullptr;
-    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane);
+    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane, cs->d_key);
     cs->d_ev_idx = saved;
     SH_TRY(rc);
     return finish_distance(cs, K, out_dist, out_best_index, out_best_dist);
@@ -408,7 +416,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
     return SLAMHIP_OK;
 }
 
-static int32_t search_enqueue(slamhip_cs *cs, const float pose[3], int first, int count)
+static int32_t search_enqueue(slamhip_cs *cs, const float pose[3], int first, int count, uint64_t *key_dst)
 {
     SH_CHECK_ARG(cs && pose);
     SH_CHECK_ARG(first >= 0 && count > 0 && first + count <= cs->n_offs + 1);
@@ -416,23 +424,21 @@ static int32_t search_enqueue(slamhip_cs *cs, const float pose[3], int first, in
     if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
     SH_TRY(ensure_shard(cs, first, count));
     const bool sane = fabsf(pose[0]) < 1.0e6f && fabsf(pose[1]) < 1.0e6f && fabsf(pose[2]) < 1.0e4f;
-    cs_launch_prep_offsets(cs, count, pose);
-    return cs_launch_distance(cs, count, false, sane);
+    cs_launch_prep_offsets(cs, count, pose, key_dst);
+    return cs_launch_distance(cs, count, false, sane, key_dst);
 }
 
 extern "C" int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count,
                                                  uint64_t *d_out_key)
 {
-    SH_CHECK_ARG(d_out_key);
-    SH_TRY(search_enqueue(cs, pose, first, count));
-    SH_HIP(hipMemcpyAsync(d_out_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToDevice, cs->ctx->stream));
-    return SLAMHIP_OK;
+    SH_CHECK_ARG(cs && d_out_key);
+    return search_enqueue(cs, pose, first, count, d_out_key);     // prep arms the key, K1/K1r min into it
 }
 
 extern "C" int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count, uint64_t *out_key)
 {
-    SH_CHECK_ARG(out_key);
-    SH_TRY(search_enqueue(cs, pose, first, count));
+    SH_CHECK_ARG(cs && out_key);
+    SH_TRY(search_enqueue(cs, pose, first, count, cs->d_key));
     SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, cs->ctx->stream));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     *out_key = *cs->h_key;
@@ -534,13 +540,26 @@ extern "C" int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out)
     return SLAMHIP_OK;
 }
 
+extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
+{
+    SH_CHECK_ARG(cs && out);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    unsigned int *h = (unsigned int *)(cs->h_key + 6);
+    SH_HIP(hipMemcpyAsync(h, cs->d_verify, sizeof(unsigned int) * 4, hipMemcpyDeviceToHost, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    *out = h[0];
+    if (getenv("SLAMHIP_K1_STATS"))
+        fprintf(stderr, "[slamhip] K1 mode stats (ray x sub-batch units): one-tile %u, sub-batch tile %u, global fallback %u\n", h[1], h[2], h[3]);
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality,
                                                 int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index)
 {
     SH_CHECK_ARG(cs && pose);
     SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
     slamhip_ctx *ctx = cs->ctx;
-    SH_TRY(search_enqueue(cs, pose, 0, cs->n_offs + 1));                    // :732
+    SH_TRY(search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key));         // :732
     hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
                        cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);   // :746-747
     SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality));   // :750

@@ -233,17 +233,19 @@ k2_fragments(const cs_ray *__restrict__ rays, const int *__restrict__ chunk_ray,
              int *__restrict__ conflict_pix, int cap_conflict)
 {
     const int chunk = blockIdx.x * (256 / K2_CHUNK) + (threadIdx.x >> 6);
-    if (chunk >= counters[0]) return;
+    if (chunk >= counters[0]) return;                 // wave-uniform
     const cs_ray r = rays[chunk_ray[chunk]];
     const int x = chunk_x0[chunk] + (threadIdx.x & 63);
-    if (x > r.dxc) return;
-    const int ptr = sh_wadd(sh_wadd(r.ptr0, sh_wmul(x, r.incmaj)), sh_wmul(k2_minor(r, x), r.incmin));
-    if (ptr < 0 || ptr >= npix) return;          // cannot happen for a clipped ray; guards the array
+    int ptr = -1;
+    if (x <= r.dxc) {
+        ptr = sh_wadd(sh_wadd(r.ptr0, sh_wmul(x, r.incmaj)), sh_wmul(k2_minor(r, x), r.incmin));
+        if (ptr < 0 || ptr >= npix) ptr = -1;         // cannot happen for a clipped ray; guards the array
+    }
     if (PASS == 0) {
-        atomicAdd(&cnt[ptr], 1u);
+        if (ptr >= 0) atomicAdd(&cnt[ptr], 1u);
         return;
     }
-    const uint32_t n = cnt[ptr];
+    const uint32_t n = ptr >= 0 ? cnt[ptr] : 0u;
     if (PASS == 1) {
         if (n > 1) {
             const int v = k2_pixval(r, x);
@@ -253,25 +255,30 @@ k2_fragments(const cs_ray *__restrict__ rays, const int *__restrict__ chunk_ray,
         return;
     }
     // PASS 2
+    int blended = 0;
     if (n == 1) {
         map[ptr] = k2_blend(map[ptr], k2_pixval(r, x), alpha);
         cnt[ptr] = 0;
-        atomicAdd(&counters[2], 1);
+        blended = 1;
     } else if (n > 1) {
         const uint32_t won = atomicExch(&cnt[ptr], 0u);      // elect one fragment per pixel
-        if (won == 0) return;
-        const int lo = vmin[ptr], hi = vmax[ptr];
-        vmin[ptr] = INT32_MAX; vmax[ptr] = INT32_MIN;
-        atomicAdd(&counters[2], (int)won);
-        if (lo == hi) {                                      // same pixval from every ray: order-free
-            uint16_t pix = map[ptr];
-            for (uint32_t k = 0; k < won; k++) pix = k2_blend(pix, lo, alpha);
-            map[ptr] = pix;
-        } else {
-            const int slot = atomicAdd(&counters[1], 1);
-            if (slot < cap_conflict) conflict_pix[slot] = ptr;
+        if (won != 0) {
+            const int lo = vmin[ptr], hi = vmax[ptr];
+            vmin[ptr] = INT32_MAX; vmax[ptr] = INT32_MIN;
+            blended = (int)won;
+            if (lo == hi) {                                  // same pixval from every ray: order-free
+                uint16_t pix = map[ptr];
+                for (uint32_t k = 0; k < won; k++) pix = k2_blend(pix, lo, alpha);
+                map[ptr] = pix;
+            } else {
+                const int slot = atomicAdd(&counters[1], 1);
+                if (slot < cap_conflict) conflict_pix[slot] = ptr;
+            }
         }
     }
+    // one atomic per wavefront for the blended-pixel statistic
+    for (int off = 32; off > 0; off >>= 1) blended += __shfl_down(blended, off, 64);
+    if ((threadIdx.x & 63) == 0 && blended) atomicAdd(&counters[2], blended);
 }
 
 // One wavefront per conflict pixel: find the rays that touch it, in ray order, and blend in that order.

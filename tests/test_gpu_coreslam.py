@@ -166,7 +166,22 @@ def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
     pose, dist, idx = dev.search(base)
     rbi, rpose, rbd, _ = oc.search(pix, size, scale, xy, base, goffs)
     assert idx == rbi and dist == rbd and (pose == rpose).all()
+    assert dev.selfcheck_failures == 0
     dev.close()
+
+
+def test_k1_tile_boxes_selfcheck():
+    """Re-run the distance tests with SLAMHIP_K1_VERIFY=1 (every end point is checked against its LDS tile
+    box) and with SLAMHIP_K1_GLOBAL=1 (global-gather fallback kernel): both must stay bit-exact."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size"
+    for env_extra in ({"SLAMHIP_K1_VERIFY": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}, {"SLAMHIP_K1_TILE_KB": "8"}):
+        env = dict(os.environ); env.update(env_extra); env["SLAMHIP_EXPECT_SELFCHECK"] = "1"
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q",
+                            "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, (env_extra, r.stdout.decode(errors="replace")[-3000:])
 
 
 # ---- K2 HoleMap ---------------------------------------------------------------------------------------------
