@@ -91,7 +91,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start);
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
-    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose); (void)hipFree(cs->d_verify);
+    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose); (void)hipFree(cs->d_verify); (void)hipFree(cs->d_plans);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
     cs_holemap_free(cs);
     cs_obstacle_free(cs);
@@ -294,8 +294,7 @@ extern "C" int32_t slamhip_cs_distance_pxcs(slamhip_cs *cs, const float *pxcs, i
     cs->shard_first = cs->shard_count = -1;        // evaluation buffers no longer hold the offset shard
     SH_HIP(hipMemcpyAsync(cs->d_pxcs, pxcs, sizeof(float) * 4 * (size_t)K, hipMemcpyHostToDevice, cs->ctx->stream));
     int *saved = cs->d_ev_idx; cs->d_ev_idx = nullptr;          // identity: evaluation order == flat order
-    cs_launch_arm_key(cs, cs->d_key);
-    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane, cs->d_key);
+    int32_t rc = cs_launch_distance(cs, 0, nullptr, K, out_dist != nullptr, sane, cs->d_key);
     cs->d_ev_idx = saved;
     SH_TRY(rc);
     return finish_distance(cs, K, out_dist, out_best_index, out_best_dist);
@@ -313,9 +312,8 @@ extern "C" int32_t slamhip_cs_distance_poses(slamhip_cs *cs, const float *poses,
     cs->shard_first = cs->shard_count = -1;
     // stage the poses in d_ev_off (same 3-float layout)
     SH_HIP(hipMemcpyAsync(cs->d_ev_off, poses, sizeof(float) * 3 * (size_t)K, hipMemcpyHostToDevice, cs->ctx->stream));
-    cs_launch_prep_poses(cs, cs->d_ev_off, K, cs->d_key);
     int *saved = cs->d_ev_idx; cs->d_ev_idx = nullptr;
-    int32_t rc = cs_launch_distance(cs, K, out_dist != nullptr, sane, cs->d_key);
+    int32_t rc = cs_launch_distance(cs, 2, nullptr, K, out_dist != nullptr, sane, cs->d_key);
     cs->d_ev_idx = saved;
     SH_TRY(rc);
     return finish_distance(cs, K, out_dist, out_best_index, out_best_dist);
@@ -424,8 +422,7 @@ static int32_t search_enqueue(slamhip_cs *cs, const float pose[3], int first, in
     if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
     SH_TRY(ensure_shard(cs, first, count));
     const bool sane = fabsf(pose[0]) < 1.0e6f && fabsf(pose[1]) < 1.0e6f && fabsf(pose[2]) < 1.0e4f;
-    cs_launch_prep_offsets(cs, count, pose, key_dst);
-    return cs_launch_distance(cs, count, false, sane, key_dst);
+    return cs_launch_distance(cs, 1, pose, count, false, sane, key_dst);
 }
 
 extern "C" int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count,

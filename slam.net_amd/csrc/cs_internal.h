@@ -6,8 +6,8 @@
 // Rays are grouped into blocks of at most CS_RB_MAX spatially close points (Z-order sorted, extent
 // limited to CS_RB_EXTENT_PX map pixels); a workgroup of the distance kernel handles
 // (1024 candidates) x (a chunk of ray blocks) and stages one HoleMap tile in LDS per ray block.
-#define CS_RB_MAX 32
-#define CS_RB_EXTENT_PX 96.0f
+#define CS_RB_MAX 64
+#define CS_RB_EXTENT_PX 128.0f
 
 struct cs_ray;      // K2 per-ray table entry (holemap.hip)
 
@@ -38,6 +38,7 @@ struct slamhip_cs {
     int cap_cand;
     float4 *d_pxcs;               // [cap_cand] (px,py,c,s) in evaluation order
     void *d_partial; size_t cap_partial;       // uint2 [n_chunks][count]: (pixel sum, in-bounds count)
+    int *d_plans; size_t cap_plans;            // K1 tile plans [groups][n_rb][32 ints]
     unsigned int *d_verify;       // SLAMHIP_K1_VERIFY=1: count of end points outside their LDS tile box (must stay 0)
     int32_t *d_dist;              // [cap_cand] per-candidate distances in FLAT order (optional output)
     uint64_t *d_key;              // packed (dist << 32 | flat index) arg-min
@@ -61,10 +62,8 @@ struct slamhip_cs {
 
 // distance.hip
 int32_t cs_alloc_candidates(slamhip_cs *cs, int count);
-int32_t cs_launch_distance(slamhip_cs *cs, int count, bool want_dist, bool cand_sane, uint64_t *key_dst);
-void    cs_launch_prep_offsets(slamhip_cs *cs, int count, const float pose[3], uint64_t *key_dst);
-void    cs_launch_prep_poses(slamhip_cs *cs, const float *d_poses, int count, uint64_t *key_dst);
-void    cs_launch_arm_key(slamhip_cs *cs, uint64_t *key_dst);
+int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int count, bool want_dist, bool cand_sane,
+                           uint64_t *key_dst);
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);
 void    cs_holemap_free(slamhip_cs *cs);
