@@ -165,7 +165,8 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key):
     import oracle_c as oc
     oc.set_trig_mode(oc.TRIG_DET)
     pix = dev.holemap_download()
-    T = os.cpu_count() or 1
+    # WaitHandle.WaitAll caps the reference's ParallelWorker at 64 threads (BaseSLAM/ParallelWorker.cs:115)
+    T = min(os.cpu_count() or 1, 64)
     n = offs.shape[0]
     iters = max(n // T, 1)
     secs, evals, bi, bd = oc.cpu_baseline_search(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, 1)

@@ -66,33 +66,55 @@ __device__ static inline void k1_wave_argmin(unsigned long long key, unsigned lo
 }
 
 // ---- K1 main, global-gather form ---------------------------------------------------------------------------
-// (a) whole-launch fallback for unsafe inputs or map sides that are not a multiple of 8 (tail == NULL);
-// (b) companion of the tiled kernel for theta-TAIL sub-batches: candidates so sparse in theta that no LDS tile
-//     covers them; they are few, so plain bounds-checked gathers with many waves in flight are the right tool.
-//     Blocks whose sub-batch is not flagged exit immediately.  Four independent gathers per iteration.
+// (a) whole-launch fallback for unsafe inputs or map sides that are not a multiple of 8 (plans == NULL);
+// (b) TAIL companion of the tiled kernel: it evaluates exactly the (sub-batch, ray block) units whose plan kind
+//     is GLOBAL -- candidates too sparse in theta, or rays too long, for an LDS tile to cover them.  Those are few,
+//     and bounds-checked gathers with many independent waves in flight are the right tool for them.  A block
+//     whose (sub-batch, chunk) has no such unit exits at once (tailmask).  Four independent gathers per iteration.
 template <bool SAFE>
 __global__ void __launch_bounds__(K1_THREADS)
 k1_distance_global(const uint16_t *__restrict__ map, int S, const float2 *__restrict__ pts,
                    const int *__restrict__ rb_start, int n_rb, int blocks_per_chunk,
                    const float4 *__restrict__ pxcs, int count, uint2 *__restrict__ partial,
-                   const int *__restrict__ tail)
+                   const int *__restrict__ plans, const int *__restrict__ tailmask)
 {
-    if (tail && !tail[blockIdx.x]) return;
-    const int j = blockIdx.x * K1_THREADS + threadIdx.x;
     const int chunk = blockIdx.y;
+    if (tailmask && !tailmask[blockIdx.x * gridDim.y + chunk]) return;
+    const int j = blockIdx.x * K1_THREADS + threadIdx.x;
     const int b0 = chunk * blocks_per_chunk;
     const int b1 = b0 + blocks_per_chunk < n_rb ? b0 + blocks_per_chunk : n_rb;
-    const int r0 = rb_start[b0], r1 = rb_start[b1];
     const float4 q = pxcs[j < count ? j : count - 1];
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    int r = r0;
-    for (; r + 3 < r1; r += 4) {
-        k1_gather_global<SAFE>(map, S, q, pts[r], s0, c0);
-        k1_gather_global<SAFE>(map, S, q, pts[r + 1], s1, c1);
-        k1_gather_global<SAFE>(map, S, q, pts[r + 2], s2, c2);
-        k1_gather_global<SAFE>(map, S, q, pts[r + 3], s3, c3);
+    for (int b = b0; b < b1; b++) {
+        if (plans) {       // sub-batch blockIdx.x = (group blockIdx.x >> 2, sub blockIdx.x & 3)
+            const int kind = plans[((size_t)(blockIdx.x >> 2) * n_rb + b) * 32 + (blockIdx.x & 3) * 8 + 6];
+            if (kind != 2) continue;
+        }
+        int r = rb_start[b];
+        const int r1 = rb_start[b + 1];
+        // eight gathers in flight per lane: these candidates have no locality, every gather is an L2/HBM round trip
+        for (; r + 7 < r1; r += 8) {
+            float fx[8], fy[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) k1_coords(q, pts[r + u], fx[u], fy[u]);
+            uint32_t v[8]; bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int ix, iy;
+                if (SAFE) { ix = sh_f2i(fx[u]); iy = sh_f2i(fy[u]); } else { ix = (int)fx[u]; iy = (int)fy[u]; }
+                ok[u] = ((unsigned)ix < (unsigned)S) & ((unsigned)iy < (unsigned)S);
+                v[u] = map[ok[u] ? (size_t)iy * S + ix : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                s0 += ok[u] ? v[u] : 0u;         c0 += ok[u] ? 1u : 0u;
+                s1 += ok[u + 1] ? v[u + 1] : 0u; c1 += ok[u + 1] ? 1u : 0u;
+                s2 += ok[u + 2] ? v[u + 2] : 0u; c2 += ok[u + 2] ? 1u : 0u;
+                s3 += ok[u + 3] ? v[u + 3] : 0u; c3 += ok[u + 3] ? 1u : 0u;
+            }
+        }
+        for (; r < r1; r++) k1_gather_global<SAFE>(map, S, q, pts[r], s0, c0);
     }
-    for (; r < r1; r++) k1_gather_global<SAFE>(map, S, q, pts[r], s0, c0);
     if (j < count) partial[(size_t)chunk * count + j] = make_uint2(s0 + s1 + s2 + s3, c0 + c1 + c2 + c3);
 }
 
@@ -106,8 +128,8 @@ k1_distance_global(const uint16_t *__restrict__ map, int S, const float2 *__rest
 #define K1_PLAN_INTS 32                // 4 sub-batch records x 8 ints, each fully resolved
 #define K1_KIND_OWN 0                  // the sub-batch has its own tile, staged by its 4 waves
 #define K1_KIND_SHARED 1               // one tile for the whole group, staged by all 16 waves
-#define K1_KIND_GLOBAL 2               // no tile: bounds-checked global gathers
-#define K1_KIND_SKIP 3                 // the whole sub-batch is a theta-tail: handled by k1_distance_tail instead
+#define K1_KIND_GLOBAL 2               // no tile fits (theta tail, long ray, map border): the unit goes to the tail kernel
+#define K1_MAX_RB 2048                 // ray blocks the prep kernel can plan (beyond: whole-launch global path)
 // sub-batch record: [0] x0a  [1] y0  [2] w8 (pitch, px)  [3] h  [4] lds byte offset  [5] shift = log2(lanes per row)
 //                   [6] kind  [7] unused.
 // Staging geometry: a wave-wide 16-byte load covers 64 >> shift tile rows of (1 << shift) vectors each
@@ -157,9 +179,10 @@ __global__ void __launch_bounds__(K1_WG)
 k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, float scale, float4 *__restrict__ pxcs,
              int count, unsigned long long *__restrict__ key, const float2 *__restrict__ pts,
              const int *__restrict__ rb_start, int n_rb, int S, int budget_shared, int budget_sub, int *__restrict__ plans,
-             int *__restrict__ tail, int n_points)
+             int *__restrict__ tailmask, int bpc_tail, int n_chunks_tail)
 {
-    __shared__ int gl_rays[4];                                   // rays per sub-batch that no tile covers
+    __shared__ unsigned char kind_all[K1_MAX_RB * 4];            // plan kind per (ray block, sub-batch) of this group
+    __shared__ int srb[K1_MAX_RB + 1];                           // rb_start staged once: every later use is an LDS read
     __shared__ float wred[16][8];
     __shared__ float bnd[5][8];
     __shared__ int boxes[K1_PLAN_BATCH * 5][4];
@@ -167,7 +190,7 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, g = blockIdx.x;
     const int j = g * K1_WG + t;
     if (j == 0) *key = ~0ull;
-    if (t < 4) gl_rays[t] = 0;
+    if (plans) for (int i = t; i <= n_rb; i += K1_WG) srb[i] = rb_start[i];
     const int jc = j < count ? j : count - 1;
     float4 q;
     if (MODE == 0) {
@@ -215,20 +238,34 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
 
     for (int base = 0; base < n_rb;) {
         int nb = n_rb - base < K1_PLAN_BATCH ? n_rb - base : K1_PLAN_BATCH;
-        const int rbase = rb_start[base];
-        while (rb_start[base + nb] - rbase > K1_PLAN_BATCH * CS_RB_MAX / 4) nb--;      // batch must fit spts (nb >= 1: a block has <= 64 rays)
-        const int npts = rb_start[base + nb] - rbase;
+        const int rbase = srb[base];
+        while (srb[base + nb] - rbase > K1_PLAN_BATCH * CS_RB_MAX / 4) nb--;      // batch must fit spts (nb >= 1: a block has <= 64 rays)
+        const int npts = srb[base + nb] - rbase;
         for (int i = t; i < npts; i += K1_WG) spts[i] = pts[rbase + i];
         __syncthreads();
         for (int pair = t; pair < nb * 5; pair += K1_WG) {
+            boxes[pair][0] = INT32_MAX; boxes[pair][1] = INT32_MAX; boxes[pair][2] = INT32_MIN; boxes[pair][3] = INT32_MIN;
+        }
+        __syncthreads();
+        // one task = (ray block, candidate set, quarter of the block's rays); LDS atomics merge the quarters
+        for (int task = t; task < nb * 20; task += K1_WG) {
+            const int pair = task >> 2, qr = task & 3;
             const int b = base + pair / 5, set = pair % 5;
+            const int ra = srb[b] - rbase, rn = srb[b + 1] - srb[b];
+            const int q0 = ra + (rn * qr) / 4, q1 = ra + (rn * (qr + 1)) / 4;
+            float bb8[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) bb8[k] = bnd[set][k];
             int x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
-            for (int r = rb_start[b] - rbase; r < rb_start[b + 1] - rbase; r++) {
+            for (int r = q0; r < q1; r++) {
                 int a0, b0, a1, b1;
-                k1_ray_box(bnd[set], spts[r], a0, b0, a1, b1);
+                k1_ray_box(bb8, spts[r], a0, b0, a1, b1);
                 x0 = min(x0, a0); y0 = min(y0, b0); x1 = max(x1, a1); y1 = max(y1, b1);
             }
-            boxes[pair][0] = x0; boxes[pair][1] = y0; boxes[pair][2] = x1; boxes[pair][3] = y1;
+            if (q1 > q0) {
+                atomicMin(&boxes[pair][0], x0); atomicMin(&boxes[pair][1], y0);
+                atomicMax(&boxes[pair][2], x1); atomicMax(&boxes[pair][3], y1);
+            }
         }
         __syncthreads();
         if (t < nb * 4) {
@@ -254,7 +291,7 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
             };
             if (tile(4, budget_shared, 0, 16)) rec[6] = K1_KIND_SHARED;
             else if (tile(sb, budget_sub, sb * budget_sub, 4)) rec[6] = K1_KIND_OWN;
-            else atomicAdd(&gl_rays[sb], rb_start[base + bb + 1] - rb_start[base + bb]);
+            kind_all[(base + bb) * 4 + sb] = (unsigned char)rec[6];
             int4 *dst = (int4 *)(plans + ((size_t)g * n_rb + base + bb) * K1_PLAN_INTS + sb * 8);
             dst[0] = make_int4(rec[0], rec[1], rec[2], rec[3]);
             dst[1] = make_int4(rec[4], rec[5], rec[6], rec[7]);
@@ -262,25 +299,25 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
         __syncthreads();
         base += nb;
     }
-    // theta-tail sub-batches (more than a quarter of their rays uncovered) leave the tiled kernel altogether
-    if (t < 4) tail[g * 4 + t] = (gl_rays[t] * 4 > n_points) ? 1 : 0;
-    // (records of SHARED tiles stay: all 16 waves are needed to stage a shared tile; what a tail sub-batch
-    //  computes there is simply ignored, K1r reads only its tail-kernel partials)
-    for (int i = t; i < n_rb * 4; i += K1_WG) {
-        const int sb = i & 3;
-        int *kindp = plans + ((size_t)g * n_rb + (i >> 2)) * K1_PLAN_INTS + sb * 8 + 6;
-        if (gl_rays[sb] * 4 > n_points && *kindp != K1_KIND_SHARED) *kindp = K1_KIND_SKIP;
+    // which (sub-batch, tail chunk) pairs hold at least one GLOBAL unit (only when a separate tail kernel is used)
+    if (tailmask)
+    for (int i = t; i < 4 * n_chunks_tail; i += K1_WG) {
+        const int sb = i / n_chunks_tail, ct = i - sb * n_chunks_tail;
+        const int c0 = ct * bpc_tail, c1 = c0 + bpc_tail < n_rb ? c0 + bpc_tail : n_rb;
+        int any = 0;
+        for (int b = c0; b < c1; b++) any |= (kind_all[b * 4 + sb] == K1_KIND_GLOBAL);
+        tailmask[((size_t)g * 4 + sb) * n_chunks_tail + ct] = any;
     }
 }
 
 // ---- the distance kernel -------------------------------------------------------------------------------------
-template <bool VERIFY>
-__global__ void __launch_bounds__(K1_WG)
+template <bool VERIFY, bool INLINE_GLOBAL>
+__global__ void __launch_bounds__(K1_WG, 8)          // 8 waves / SIMD = two 1024-lane workgroups per CU (<= 64 VGPRs)
 k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restrict__ pts,
                   const int *__restrict__ rb_start, int n_rb, int blocks_per_chunk,
                   const float4 *__restrict__ pxcs, int count, const int *__restrict__ plans,
                   uint2 *__restrict__ partial,                      // [n_chunks][count]
-                  unsigned int *__restrict__ verify_fail)
+                  unsigned int *__restrict__ verify_fail, int n_chunks_grid)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte address
@@ -289,7 +326,21 @@ k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restr
     int zv;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));                   // opaque zero (see k1_point_lds)
     const int sub = __builtin_amdgcn_readfirstlane(t >> 8);        // sub-batch of this wave
-    const int g = blockIdx.x, chunk = blockIdx.y;
+    // Workgroups are dispatched in blockIdx order; two orders, both measured on MI355X:
+    //  - large launches (GLOBAL units go to the tail kernel): chunk-major, so the workgroups in flight work on the
+    //    SAME ray blocks for neighbouring theta groups, whose tiles overlap almost completely (L2 reuse, ~1.5x);
+    //  - small launches (GLOBAL units inline): group-major with the theta-extreme groups first (0, n-1, 1, n-2, ...):
+    //    their global-gather units take longest, so they overlap the bulk instead of trailing it.
+    const int ng_ = gridDim.x / (unsigned)n_chunks_grid;
+    int g, chunk;
+    if (INLINE_GLOBAL) {
+        const int gi = blockIdx.x / (unsigned)n_chunks_grid;
+        chunk = blockIdx.x - gi * n_chunks_grid;
+        g = (gi & 1) ? ng_ - 1 - (gi >> 1) : (gi >> 1);
+    } else {
+        chunk = blockIdx.x / (unsigned)ng_;
+        g = blockIdx.x - chunk * ng_;
+    }
     const int j = g * K1_WG + t;
     const float4 q = pxcs[j < count ? j : count - 1];
     uint32_t sum = 0, cnt = 0;
@@ -315,7 +366,7 @@ k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restr
     {                                                                                               \
         const int4 pa_ = *(const int4 *)((planp) + sub * 8), pb_ = *(const int4 *)((planp) + sub * 8 + 4); \
         const int kind_ = pb_.z, shift_ = pb_.y, w8_ = pa_.z;                                       \
-        const int h_ = kind_ >= K1_KIND_GLOBAL ? 0 : pa_.w;                                         \
+        const int h_ = kind_ == K1_KIND_GLOBAL ? 0 : pa_.w;                                         \
         const int rpi = 64 >> shift_;                           /* tile rows per wave-wide load */   \
         const int srow = lane >> shift_, scol = lane & ((1 << shift_) - 1);                         \
         const bool colok = scol < (w8_ >> 3);                                                       \
@@ -402,10 +453,27 @@ k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restr
             sum += sumb;
             cnt += (uint32_t)nr;
             if (VERIFY && (t & (K1_SUB - 1)) == 0) atomicAdd(verify_fail + (kind == K1_KIND_SHARED ? 1 : 2), (unsigned)nr);
-        } else if (kind == K1_KIND_GLOBAL) {
-            // box too large for LDS or touching the map border: bounds-checked global gathers
+        } else if (INLINE_GLOBAL) {
+            // No tile covers this unit (theta tail, long ray, map border): bounds-checked global gathers, four in
+            // flight per lane -- these candidates have no locality, every gather is an L2 / MALL round trip; the
+            // other waves of the CU keep computing from LDS meanwhile.  (Large launches leave these units to the
+            // separate tail kernel instead: INLINE_GLOBAL == false.)
             const unsigned pbase = smem_lds + (unsigned)zv;
-            for (int r = 0; r < nr; r++) k1_gather_global<false>(map, S, q, k1_point_lds(pbase + r * 8), sum, cnt);
+            int r = 0;
+            for (; r + 3 < nr; r += 4) {
+                uint32_t v[4]; bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    float fx, fy;
+                    k1_coords(q, k1_point_lds(pbase + (r + u) * 8), fx, fy);
+                    const int ix = (int)fx, iy = (int)fy;
+                    ok[u] = ((unsigned)ix < (unsigned)S) & ((unsigned)iy < (unsigned)S);
+                    v[u] = map[ok[u] ? (size_t)iy * S + ix : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { sum += ok[u] ? v[u] : 0u; cnt += ok[u] ? 1u : 0u; }
+            }
+            for (; r < nr; r++) k1_gather_global<false>(map, S, q, k1_point_lds(pbase + r * 8), sum, cnt);
             if (VERIFY && (t & (K1_SUB - 1)) == 0) atomicAdd(verify_fail + 3, (unsigned)nr);
         }
     }
@@ -417,43 +485,58 @@ k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restr
 }
 
 // ---- K1r: per-candidate reduction of the chunk partials + arg-min ----------------------------------------
-// Grid-stride over candidates; ONE atomicMin per workgroup: same-address device atomics serialise at
-// ~12 ns each on MI355X, so per-wave atomics would dominate at K >= 1e5.
+// A block works on 64 candidates at a time with its 4 waves splitting the partial rows; blocks grid-stride
+// over the candidates and issue ONE atomicMin each (same-address device atomics serialise at ~12 ns each on
+// MI355X, so per-wave atomics would dominate at K >= 1e5).
 __global__ void __launch_bounds__(256)
-k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int n_chunks_tail, const int *__restrict__ tail,
+k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int n_chunks_tail, const int *__restrict__ tailmask,
           int count, int n_points, const int *__restrict__ ev_idx, int32_t *__restrict__ dist_out,
           unsigned long long *__restrict__ key_out)
 {
-    __shared__ unsigned long long wkey[4];
+    __shared__ uint32_t ssum[4][64], scnt[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned long long key = ~0ull;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < count; j += gridDim.x * 256) {
+    for (int base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
+        const int j = base + lane;
         uint32_t sum = 0, cnt = 0;
-        // rows [0, n_chunks) come from the tiled (or whole-launch global) kernel, rows [n_chunks, +n_chunks_tail)
-        // from the tail kernel; a candidate's sub-batch (j >> 8) tells which set holds its partials
-        const bool is_tail = tail && tail[j >> 8];
-        int c = is_tail ? n_chunks : 0;
-        const int c_end = is_tail ? n_chunks + n_chunks_tail : n_chunks;
-        for (; c + 3 < c_end; c += 4) {
-            const uint2 p0 = partial[(size_t)c * count + j], p1 = partial[(size_t)(c + 1) * count + j];
-            const uint2 p2 = partial[(size_t)(c + 2) * count + j], p3 = partial[(size_t)(c + 3) * count + j];
-            sum += p0.x + p1.x + p2.x + p3.x; cnt += p0.y + p1.y + p2.y + p3.y;
+        if (j < count) {
+            // rows [0, n_chunks): tiled (or whole-launch global) kernel
+            int c = w;
+            for (; c + 12 < n_chunks; c += 16) {
+                const uint2 p0 = partial[(size_t)c * count + j], p1 = partial[(size_t)(c + 4) * count + j];
+                const uint2 p2 = partial[(size_t)(c + 8) * count + j], p3 = partial[(size_t)(c + 12) * count + j];
+                sum += p0.x + p1.x + p2.x + p3.x; cnt += p0.y + p1.y + p2.y + p3.y;
+            }
+            for (; c < n_chunks; c += 4) {
+                const uint2 p = partial[(size_t)c * count + j];
+                sum += p.x; cnt += p.y;
+            }
+            // rows [n_chunks, n_chunks + n_chunks_tail): tail kernel, only where the sub-batch has GLOBAL units
+            if (tailmask) {
+                const int *tm = tailmask + (size_t)(j >> 8) * n_chunks_tail;
+                for (int ct = w; ct < n_chunks_tail; ct += 4)
+                    if (tm[ct]) {
+                        const uint2 p = partial[(size_t)(n_chunks + ct) * count + j];
+                        sum += p.x; cnt += p.y;
+                    }
+            }
         }
-        for (; c < c_end; c++) {
-            const uint2 p = partial[(size_t)c * count + j];
-            sum += p.x; cnt += p.y;
+        ssum[w][lane] = sum; scnt[w][lane] = cnt;
+        __syncthreads();
+        if (w == 0 && j < count) {
+            const uint64_t s = (uint64_t)ssum[0][lane] + ssum[1][lane] + ssum[2][lane] + ssum[3][lane];
+            const uint32_t c = scnt[0][lane] + scnt[1][lane] + scnt[2][lane] + scnt[3][lane];
+            const unsigned long long k = k1_finish(s, c, n_points, ev_idx ? ev_idx[j] : j, dist_out);
+            key = k < key ? k : key;
         }
-        const unsigned long long k = k1_finish(sum, cnt, n_points, ev_idx ? ev_idx[j] : j, dist_out);
-        key = k < key ? k : key;
+        __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_down(key, off, 64);
-        key = o < key ? o : key;
-    }
-    if ((threadIdx.x & 63) == 0) wkey[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) key = wkey[w] < key ? wkey[w] : key;
-        if (key != ~0ull) atomicMin(key_out, key);
+    if (w == 0) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off, 64);
+            key = o < key ? o : key;
+        }
+        if (lane == 0 && key != ~0ull) atomicMin(key_out, key);
     }
 }
 
@@ -518,7 +601,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     static const int tile_kb = env_int("SLAMHIP_K1_TILE_KB", 60);
     static const int target_wgs = env_int("SLAMHIP_K1_TARGET_WGS", 768);
     const bool sane = cs->pts_sane && cand_sane;
-    const bool tiled = sane && (cs->hs % 8 == 0) && !force_global;
+    const bool tiled = sane && (cs->hs % 8 == 0) && !force_global && cs->n_rb <= K1_MAX_RB;
     const int n_rb = cs->n_rb;
     int32_t *dist = want_dist ? cs->d_dist : nullptr;
     unsigned long long *key = (unsigned long long *)key_dst;
@@ -534,26 +617,35 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     budget_sub &= ~15;
     if (budget_sub > K1_SUB * K1_PF * 16) budget_sub = K1_SUB * K1_PF * 16;
     const int budget_shared_eff = no_shared ? 0 : budget_shared;
-    if (tiled) SH_TRY(ensure_plans(cs, (size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * 4));
-    int *tailp = tiled ? cs->d_plans + (size_t)n_groups * n_rb * K1_PLAN_INTS : nullptr;      // tail flag per sub-batch
+    // tail kernel geometry: 256-lane blocks, ~32 rays per chunk
+    int bpc_t = sh_div_up(32 * n_rb, cs->n_points > 0 ? cs->n_points : 1);
+    if (bpc_t < 1) bpc_t = 1;
+    if (bpc_t > n_rb) bpc_t = n_rb;
+    const int n_chunks_t = sh_div_up(n_rb, bpc_t);
+    if (tiled) SH_TRY(ensure_plans(cs, (size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * 4 * n_chunks_t));
+    // GLOBAL units (no LDS tile fits): small launches evaluate them inline in the tiled kernel, where the other waves
+    // hide their latency; from ~48k candidates on, a separate many-wave tail kernel is faster (measured on MI355X)
+    static const int tail_threshold = env_int("SLAMHIP_K1_TAIL_KERNEL_FROM", 49152);
+    const bool use_tail_kernel = tiled && count >= tail_threshold;
+    int *tailp = use_tail_kernel ? cs->d_plans + (size_t)n_groups * n_rb * K1_PLAN_INTS : nullptr;   // tailmask [sub-batch][tail chunk]
     {
         sh_timer t(ctx, SLAMHIP_K_CS_PREP);
         int *plans = tiled ? cs->d_plans : nullptr;
 #define K1_PREP(M) hipLaunchKernelGGL(k1_prep_plan<M>, dim3(n_groups), dim3(K1_WG), 0, ctx->stream, (const float *)cs->d_ev_off, \
                        bx, by, bth, cs->hscale, cs->d_pxcs, count, key, (const float2 *)cs->d_pts_sorted, (const int *)cs->d_rb_start, \
-                       n_rb, cs->hs, budget_shared_eff, budget_sub, plans, tailp, cs->n_points)
+                       n_rb, cs->hs, budget_shared_eff, budget_sub, plans, tailp, bpc_t, n_chunks_t)
         if (mode == 0) K1_PREP(0); else if (mode == 1) K1_PREP(1); else K1_PREP(2);
 #undef K1_PREP
     }
     static const int dump = env_int("SLAMHIP_K1_DUMP", 0);
     if (dump && tiled) {                                           // debugging aid: histogram of plan kinds
-        std::vector<int> h((size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * 4);
+        std::vector<int> h((size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * 4 * n_chunks_t);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipMemcpy(h.data(), cs->d_plans, sizeof(int) * h.size(), hipMemcpyDeviceToHost);
         int kinds[4] = { 0, 0, 0, 0 }, tails = 0;
         for (size_t i = 0; i < (size_t)n_groups * n_rb * 4; i++) kinds[h[i * 8 + 6] & 3]++;
-        for (int i = 0; i < n_groups * 4; i++) tails += h[(size_t)n_groups * n_rb * K1_PLAN_INTS + i];
-        fprintf(stderr, "[slamhip] K1 plans: count %d groups %d n_rb %d budgets %d/%d | own %d shared %d global %d skip %d | tail sub-batches %d\n",
+
+        fprintf(stderr, "[slamhip] K1 plans: count %d groups %d n_rb %d budgets %d/%d | own %d shared %d global %d (-) %d | tail (sub-batch,chunk) pairs %d\n",
                 count, n_groups, n_rb, budget_shared_eff, budget_sub, kinds[0], kinds[1], kinds[2], kinds[3], tails);
         for (int b = 0; b < (n_rb < 3 ? n_rb : 3); b++)
             for (int sb = 0; sb < 4; sb++) {
@@ -561,38 +653,31 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                 fprintf(stderr, "   g0 b%d sb%d: x0a %d y0 %d w8 %d h %d lds %d shift %d kind %d\n", b, sb, r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
             }
     }
-    const int rblocks = sh_div_up(count, 256) < 256 ? sh_div_up(count, 256) : 256;
+    const int rblocks = sh_div_up(count, 64) < 512 ? sh_div_up(count, 64) : 512;
     if (tiled) {
         int bpc = (int)(((long long)n_groups * n_rb) / target_wgs);
         if (bpc < 1) bpc = 1;
         if (bpc > n_rb) bpc = n_rb;
         const int n_chunks = sh_div_up(n_rb, bpc);
-        // tail kernel: 256-lane blocks, ~64 rays per chunk
-        int bpc_t = sh_div_up(64 * n_rb, cs->n_points > 0 ? cs->n_points : 1);
-        if (bpc_t < 1) bpc_t = 1;
-        if (bpc_t > n_rb) bpc_t = n_rb;
-        const int n_chunks_t = sh_div_up(n_rb, bpc_t);
-        SH_TRY(ensure_partial(cs, (size_t)(n_chunks + n_chunks_t) * count));
+        SH_TRY(ensure_partial(cs, (size_t)(n_chunks + (use_tail_kernel ? n_chunks_t : 0)) * count));
         const size_t lds = (size_t)K1_PTS_BYTES + (size_t)(budget_shared > 4 * budget_sub ? budget_shared : 4 * budget_sub);
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
-            dim3 grid(n_groups, n_chunks);
-            if (verify)
-                hipLaunchKernelGGL(k1_distance_tiled<true>, grid, dim3(K1_WG), lds, ctx->stream,
-                                   cs->d_hole, cs->hs, cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, cs->d_plans,
-                                   (uint2 *)cs->d_partial, cs->d_verify);
-            else
-                hipLaunchKernelGGL(k1_distance_tiled<false>, grid, dim3(K1_WG), lds, ctx->stream,
-                                   cs->d_hole, cs->hs, cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, cs->d_plans,
-                                   (uint2 *)cs->d_partial, cs->d_verify);
-            hipLaunchKernelGGL(k1_distance_global<false>, dim3(sh_div_up(count, K1_THREADS), n_chunks_t), dim3(K1_THREADS), 0, ctx->stream,
-                               cs->d_hole, cs->hs, cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc_t, cs->d_pxcs, count,
-                               (uint2 *)cs->d_partial + (size_t)n_chunks * count, (const int *)tailp);
+            dim3 grid(n_groups * n_chunks);
+#define K1_LAUNCH(V, I) hipLaunchKernelGGL((k1_distance_tiled<V, I>), grid, dim3(K1_WG), lds, ctx->stream, cs->d_hole, cs->hs, \
+                       cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, cs->d_plans, (uint2 *)cs->d_partial, cs->d_verify, n_chunks)
+            if (verify) { if (use_tail_kernel) K1_LAUNCH(true, false); else K1_LAUNCH(true, true); }
+            else        { if (use_tail_kernel) K1_LAUNCH(false, false); else K1_LAUNCH(false, true); }
+#undef K1_LAUNCH
+            if (use_tail_kernel)
+                hipLaunchKernelGGL(k1_distance_global<false>, dim3(n_groups * 4, n_chunks_t), dim3(K1_THREADS), 0, ctx->stream,
+                                   cs->d_hole, cs->hs, cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc_t, cs->d_pxcs, count,
+                                   (uint2 *)cs->d_partial + (size_t)n_chunks * count, (const int *)cs->d_plans, (const int *)tailp);
         }
         {
             sh_timer t(ctx, SLAMHIP_K_CS_REDUCE);
-            hipLaunchKernelGGL(k1_reduce, dim3(rblocks), dim3(256), 0, ctx->stream, (const uint2 *)cs->d_partial, n_chunks, n_chunks_t,
-                               (const int *)tailp, count, cs->n_points, cs->d_ev_idx, dist, key);
+            hipLaunchKernelGGL(k1_reduce, dim3(rblocks), dim3(256), 0, ctx->stream, (const uint2 *)cs->d_partial, n_chunks,
+                               use_tail_kernel ? n_chunks_t : 0, (const int *)tailp, count, cs->n_points, cs->d_ev_idx, dist, key);
         }
     } else {
         int bpc = (int)(((long long)sh_div_up(count, K1_THREADS) * n_rb) / 4096);
@@ -605,10 +690,12 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             dim3 grid(sh_div_up(count, K1_THREADS), n_chunks);
             if (sane)
                 hipLaunchKernelGGL(k1_distance_global<false>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
-                                   cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial, (const int *)nullptr);
+                                   cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial,
+                                   (const int *)nullptr, (const int *)nullptr);
             else
                 hipLaunchKernelGGL(k1_distance_global<true>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
-                                   cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial, (const int *)nullptr);
+                                   cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial,
+                                   (const int *)nullptr, (const int *)nullptr);
         }
         {
             sh_timer t(ctx, SLAMHIP_K_CS_REDUCE);

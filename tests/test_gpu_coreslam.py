@@ -177,7 +177,10 @@ def test_k1_tile_boxes_selfcheck():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size"
-    for env_extra in ({"SLAMHIP_K1_VERIFY": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}, {"SLAMHIP_K1_TILE_KB": "8"}):
+    for env_extra in ({"SLAMHIP_K1_VERIFY": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}, {"SLAMHIP_K1_TILE_KB": "8"},
+                      {"SLAMHIP_K1_TAIL_KERNEL_FROM": "1"}, {"SLAMHIP_K1_TAIL_KERNEL_FROM": "1", "SLAMHIP_K1_TILE_KB": "24"},
+                      {"SLAMHIP_K1_TAIL_KERNEL_FROM": "1000000000", "SLAMHIP_K1_VERIFY": "1"},
+                      {"SLAMHIP_K1_TARGET_WGS": "64"}, {"SLAMHIP_K1_TARGET_WGS": "100000"}):
         env = dict(os.environ); env.update(env_extra); env["SLAMHIP_EXPECT_SELFCHECK"] = "1"
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q",
                             "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
