@@ -11,9 +11,10 @@
 // K5 replaces OccGridMap.UpdateByScan and friends (HectorSLAM/Map/OccGridMap.cs:114-239) for every level of
 // the pyramid (MapRepMultiMap.cs:73-77).  The once-per-scan guards make a cell's new value depend only on
 // (a) whether it is touched as free, (b) whether it is an end point, and (c) whether the first free touch
-// precedes the first end-point touch in ray order.  Pass 1 walks every ray and records
-// atomicMin(2*ray + isOcc) plus an end-point flag per cell; pass 2 re-walks, elects one fragment per cell
-// and replays the at most two state transitions literally -- bit-exact fp32 cell values.
+// precedes the first end-point touch in ray order.  Every cell of every line is an
+// independent fragment (closed-form Bresenham position): pass 0 records atomicMin(2*ray + isOcc) plus an
+// end-point flag per cell; pass 1 elects one fragment per cell and replays the at most two state
+// transitions literally -- bit-exact fp32 cell values.
 #include "common.h"
 #include "m3x2.h"
 #include <vector>
@@ -47,6 +48,10 @@ struct slamhip_hs {
     int n_points, cap_points;
     float2 *d_pts; float origin[2];
     float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
+    // K5 scratch: per (level, ray) line records, 64-fragment chunks, per-level chunk counts
+    struct k5_ray *d_rays; int cap_rays;
+    int *d_chunk_ray, *d_chunk_i0; int cap_chunks_per_level;
+    int *d_k5_counters;
 };
 
 struct hs_levels_arg { hs_level_dev lv[HS_MAX_LEVELS]; int n; };
@@ -187,71 +192,131 @@ k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, co
 struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; uint32_t *minkey; uint8_t *occ; int mark_free, mark_occ; };
 struct k5_arg { k5_level lv[HS_MAX_LEVELS]; int n; };
 
-// UpdateByScan (:126-141) + UpdateLineBresenhami (:155-190) + Bresenham2D (:220-239) for one ray on one
-// level; calls f(cell_index, is_occ) for every cell the reference would touch, in its order.
-template <typename F>
-__device__ static inline void k5_walk(const k5_level &L, float ox, float oy, float2 p, F f)
+// One line of OccGridMap.UpdateByScan on one level: UpdateLineBresenhami (:155-190) + Bresenham2D (:220-239).
+// The line has da "free" cells (steps i = 0..da-1, the end point excluded, :224-238) plus the occupied end cell.
+// Closed form of the error recurrence (:228-235): after i steps the walk has taken (e0 + i*db) / da minor steps
+// (db <= da, so at most one per step), which makes every cell of every ray an independent fragment.
+struct k5_ray {
+    int valid;
+    int start;            // begin.Y * W + begin.X                     (:172)
+    int da, db, e0;       // dominant / minor extent, initial error     (:175-185)
+    int oa, ob;           // index increments along dominant / minor    (:169-170)
+    int end_cell;         // end.Y * W + end.X                          (:187)
+    int chunk0, nchunks;  // 64-fragment chunks of the da + 1 fragments
+};
+#define K5_CHUNK 64
+
+__global__ void __launch_bounds__(256)
+k5_setup(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, k5_ray *__restrict__ rays, int cap_rays)
 {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const k5_level &L = A.lv[blockIdx.y];
+    k5_ray r;
+    memset(&r, 0, sizeof(r));
     float bxf, byf, exf, eyf;
     sh_v2_transform(ox, oy, L.t, &bxf, &byf);                              // :126
-    sh_v2_transform(p.x, p.y, L.t, &exf, &eyf);                            // :133
+    sh_v2_transform(pts[i].x, pts[i].y, L.t, &exf, &eyf);                  // :133
     const int bx = sh_f2i(rintf(bxf)), by = sh_f2i(rintf(byf));            // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
     const int ex = sh_f2i(rintf(exf)), ey = sh_f2i(rintf(eyf));            // :134
-    if (bx == ex && by == ey) return;                                      // :137
-    if (!(bx >= 0 && by >= 0 && bx < L.w && by < L.h) || !(ex >= 0 && ey >= 0 && ex < L.w && ey < L.h)) return;   // :158-161
-    const int dx = ex - bx, dy = ey - by;
-    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-    const int odx = sh_sign(dx), ody = sh_sign(dy) * L.w;                  // :169-170
-    int offset = by * L.w + bx;                                            // :172
-    int da, db, err, oa, ob;
-    if (adx >= ady) { da = adx; db = ady; err = adx / 2; oa = odx; ob = ody; }      // :175-179
-    else            { da = ady; db = adx; err = ady / 2; oa = ody; ob = odx; }      // :180-185
-    f(offset, 0);                                                          // :222
-    for (int i = 0; i < da - 1; ++i) {                                     // :224-226
-        offset += oa;
-        err += db;
-        if (err >= da) { offset += ob; err -= da; }                        // :231-235
-        f(offset, 0);                                                      // :237
+    const bool same = (bx == ex) & (by == ey);                             // :137
+    const bool inside = (bx >= 0) & (by >= 0) & (bx < L.w) & (by < L.h) & (ex >= 0) & (ey >= 0) & (ex < L.w) & (ey < L.h);   // :158-161
+    if (!same && inside) {
+        const int dx = ex - bx, dy = ey - by;
+        const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+        const int odx = sh_sign(dx), ody = sh_sign(dy) * L.w;              // :169-170
+        r.valid = 1;
+        r.start = by * L.w + bx;                                           // :172
+        if (adx >= ady) { r.da = adx; r.db = ady; r.e0 = adx / 2; r.oa = odx; r.ob = ody; }      // :175-179
+        else            { r.da = ady; r.db = adx; r.e0 = ady / 2; r.oa = ody; r.ob = odx; }      // :180-185
+        r.end_cell = ey * L.w + ex;                                        // :187
+        r.nchunks = (r.da + 1 + K5_CHUNK - 1) / K5_CHUNK;
     }
-    f(ey * L.w + ex, 1);                                                   // :187-189
+    rays[(size_t)blockIdx.y * cap_rays + i] = r;
+}
+
+// exclusive prefix of nchunks over the rays of one level (one workgroup per level)
+__global__ void __launch_bounds__(1024)
+k5_scan_chunks(k5_ray *__restrict__ rays_all, int n, int cap_rays, int *__restrict__ counters)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    k5_ray *rays = rays_all + (size_t)blockIdx.x * cap_rays;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < n && rays[i].valid) ? rays[i].nchunks : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; w++) woff += wsum[w];
+        const int excl = carry + woff + incl - v;
+        if (i < n) rays[i].chunk0 = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counters[blockIdx.x] = carry;
 }
 
 __global__ void __launch_bounds__(256)
-k5_mark(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy)
+k5_fill_chunks(const k5_ray *__restrict__ rays_all, int n, int cap_rays, int *__restrict__ chunk_ray, int *__restrict__ chunk_i0,
+               int cap_chunks)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const k5_ray r = rays_all[(size_t)blockIdx.y * cap_rays + i];
+    if (!r.valid) return;
+    int *cr = chunk_ray + (size_t)blockIdx.y * cap_chunks, *ci = chunk_i0 + (size_t)blockIdx.y * cap_chunks;
+    for (int k = 0; k < r.nchunks; k++)
+        if (r.chunk0 + k < cap_chunks) { cr[r.chunk0 + k] = i; ci[r.chunk0 + k] = k * K5_CHUNK; }
+}
+
+// One lane per fragment.  PASS 0 records, per cell, the earliest touch in ray order as atomicMin(2*ray + isOcc)
+// plus an end-point flag; PASS 1 elects one fragment per touched cell and replays the (at most two) state
+// transitions of BresenhamCellFree / BresenhamCellOcc literally.
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k5_fragments(k5_arg A, const k5_ray *__restrict__ rays_all, int cap_rays, const int *__restrict__ chunk_ray,
+             const int *__restrict__ chunk_i0, int cap_chunks, const int *__restrict__ counters, float lo_free, float lo_occ)
+{
+    const int chunk = blockIdx.x * (256 / K5_CHUNK) + (threadIdx.x >> 6);
+    if (chunk >= counters[blockIdx.y]) return;                             // wave-uniform
     const k5_level &L = A.lv[blockIdx.y];
-    k5_walk(L, ox, oy, pts[i], [&](int cell, int is_occ) {
-        atomicMin(&L.minkey[cell], 2u * (uint32_t)i + (uint32_t)is_occ);
+    const int ray = chunk_ray[(size_t)blockIdx.y * cap_chunks + chunk];
+    const k5_ray r = rays_all[(size_t)blockIdx.y * cap_rays + ray];
+    const int i = chunk_i0[(size_t)blockIdx.y * cap_chunks + chunk] + (threadIdx.x & 63);
+    if (i > r.da) return;
+    const int is_occ = i == r.da;
+    const int cell = is_occ ? r.end_cell : r.start + i * r.oa + ((r.e0 + i * r.db) / r.da) * r.ob;
+    if (PASS == 0) {
+        atomicMin(&L.minkey[cell], 2u * (uint32_t)ray + (uint32_t)is_occ);
         if (is_occ) L.occ[cell] = 1;
-    });
-}
-
-__global__ void __launch_bounds__(256)
-k5_resolve(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, float lo_free, float lo_occ)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const k5_level &L = A.lv[blockIdx.y];
-    k5_walk(L, ox, oy, pts[i], [&](int cell, int) {
-        const uint32_t k = atomicExch(&L.minkey[cell], HS_NONE);          // elect one fragment per cell
-        if (k == HS_NONE) return;
-        const bool has_occ = L.occ[cell] != 0;
-        L.occ[cell] = 0;
-        float v = L.value[cell];
-        int u = L.upd[cell];
-        if ((k & 1u) == 0u) {                                              // first touch in ray order is "free"
-            if (u < L.mark_free) { v += lo_free; u = L.mark_free; }        // BresenhamCellFree :192-199
-        }
-        if (has_occ && u < L.mark_occ) {                                   // BresenhamCellOcc :201-218
-            if (u == L.mark_free) v -= lo_free;                            // :206-209
-            if (v < 50.0f) v += lo_occ;                                    // :211-214
-            u = L.mark_occ;                                                // :216
-        }
-        L.value[cell] = v;
-        L.upd[cell] = u;
-    });
+        return;
+    }
+    const uint32_t k = atomicExch(&L.minkey[cell], HS_NONE);               // elect one fragment per cell
+    if (k == HS_NONE) return;
+    const bool has_occ = L.occ[cell] != 0;
+    L.occ[cell] = 0;
+    float v = L.value[cell];
+    int u = L.upd[cell];
+    if ((k & 1u) == 0u) {                                                  // first touch in ray order is "free"
+        if (u < L.mark_free) { v += lo_free; u = L.mark_free; }            // BresenhamCellFree :192-199
+    }
+    if (has_occ && u < L.mark_occ) {                                       // BresenhamCellOcc :201-218
+        if (u == L.mark_free) v -= lo_free;                                // :206-209
+        if (v < 50.0f) v += lo_occ;                                        // :211-214
+        u = L.mark_occ;                                                    // :216
+    }
+    L.value[cell] = v;
+    L.upd[cell] = u;
 }
 
 __global__ void k5_fill_cells(float *value, int32_t *upd, uint32_t *minkey, uint8_t *occ, size_t n)
@@ -313,6 +378,7 @@ extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
         (void)hipFree(hs->lv[l].d_minkey); (void)hipFree(hs->lv[l].d_occ);
     }
     (void)hipFree(hs->d_pts); (void)hipFree(hs->d_io);
+    (void)hipFree(hs->d_rays); (void)hipFree(hs->d_chunk_ray); (void)hipFree(hs->d_chunk_i0); (void)hipFree(hs->d_k5_counters);
     if (hs->h_io) (void)hipHostFree(hs->h_io);
     free(hs);
     return SLAMHIP_OK;
@@ -577,11 +643,37 @@ extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3]
         A.lv[l].mark_occ = L.curr_update_index + 2;                       // :117
     }
     if (n > 0) {
+        if (n > hs->cap_rays || !hs->d_k5_counters) {
+            (void)hipFree(hs->d_rays); (void)hipFree(hs->d_chunk_ray); (void)hipFree(hs->d_chunk_i0);
+            hs->d_rays = nullptr; hs->d_chunk_ray = hs->d_chunk_i0 = nullptr; hs->cap_rays = 0;
+            const int cap = n + n / 4 + 64;
+            int maxdim = 0;
+            for (int l = 0; l < hs->n_levels; l++) { if (hs->lv[l].w > maxdim) maxdim = hs->lv[l].w; if (hs->lv[l].h > maxdim) maxdim = hs->lv[l].h; }
+            const long long cpl = (long long)cap * ((maxdim + 1 + K5_CHUNK - 1) / K5_CHUNK + 1);      // da + 1 <= max(w, h)
+            SH_HIP(hipMalloc(&hs->d_rays, sizeof(k5_ray) * (size_t)cap * HS_MAX_LEVELS));
+            SH_HIP(hipMalloc(&hs->d_chunk_ray, sizeof(int) * (size_t)cpl * hs->n_levels));
+            SH_HIP(hipMalloc(&hs->d_chunk_i0, sizeof(int) * (size_t)cpl * hs->n_levels));
+            if (!hs->d_k5_counters) SH_HIP(hipMalloc(&hs->d_k5_counters, sizeof(int) * HS_MAX_LEVELS));
+            hs->cap_rays = cap; hs->cap_chunks_per_level = (int)cpl;
+        }
         sh_timer t(ctx, SLAMHIP_K_HS_UPDATE);
-        const dim3 grid(sh_div_up(n, 256), hs->n_levels);                 // all levels in one launch (MapRepMultiMap.cs:76)
-        hipLaunchKernelGGL(k5_mark, grid, dim3(256), 0, ctx->stream, A, hs->d_pts, n, hs->origin[0], hs->origin[1]);
-        hipLaunchKernelGGL(k5_resolve, grid, dim3(256), 0, ctx->stream, A, hs->d_pts, n, hs->origin[0], hs->origin[1],
-                           hs->lo_free, hs->lo_occ);
+        const dim3 rgrid(sh_div_up(n, 256), hs->n_levels);                // all levels in every launch (MapRepMultiMap.cs:76)
+        hipLaunchKernelGGL(k5_setup, rgrid, dim3(256), 0, ctx->stream, A, hs->d_pts, n, hs->origin[0], hs->origin[1], hs->d_rays, hs->cap_rays);
+        hipLaunchKernelGGL(k5_scan_chunks, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, hs->d_rays, n, hs->cap_rays, hs->d_k5_counters);
+        hipLaunchKernelGGL(k5_fill_chunks, rgrid, dim3(256), 0, ctx->stream, (const k5_ray *)hs->d_rays, n, hs->cap_rays,
+                           hs->d_chunk_ray, hs->d_chunk_i0, hs->cap_chunks_per_level);
+        // upper bound of chunks per level for the grid: every ray at the longest line of the finest level
+        int maxdim = 0;
+        for (int l = 0; l < hs->n_levels; l++) { if (hs->lv[l].w > maxdim) maxdim = hs->lv[l].w; if (hs->lv[l].h > maxdim) maxdim = hs->lv[l].h; }
+        long long bound = (long long)n * ((maxdim + 1 + K5_CHUNK - 1) / K5_CHUNK);
+        if (bound > hs->cap_chunks_per_level) bound = hs->cap_chunks_per_level;
+        const dim3 fgrid(sh_div_up((int)bound, 256 / K5_CHUNK), hs->n_levels);
+        hipLaunchKernelGGL(k5_fragments<0>, fgrid, dim3(256), 0, ctx->stream, A, (const k5_ray *)hs->d_rays, hs->cap_rays,
+                           (const int *)hs->d_chunk_ray, (const int *)hs->d_chunk_i0, hs->cap_chunks_per_level,
+                           (const int *)hs->d_k5_counters, hs->lo_free, hs->lo_occ);
+        hipLaunchKernelGGL(k5_fragments<1>, fgrid, dim3(256), 0, ctx->stream, A, (const k5_ray *)hs->d_rays, hs->cap_rays,
+                           (const int *)hs->d_chunk_ray, (const int *)hs->d_chunk_i0, hs->cap_chunks_per_level,
+                           (const int *)hs->d_k5_counters, hs->lo_free, hs->lo_occ);
     }
     SH_HIP(hipGetLastError());
     for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144

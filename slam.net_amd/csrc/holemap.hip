@@ -154,12 +154,18 @@ k2_scan_chunks(cs_ray *__restrict__ rays, int n, int *__restrict__ counters)
 {
     __shared__ int wsum[16];
     __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
+    __shared__ int total_px;
+    if (threadIdx.x == 0) { carry = 0; total_px = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
         int v = (i < n && rays[i].valid) ? rays[i].nchunks : 0;
+        // every step x = 0..dxc of a valid ray blends exactly one pixel (:404,:431): the blended-pixel statistic is
+        // a plain sum (a per-wave atomic on one address would serialise at ~12 ns each and dominate the update)
+        int px = (i < n && rays[i].valid) ? rays[i].dxc + 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) px += __shfl_down(px, off, 64);
+        if (lane == 0 && px) atomicAdd(&total_px, px);
         int incl = v;
         for (int off = 1; off < 64; off <<= 1) {
             int o = __shfl_up(incl, off, 64);
@@ -175,7 +181,7 @@ k2_scan_chunks(cs_ray *__restrict__ rays, int n, int *__restrict__ counters)
         if (threadIdx.x == 1023) carry = excl + v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { counters[0] = carry; counters[1] = 0; counters[2] = 0; }
+    if (threadIdx.x == 0) { counters[0] = carry; counters[1] = 0; counters[2] = total_px; }
 }
 
 __global__ void __launch_bounds__(256)
@@ -255,17 +261,14 @@ k2_fragments(const cs_ray *__restrict__ rays, const int *__restrict__ chunk_ray,
         return;
     }
     // PASS 2
-    int blended = 0;
     if (n == 1) {
         map[ptr] = k2_blend(map[ptr], k2_pixval(r, x), alpha);
         cnt[ptr] = 0;
-        blended = 1;
     } else if (n > 1) {
         const uint32_t won = atomicExch(&cnt[ptr], 0u);      // elect one fragment per pixel
         if (won != 0) {
             const int lo = vmin[ptr], hi = vmax[ptr];
             vmin[ptr] = INT32_MAX; vmax[ptr] = INT32_MIN;
-            blended = (int)won;
             if (lo == hi) {                                  // same pixval from every ray: order-free
                 uint16_t pix = map[ptr];
                 for (uint32_t k = 0; k < won; k++) pix = k2_blend(pix, lo, alpha);
@@ -276,9 +279,6 @@ k2_fragments(const cs_ray *__restrict__ rays, const int *__restrict__ chunk_ray,
             }
         }
     }
-    // one atomic per wavefront for the blended-pixel statistic
-    for (int off = 32; off > 0; off >>= 1) blended += __shfl_down(blended, off, 64);
-    if ((threadIdx.x & 63) == 0 && blended) atomicAdd(&counters[2], blended);
 }
 
 // One wavefront per conflict pixel: find the rays that touch it, in ray order, and blend in that order.
