@@ -51,6 +51,7 @@ def main():
     import slam.net_amd.capi as capi
     import slam.net_amd.coreslam as cs
     import slam.net_amd.sim as sim
+    import slam.net_amd.distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -82,7 +83,7 @@ def main():
     offs = sim.gaussian_offsets(K_total - 1, 0.1, math.radians(10.0), seed=42)
     dev.set_scan(xy)
     dev.set_offsets(offs)
-    first, count = rank * a.cands, a.cands
+    first, count = D.shard_range(rank, world, K_total)            # contiguous block of the flat list per rank
 
     key = torch.full((1,), -1, dtype=torch.int64, device="cuda")
     ext = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", local))
@@ -91,7 +92,7 @@ def main():
         dev.search_shard_async(base, first, count, key.data_ptr())
         if world > 1:
             with torch.cuda.stream(ext):
-                dist.all_reduce(key, op=dist.ReduceOp.MIN)
+                D.allreduce_min_key(key)                           # one 8-byte RCCL min all-reduce per step
 
     def sync_all():
         ctx.synchronize()
@@ -133,7 +134,7 @@ def main():
             avg_s = (k1_ms / k1_n) * 1e-3
             achieved = a.cands * bytes_per_eval / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a),
                     "kernel": "k1_distance", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
                     "bytes_per_launch": a.cands * bytes_per_eval}
         out = {
@@ -156,6 +157,22 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(a):
+    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of this very command, gfx950 read-side correction applied; profiles/r01_k1_traffic.json).
+    PMC counters cannot be read from inside the timed run, so the figure is only reported when the committed
+    profile was taken on the same workload; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_k1_traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if (w["map"], w["rays"], w["candidates_per_gpu"]) == (a.size, a.rays, a.cands):
+            return int(t["hbm_bytes_per_launch_gfx950_corrected"])
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(a, dev, xy, base, offs, gpu_key):

@@ -16,7 +16,7 @@
 //   resolve  one wavefront per conflict pixel: test all rays in ray order (closed form), apply the
 //            matching fragments' blends in that order
 // Closed form: after i iterations of the error recurrence (:394-396,:433-441) the walk has taken
-//   m(i) = min(i, max(0, ceil((2*dyc*i - dxc) / (2*dxc))))   minor steps     (tests/test_holemap_closed_form.py)
+//   m(i) = min(i, max(0, ceil((2*dyc*i - dxc) / (2*dxc))))   minor steps     (tests/test_closed_forms.py)
 // All integer arithmetic wraps like C# unchecked int; float->int follows cvttss2si (sh_f2i).
 // Deviations from the reference (all in exception / platform-dependent territory; the oracle does the same):
 //   D1 non-representable pixel coordinates (NaN/inf, e.g. zero-range point) skip the ray;
