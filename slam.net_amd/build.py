@@ -22,6 +22,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
+def extra_defs():
+    """Compile-time tunables (measured defaults live in the sources)."""
+    d = []
+    if os.environ.get("SLAMHIP_K1_WG"):
+        d.append("-DK1_WG=%d" % int(os.environ["SLAMHIP_K1_WG"]))
+    return d
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -53,7 +61,7 @@ def build(force=False, verbose=False):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
                 and os.path.getmtime(obj) > hdr_t and os.path.getmtime(obj) > os.path.getmtime(os.path.abspath(__file__))):
             continue
-        cmd = [cc] + FLAGS + ["-c", spath, "-o", obj]
+        cmd = [cc] + FLAGS + extra_defs() + ["-c", spath, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(K1_THREADS)
 k1_distance_global(const uint16_t *__restrict__ map, int S, const float2 *__restrict__ pts,
                    const int *__restrict__ rb_start, int n_rb, int blocks_per_chunk,
                    const float4 *__restrict__ pxcs, int count, uint2 *__restrict__ partial,
-                   const int *__restrict__ plans, const int *__restrict__ tailmask)
+                   const int *__restrict__ plans, const int *__restrict__ tailmask, int nsub)
 {
     const int chunk = blockIdx.y;
     if (tailmask && !tailmask[blockIdx.x * gridDim.y + chunk]) return;
@@ -86,8 +86,8 @@ k1_distance_global(const uint16_t *__restrict__ map, int S, const float2 *__rest
     const float4 q = pxcs[j < count ? j : count - 1];
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     for (int b = b0; b < b1; b++) {
-        if (plans) {       // sub-batch blockIdx.x = (group blockIdx.x >> 2, sub blockIdx.x & 3)
-            const int kind = plans[((size_t)(blockIdx.x >> 2) * n_rb + b) * 32 + (blockIdx.x & 3) * 8 + 6];
+        if (plans) {       // sub-batch blockIdx.x = (group blockIdx.x / nsub, sub blockIdx.x % nsub)
+            const int kind = plans[((size_t)(blockIdx.x / nsub) * n_rb + b) * 32 + (blockIdx.x % nsub) * 8 + 6];
             if (kind != 2) continue;
         }
         int r = rb_start[b];
@@ -122,8 +122,12 @@ k1_distance_global(const uint16_t *__restrict__ map, int S, const float2 *__rest
 // A workgroup = 1024 lanes = 1024 theta-consecutive candidates ("group") = 4 sub-batches of 256.
 // For every (group, ray block) the prep kernel has written a PLAN: either one shared tile that bounds the
 // end points of all 1024 candidates, or one tile per sub-batch, or (per sub-batch) "global fallback".
-#define K1_WG 1024
+#ifndef K1_WG
+#define K1_WG 1024                     // lanes = candidates per workgroup ("group"); 512 or 1024
+#endif
 #define K1_SUB 256
+#define K1_NSUB (K1_WG / K1_SUB)        // sub-batches per group
+#define K1_NWAVES (K1_WG / 64)
 #define K1_PF 5                        // prefetch registers (16-byte vectors) per lane
 #define K1_PLAN_INTS 32                // 4 sub-batch records x 8 ints, each fully resolved
 #define K1_KIND_OWN 0                  // the sub-batch has its own tile, staged by its 4 waves
@@ -183,9 +187,9 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
 {
     __shared__ unsigned char kind_all[K1_MAX_RB * 4];            // plan kind per (ray block, sub-batch) of this group
     __shared__ int srb[K1_MAX_RB + 1];                           // rb_start staged once: every later use is an LDS read
-    __shared__ float wred[16][8];
-    __shared__ float bnd[5][8];
-    __shared__ int boxes[K1_PLAN_BATCH * 5][4];
+    __shared__ float wred[K1_NWAVES][8];
+    __shared__ float bnd[K1_NSUB + 1][8];                        // per sub-batch, then the whole group
+    __shared__ int boxes[K1_PLAN_BATCH * (K1_NSUB + 1)][4];
     __shared__ float2 spts[K1_PLAN_BATCH * CS_RB_MAX / 4];       // the points of one batch of ray blocks (<= 2048)
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, g = blockIdx.x;
     const int j = g * K1_WG + t;
@@ -221,7 +225,7 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
         }
     }
     __syncthreads();
-    if (t < 32) {
+    if (t < K1_NSUB * 8) {
         const int sb = t >> 3, k = t & 7;
         float x = wred[sb * 4][k];
         for (int w = 1; w < 4; w++) x = (k & 1) ? fmaxf(x, wred[sb * 4 + w][k]) : fminf(x, wred[sb * 4 + w][k]);
@@ -230,8 +234,8 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
     __syncthreads();
     if (t < 8) {
         float x = bnd[0][t];
-        for (int i = 1; i < 4; i++) x = (t & 1) ? fmaxf(x, bnd[i][t]) : fminf(x, bnd[i][t]);
-        bnd[4][t] = x;
+        for (int i = 1; i < K1_NSUB; i++) x = (t & 1) ? fmaxf(x, bnd[i][t]) : fminf(x, bnd[i][t]);
+        bnd[K1_NSUB][t] = x;
     }
     __syncthreads();
     if (!plans) return;
@@ -243,14 +247,14 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
         const int npts = srb[base + nb] - rbase;
         for (int i = t; i < npts; i += K1_WG) spts[i] = pts[rbase + i];
         __syncthreads();
-        for (int pair = t; pair < nb * 5; pair += K1_WG) {
+        for (int pair = t; pair < nb * (K1_NSUB + 1); pair += K1_WG) {
             boxes[pair][0] = INT32_MAX; boxes[pair][1] = INT32_MAX; boxes[pair][2] = INT32_MIN; boxes[pair][3] = INT32_MIN;
         }
         __syncthreads();
         // one task = (ray block, candidate set, quarter of the block's rays); LDS atomics merge the quarters
-        for (int task = t; task < nb * 20; task += K1_WG) {
+        for (int task = t; task < nb * (K1_NSUB + 1) * 4; task += K1_WG) {
             const int pair = task >> 2, qr = task & 3;
-            const int b = base + pair / 5, set = pair % 5;
+            const int b = base + pair / (K1_NSUB + 1), set = pair % (K1_NSUB + 1);
             const int ra = srb[b] - rbase, rn = srb[b + 1] - srb[b];
             const int q0 = ra + (rn * qr) / 4, q1 = ra + (rn * (qr + 1)) / 4;
             float bb8[8];
@@ -268,13 +272,13 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
             }
         }
         __syncthreads();
-        if (t < nb * 4) {
+        if (t < nb * K1_NSUB) {
             // one thread per (ray block, sub-batch): the record is fully resolved, no second lookup in K1
-            const int bb = t >> 2, sb = t & 3;
+            const int bb = t / K1_NSUB, sb = t % K1_NSUB;
             int rec[8] = { 0, 0, 8, 0, 0, 0, K1_KIND_GLOBAL, 0 };
             auto tile = [&](int set, int budget, int lds_off, int n_waves) -> bool {
-                const int x0 = boxes[bb * 5 + set][0], y0 = boxes[bb * 5 + set][1];
-                const int x1 = boxes[bb * 5 + set][2], y1 = boxes[bb * 5 + set][3];
+                const int x0 = boxes[bb * (K1_NSUB + 1) + set][0], y0 = boxes[bb * (K1_NSUB + 1) + set][1];
+                const int x1 = boxes[bb * (K1_NSUB + 1) + set][2], y1 = boxes[bb * (K1_NSUB + 1) + set][3];
                 const bool inside = (x0 >= 0) & (y0 >= 0) & (x1 < S) & (y1 < S) & (x1 >= x0) & (y1 >= y0);
                 if (!inside) return false;
                 const int x0a = x0 & ~7;
@@ -289,7 +293,7 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
                 rec[0] = x0a; rec[1] = y0; rec[2] = w8; rec[3] = h; rec[4] = lds_off; rec[5] = shift;
                 return true;
             };
-            if (tile(4, budget_shared, 0, 16)) rec[6] = K1_KIND_SHARED;
+            if (tile(K1_NSUB, budget_shared, 0, K1_NWAVES)) rec[6] = K1_KIND_SHARED;
             else if (tile(sb, budget_sub, sb * budget_sub, 4)) rec[6] = K1_KIND_OWN;
             kind_all[(base + bb) * 4 + sb] = (unsigned char)rec[6];
             int4 *dst = (int4 *)(plans + ((size_t)g * n_rb + base + bb) * K1_PLAN_INTS + sb * 8);
@@ -301,18 +305,18 @@ k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, floa
     }
     // which (sub-batch, tail chunk) pairs hold at least one GLOBAL unit (only when a separate tail kernel is used)
     if (tailmask)
-    for (int i = t; i < 4 * n_chunks_tail; i += K1_WG) {
+    for (int i = t; i < K1_NSUB * n_chunks_tail; i += K1_WG) {
         const int sb = i / n_chunks_tail, ct = i - sb * n_chunks_tail;
         const int c0 = ct * bpc_tail, c1 = c0 + bpc_tail < n_rb ? c0 + bpc_tail : n_rb;
         int any = 0;
         for (int b = c0; b < c1; b++) any |= (kind_all[b * 4 + sb] == K1_KIND_GLOBAL);
-        tailmask[((size_t)g * 4 + sb) * n_chunks_tail + ct] = any;
+        tailmask[((size_t)g * K1_NSUB + sb) * n_chunks_tail + ct] = any;
     }
 }
 
 // ---- the distance kernel -------------------------------------------------------------------------------------
 template <bool VERIFY, bool INLINE_GLOBAL>
-__global__ void __launch_bounds__(K1_WG, 8)          // 8 waves / SIMD = two 1024-lane workgroups per CU (<= 64 VGPRs)
+__global__ void __launch_bounds__(K1_WG, 8)          // 8 waves / SIMD resident (<= 64 VGPRs): 32 waves per CU
 k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restrict__ pts,
                   const int *__restrict__ rb_start, int n_rb, int blocks_per_chunk,
                   const float4 *__restrict__ pxcs, int count, const int *__restrict__ plans,
@@ -375,7 +379,7 @@ k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restr
         const int pitchb = w8_ << 1;                                                                \
         const int ldsb = pb_.x + (cc << 4);                                                         \
         const int wslot = kind_ == K1_KIND_SHARED ? wv : (wv & 3);                                  \
-        const int nwv = kind_ == K1_KIND_SHARED ? 16 : 4;                                           \
+        const int nwv = kind_ == K1_KIND_SHARED ? K1_NWAVES : 4;                                    \
         K1_STAGE_ONE(R0, d0, 0) K1_STAGE_ONE(R1, d1, 1) K1_STAGE_ONE(R2, d2, 2)                     \
         K1_STAGE_ONE(R3, d3, 3) K1_STAGE_ONE(R4, d4, 4)                                             \
     }
@@ -610,7 +614,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 
     int budget_shared = tile_kb * 1024;
     if (budget_shared > K1_WG * K1_PF * 16) budget_shared = K1_WG * K1_PF * 16;      // what 4 prefetch vectors/lane can stage
-    int budget_sub = budget_shared / 4;
+    int budget_sub = budget_shared / K1_NSUB;
     static const int sub_kb = env_int("SLAMHIP_K1_SUB_KB", 0);         // debugging: decouple the two budgets
     static const int no_shared = env_int("SLAMHIP_K1_NOSHARED", 0);
     if (sub_kb > 0) budget_sub = sub_kb * 1024;
@@ -622,7 +626,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     if (bpc_t < 1) bpc_t = 1;
     if (bpc_t > n_rb) bpc_t = n_rb;
     const int n_chunks_t = sh_div_up(n_rb, bpc_t);
-    if (tiled) SH_TRY(ensure_plans(cs, (size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * 4 * n_chunks_t));
+    if (tiled) SH_TRY(ensure_plans(cs, (size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * K1_NSUB * n_chunks_t));
     // GLOBAL units (no LDS tile fits): small launches evaluate them inline in the tiled kernel, where the other waves
     // hide their latency; from ~48k candidates on, a separate many-wave tail kernel is faster (measured on MI355X)
     static const int tail_threshold = env_int("SLAMHIP_K1_TAIL_KERNEL_FROM", 49152);
@@ -639,7 +643,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     }
     static const int dump = env_int("SLAMHIP_K1_DUMP", 0);
     if (dump && tiled) {                                           // debugging aid: histogram of plan kinds
-        std::vector<int> h((size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * 4 * n_chunks_t);
+        std::vector<int> h((size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * K1_NSUB * n_chunks_t);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipMemcpy(h.data(), cs->d_plans, sizeof(int) * h.size(), hipMemcpyDeviceToHost);
         int kinds[4] = { 0, 0, 0, 0 }, tails = 0;
@@ -660,7 +664,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         if (bpc > n_rb) bpc = n_rb;
         const int n_chunks = sh_div_up(n_rb, bpc);
         SH_TRY(ensure_partial(cs, (size_t)(n_chunks + (use_tail_kernel ? n_chunks_t : 0)) * count));
-        const size_t lds = (size_t)K1_PTS_BYTES + (size_t)(budget_shared > 4 * budget_sub ? budget_shared : 4 * budget_sub);
+        const size_t lds = (size_t)K1_PTS_BYTES + (size_t)(budget_shared > K1_NSUB * budget_sub ? budget_shared : K1_NSUB * budget_sub);
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
             dim3 grid(n_groups * n_chunks);
@@ -670,9 +674,9 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             else        { if (use_tail_kernel) K1_LAUNCH(false, false); else K1_LAUNCH(false, true); }
 #undef K1_LAUNCH
             if (use_tail_kernel)
-                hipLaunchKernelGGL(k1_distance_global<false>, dim3(n_groups * 4, n_chunks_t), dim3(K1_THREADS), 0, ctx->stream,
+                hipLaunchKernelGGL(k1_distance_global<false>, dim3(n_groups * K1_NSUB, n_chunks_t), dim3(K1_THREADS), 0, ctx->stream,
                                    cs->d_hole, cs->hs, cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc_t, cs->d_pxcs, count,
-                                   (uint2 *)cs->d_partial + (size_t)n_chunks * count, (const int *)cs->d_plans, (const int *)tailp);
+                                   (uint2 *)cs->d_partial + (size_t)n_chunks * count, (const int *)cs->d_plans, (const int *)tailp, K1_NSUB);
         }
         {
             sh_timer t(ctx, SLAMHIP_K_CS_REDUCE);
@@ -691,11 +695,11 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             if (sane)
                 hipLaunchKernelGGL(k1_distance_global<false>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
                                    cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial,
-                                   (const int *)nullptr, (const int *)nullptr);
+                                   (const int *)nullptr, (const int *)nullptr, 1);
             else
                 hipLaunchKernelGGL(k1_distance_global<true>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
                                    cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial,
-                                   (const int *)nullptr, (const int *)nullptr);
+                                   (const int *)nullptr, (const int *)nullptr, 1);
         }
         {
             sh_timer t(ctx, SLAMHIP_K_CS_REDUCE);
