@@ -25,8 +25,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 def extra_defs():
     """Compile-time tunables (measured defaults live in the sources)."""
     d = []
-    if os.environ.get("SLAMHIP_K1_WG"):
-        d.append("-DK1_WG=%d" % int(os.environ["SLAMHIP_K1_WG"]))
+    if os.environ.get("SLAMHIP_K1_TIMES"):      # developer build: per-workgroup phase stamps in the fused K1 kernel
+        d.append("-DK1_TIMES=1")
+    if os.environ.get("SLAMHIP_K1_FAKETRIG"):   # developer experiment only (wrong results): cost of the trigonometry
+        d.append("-DK1_FAKETRIG=1")
+    if os.environ.get("SLAMHIP_K1_EXP"):        # developer experiments only (wrong results)
+        d.append("-DK1_EXP%s=1" % os.environ["SLAMHIP_K1_EXP"])
     return d
 
 

@@ -23,12 +23,15 @@ __global__ void k_pack_holemap(const uint16_t *__restrict__ pix, uint8_t *__rest
 }
 
 // evaluation list: ev_idx[j] (or first + j) is a flat candidate index; flat 0 is the un-jittered pose
+// (theta-sorted flat lists: the un-jittered pose, dtheta = 0, is evaluated at position zero_pos, between the
+// negative and the positive dtheta, so that it does not widen the theta range of the first group)
 __global__ void k_gather_offsets(const float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first,
-                                 int count, float *__restrict__ ev_off, int *__restrict__ ev_idx_out)
+                                 int count, int zero_pos, float *__restrict__ ev_off, int *__restrict__ ev_idx_out)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    const int flat = ev_idx_in ? ev_idx_in[j] : first + j;
+    int flat = ev_idx_in ? ev_idx_in[j] : first + j;
+    if (!ev_idx_in && zero_pos >= 0) flat = j < zero_pos ? j + 1 : j == zero_pos ? 0 : j;
     float ox = 0.f, oy = 0.f, ot = 0.f;
     if (flat > 0) { ox = offs_flat[3 * (flat - 1)]; oy = offs_flat[3 * (flat - 1) + 1]; ot = offs_flat[3 * (flat - 1) + 2]; }
     ev_off[3 * j] = ox; ev_off[3 * j + 1] = oy; ev_off[3 * j + 2] = ot;
@@ -88,10 +91,11 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipSetDevice(cs->ctx->device);
     (void)hipStreamSynchronize(cs->ctx->stream);
     (void)hipFree(cs->d_hole); (void)hipFree(cs->d_obst);
-    (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start);
+    (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start); (void)hipFree(cs->d_ray_blk);
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
-    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose); (void)hipFree(cs->d_verify); (void)hipFree(cs->d_plans);
+    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose); (void)hipFree(cs->d_verify);
+    (void)hipFree(cs->d_k1_tickets); (void)hipFree(cs->d_k1_gkey); (void)hipFree(cs->d_k1_acc);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
     cs_holemap_free(cs);
     cs_obstacle_free(cs);
@@ -111,15 +115,16 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
     cs->hs = hole_size; cs->hscale = (float)hole_size / physical;          // HoleMap.cs:19-20
     cs->os = obst_size; cs->oscale = (float)obst_size / physical;          // ObstacleMap.cs:19-20
     cs->shard_first = cs->shard_count = -1;
+    cs->offs_theta_small = true; cs->k1_layout_dirty = true; cs->k1_tickets_groups = -1;
     int32_t rc = SLAMHIP_OK;
     do {
         if (hipMalloc(&cs->d_hole, sizeof(uint16_t) * (size_t)hole_size * hole_size) != hipSuccess ||
             hipMalloc(&cs->d_obst, (size_t)obst_size * obst_size) != hipSuccess ||
             hipMalloc(&cs->d_key, sizeof(uint64_t)) != hipSuccess ||
             hipMalloc(&cs->d_best_pose, sizeof(float) * 4) != hipSuccess ||
-            hipMalloc(&cs->d_verify, sizeof(unsigned int) * 4) != hipSuccess ||
-            hipHostMalloc(&cs->h_key, 64) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
-        if (hipMemset(cs->d_verify, 0, sizeof(unsigned int) * 4) != hipSuccess) { slamhip_set_error("hipMemset failed"); rc = SLAMHIP_ERR_HIP; break; }
+            hipMalloc(&cs->d_verify, sizeof(unsigned int) * 8) != hipSuccess ||
+            hipHostMalloc(&cs->h_key, 128) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
+        if (hipMemset(cs->d_verify, 0, sizeof(unsigned int) * 8) != hipSuccess) { slamhip_set_error("hipMemset failed"); rc = SLAMHIP_ERR_HIP; break; }
         if ((rc = cs_holemap_alloc(cs)) != SLAMHIP_OK) break;
         if ((rc = cs_obstacle_alloc(cs)) != SLAMHIP_OK) break;
         if ((rc = slamhip_cs_reset(cs, -5)) != SLAMHIP_OK) break;          // CoreSLAMProcessor.cs:96,:140
@@ -218,9 +223,10 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     cs->n_rb = 0;
     if (n == 0) return SLAMHIP_OK;
     if (n > cs->cap_points) {
-        (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start);
-        cs->d_pts = cs->d_pts_sorted = nullptr; cs->d_rb_start = nullptr; cs->cap_points = 0;
+        (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start); (void)hipFree(cs->d_ray_blk);
+        cs->d_pts = cs->d_pts_sorted = nullptr; cs->d_rb_start = nullptr; cs->d_ray_blk = nullptr; cs->cap_points = 0;
         const int cap = n + n / 4 + 64;
+        SH_HIP(hipMalloc(&cs->d_ray_blk, sizeof(int4) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_pts, sizeof(float2) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_pts_sorted, sizeof(float2) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_rb_start, sizeof(int) * (size_t)(cap + 2)));
@@ -262,6 +268,26 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     rb.push_back(n);
     cs->n_rb = (int)rb.size() - 1;
     cs->pts_sane = sane;
+    // K1's view: per sorted ray its block (a workgroup's chunk is a ray range, cut into pieces at block
+    // boundaries), and per block the figures the launch layout is balanced with
+    const int n_rb = cs->n_rb;
+    std::vector<int> rayblk((size_t)n * 4);
+    cs->h_rb_start = rb;
+    cs->h_rb_ext.resize((size_t)n_rb); cs->h_rb_reach.resize((size_t)n_rb);
+    for (int b = 0; b < n_rb; b++) {
+        const int r0 = rb[(size_t)b], r1 = rb[(size_t)b + 1];
+        float x0 = sorted[2 * (size_t)r0], x1 = x0, y0 = sorted[2 * (size_t)r0 + 1], y1 = y0, reach = 0.0f;
+        for (int r = r0; r < r1; r++) {
+            const float X = sorted[2 * (size_t)r], Y = sorted[2 * (size_t)r + 1];
+            x0 = fminf(x0, X); x1 = fmaxf(x1, X); y0 = fminf(y0, Y); y1 = fmaxf(y1, Y);
+            reach = fmaxf(reach, sqrtf(X * X + Y * Y));
+            rayblk[4 * (size_t)r] = r0; rayblk[4 * (size_t)r + 1] = r1; rayblk[4 * (size_t)r + 2] = b; rayblk[4 * (size_t)r + 3] = 0;
+        }
+        cs->h_rb_ext[(size_t)b] = fmaxf(x1 - x0, y1 - y0) * cs->hscale;
+        cs->h_rb_reach[(size_t)b] = reach * cs->hscale;
+    }
+    cs->k1_layout_dirty = true;
+    SH_HIP(hipMemcpyAsync(cs->d_ray_blk, rayblk.data(), sizeof(int) * rayblk.size(), hipMemcpyHostToDevice, cs->ctx->stream));
     SH_HIP(hipMemcpyAsync(cs->d_pts, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, cs->ctx->stream));
     SH_HIP(hipMemcpyAsync(cs->d_pts_sorted, sorted.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, cs->ctx->stream));
     SH_HIP(hipMemcpyAsync(cs->d_rb_start, rb.data(), sizeof(int) * rb.size(), hipMemcpyHostToDevice, cs->ctx->stream));
@@ -308,7 +334,7 @@ extern "C" int32_t slamhip_cs_distance_poses(slamhip_cs *cs, const float *poses,
     if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
     SH_TRY(cs_alloc_candidates(cs, K));
     bool sane = true;
-    for (size_t i = 0; i < (size_t)K * 3; i++) if (!(fabsf(poses[i]) < 1.0e6f)) { sane = false; break; }
+    for (size_t i = 0; i < (size_t)K * 3; i++) if (!(fabsf(poses[i]) < (i % 3 == 2 ? 6.0e4f : 1.0e6f))) { sane = false; break; }
     cs->shard_first = cs->shard_count = -1;
     // stage the poses in d_ev_off (same 3-float layout)
     SH_HIP(hipMemcpyAsync(cs->d_ev_off, poses, sizeof(float) * 3 * (size_t)K, hipMemcpyHostToDevice, cs->ctx->stream));
@@ -338,6 +364,8 @@ extern "C" int32_t slamhip_cs_set_offsets(slamhip_cs *cs, const float *offs, int
     SH_TRY(ensure_offsets_capacity(cs, n));
     cs->n_offs = n;
     cs->h_offs.assign(offs, offs + (size_t)n * 3);
+    cs->offs_theta_small = true;
+    for (size_t i = 0; i < (size_t)n * 3; i++) if (!(fabsf(offs[i]) < (i % 3 == 2 ? 1.0e4f : 1.0e6f))) { cs->offs_theta_small = false; break; }
     cs->offs_on_device_sorted = false;
     cs->shard_first = cs->shard_count = -1;
     if (n > 0) SH_HIP(hipMemcpy(cs->d_offs_flat, offs, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
@@ -355,6 +383,8 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
     }
     cs->n_offs = n;
     cs->h_offs.clear();
+    cs->offs_theta_small = fabsf(sigma_theta) < 1.0e3f && fabsf(sigma_xy) < 1.0e5f;     // |normcdfinvf| < 6 for float quantiles
+    cs->gen_sigma_xy = sigma_xy; cs->gen_sigma_theta = sigma_theta;
     cs->offs_on_device_sorted = true;
     cs->shard_first = cs->shard_count = -1;
     if (n > 0)
@@ -387,14 +417,48 @@ static int32_t host_offsets(slamhip_cs *cs)
     return SLAMHIP_OK;
 }
 
+// quantile function of N(0,1) (Acklam's rational approximation, |error| < 1.2e-9): host-side layout heuristics only
+static double host_normcdfinv(double p)
+{
+    static const double a[6] = { -3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                                 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00 };
+    static const double b[5] = { -5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                                 6.680131188771972e+01, -1.328068155288572e+01 };
+    static const double c[6] = { -7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                                 -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00 };
+    static const double d[4] = { 7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00 };
+    if (p < 0.02425) {
+        const double q = sqrt(-2.0 * log(p));
+        return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+    }
+    if (p > 1.0 - 0.02425) return -host_normcdfinv(1.0 - p);
+    const double q = p - 0.5, r = q * q;
+    return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+           (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
+}
+
 // materialise the theta-sorted evaluation list of flat candidates [first, first+count)
 static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
 {
     if (cs->shard_first == first && cs->shard_count == count) return SLAMHIP_OK;
     slamhip_ctx *ctx = cs->ctx;
+    const int ng = sh_div_up(count, K1_GROUP);
+    cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);
+    cs->k1_layout_dirty = true;
     if (cs->offs_on_device_sorted) {
+        // flat candidates first .. first+count-1 = the un-jittered pose (flat 0) and jitters in ascending dtheta
+        const int n = cs->n_offs;
+        const int zero_pos = first == 0 ? (count - 1 < n / 2 ? count - 1 : n / 2) : -1;
         hipLaunchKernelGGL(k_gather_offsets, dim3(sh_div_up(count, 256)), dim3(256), 0, ctx->stream,
-                           cs->d_offs_flat, (const int *)nullptr, first, count, cs->d_ev_off, cs->d_ev_idx);
+                           cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx);
+        // the jitters are the strata of N(0, sigma): group ranges from the quantile function (layout balance only)
+        for (int g = 0; g < ng; g++) {
+            const int k0 = first + g * K1_GROUP, k1 = (first + count < k0 + K1_GROUP ? first + count : k0 + K1_GROUP) - 1;
+            const double q0 = fmin(fmax((k0 - 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
+            const double q1 = fmin(fmax((k1 + 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
+            cs->h_grp_dth[(size_t)g] = (float)(fabs(cs->gen_sigma_theta) * (host_normcdfinv(q1) - host_normcdfinv(q0)));
+            cs->h_grp_dxy[(size_t)g] = 7.0f * fabsf(cs->gen_sigma_xy) * cs->hscale;
+        }
     } else {
         // theta = search_pose.Z + dtheta and float addition is monotone, so sorting by dtheta sorts by theta
         std::vector<int> perm((size_t)count);
@@ -404,9 +468,21 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             const float ta = a > 0 ? o[3 * (size_t)(a - 1) + 2] : 0.0f, tb = b > 0 ? o[3 * (size_t)(b - 1) + 2] : 0.0f;
             return ta < tb;
         });
+        for (int g = 0; g < ng; g++) {
+            float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+            for (int j = g * K1_GROUP; j < count && j < (g + 1) * K1_GROUP; j++) {
+                const int flat = perm[(size_t)j];
+                for (int k = 0; k < 3; k++) {
+                    const float v = flat > 0 ? o[3 * (size_t)(flat - 1) + k] : 0.0f;
+                    lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v);
+                }
+            }
+            cs->h_grp_dth[(size_t)g] = hi[2] - lo[2];
+            cs->h_grp_dxy[(size_t)g] = fmaxf(hi[0] - lo[0], hi[1] - lo[1]) * cs->hscale;
+        }
         SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_gather_offsets, dim3(sh_div_up(count, 256)), dim3(256), 0, ctx->stream,
-                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, cs->d_ev_off, (int *)nullptr);
+                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr);
         SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
     }
     SH_HIP(hipGetLastError());
@@ -421,7 +497,7 @@ static int32_t search_enqueue(slamhip_cs *cs, const float pose[3], int first, in
     SH_HIP(hipSetDevice(cs->ctx->device));
     if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
     SH_TRY(ensure_shard(cs, first, count));
-    const bool sane = fabsf(pose[0]) < 1.0e6f && fabsf(pose[1]) < 1.0e6f && fabsf(pose[2]) < 1.0e4f;
+    const bool sane = fabsf(pose[0]) < 1.0e6f && fabsf(pose[1]) < 1.0e6f && fabsf(pose[2]) < 1.0e4f && cs->offs_theta_small;
     return cs_launch_distance(cs, 1, pose, count, false, sane, key_dst);
 }
 
@@ -541,12 +617,13 @@ extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
 {
     SH_CHECK_ARG(cs && out);
     SH_HIP(hipSetDevice(cs->ctx->device));
-    unsigned int *h = (unsigned int *)(cs->h_key + 6);
-    SH_HIP(hipMemcpyAsync(h, cs->d_verify, sizeof(unsigned int) * 4, hipMemcpyDeviceToHost, cs->ctx->stream));
+    unsigned int *h = (unsigned int *)(cs->h_key + 8);
+    SH_HIP(hipMemcpyAsync(h, cs->d_verify, sizeof(unsigned int) * 8, hipMemcpyDeviceToHost, cs->ctx->stream));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     *out = h[0];
     if (getenv("SLAMHIP_K1_STATS"))
-        fprintf(stderr, "[slamhip] K1 mode stats (ray x sub-batch units): one-tile %u, sub-batch tile %u, global fallback %u\n", h[1], h[2], h[3]);
+        fprintf(stderr, "[slamhip] K1 step kinds (ray x sub-batch units): group tile %u, sub-batch tiles %u, banded %u, global gathers %u\n",
+                h[1], h[2], h[4], h[3]);
     return SLAMHIP_OK;
 }
 

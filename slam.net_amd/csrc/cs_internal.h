@@ -8,6 +8,7 @@
 // (1024 candidates) x (a chunk of ray blocks) and stages one HoleMap tile in LDS per ray block.
 #define CS_RB_MAX 64
 #define CS_RB_EXTENT_PX 128.0f
+#define K1_GROUP 1024                  // theta-consecutive candidates per K1 workgroup ("group"): 256 lanes x 4
 
 struct cs_ray;      // K2 per-ray table entry (holemap.hip)
 
@@ -23,6 +24,9 @@ struct slamhip_cs {
     int n_points, cap_points;
     float2 *d_pts;                // original order: K2/K3 are ray-order dependent
     float2 *d_pts_sorted;         // spatially sorted copy for K1 (integer sum: any order is exact)
+    int4 *d_ray_blk;              // per sorted ray: (first ray of its block, one past its last, block index, 0)
+    std::vector<int> h_rb_start;  // host copy of the block table
+    std::vector<float> h_rb_ext, h_rb_reach;   // per ray block: pixel extent, reach (max |p| in pixels)
     int n_rb;                     // ray blocks over d_pts_sorted
     int *d_rb_start;              // [n_rb + 1]
     bool pts_sane;                // all |coords| < 1e9: fast kernels need no NaN/overflow handling
@@ -37,9 +41,19 @@ struct slamhip_cs {
     int *d_ev_idx;                // [cap_cand] evaluation position -> flat index
     int cap_cand;
     float4 *d_pxcs;               // [cap_cand] (px,py,c,s) in evaluation order
-    void *d_partial; size_t cap_partial;       // uint2 [n_chunks][count]: (pixel sum, in-bounds count)
-    int *d_plans; size_t cap_plans;            // K1 tile plans [groups][n_rb][32 ints]
-    unsigned int *d_verify;       // SLAMHIP_K1_VERIFY=1: count of end points outside their LDS tile box (must stay 0)
+    void *d_partial; size_t cap_partial;       // K1 partial rows (bytes)
+    unsigned int *d_k1_tickets;   // K1: [groups] chunk arrivals + [1] group arrivals (zero between launches)
+    unsigned long long *d_k1_gkey;              // K1: per-group arg-min keys
+    unsigned long long *d_k1_acc;               // K1: per-candidate accumulators [groups][K1_GROUP] (zero between launches)
+    int k1_cap_groups, k1_tickets_groups;
+    // K1 launch layout: per group of 1024 evaluation-order candidates the theta range (rad) and translation spread
+    // (pixels) -- from the offsets (ensure_shard) -- and the chunks per group derived from them and the scan
+    std::vector<float> h_grp_dth, h_grp_dxy;
+    std::vector<int> k1_tab_group, k1_tab_nc; int k1_uni_g0, k1_uni_ng, k1_uni_nc;
+    bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups;
+    float gen_sigma_xy, gen_sigma_theta;        // offsets generated on the device: their distribution
+    bool offs_theta_small;        // every |dtheta| <= 1e4: the tiled kernel's trigonometry needs no huge-angle branch
+    unsigned int *d_verify;       // [8] SLAMHIP_K1_VERIFY=1: [0] tile self-check failures (must stay 0), [1..4] unit counts per kind
     int32_t *d_dist;              // [cap_cand] per-candidate distances in FLAT order (optional output)
     uint64_t *d_key;              // packed (dist << 32 | flat index) arg-min
     uint64_t *h_key;              // pinned

@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+// |a| <= 65536 (caller's contract): the deterministic kernel alone
+__host__ __device__ static inline void sh_det_sincosf_small(float a, float *s, float *c);
+
 __host__ __device__ static inline void sh_det_sincosf(float a, float *s, float *c)
 {
     if (!(fabsf(a) <= 65536.0f)) {        // huge / inf / NaN: outside the deterministic contract
@@ -18,6 +21,11 @@ __host__ __device__ static inline void sh_det_sincosf(float a, float *s, float *
         *c = cosf(a);
         return;
     }
+    sh_det_sincosf_small(a, s, c);
+}
+
+__host__ __device__ static inline void sh_det_sincosf_small(float a, float *s, float *c)
+{
     const double TWO_OVER_PI = 6.36619772367581382433e-01;
     const double P1 = 1.57079632673412561417e+00, P2 = 6.07710050630396597660e-11, P2T = 2.02226624879595063154e-21;
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
@@ -32,9 +40,9 @@ __host__ __device__ static inline void sh_det_sincosf(float a, float *s, float *
     double sn = r + (z * r) * (S1 + z * ps);
     double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
     double cs = 1.0 - (0.5 * z - z * pc);
-    long long q = (long long)k;
+    const int q = (int)k;                 // |k| <= 41722: exact
     double so, co;
-    switch ((int)(q & 3)) {
+    switch (q & 3) {
     case 0:  so = sn;  co = cs;  break;
     case 1:  so = cs;  co = -sn; break;
     case 2:  so = -sn; co = -cs; break;

@@ -9,17 +9,24 @@
 // candidates in theta-sorted order; the arg-min key (distance << 32 | flat index) restores the
 // reference tie-break (first strictly smaller wins, :644,:700).
 //
-// Kernel design (k1_distance_tiled): a workgroup owns 1024 theta-consecutive candidates (256 lanes x 4
-// candidates per lane) and a chunk of ray blocks.  For every ray block it bounds the end-point pixels of
-// ALL its candidates by interval arithmetic on the very same float operations (rounding is monotone, so
-// the box is rigorous), stages that HoleMap tile in LDS with coalesced 16-byte loads, and gathers from
-// LDS: ~14 VALU + 1 ds_read_u16 per point evaluation and no bounds test (the box lies inside the map).
-// When the 1024-candidate box does not fit the LDS budget (tails of the theta distribution, long rays)
-// the four 256-candidate sub-batches get their own tiles; a sub-batch whose box still does not fit or
-// that touches the map border falls back to bounds-checked global gathers.
+// One launch per search (k1_search_tiled).  A workgroup owns 1024 theta-consecutive candidates (a "group",
+// one per lane) and a chunk of ray blocks:
+//   prologue  (px,py,c,s) of its candidates (deterministic trigonometry), their min/max bounds, and -- by interval
+//             arithmetic on the reference's very float operations (rounding is monotone, so the box is rigorous)
+//             -- the pixel box every candidate's end points of a ray block fall into; from the boxes a list
+//             of STEPS: one HoleMap tile in LDS per ray block when the box fits (SHARED), one tile per 256-
+//             candidate sub-batch (OWN), or the box cut into row BANDs that are staged one after the other
+//             with a per-gather range test (theta tails, long rays, boxes clipped at the map border);
+//   steps     the tile is staged with coalesced 16-byte loads that were issued one step ahead (registers),
+//             then ~14 VALU + 1 ds_read_u16 per point evaluation, no bounds test for SHARED / OWN;
+//   epilogue  the partial row is published write-through, the last workgroup of the group to arrive (ticket)
+//             sums the group's rows and takes the group arg-min, the last group the overall arg-min.
+// Inputs the fast path cannot take (NaN / huge coordinates, map sides that are not a multiple of 8) run the
+// bounds-checked global-gather kernels (k1_prep_pxcs, k1_distance_global, k1_reduce).
 #include "cs_internal.h"
 #include "det_trig.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define K1_THREADS 256
 
@@ -56,88 +63,172 @@ __device__ static inline unsigned long long k1_finish(uint64_t sum, uint32_t cnt
     return ((unsigned long long)(uint32_t)d << 32) | (uint32_t)flat;
 }
 
-__device__ static inline void k1_wave_argmin(unsigned long long key, unsigned long long *__restrict__ key_out)
+// (px,py,c,s) of a candidate (:232-235).  MODE 1: search_pose + jitter (:635-637); MODE 2: pose.
+template <int MODE, bool SMALL>
+__device__ static inline float4 k1_candidate(const float c3[3], float bx, float by, float bth, float scale)
 {
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_down(key, off, 64);
-        key = o < key ? o : key;
-    }
-    if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(key_out, key);
+    float x, y, th;
+    if (MODE == 1) { x = bx + c3[0]; y = by + c3[1]; th = bth + c3[2]; }
+    else           { x = c3[0];      y = c3[1];      th = c3[2]; }
+    float s, c;
+#ifdef K1_FAKETRIG
+    s = th * 0.9f; c = 1.0f - th * th * 0.5f;
+#else
+    if (SMALL) sh_det_sincosf_small(th, &s, &c); else sh_det_sincosf(th, &s, &c);
+#endif
+    float4 q;
+    q.x = x * scale + 0.5f;
+    q.y = y * scale + 0.5f;
+    q.z = c * scale;
+    q.w = s * scale;
+    return q;
 }
 
-// ---- K1 main, global-gather form ---------------------------------------------------------------------------
-// (a) whole-launch fallback for unsafe inputs or map sides that are not a multiple of 8 (plans == NULL);
-// (b) TAIL companion of the tiled kernel: it evaluates exactly the (sub-batch, ray block) units whose plan kind
-//     is GLOBAL -- candidates too sparse in theta, or rays too long, for an LDS tile to cover them.  Those are few,
-//     and bounds-checked gathers with many independent waves in flight are the right tool for them.  A block
-//     whose (sub-batch, chunk) has no such unit exits at once (tailmask).  Four independent gathers per iteration.
+// ---- fallback path: global gathers ---------------------------------------------------------------------------
+// MODE 0: pxcs given; 1: search_pose + jitter; 2: poses.  Arms the arg-min key.
+template <int MODE>
+__global__ void __launch_bounds__(K1_THREADS)
+k1_prep_pxcs(const float *__restrict__ src3, float bx, float by, float bth, float scale, float4 *__restrict__ pxcs,
+             int count, unsigned long long *__restrict__ key)
+{
+    const int j = blockIdx.x * K1_THREADS + threadIdx.x;
+    if (j == 0) *key = ~0ull;
+    if (MODE != 0 && j < count) pxcs[j] = k1_candidate<MODE == 0 ? 1 : MODE, false>(src3 + 3 * (size_t)j, bx, by, bth, scale);
+}
+
 template <bool SAFE>
 __global__ void __launch_bounds__(K1_THREADS)
 k1_distance_global(const uint16_t *__restrict__ map, int S, const float2 *__restrict__ pts,
                    const int *__restrict__ rb_start, int n_rb, int blocks_per_chunk,
-                   const float4 *__restrict__ pxcs, int count, uint2 *__restrict__ partial,
-                   const int *__restrict__ plans, const int *__restrict__ tailmask, int nsub)
+                   const float4 *__restrict__ pxcs, int count, uint2 *__restrict__ partial)
 {
     const int chunk = blockIdx.y;
-    if (tailmask && !tailmask[blockIdx.x * gridDim.y + chunk]) return;
     const int j = blockIdx.x * K1_THREADS + threadIdx.x;
     const int b0 = chunk * blocks_per_chunk;
     const int b1 = b0 + blocks_per_chunk < n_rb ? b0 + blocks_per_chunk : n_rb;
     const float4 q = pxcs[j < count ? j : count - 1];
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    for (int b = b0; b < b1; b++) {
-        if (plans) {       // sub-batch blockIdx.x = (group blockIdx.x / nsub, sub blockIdx.x % nsub)
-            const int kind = plans[((size_t)(blockIdx.x / nsub) * n_rb + b) * 32 + (blockIdx.x % nsub) * 8 + 6];
-            if (kind != 2) continue;
+    int r = rb_start[b0];
+    const int r1 = rb_start[b1];
+    // eight gathers in flight per lane: every gather is an L2 / HBM round trip
+    for (; r + 7 < r1; r += 8) {
+        float fx[8], fy[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) k1_coords(q, pts[r + u], fx[u], fy[u]);
+        uint32_t v[8]; bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int ix, iy;
+            if (SAFE) { ix = sh_f2i(fx[u]); iy = sh_f2i(fy[u]); } else { ix = (int)fx[u]; iy = (int)fy[u]; }
+            ok[u] = ((unsigned)ix < (unsigned)S) & ((unsigned)iy < (unsigned)S);
+            v[u] = map[ok[u] ? (size_t)iy * S + ix : 0];
         }
-        int r = rb_start[b];
-        const int r1 = rb_start[b + 1];
-        // eight gathers in flight per lane: these candidates have no locality, every gather is an L2/HBM round trip
-        for (; r + 7 < r1; r += 8) {
-            float fx[8], fy[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) k1_coords(q, pts[r + u], fx[u], fy[u]);
-            uint32_t v[8]; bool ok[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                int ix, iy;
-                if (SAFE) { ix = sh_f2i(fx[u]); iy = sh_f2i(fy[u]); } else { ix = (int)fx[u]; iy = (int)fy[u]; }
-                ok[u] = ((unsigned)ix < (unsigned)S) & ((unsigned)iy < (unsigned)S);
-                v[u] = map[ok[u] ? (size_t)iy * S + ix : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u += 4) {
-                s0 += ok[u] ? v[u] : 0u;         c0 += ok[u] ? 1u : 0u;
-                s1 += ok[u + 1] ? v[u + 1] : 0u; c1 += ok[u + 1] ? 1u : 0u;
-                s2 += ok[u + 2] ? v[u + 2] : 0u; c2 += ok[u + 2] ? 1u : 0u;
-                s3 += ok[u + 3] ? v[u + 3] : 0u; c3 += ok[u + 3] ? 1u : 0u;
-            }
+        for (int u = 0; u < 8; u += 4) {
+            s0 += ok[u] ? v[u] : 0u;         c0 += ok[u] ? 1u : 0u;
+            s1 += ok[u + 1] ? v[u + 1] : 0u; c1 += ok[u + 1] ? 1u : 0u;
+            s2 += ok[u + 2] ? v[u + 2] : 0u; c2 += ok[u + 2] ? 1u : 0u;
+            s3 += ok[u + 3] ? v[u + 3] : 0u; c3 += ok[u + 3] ? 1u : 0u;
         }
-        for (; r < r1; r++) k1_gather_global<SAFE>(map, S, q, pts[r], s0, c0);
     }
+    for (; r < r1; r++) k1_gather_global<SAFE>(map, S, q, pts[r], s0, c0);
     if (j < count) partial[(size_t)chunk * count + j] = make_uint2(s0 + s1 + s2 + s3, c0 + c1 + c2 + c3);
 }
 
-// ---- K1 main, LDS-tiled form ----------------------------------------------------------------------------
-// A workgroup = 1024 lanes = 1024 theta-consecutive candidates ("group") = 4 sub-batches of 256.
-// For every (group, ray block) the prep kernel has written a PLAN: either one shared tile that bounds the
-// end points of all 1024 candidates, or one tile per sub-batch, or (per sub-batch) "global fallback".
-#ifndef K1_WG
-#define K1_WG 1024                     // lanes = candidates per workgroup ("group"); 512 or 1024
-#endif
-#define K1_SUB 256
-#define K1_NSUB (K1_WG / K1_SUB)        // sub-batches per group
-#define K1_NWAVES (K1_WG / 64)
-#define K1_PF 5                        // prefetch registers (16-byte vectors) per lane
-#define K1_PLAN_INTS 32                // 4 sub-batch records x 8 ints, each fully resolved
-#define K1_KIND_OWN 0                  // the sub-batch has its own tile, staged by its 4 waves
-#define K1_KIND_SHARED 1               // one tile for the whole group, staged by all 16 waves
-#define K1_KIND_GLOBAL 2               // no tile fits (theta tail, long ray, map border): the unit goes to the tail kernel
-#define K1_MAX_RB 2048                 // ray blocks the prep kernel can plan (beyond: whole-launch global path)
-// sub-batch record: [0] x0a  [1] y0  [2] w8 (pitch, px)  [3] h  [4] lds byte offset  [5] shift = log2(lanes per row)
-//                   [6] kind  [7] unused.
+// per-candidate reduction of the chunk partials + arg-min: a block works on 64 candidates at a time with its 4
+// waves splitting the partial rows and issues ONE atomicMin (same-address device atomics serialise at ~12 ns)
+__global__ void __launch_bounds__(256)
+k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_points, const int *__restrict__ ev_idx,
+          int32_t *__restrict__ dist_out, unsigned long long *__restrict__ key_out)
+{
+    __shared__ uint32_t ssum[4][64], scnt[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long key = ~0ull;
+    for (int base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
+        const int j = base + lane;
+        uint32_t sum = 0, cnt = 0;
+        if (j < count)
+            for (int c = w; c < n_chunks; c += 4) {
+                const uint2 p = partial[(size_t)c * count + j];
+                sum += p.x; cnt += p.y;
+            }
+        ssum[w][lane] = sum; scnt[w][lane] = cnt;
+        __syncthreads();
+        if (w == 0 && j < count) {
+            const uint64_t s = (uint64_t)ssum[0][lane] + ssum[1][lane] + ssum[2][lane] + ssum[3][lane];
+            const uint32_t c = scnt[0][lane] + scnt[1][lane] + scnt[2][lane] + scnt[3][lane];
+            const unsigned long long k = k1_finish(s, c, n_points, ev_idx ? ev_idx[j] : j, dist_out);
+            key = k < key ? k : key;
+        }
+        __syncthreads();
+    }
+    if (w == 0) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off, 64);
+            key = o < key ? o : key;
+        }
+        if (lane == 0 && key != ~0ull) atomicMin(key_out, key);
+    }
+}
+
+// ---- the tiled search kernel -----------------------------------------------------------------------------------
+// Workgroup = one group of 1024 theta-consecutive candidates = LANES lanes x CPL candidates per lane (candidate
+// k*LANES + t of the group lives in slot k of lane t).  Two instantiations, chosen per launch (both measured on MI355X):
+//   CPL 1 (1024 lanes, 16 waves, 8 waves / SIMD): the VALU stays saturated by thread-level parallelism -- the
+//         throughput form, for launches of many workgroups per CU;
+//   CPL 4 (256 lanes, 4 waves): a wave costs ~0.15 us to launch, so a 16-wave workgroup starts over ~2.5 us; four
+//         fat waves start in ~0.3 us and share every ray point four ways -- the latency form, for launches whose
+//         workgroups all run at once.
+#define K1_KIND_SHARED 1               // one tile holds the end points of the whole group: gathers need no test
+#define K1_KIND_GLOBAL 2               // no tile (box wider than 512 px or more than K1_MAXBANDS bands): global gathers
+#define K1_KIND_BAND 3                 // a row band of the group's box clipped to the map; gathers are range-tested
+#define K1_MAXP 16                     // pieces (ray block fragments) per chunk
+#define K1_MAXR 512                    // rays per chunk
+#define K1_MAXBANDS 4
+#define K1_MAXSTEPS (K1_MAXP * K1_MAXBANDS)
+#define K1_TABLE_G 64                  // groups with their own chunk count (the rest: one uniform count)
+#define K1_TABLE_WGS 2048
+#define K1_ZERO_OFS 0                  // dynamic LDS: a zero word (16 bytes), then the tile
+#define K1_TILE_OFS 16
+// step record: [0] x0a  [1] y0  [2] w8 (pitch, px)  [3] h  [4] shift = log2(lanes per row)  [5] kind
+//              [6] piece: first ray (chunk-relative) | rays << 16   [7] -
 // Staging geometry: a wave-wide 16-byte load covers 64 >> shift tile rows of (1 << shift) vectors each
 // (lanes beyond w8/8 vectors idle), so no division is needed to map lanes to tile vectors.
+
+struct k1_args {
+    const uint16_t *map; int S;
+    const float2 *pts;                 // spatially sorted rays
+    const int4 *ray_blk;               // per ray: (first ray of its block, one past the last, block index, -)
+    int n_rays;
+    const float4 *pxcs;                // MODE 0
+    const float *src3;                 // MODE 1: jitters, MODE 2: poses (evaluation order)
+    float bx, by, bth, scale;
+    int count, n_groups;
+    int budget;                        // tile bytes
+    unsigned long long *acc;           // [n_groups][K1_GROUP] per-candidate accumulators; zero between launches
+    unsigned *tickets;                 // [n_groups] chunk arrivals + [1] group arrivals; zero between launches
+    unsigned long long *gkey;          // [n_groups] group minima
+    const int *ev_idx;
+    int32_t *dist_out;
+    unsigned long long *key_out;
+    unsigned *verify;
+    // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
+    // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
+    // rays at the same time: their tiles overlap almost completely, L2 reuse)
+    int n_tab_wgs, uni_g0, uni_ng, uni_nc;
+    unsigned short tab_group[K1_TABLE_G];
+    unsigned wg_first[K1_TABLE_G + 1]; // dispatch position p -> first workgroup
+    unsigned char wg_pos[K1_TABLE_WGS];// workgroup -> dispatch position
+};
+
+#ifdef K1_TIMES
+// developer instrumentation (build with SLAMHIP_K1_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
+__device__ unsigned long long g_k1_times[4096 * 16];
+__device__ unsigned long long g_k1_wstart[4096 * 16];
+#define K1_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 4096) g_k1_times[blockIdx.x * 16 + (k)] = wall_clock64(); }
+#else
+#define K1_STAMP(k) {}
+#endif
 
 // byte address of pixel (ix,iy) in the staged tile: iy*pitch2 + 2*ix + kofs, as exactly two VALU ops
 __device__ static inline unsigned k1_tile_addr(int ix, int iy, int pitch2, int kofs)
@@ -159,7 +250,6 @@ __device__ static inline float2 k1_point_lds(unsigned lds_addr)
     k1_lds_f *p = (k1_lds_f *)(size_t)lds_addr;
     return make_float2(p[0], p[1]);
 }
-#define K1_PTS_BYTES 512               // 64 rays x float2 at the start of dynamic LDS
 
 // end-point pixel box of one ray over a candidate set, by interval arithmetic on the reference's own
 // float operations: every rounding step is monotone, so [lo,hi] bounds every candidate's coordinate.
@@ -175,373 +265,446 @@ __device__ static inline void k1_ray_box(const float *b, const float2 p, int &x0
     x0 = (int)xlo; x1 = (int)xhi; y0 = (int)ylo; y1 = (int)yhi;
 }
 
-// ---- prep + plan: one workgroup per candidate group -------------------------------------------------------
-// MODE 0: pxcs given; 1: search_pose + jitter (:635-637); 2: poses.  (px,py,c,s) per :232-235.
-#define K1_PLAN_BATCH 128
-template <int MODE>
-__global__ void __launch_bounds__(K1_WG)
-k1_prep_plan(const float *__restrict__ src3, float bx, float by, float bth, float scale, float4 *__restrict__ pxcs,
-             int count, unsigned long long *__restrict__ key, const float2 *__restrict__ pts,
-             const int *__restrict__ rb_start, int n_rb, int S, int budget_shared, int budget_sub, int *__restrict__ plans,
-             int *__restrict__ tailmask, int bpc_tail, int n_chunks_tail)
+// wave-wide reduction (min / max) in six DPP steps, no LDS traffic: butterfly inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  The result is valid in lanes 48..63
+// (row 3); lanes that a step's row mask excludes combine with themselves (min(x,x) = x).
+template <int CTRL, int ROWS> __device__ static inline int k1_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }
+template <bool MAX> __device__ static inline int k1_wave_red(int x)
 {
-    __shared__ unsigned char kind_all[K1_MAX_RB * 4];            // plan kind per (ray block, sub-batch) of this group
-    __shared__ int srb[K1_MAX_RB + 1];                           // rb_start staged once: every later use is an LDS read
-    __shared__ float wred[K1_NWAVES][8];
-    __shared__ float bnd[K1_NSUB + 1][8];                        // per sub-batch, then the whole group
-    __shared__ int boxes[K1_PLAN_BATCH * (K1_NSUB + 1)][4];
-    __shared__ float2 spts[K1_PLAN_BATCH * CS_RB_MAX / 4];       // the points of one batch of ray blocks (<= 2048)
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, g = blockIdx.x;
-    const int j = g * K1_WG + t;
-    if (j == 0) *key = ~0ull;
-    if (plans) for (int i = t; i <= n_rb; i += K1_WG) srb[i] = rb_start[i];
-    const int jc = j < count ? j : count - 1;
-    float4 q;
-    if (MODE == 0) {
-        q = pxcs[jc];
-    } else {
-        float x, y, th;
-        if (MODE == 1) { x = bx + src3[3 * jc]; y = by + src3[3 * jc + 1]; th = bth + src3[3 * jc + 2]; }
-        else           { x = src3[3 * jc];      y = src3[3 * jc + 1];      th = src3[3 * jc + 2]; }
-        float s, c;
-        sh_det_sincosf(th, &s, &c);
-        q.x = x * scale + 0.5f;
-        q.y = y * scale + 0.5f;
-        q.z = c * scale;
-        q.w = s * scale;
-        if (j < count) pxcs[j] = q;
-    }
-    // bounds: per wave -> per sub-batch (4 waves) -> whole group
-    {
-        float v[8] = { q.x, q.x, q.y, q.y, q.z, q.z, q.w, q.w };
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float x = v[k];
-            for (int off = 32; off > 0; off >>= 1) {
-                const float o = __shfl_xor(x, off, 64);
-                x = (k & 1) ? fmaxf(x, o) : fminf(x, o);
-            }
-            if (lane == 0) wred[wid][k] = x;
-        }
-    }
-    __syncthreads();
-    if (t < K1_NSUB * 8) {
-        const int sb = t >> 3, k = t & 7;
-        float x = wred[sb * 4][k];
-        for (int w = 1; w < 4; w++) x = (k & 1) ? fmaxf(x, wred[sb * 4 + w][k]) : fminf(x, wred[sb * 4 + w][k]);
-        bnd[sb][k] = x;
-    }
-    __syncthreads();
-    if (t < 8) {
-        float x = bnd[0][t];
-        for (int i = 1; i < K1_NSUB; i++) x = (t & 1) ? fmaxf(x, bnd[i][t]) : fminf(x, bnd[i][t]);
-        bnd[K1_NSUB][t] = x;
-    }
-    __syncthreads();
-    if (!plans) return;
-
-    for (int base = 0; base < n_rb;) {
-        int nb = n_rb - base < K1_PLAN_BATCH ? n_rb - base : K1_PLAN_BATCH;
-        const int rbase = srb[base];
-        while (srb[base + nb] - rbase > K1_PLAN_BATCH * CS_RB_MAX / 4) nb--;      // batch must fit spts (nb >= 1: a block has <= 64 rays)
-        const int npts = srb[base + nb] - rbase;
-        for (int i = t; i < npts; i += K1_WG) spts[i] = pts[rbase + i];
-        __syncthreads();
-        for (int pair = t; pair < nb * (K1_NSUB + 1); pair += K1_WG) {
-            boxes[pair][0] = INT32_MAX; boxes[pair][1] = INT32_MAX; boxes[pair][2] = INT32_MIN; boxes[pair][3] = INT32_MIN;
-        }
-        __syncthreads();
-        // one task = (ray block, candidate set, quarter of the block's rays); LDS atomics merge the quarters
-        for (int task = t; task < nb * (K1_NSUB + 1) * 4; task += K1_WG) {
-            const int pair = task >> 2, qr = task & 3;
-            const int b = base + pair / (K1_NSUB + 1), set = pair % (K1_NSUB + 1);
-            const int ra = srb[b] - rbase, rn = srb[b + 1] - srb[b];
-            const int q0 = ra + (rn * qr) / 4, q1 = ra + (rn * (qr + 1)) / 4;
-            float bb8[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) bb8[k] = bnd[set][k];
-            int x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
-            for (int r = q0; r < q1; r++) {
-                int a0, b0, a1, b1;
-                k1_ray_box(bb8, spts[r], a0, b0, a1, b1);
-                x0 = min(x0, a0); y0 = min(y0, b0); x1 = max(x1, a1); y1 = max(y1, b1);
-            }
-            if (q1 > q0) {
-                atomicMin(&boxes[pair][0], x0); atomicMin(&boxes[pair][1], y0);
-                atomicMax(&boxes[pair][2], x1); atomicMax(&boxes[pair][3], y1);
-            }
-        }
-        __syncthreads();
-        if (t < nb * K1_NSUB) {
-            // one thread per (ray block, sub-batch): the record is fully resolved, no second lookup in K1
-            const int bb = t / K1_NSUB, sb = t % K1_NSUB;
-            int rec[8] = { 0, 0, 8, 0, 0, 0, K1_KIND_GLOBAL, 0 };
-            auto tile = [&](int set, int budget, int lds_off, int n_waves) -> bool {
-                const int x0 = boxes[bb * (K1_NSUB + 1) + set][0], y0 = boxes[bb * (K1_NSUB + 1) + set][1];
-                const int x1 = boxes[bb * (K1_NSUB + 1) + set][2], y1 = boxes[bb * (K1_NSUB + 1) + set][3];
-                const bool inside = (x0 >= 0) & (y0 >= 0) & (x1 < S) & (y1 < S) & (x1 >= x0) & (y1 >= y0);
-                if (!inside) return false;
-                const int x0a = x0 & ~7;
-                const int w8 = ((x1 - x0a + 1) + 7) & ~7;           // tile pitch in pixels (multiple of 8)
-                const int h = y1 - y0 + 1;
-                const int vpr = w8 >> 3;
-                if (vpr > 64) return false;
-                int shift = 0;
-                while ((1 << shift) < vpr) shift++;
-                const int rows_per_pass = n_waves * (64 >> shift);
-                if ((long long)w8 * h * 2 > (long long)budget || h > K1_PF * rows_per_pass) return false;
-                rec[0] = x0a; rec[1] = y0; rec[2] = w8; rec[3] = h; rec[4] = lds_off; rec[5] = shift;
-                return true;
-            };
-            if (tile(K1_NSUB, budget_shared, 0, K1_NWAVES)) rec[6] = K1_KIND_SHARED;
-            else if (tile(sb, budget_sub, sb * budget_sub, 4)) rec[6] = K1_KIND_OWN;
-            kind_all[(base + bb) * 4 + sb] = (unsigned char)rec[6];
-            int4 *dst = (int4 *)(plans + ((size_t)g * n_rb + base + bb) * K1_PLAN_INTS + sb * 8);
-            dst[0] = make_int4(rec[0], rec[1], rec[2], rec[3]);
-            dst[1] = make_int4(rec[4], rec[5], rec[6], rec[7]);
-        }
-        __syncthreads();
-        base += nb;
-    }
-    // which (sub-batch, tail chunk) pairs hold at least one GLOBAL unit (only when a separate tail kernel is used)
-    if (tailmask)
-    for (int i = t; i < K1_NSUB * n_chunks_tail; i += K1_WG) {
-        const int sb = i / n_chunks_tail, ct = i - sb * n_chunks_tail;
-        const int c0 = ct * bpc_tail, c1 = c0 + bpc_tail < n_rb ? c0 + bpc_tail : n_rb;
-        int any = 0;
-        for (int b = c0; b < c1; b++) any |= (kind_all[b * 4 + sb] == K1_KIND_GLOBAL);
-        tailmask[((size_t)g * K1_NSUB + sb) * n_chunks_tail + ct] = any;
-    }
+#define K1_MM(a, b) (MAX ? max(a, b) : min(a, b))
+    x = K1_MM(x, (k1_dpp<0xB1, 0xf>(x)));       // quad_perm [1,0,3,2]
+    x = K1_MM(x, (k1_dpp<0x4E, 0xf>(x)));       // quad_perm [2,3,0,1]
+    x = K1_MM(x, (k1_dpp<0x124, 0xf>(x)));      // row_ror:4
+    x = K1_MM(x, (k1_dpp<0x128, 0xf>(x)));      // row_ror:8
+    x = K1_MM(x, (k1_dpp<0x142, 0xa>(x)));      // row_bcast:15 -> rows 1, 3
+    x = K1_MM(x, (k1_dpp<0x143, 0xc>(x)));      // row_bcast:31 -> rows 2, 3
+#undef K1_MM
+    return x;
+}
+template <bool MAX> __device__ static inline float k1_wave_redf(float x)      // no NaNs (sane candidates)
+{
+#define K1_MM(a, b) (MAX ? fmaxf(a, b) : fminf(a, b))
+    x = K1_MM(x, __int_as_float(k1_dpp<0xB1, 0xf>(__float_as_int(x))));
+    x = K1_MM(x, __int_as_float(k1_dpp<0x4E, 0xf>(__float_as_int(x))));
+    x = K1_MM(x, __int_as_float(k1_dpp<0x124, 0xf>(__float_as_int(x))));
+    x = K1_MM(x, __int_as_float(k1_dpp<0x128, 0xf>(__float_as_int(x))));
+    x = K1_MM(x, __int_as_float(k1_dpp<0x142, 0xa>(__float_as_int(x))));
+    x = K1_MM(x, __int_as_float(k1_dpp<0x143, 0xc>(__float_as_int(x))));
+#undef K1_MM
+    return x;
 }
 
-// ---- the distance kernel -------------------------------------------------------------------------------------
-template <bool VERIFY, bool INLINE_GLOBAL>
-__global__ void __launch_bounds__(K1_WG, 8)          // 8 waves / SIMD resident (<= 64 VGPRs): 32 waves per CU
-k1_distance_tiled(const uint16_t *__restrict__ map, int S, const float2 *__restrict__ pts,
-                  const int *__restrict__ rb_start, int n_rb, int blocks_per_chunk,
-                  const float4 *__restrict__ pxcs, int count, const int *__restrict__ plans,
-                  uint2 *__restrict__ partial,                      // [n_chunks][count]
-                  unsigned int *__restrict__ verify_fail, int n_chunks_grid)
+typedef unsigned int k1_u32x4 __attribute__((ext_vector_type(4)));   // a staging register quad (native vector: stays in VGPRs)
+
+template <int MODE, bool VERIFY, int CPL>
+__global__ void __launch_bounds__(K1_GROUP / CPL, K1_GROUP / CPL / 64 / 2)      // two workgroups per CU
+k1_search_tiled(const k1_args a)
 {
+    constexpr int LANES = K1_GROUP / CPL, NW = LANES / 64, PF = 4 * CPL;      // PF staging vectors per lane: 64 KB per pass
+    constexpr int RU = (K1_MAXR + LANES - 1) / LANES;                          // ray slots per lane in the prologue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte address
+    __shared__ __attribute__((aligned(16))) int stepbuf[K1_MAXSTEPS * 8];
+    __shared__ __attribute__((aligned(16))) float2 cpts[K1_MAXR + 4];    // the chunk's ray points (+ slack: the point prefetch over-reads)
+    __shared__ int2 pieces[K1_MAXP];                     // (first ray, rays), chunk-relative
+    __shared__ __attribute__((aligned(16))) float wred[NW][8];
+    __shared__ __attribute__((aligned(16))) float bnd[8];
+    __shared__ __attribute__((aligned(16))) int boxes[K1_MAXP][4];
+    __shared__ unsigned long long wkey[NW];
+    __shared__ int s_nsteps, s_last;
+    const unsigned cpts_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cpts;
 
+    const uint16_t *__restrict__ map = a.map;
+    const int S = a.S, count = a.count;
     const int t = threadIdx.x, lane = t & 63;
     int zv;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));                   // opaque zero (see k1_point_lds)
-    const int sub = __builtin_amdgcn_readfirstlane(t >> 8);        // sub-batch of this wave
-    // Workgroups are dispatched in blockIdx order; two orders, both measured on MI355X:
-    //  - large launches (GLOBAL units go to the tail kernel): chunk-major, so the workgroups in flight work on the
-    //    SAME ray blocks for neighbouring theta groups, whose tiles overlap almost completely (L2 reuse, ~1.5x);
-    //  - small launches (GLOBAL units inline): group-major with the theta-extreme groups first (0, n-1, 1, n-2, ...):
-    //    their global-gather units take longest, so they overlap the bulk instead of trailing it.
-    const int ng_ = gridDim.x / (unsigned)n_chunks_grid;
-    int g, chunk;
-    if (INLINE_GLOBAL) {
-        const int gi = blockIdx.x / (unsigned)n_chunks_grid;
-        chunk = blockIdx.x - gi * n_chunks_grid;
-        g = (gi & 1) ? ng_ - 1 - (gi >> 1) : (gi >> 1);
-    } else {
-        chunk = blockIdx.x / (unsigned)ng_;
-        g = blockIdx.x - chunk * ng_;
-    }
-    const int j = g * K1_WG + t;
-    const float4 q = pxcs[j < count ? j : count - 1];
-    uint32_t sum = 0, cnt = 0;
-
-    const int b0 = chunk * blocks_per_chunk;
-    const int b1 = b0 + blocks_per_chunk < n_rb ? b0 + blocks_per_chunk : n_rb;
-
-    // Tile staging through registers: the global loads of the NEXT ray block's tile are issued before the
-    // current block is consumed and stay in flight meanwhile.  Exactly K1_PF loads are always issued (lanes
-    // without work re-read row 0) so that the compiler can count them.
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);         // wave index in the workgroup
-    uint4 R0, R1, R2, R3, R4;
-    int d0, d1, d2, d3, d4;
-#define K1_STAGE_ONE(Rk, dk, k)                                                                     \
-    {                                                                                               \
-        const int row = (wslot + (k) * nwv) * rpi + srow;                                           \
-        const bool live = colok & (row < h_);                                                       \
-        const int rr = live ? row : 0;                                                              \
-        Rk = *(const uint4 *)(gbase + (size_t)rr * S);                                              \
-        dk = live ? K1_PTS_BYTES + ldsb + rr * pitchb : -1;                                         \
+    const int ng = a.n_groups;
+    int g, chunk, nc, rowbase;
+    if ((int)blockIdx.x < a.n_tab_wgs) {
+        const int p = a.wg_pos[blockIdx.x];
+        rowbase = (int)a.wg_first[p];
+        nc = (int)a.wg_first[p + 1] - rowbase;
+        chunk = blockIdx.x - rowbase;
+        g = a.tab_group[p];
+    } else {
+        const int b = blockIdx.x - a.n_tab_wgs;
+        nc = a.uni_nc;
+        chunk = b / (unsigned)a.uni_ng;
+        const int gi = b - chunk * a.uni_ng;
+        g = a.uni_g0 + gi;
+        rowbase = a.n_tab_wgs + gi * nc;
     }
-#define K1_PREFETCH(planp)                                                                          \
-    {                                                                                               \
-        const int4 pa_ = *(const int4 *)((planp) + sub * 8), pb_ = *(const int4 *)((planp) + sub * 8 + 4); \
-        const int kind_ = pb_.z, shift_ = pb_.y, w8_ = pa_.z;                                       \
-        const int h_ = kind_ == K1_KIND_GLOBAL ? 0 : pa_.w;                                         \
-        const int rpi = 64 >> shift_;                           /* tile rows per wave-wide load */   \
-        const int srow = lane >> shift_, scol = lane & ((1 << shift_) - 1);                         \
-        const bool colok = scol < (w8_ >> 3);                                                       \
-        const int cc = colok ? scol : 0;                                                            \
-        const uint16_t *__restrict__ gbase = map + (size_t)pa_.y * S + pa_.x + (cc << 3);           \
-        const int pitchb = w8_ << 1;                                                                \
-        const int ldsb = pb_.x + (cc << 4);                                                         \
-        const int wslot = kind_ == K1_KIND_SHARED ? wv : (wv & 3);                                  \
-        const int nwv = kind_ == K1_KIND_SHARED ? K1_NWAVES : 4;                                    \
-        K1_STAGE_ONE(R0, d0, 0) K1_STAGE_ONE(R1, d1, 1) K1_STAGE_ONE(R2, d2, 2)                     \
-        K1_STAGE_ONE(R3, d3, 3) K1_STAGE_ONE(R4, d4, 4)                                             \
-    }
+    K1_STAMP(0)
+#ifdef K1_TIMES
+    if (t == 0 && blockIdx.x < 4096) { for (int k = 10; k < 16; k++) g_k1_times[blockIdx.x * 16 + k] = 0; g_k1_times[blockIdx.x * 16 + 14] = (unsigned long long)g; g_k1_times[blockIdx.x * 16 + 15] = (unsigned long long)nc; }
+    if (lane == 0 && blockIdx.x < 4096) g_k1_wstart[blockIdx.x * 16 + (wv & 15)] = wall_clock64();
+#endif
+    // the chunk = rays [rlo, rhi) of the sorted scan, cut into pieces at ray block boundaries (host: <= K1_MAXR
+    // rays, <= K1_MAXP pieces)
+    const int rlo = (int)(((long long)chunk * a.n_rays) / nc), rhi = (int)(((long long)(chunk + 1) * a.n_rays) / nc);
+    const int nrays = rhi - rlo;
+    const int blk_first = a.ray_blk[rlo].z;
+    const int npieces = a.ray_blk[rhi - 1].z - blk_first + 1;
 
-    const int *__restrict__ plan = plans + ((size_t)g * n_rb + b0) * K1_PLAN_INTS;
-    K1_PREFETCH(plan)
-    // the ray block's points travel the same way: lane r of every wave holds ray r of the NEXT block
-    int r0n = rb_start[b0], nrn = rb_start[b0 + 1] - r0n;
-    float2 mypt_next = pts[r0n + (lane < nrn ? lane : 0)];
-    for (int b = b0; b < b1; b++) {
-        __syncthreads();                                           // the previous tile is no longer read
-        if (d0 >= 0) *(uint4 *)(smem + d0) = R0;
-        if (d1 >= 0) *(uint4 *)(smem + d1) = R1;
-        if (d2 >= 0) *(uint4 *)(smem + d2) = R2;
-        if (d3 >= 0) *(uint4 *)(smem + d3) = R3;
-        if (d4 >= 0) *(uint4 *)(smem + d4) = R4;
-        if (wv == 0) ((float2 *)smem)[lane] = mypt_next;           // this block's ray points (lanes >= nr: duplicates)
-        const int nr = nrn;                                        // <= CS_RB_MAX (32) <= 64 lanes
-        __syncthreads();
-        const int *__restrict__ cur = plan;
-        plan += K1_PLAN_INTS;
-        {   // issue the next block's loads now; nothing in the compute loop below waits on vector memory
-            const bool more = b + 1 < b1;
-            const int *__restrict__ nplan = more ? plan : cur;
-            K1_PREFETCH(nplan)
-            const int bn = more ? b + 1 : b;
-            r0n = rb_start[bn]; nrn = rb_start[bn + 1] - r0n;
-            mypt_next = pts[r0n + (lane < nrn ? lane : 0)];
+    // ---- prologue: rays, candidates, bounds, boxes, steps ----------------------------------------------------------
+    // every global load first, then the arithmetic
+    int4 rinfo[RU];
+    float2 rpt[RU];
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+        const int i = u * LANES + t;
+        const int r = rlo + (i < nrays ? i : 0);
+        rinfo[u] = a.ray_blk[r];
+        rpt[u] = a.pts[r];
+    }
+    float4 q[CPL];
+    float c3[CPL][3];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+        const int j = g * K1_GROUP + k * LANES + t;
+        const int jc = j < count ? j : count - 1;
+        if (MODE == 0) q[k] = a.pxcs[jc];
+        else { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
+    }
+    if (t == 0) { s_nsteps = 0; *(unsigned *)(smem + K1_ZERO_OFS) = 0u; }
+    if (MODE != 0) {
+#pragma unroll
+        for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
+    }
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+        const int i = u * LANES + t;
+        if (i < nrays) {
+            cpts[i] = rpt[u];
+            if (i == 0 || rinfo[u].x == rlo + i)
+                pieces[rinfo[u].z - blk_first] = make_int2(i, (rinfo[u].y < rhi ? rinfo[u].y : rhi) - (rlo + i));
         }
+    }
+    K1_STAMP(1)
+    {   // min / max of (px, py, c, s) over the group: the lane's candidates, the wave (DPP), the waves (LDS)
+        float lo[4] = { q[0].x, q[0].y, q[0].z, q[0].w }, hi[4] = { q[0].x, q[0].y, q[0].z, q[0].w };
+#pragma unroll
+        for (int k = 1; k < CPL; k++) {
+            lo[0] = fminf(lo[0], q[k].x); hi[0] = fmaxf(hi[0], q[k].x); lo[1] = fminf(lo[1], q[k].y); hi[1] = fmaxf(hi[1], q[k].y);
+            lo[2] = fminf(lo[2], q[k].z); hi[2] = fmaxf(hi[2], q[k].z); lo[3] = fminf(lo[3], q[k].w); hi[3] = fmaxf(hi[3], q[k].w);
+        }
+        const float m0 = k1_wave_redf<false>(lo[0]), m1 = k1_wave_redf<true>(hi[0]);
+        const float m2 = k1_wave_redf<false>(lo[1]), m3 = k1_wave_redf<true>(hi[1]);
+        const float m4 = k1_wave_redf<false>(lo[2]), m5 = k1_wave_redf<true>(hi[2]);
+        const float m6 = k1_wave_redf<false>(lo[3]), m7 = k1_wave_redf<true>(hi[3]);
+        if (lane == 63) {
+            *(float4 *)&wred[wv][0] = make_float4(m0, m1, m2, m3);
+            *(float4 *)&wred[wv][4] = make_float4(m4, m5, m6, m7);
+        }
+    }
+    __syncthreads();
+    K1_STAMP(2)
+    if (t < 8) {
+        float v[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) v[w] = wred[w][t];
+        float x = v[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) x = (t & 1) ? fmaxf(x, v[w]) : fminf(x, v[w]);
+        bnd[t] = x;
+    }
+    __syncthreads();
+    K1_STAMP(3)
+    for (int p = wv; p < npieces; p += NW) {                       // one wave per piece, one lane per ray
+        const int2 pi = pieces[p];
+        const float2 pt = cpts[pi.x + (lane < pi.y ? lane : pi.y - 1)];
+        const float4 b0 = *(const float4 *)&bnd[0], b1 = *(const float4 *)&bnd[4];
+        const float bb8[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+        int x0, y0, x1, y1;
+        k1_ray_box(bb8, pt, x0, y0, x1, y1);
+        x0 = k1_wave_red<false>(x0); y0 = k1_wave_red<false>(y0);
+        x1 = k1_wave_red<true>(x1);  y1 = k1_wave_red<true>(y1);
+        if (lane == 63) *(int4 *)&boxes[p][0] = make_int4(x0, y0, x1, y1);
+    }
+    __syncthreads();
+    K1_STAMP(4)
+    if (t < npieces * K1_MAXBANDS) {
+        // one thread per (piece, band); the threads of a piece take the same decision.  Steps are appended in
+        // arrival order: any order gives the same integer sums.
+        const int pc = t / K1_MAXBANDS, band = t - pc * K1_MAXBANDS;
+        const int4 bx = *(const int4 *)&boxes[pc][0];
+        const int prec = pieces[pc].x | (pieces[pc].y << 16);
+        // the box clipped to the map, cut into row bands that fit the tile budget (one band, not clipped: SHARED)
+        const int cx0 = max(bx.x, 0), cy0 = max(bx.y, 0), cx1 = min(bx.z, S - 1), cy1 = min(bx.w, S - 1);
+        int kind = K1_KIND_GLOBAL, nsteps = 1;
+        int x0a = 0, w8 = 8, y0 = 0, h = 0, shift = 0;
+        if (cx1 < cx0 || cy1 < cy0) nsteps = 0;                    // no candidate has an end point of this piece in the map
+        else {
+            const int xa = cx0 & ~7, ww = ((cx1 - xa + 1) + 7) & ~7, vpr = ww >> 3;
+            const int sh = vpr <= 1 ? 0 : 32 - __clz(vpr - 1);
+            const int hmax = min(a.budget / (ww * 2), PF * NW * (64 >> (sh & 31)));
+            const int H = cy1 - cy0 + 1;
+            if (vpr <= 64 && hmax >= 1 && (H + hmax - 1) / hmax <= K1_MAXBANDS) {
+                nsteps = (H + hmax - 1) / hmax;
+                const int hb = (H + nsteps - 1) / nsteps;
+                const bool whole = nsteps == 1 && cx0 == bx.x && cy0 == bx.y && cx1 == bx.z && cy1 == bx.w;
+                kind = whole ? K1_KIND_SHARED : K1_KIND_BAND;
+                x0a = xa; w8 = ww; shift = sh;
+                y0 = cy0 + band * hb;
+                h = min(hb, cy1 + 1 - y0);
+                if (h <= 0) nsteps = 0;                            // (rounding can leave the last band empty)
+            }
+        }
+        if (band < nsteps) {
+            int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
+            dst[0] = make_int4(x0a, y0, w8, h);
+            dst[1] = make_int4(shift, kind, prec, 0);
+        }
+    }
+    __syncthreads();
+    const int nsteps = s_nsteps;
+    K1_STAMP(5)
 
-        const int4 ca = *(const int4 *)(cur + sub * 8), cb = *(const int4 *)(cur + sub * 8 + 4);
-        const int kind = cb.z;
-        if (kind < K1_KIND_GLOBAL) {
-            const int x0a = ca.x, y0 = ca.y, w8 = ca.z, lds = cb.x;
+    // ---- steps ---------------------------------------------------------------------------------------------------
+    // Tile staging through registers: the global loads of the NEXT step's tile are issued before the current
+    // step is consumed and stay in flight meanwhile.  Exactly PF loads are always issued (lanes without work
+    // re-read row 0) so that the compiler can count them.
+    uint32_t sum[CPL], cnt[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) { sum[k] = 0; cnt[k] = 0; }
+    uint32_t cnt_all = 0;                                          // rays of the unchecked steps: in the map for every candidate
+    if (nsteps > 0) {
+        k1_u32x4 R[PF];
+        int dst[PF];
+#define K1_PREFETCH(step)                                                                           \
+        {                                                                                           \
+            const int4 pa_ = *(const int4 *)&stepbuf[(step) * 8];                                   \
+            const int shift_ = __builtin_amdgcn_readfirstlane(stepbuf[(step) * 8 + 4]);             \
+            const int w8_ = __builtin_amdgcn_readfirstlane(pa_.z), h_ = __builtin_amdgcn_readfirstlane(pa_.w); \
+            const int rpi = 64 >> shift_;                       /* tile rows per wave-wide load */   \
+            const int srow = lane >> shift_, scol = lane & ((1 << shift_) - 1);                     \
+            const bool colok = scol < (w8_ >> 3);                                                   \
+            const int cc = colok ? scol : 0;                                                        \
+            const uint16_t *__restrict__ gbase = map + (size_t)__builtin_amdgcn_readfirstlane(pa_.y) * S + __builtin_amdgcn_readfirstlane(pa_.x) + (cc << 3); \
+            const int pitchb = w8_ << 1;                                                            \
+            const int ldsb = K1_TILE_OFS + (cc << 4);                                               \
+            _Pragma("unroll") for (int k_ = 0; k_ < PF; k_++) {                                     \
+                const int row = (wv + k_ * NW) * rpi + srow;                                        \
+                const bool live = colok & (row < h_);                                               \
+                const int rr = live ? row : 0;                                                      \
+                R[k_] = *(const k1_u32x4 *)(gbase + (size_t)rr * S);                                \
+                dst[k_] = live ? ldsb + rr * pitchb : -1;                                           \
+            }                                                                                       \
+        }
+        K1_PREFETCH(0)
+        for (int s = 0; s < nsteps; s++) {
+            __syncthreads();                                       // the previous tile is no longer read
+#pragma unroll
+            for (int k = 0; k < PF; k++) if (dst[k] >= 0) *(k1_u32x4 *)(smem + dst[k]) = R[k];
+            __syncthreads();
+            if (s == 0) K1_STAMP(6)
+            const int4 ca = *(const int4 *)&stepbuf[s * 8], cb = *(const int4 *)&stepbuf[s * 8 + 4];
+            {   // issue the next step's loads now; nothing in the compute loops below waits on vector memory
+                const int sn = s + 1 < nsteps ? s + 1 : s;
+                K1_PREFETCH(sn)
+            }
+            const int kind = __builtin_amdgcn_readfirstlane(cb.y);             // (the record is uniform: keep it in SGPRs)
+            const int nr = __builtin_amdgcn_readfirstlane(cb.z) >> 16;         // <= CS_RB_MAX = 64
+#ifdef K1_TIMES
+            if (t == 0 && blockIdx.x < 4096) g_k1_times[blockIdx.x * 16 + 10 + kind] += (unsigned long long)nr;
+#endif
+            const unsigned pbase = cpts_lds + (unsigned)zv + (unsigned)(__builtin_amdgcn_readfirstlane(cb.z) & 0xffff) * 8u;
+            const int x0a = __builtin_amdgcn_readfirstlane(ca.x), y0 = __builtin_amdgcn_readfirstlane(ca.y);
+            const int w8 = __builtin_amdgcn_readfirstlane(ca.z), h = __builtin_amdgcn_readfirstlane(ca.w);
             const int pitch2 = w8 << 1;
-            const int kofs = (int)smem_lds + K1_PTS_BYTES + lds - ((y0 * w8 + x0a) << 1);
-            const unsigned pbase = smem_lds + (unsigned)zv;
-            uint32_t sumb = 0;                                     // second accumulator: two gathers in flight
-            int r = 0;
-            for (; r + 1 < nr; r += 2) {
-                const float2 pa = k1_point_lds(pbase + r * 8), pb = k1_point_lds(pbase + r * 8 + 8);
-                float fxa, fya, fxb, fyb;
-                k1_coords(q, pa, fxa, fya);
-                k1_coords(q, pb, fxb, fyb);
-                const int ixa = (int)fxa, iya = (int)fya, ixb = (int)fxb, iyb = (int)fyb;
-                if (VERIFY) {
-                    const int h = ca.w;
-                    if (ixa < x0a || ixa >= x0a + w8 || iya < y0 || iya >= y0 + h ||
-                        ixb < x0a || ixb >= x0a + w8 || iyb < y0 || iyb >= y0 + h) { atomicAdd(verify_fail, 1u); continue; }
-                }
-                const uint32_t va = k1_lds_load(k1_tile_addr(ixa, iya, pitch2, kofs));
-                const uint32_t vb = k1_lds_load(k1_tile_addr(ixb, iyb, pitch2, kofs));
-                if (VERIFY) {                                      // the staged tile must equal the map
-                    if (va != map[(size_t)iya * S + ixa]) atomicAdd(verify_fail, 1u);
-                    if (vb != map[(size_t)iyb * S + ixb]) atomicAdd(verify_fail, 1u);
-                }
-                sum += va;
-                sumb += vb;
-            }
-            if (r < nr) {
-                float fx, fy;
-                k1_coords(q, k1_point_lds(pbase + r * 8), fx, fy);
-                const int ix = (int)fx, iy = (int)fy;
-                bool okv = true;
-                if (VERIFY) {
-                    const int h = ca.w;
-                    if (ix < x0a || ix >= x0a + w8 || iy < y0 || iy >= y0 + h) { atomicAdd(verify_fail, 1u); okv = false; }
-                }
-                if (okv) {
-                    const uint32_t v = k1_lds_load(k1_tile_addr(ix, iy, pitch2, kofs));
-                    if (VERIFY) { if (v != map[(size_t)iy * S + ix]) atomicAdd(verify_fail, 1u); }
-                    sum += v;
-                }
-            }
-            sum += sumb;
-            cnt += (uint32_t)nr;
-            if (VERIFY && (t & (K1_SUB - 1)) == 0) atomicAdd(verify_fail + (kind == K1_KIND_SHARED ? 1 : 2), (unsigned)nr);
-        } else if (INLINE_GLOBAL) {
-            // No tile covers this unit (theta tail, long ray, map border): bounds-checked global gathers, four in
-            // flight per lane -- these candidates have no locality, every gather is an L2 / MALL round trip; the
-            // other waves of the CU keep computing from LDS meanwhile.  (Large launches leave these units to the
-            // separate tail kernel instead: INLINE_GLOBAL == false.)
-            const unsigned pbase = smem_lds + (unsigned)zv;
-            int r = 0;
-            for (; r + 3 < nr; r += 4) {
-                uint32_t v[4]; bool ok[4];
+            const int kofs = (int)smem_lds + K1_TILE_OFS - ((y0 * w8 + x0a) << 1);
+            const unsigned zaddr = smem_lds + K1_ZERO_OFS + (unsigned)zv;
+            if (kind != K1_KIND_GLOBAL) {
+                // SHARED: every end point of every candidate lies in the tile (the box is rigorous).  BAND: the band
+                // holds rows [y0, y0+h) x columns [x0a, x0a+w8) of the map; an end point outside it (another band's,
+                // or outside the map) reads the zero word instead, and every in-map end point is in exactly one band.
+                // Software pipeline: the gathers of a ray pair are issued together and consumed one iteration later,
+                // under the address arithmetic of the next pair.  LDS returns in order and the compiler's wait for the
+                // prefetched points is the minimum over all paths into the loop of the number of younger LDS
+                // operations: the pipeline is therefore primed with loads of the zero word, not with constants.
+                const bool checked = kind == K1_KIND_BAND;
+                uint32_t va[CPL], vb[CPL];
+                int r = 0;
+                float2 pa_n = k1_point_lds(pbase), pb_n = k1_point_lds(pbase + 8);      // (cpts has room for the over-read)
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    float fx, fy;
-                    k1_coords(q, k1_point_lds(pbase + (r + u) * 8), fx, fy);
-                    const int ix = (int)fx, iy = (int)fy;
-                    ok[u] = ((unsigned)ix < (unsigned)S) & ((unsigned)iy < (unsigned)S);
-                    v[u] = map[ok[u] ? (size_t)iy * S + ix : 0];
-                }
+                for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(zaddr); vb[k] = k1_lds_load(zaddr); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!checked) {
+                    for (; r + 1 < nr; r += 2) {
+                        const float2 pa = pa_n, pb = pb_n;
+                        pa_n = k1_point_lds(pbase + r * 8 + 16); pb_n = k1_point_lds(pbase + r * 8 + 24);
+                        unsigned ada[CPL], adb[CPL];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { sum += ok[u] ? v[u] : 0u; cnt += ok[u] ? 1u : 0u; }
-            }
-            for (; r < nr; r++) k1_gather_global<false>(map, S, q, k1_point_lds(pbase + r * 8), sum, cnt);
-            if (VERIFY && (t & (K1_SUB - 1)) == 0) atomicAdd(verify_fail + 3, (unsigned)nr);
-        }
-    }
-#undef K1_PREFETCH
-#undef K1_STAGE_ONE
-
-    // ---- epilogue: one (sum, in-bounds count) per candidate and chunk; K1r finishes --------------------------
-    if (j < count) partial[(size_t)chunk * count + j] = make_uint2(sum, cnt);
-}
-
-// ---- K1r: per-candidate reduction of the chunk partials + arg-min ----------------------------------------
-// A block works on 64 candidates at a time with its 4 waves splitting the partial rows; blocks grid-stride
-// over the candidates and issue ONE atomicMin each (same-address device atomics serialise at ~12 ns each on
-// MI355X, so per-wave atomics would dominate at K >= 1e5).
-__global__ void __launch_bounds__(256)
-k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int n_chunks_tail, const int *__restrict__ tailmask,
-          int count, int n_points, const int *__restrict__ ev_idx, int32_t *__restrict__ dist_out,
-          unsigned long long *__restrict__ key_out)
-{
-    __shared__ uint32_t ssum[4][64], scnt[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long key = ~0ull;
-    for (int base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
-        const int j = base + lane;
-        uint32_t sum = 0, cnt = 0;
-        if (j < count) {
-            // rows [0, n_chunks): tiled (or whole-launch global) kernel
-            int c = w;
-            for (; c + 12 < n_chunks; c += 16) {
-                const uint2 p0 = partial[(size_t)c * count + j], p1 = partial[(size_t)(c + 4) * count + j];
-                const uint2 p2 = partial[(size_t)(c + 8) * count + j], p3 = partial[(size_t)(c + 12) * count + j];
-                sum += p0.x + p1.x + p2.x + p3.x; cnt += p0.y + p1.y + p2.y + p3.y;
-            }
-            for (; c < n_chunks; c += 4) {
-                const uint2 p = partial[(size_t)c * count + j];
-                sum += p.x; cnt += p.y;
-            }
-            // rows [n_chunks, n_chunks + n_chunks_tail): tail kernel, only where the sub-batch has GLOBAL units
-            if (tailmask) {
-                const int *tm = tailmask + (size_t)(j >> 8) * n_chunks_tail;
-                for (int ct = w; ct < n_chunks_tail; ct += 4)
-                    if (tm[ct]) {
-                        const uint2 p = partial[(size_t)(n_chunks + ct) * count + j];
-                        sum += p.x; cnt += p.y;
+                        for (int k = 0; k < CPL; k++) {
+                            float fxa, fya, fxb, fyb;
+                            k1_coords(q[k], pa, fxa, fya);
+                            k1_coords(q[k], pb, fxb, fyb);
+                            const int ixa = (int)fxa, iya = (int)fya, ixb = (int)fxb, iyb = (int)fyb;
+                            ada[k] = k1_tile_addr(ixa, iya, pitch2, kofs);
+                            adb[k] = k1_tile_addr(ixb, iyb, pitch2, kofs);
+                            if (VERIFY) {
+                                if (ixa < x0a || ixa >= x0a + w8 || iya < y0 || iya >= y0 + h ||
+                                    ixb < x0a || ixb >= x0a + w8 || iyb < y0 || iyb >= y0 + h) atomicAdd(a.verify, 1u);
+                                else if (map[(size_t)iya * S + ixa] != *(const uint16_t *)(smem + (ada[k] - smem_lds)) ||
+                                         map[(size_t)iyb * S + ixb] != *(const uint16_t *)(smem + (adb[k] - smem_lds)))
+                                    atomicAdd(a.verify, 1u);               // the staged tile must equal the map
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) sum[k] += va[k] + vb[k];
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(ada[k]); vb[k] = k1_lds_load(adb[k]); }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    cnt_all += (uint32_t)nr;
+                } else {
+                    for (; r + 1 < nr; r += 2) {
+                        const float2 pa = pa_n, pb = pb_n;
+                        pa_n = k1_point_lds(pbase + r * 8 + 16); pb_n = k1_point_lds(pbase + r * 8 + 24);
+                        unsigned ada[CPL], adb[CPL];
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) {
+                            float fxa, fya, fxb, fyb;
+                            k1_coords(q[k], pa, fxa, fya);
+                            k1_coords(q[k], pb, fxb, fyb);
+                            const int ixa = (int)fxa, iya = (int)fya, ixb = (int)fxb, iyb = (int)fyb;
+                            const bool oka = ((unsigned)(ixa - x0a) < (unsigned)w8) & ((unsigned)(iya - y0) < (unsigned)h);
+                            const bool okb = ((unsigned)(ixb - x0a) < (unsigned)w8) & ((unsigned)(iyb - y0) < (unsigned)h);
+                            const unsigned ta = k1_tile_addr(ixa, iya, pitch2, kofs), tb = k1_tile_addr(ixb, iyb, pitch2, kofs);
+                            if (VERIFY) {
+                                if (oka && map[(size_t)iya * S + ixa] != *(const uint16_t *)(smem + (ta - smem_lds))) atomicAdd(a.verify, 1u);
+                                if (okb && map[(size_t)iyb * S + ixb] != *(const uint16_t *)(smem + (tb - smem_lds))) atomicAdd(a.verify, 1u);
+                            }
+                            ada[k] = oka ? ta : zaddr;
+                            adb[k] = okb ? tb : zaddr;
+                            cnt[k] += (oka ? 1u : 0u) + (okb ? 1u : 0u);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) sum[k] += va[k] + vb[k];
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(ada[k]); vb[k] = k1_lds_load(adb[k]); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (r < nr) {                                      // odd ray count: the last ray (range-tested in both kinds)
+                    const float2 pa = pa_n;
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) {
+                        float fx, fy;
+                        k1_coords(q[k], pa, fx, fy);
+                        const int ix = (int)fx, iy = (int)fy;
+                        const bool ok = ((unsigned)(ix - x0a) < (unsigned)w8) & ((unsigned)(iy - y0) < (unsigned)h);
+                        if (VERIFY) {
+                            if (!ok && !checked) atomicAdd(a.verify, 1u);
+                            if (ok && map[(size_t)iy * S + ix] != *(const uint16_t *)(smem + (k1_tile_addr(ix, iy, pitch2, kofs) - smem_lds))) atomicAdd(a.verify, 1u);
+                        }
+                        sum[k] += k1_lds_load(ok ? k1_tile_addr(ix, iy, pitch2, kofs) : zaddr);
+                        if (checked) cnt[k] += ok ? 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CPL; k++) sum[k] += va[k] + vb[k];
+                if (VERIFY && t == 0) atomicAdd(a.verify + (checked ? 4 : 1), (unsigned)(nr * 4));
+            } else {
+                // no tile covers this piece (box wider than 512 px or taller than K1_MAXBANDS bands: candidates spread
+                // over a large part of the map): bounds-checked global gathers, several in flight per lane
+                int r = 0;
+                for (; r + 1 < nr; r += 2) {
+                    const float2 pa = k1_point_lds(pbase + r * 8), pb = k1_point_lds(pbase + r * 8 + 8);
+                    uint32_t ga[CPL], gb[CPL]; bool oka[CPL], okb[CPL];
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) {
+                        float fxa, fya, fxb, fyb;
+                        k1_coords(q[k], pa, fxa, fya);
+                        k1_coords(q[k], pb, fxb, fyb);
+                        const int ixa = (int)fxa, iya = (int)fya, ixb = (int)fxb, iyb = (int)fyb;
+                        oka[k] = ((unsigned)ixa < (unsigned)S) & ((unsigned)iya < (unsigned)S);
+                        okb[k] = ((unsigned)ixb < (unsigned)S) & ((unsigned)iyb < (unsigned)S);
+                        ga[k] = map[oka[k] ? (size_t)iya * S + ixa : 0];
+                        gb[k] = map[okb[k] ? (size_t)iyb * S + ixb : 0];
+                    }
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) {
+                        sum[k] += (oka[k] ? ga[k] : 0u) + (okb[k] ? gb[k] : 0u);
+                        cnt[k] += (oka[k] ? 1u : 0u) + (okb[k] ? 1u : 0u);
+                    }
+                }
+                if (r < nr) {
+                    const float2 pa = k1_point_lds(pbase + r * 8);
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) k1_gather_global<false>(map, S, q[k], pa, sum[k], cnt[k]);
+                }
+                if (VERIFY && t == 0) atomicAdd(a.verify + 3, (unsigned)(nr * 4));
             }
         }
-        ssum[w][lane] = sum; scnt[w][lane] = cnt;
-        __syncthreads();
-        if (w == 0 && j < count) {
-            const uint64_t s = (uint64_t)ssum[0][lane] + ssum[1][lane] + ssum[2][lane] + ssum[3][lane];
-            const uint32_t c = scnt[0][lane] + scnt[1][lane] + scnt[2][lane] + scnt[3][lane];
-            const unsigned long long k = k1_finish(s, c, n_points, ev_idx ? ev_idx[j] : j, dist_out);
-            key = k < key ? k : key;
-        }
-        __syncthreads();
+#undef K1_PREFETCH
     }
-    if (w == 0) {
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_down(key, off, 64);
-            key = o < key ? o : key;
-        }
-        if (lane == 0 && key != ~0ull) atomicMin(key_out, key);
+    K1_STAMP(7)
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // Every candidate has one 64-bit accumulator (pixel sum | steps with an in-map end point << 40): the workgroup adds
+    // its partial sums with agent-scope atomics (performed at the memory side: correct for any placement of the group's
+    // workgroups over CUs and XCDs), drains every wave, then ONE lane takes the group's arrival ticket.  The workgroup
+    // that draws the last ticket of the group swaps the accumulators back to zero (read + reset for the next launch in
+    // one round trip, whatever the number of chunks), finishes the distances and takes the group arg-min; the last
+    // group takes the overall arg-min.  No fences, no spinning; tickets and accumulators are zero between launches.
+    typedef unsigned long long u64;
+    u64 *acc = a.acc + (size_t)g * K1_GROUP + (size_t)t * CPL;                 // (the candidates of a lane are adjacent)
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+        const u64 add = (u64)sum[k] | ((u64)((cnt[k] | cnt_all) ? 1u : 0u) << 40);
+        if (add) __hip_atomic_fetch_add(acc + k, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (unsigned)nc - 1u;
+        if (s_last) __hip_atomic_store(a.tickets + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    K1_STAMP(8)
+    if (!s_last) return;
+    u64 key = ~0ull;
+    {
+        u64 tot[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; k++) tot[k] = __hip_atomic_exchange(acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int j = g * K1_GROUP + k * LANES + t;
+            if (j < count) {
+                const u64 kk = k1_finish(tot[k] & ((1ull << 40) - 1), (uint32_t)(tot[k] >> 40), a.n_rays, a.ev_idx ? a.ev_idx[j] : j, a.dist_out);
+                key = kk < key ? kk : key;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_down(key, off, 64);
+        key = o < key ? o : key;
+    }
+    if (lane == 0) wkey[wv] = key;
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < NW; w++) key = wkey[w] < key ? wkey[w] : key;
+        __hip_atomic_store(a.gkey + g, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned old = __hip_atomic_fetch_add(a.tickets + ng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)ng - 1u) {                            // the last group: minimum over the groups
+            __hip_atomic_store(a.tickets + ng, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64 best = ~0ull;
+            for (int i = 0; i < ng; i++) {
+                const u64 k = __hip_atomic_load(a.gkey + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                best = k < best ? k : best;
+            }
+            *a.key_out = best;
+        }
+    }
+    K1_STAMP(9)
 }
 
 // ---- host side --------------------------------------------------------------------------------------
@@ -563,14 +726,14 @@ int32_t cs_alloc_candidates(slamhip_cs *cs, int count)
     return SLAMHIP_OK;
 }
 
-static int32_t ensure_partial(slamhip_cs *cs, size_t need)
+static int32_t ensure_partial(slamhip_cs *cs, size_t bytes)
 {
-    if (need <= cs->cap_partial) return SLAMHIP_OK;
+    if (bytes <= cs->cap_partial) return SLAMHIP_OK;
     if (cs->d_partial) (void)hipFree(cs->d_partial);
     cs->d_partial = nullptr; cs->cap_partial = 0;
-    need += need / 4;
-    SH_HIP(hipMalloc(&cs->d_partial, sizeof(uint2) * need));
-    cs->cap_partial = need;
+    bytes += bytes / 4;
+    SH_HIP(hipMalloc(&cs->d_partial, bytes));
+    cs->cap_partial = bytes;
     return SLAMHIP_OK;
 }
 
@@ -580,21 +743,140 @@ static int env_int(const char *name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
-static int32_t ensure_plans(slamhip_cs *cs, size_t ints)
+// Smallest chunk count >= nc whose chunks (equal ray ranges) hold at most K1_MAXR rays and K1_MAXP block pieces.
+static int k1_legal_chunks(const slamhip_cs *cs, int nc)
 {
-    if (ints <= cs->cap_plans) return SLAMHIP_OK;
-    if (cs->d_plans) (void)hipFree(cs->d_plans);
-    cs->d_plans = nullptr; cs->cap_plans = 0;
-    ints += ints / 4;
-    SH_HIP(hipMalloc(&cs->d_plans, sizeof(int) * ints));
-    cs->cap_plans = ints;
-    return SLAMHIP_OK;
+    const int R = cs->n_points, n_rb = cs->n_rb;
+    const int *rb = cs->h_rb_start.data();
+    if (nc < sh_div_up(R, K1_MAXR)) nc = sh_div_up(R, K1_MAXR);
+    if (nc > R) nc = R;
+    for (; nc < R; nc++) {
+        bool ok = true;
+        int b = 0;
+        for (int c = 0; c < nc && ok; c++) {
+            const int rlo = (int)(((long long)c * R) / nc), rhi = (int)(((long long)(c + 1) * R) / nc);
+            while (b + 1 < n_rb && rb[b + 1] <= rlo) b++;              // block of ray rlo
+            int e = b;
+            while (e + 1 < n_rb && rb[e + 1] < rhi) e++;               // block of ray rhi - 1
+            if (e - b + 1 > K1_MAXP || rhi - rlo > K1_MAXR) ok = false;
+        }
+        if (ok) break;
+    }
+    return nc;
 }
 
-// Candidate preparation (+ tile plans) followed by K1 (+ K1r) over `count` candidates in evaluation order
-// (d_ev_idx maps to flat indices).  mode 0: d_pxcs already holds (px,py,c,s); 1: d_ev_off holds jitters added
-// to `pose`; 2: d_ev_off holds poses.  The packed arg-min key is min-ed into key_dst (armed by the prep
-// kernel).  Asynchronous on the context's stream.
+// Estimated cost of a group in ray units (tile steps cost 1 per ray): from the theta range and the translation spread
+// of the group (ensure_shard) and the reach of each ray block (set_scan).  The end points of a block sweep a box of
+// about (extent + reach * dtheta + spread) pixels squared; a box beyond the tile budget is staged in bands with
+// range-tested gathers.  Only the balance of the launch depends on this estimate.
+static double k1_group_cost(const slamhip_cs *cs, int g, int budget)
+{
+    const double dth = cs->h_grp_dth[(size_t)g], dxy = cs->h_grp_dxy[(size_t)g];
+    double c = 0.0;
+    for (int b = 0; b < cs->n_rb; b++) {
+        const double w = cs->h_rb_ext[(size_t)b] + cs->h_rb_reach[(size_t)b] * dth + dxy + 10.0;
+        const double bytes = 2.0 * w * w;
+        double f = 1.0;
+        if (bytes > budget) {
+            const double bands = ceil(bytes / budget);
+            f = bands <= K1_MAXBANDS && w <= 512.0 ? 2.5 * bands : 12.0;
+        }
+        c += f * (cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b]);
+    }
+    return c;
+}
+
+// Launch layout (cs->k1_*): the groups whose estimated cost per ray is well above a plain group's get their own,
+// larger chunk counts (at most K1_TABLE_G groups, the most expensive first); the rest share one count.
+static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int budget, bool have_spread)
+{
+    const int R = cs->n_points;
+    cs->k1_tab_group.clear(); cs->k1_tab_nc.clear();
+    int uni_target = (int)((double)target_wgs / n_groups + 0.5);
+    if (have_spread) {
+        // candidates for the table: all groups if few, else the theta tails (the only ones that can be expensive)
+        std::vector<std::pair<double, int>> cand;
+        const int side = n_groups <= K1_TABLE_G ? n_groups : K1_TABLE_G / 2;
+        for (int g = 0; g < n_groups; g++) {
+            if (n_groups > K1_TABLE_G && g >= side && g < n_groups - side) continue;
+            cand.push_back(std::make_pair(k1_group_cost(cs, g, budget), g));
+        }
+        if (n_groups <= K1_TABLE_G) {
+            double total = 0.0;
+            for (size_t i = 0; i < cand.size(); i++) total += cand[i].first;
+            for (size_t i = 0; i < cand.size(); i++) {
+                int v = (int)floor(cand[i].first / total * target_wgs + 0.5);
+                if (v < 1) v = 1;
+                if (v > R / 4) v = R / 4 > 0 ? R / 4 : 1;
+                cs->k1_tab_group.push_back(cand[i].second);
+                cs->k1_tab_nc.push_back(v);
+            }
+            // dispatch order: theta extremes first (0, n-1, 1, n-2, ...): the expensive groups start first
+            std::vector<int> og, on;
+            for (int p = 0; p < n_groups; p++) {
+                const int g = (p & 1) ? n_groups - 1 - (p >> 1) : (p >> 1);
+                og.push_back(g); on.push_back(cs->k1_tab_nc[(size_t)g]);
+            }
+            cs->k1_tab_group = og; cs->k1_tab_nc = on;
+            cs->k1_uni_g0 = 0; cs->k1_uni_ng = 0; cs->k1_uni_nc = 1;
+        } else {
+            // many groups: a plain group costs R ray units and gets uni_target chunks; tail groups in proportion
+            int lo = 0, hi = n_groups;                             // uniform range [lo, hi)
+            std::vector<std::pair<double, int>> tail;
+            for (size_t i = 0; i < cand.size(); i++) if (cand[i].first > 1.25 * R) tail.push_back(cand[i]);
+            std::sort(tail.begin(), tail.end());
+            // the table must be a prefix and a suffix of the group range: extend to the outermost cheap group
+            int left = 0, right = 0;
+            for (size_t i = 0; i < tail.size(); i++) {
+                if (tail[i].second < side) left = std::max(left, tail[i].second + 1);
+                else right = std::max(right, n_groups - tail[i].second);
+            }
+            lo = left; hi = n_groups - right;
+            for (int p = 0; p < left + right; p++) {               // extremes first
+                const int g = (p & 1) ? (n_groups - 1 - (p >> 1)) : (p >> 1);
+                const int gg = (p >> 1) < ((p & 1) ? right : left) ? g : -1;
+                if (gg < 0) continue;
+                double c = 0.0;
+                for (size_t i = 0; i < cand.size(); i++) if (cand[i].second == gg) c = cand[i].first;
+                int v = (int)floor(c / R * (uni_target > 0 ? uni_target : 1) + 0.5);
+                if (v < 1) v = 1;
+                if (v > R / 4) v = R / 4 > 0 ? R / 4 : 1;
+                cs->k1_tab_group.push_back(gg); cs->k1_tab_nc.push_back(v);
+            }
+            cs->k1_uni_g0 = lo; cs->k1_uni_ng = hi - lo; cs->k1_uni_nc = uni_target > 0 ? uni_target : 1;
+        }
+    } else {
+        cs->k1_uni_g0 = 0; cs->k1_uni_ng = n_groups; cs->k1_uni_nc = uni_target > 0 ? uni_target : 1;
+    }
+    // the listed part is addressed through a K1_TABLE_WGS-entry table: scale oversized requests down
+    {
+        long long tot = 0;
+        for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
+        if (tot > K1_TABLE_WGS / 2)
+            for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) {
+                cs->k1_tab_nc[i] = (int)((long long)cs->k1_tab_nc[i] * (K1_TABLE_WGS / 2) / tot);
+                if (cs->k1_tab_nc[i] < 1) cs->k1_tab_nc[i] = 1;
+            }
+    }
+    // legal chunk counts (rays and pieces per chunk); identical requests share the search
+    int req = -1, res = -1;
+    for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) {
+        if (cs->k1_tab_nc[i] != req) { req = cs->k1_tab_nc[i]; res = k1_legal_chunks(cs, req); }
+        cs->k1_tab_nc[i] = res;
+    }
+    cs->k1_uni_nc = k1_legal_chunks(cs, cs->k1_uni_nc);
+    long long tot = 0;
+    for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
+    if (tot > K1_TABLE_WGS) {                                      // (huge scans: legal chunk counts alone overflow the table)
+        cs->k1_tab_group.clear(); cs->k1_tab_nc.clear();
+        cs->k1_uni_g0 = 0; cs->k1_uni_ng = n_groups;
+        cs->k1_uni_nc = k1_legal_chunks(cs, uni_target > 0 ? uni_target : 1);
+    }
+}
+
+// K1 over `count` candidates in evaluation order (d_ev_idx maps to flat indices).  mode 0: d_pxcs already holds
+// (px,py,c,s); 1: d_ev_off holds jitters added to `pose`; 2: d_ev_off holds poses.  The packed arg-min key of the
+// launch is written to key_dst.  Asynchronous on the context's stream.
 int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int count, bool want_dist, bool cand_sane,
                            uint64_t *key_dst)
 {
@@ -603,109 +885,170 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     static const int force_global = env_int("SLAMHIP_K1_GLOBAL", 0);
     static const int verify = env_int("SLAMHIP_K1_VERIFY", 0);
     static const int tile_kb = env_int("SLAMHIP_K1_TILE_KB", 60);
-    static const int target_wgs = env_int("SLAMHIP_K1_TARGET_WGS", 768);
+    static const int target_wgs = env_int("SLAMHIP_K1_TARGET_WGS", 512);
+    static const int target_wgs_uniform = env_int("SLAMHIP_K1_TARGET_WGS_UNIFORM", 768);
+    static const int cpl_env = env_int("SLAMHIP_K1_CPL", 0);           // candidates per lane: 0 = by launch size
+    static const int no_table = env_int("SLAMHIP_K1_NOTABLE", 0);
     const bool sane = cs->pts_sane && cand_sane;
-    const bool tiled = sane && (cs->hs % 8 == 0) && !force_global && cs->n_rb <= K1_MAX_RB;
+    const bool tiled = sane && (cs->hs % 8 == 0) && !force_global;
     const int n_rb = cs->n_rb;
     int32_t *dist = want_dist ? cs->d_dist : nullptr;
     unsigned long long *key = (unsigned long long *)key_dst;
     const float bx = pose ? pose[0] : 0.f, by = pose ? pose[1] : 0.f, bth = pose ? pose[2] : 0.f;
-    const int n_groups = sh_div_up(count, K1_WG);
 
-    int budget_shared = tile_kb * 1024;
-    if (budget_shared > K1_WG * K1_PF * 16) budget_shared = K1_WG * K1_PF * 16;      // what 4 prefetch vectors/lane can stage
-    int budget_sub = budget_shared / K1_NSUB;
-    static const int sub_kb = env_int("SLAMHIP_K1_SUB_KB", 0);         // debugging: decouple the two budgets
-    static const int no_shared = env_int("SLAMHIP_K1_NOSHARED", 0);
-    if (sub_kb > 0) budget_sub = sub_kb * 1024;
-    budget_sub &= ~15;
-    if (budget_sub > K1_SUB * K1_PF * 16) budget_sub = K1_SUB * K1_PF * 16;
-    const int budget_shared_eff = no_shared ? 0 : budget_shared;
-    // tail kernel geometry: 256-lane blocks, ~32 rays per chunk
-    int bpc_t = sh_div_up(32 * n_rb, cs->n_points > 0 ? cs->n_points : 1);
-    if (bpc_t < 1) bpc_t = 1;
-    if (bpc_t > n_rb) bpc_t = n_rb;
-    const int n_chunks_t = sh_div_up(n_rb, bpc_t);
-    if (tiled) SH_TRY(ensure_plans(cs, (size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * K1_NSUB * n_chunks_t));
-    // GLOBAL units (no LDS tile fits): small launches evaluate them inline in the tiled kernel, where the other waves
-    // hide their latency; from ~48k candidates on, a separate many-wave tail kernel is faster (measured on MI355X)
-    static const int tail_threshold = env_int("SLAMHIP_K1_TAIL_KERNEL_FROM", 49152);
-    const bool use_tail_kernel = tiled && count >= tail_threshold;
-    int *tailp = use_tail_kernel ? cs->d_plans + (size_t)n_groups * n_rb * K1_PLAN_INTS : nullptr;   // tailmask [sub-batch][tail chunk]
+    if (tiled) {
+        const int n_groups = sh_div_up(count, K1_GROUP);
+        int budget = tile_kb * 1024;
+        if (budget > 64 * 1024) budget = 64 * 1024;                // what the staging registers hold per pass
+        const size_t lds = (size_t)K1_TILE_OFS + (size_t)budget;
+
+        k1_args a;
+        a.map = cs->d_hole; a.S = cs->hs; a.pts = cs->d_pts_sorted; a.ray_blk = cs->d_ray_blk; a.n_rays = cs->n_points;
+        a.pxcs = cs->d_pxcs; a.src3 = cs->d_ev_off; a.bx = bx; a.by = by; a.bth = bth; a.scale = cs->hscale;
+        a.count = count; a.n_groups = n_groups; a.budget = budget;
+        a.ev_idx = cs->d_ev_idx; a.dist_out = dist; a.key_out = key; a.verify = cs->d_verify;
+
+        // launch layout
+        const bool have_spread = mode == 1 && !no_table && (int)cs->h_grp_dth.size() == n_groups;
+        if (cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread) {
+            k1_make_layout(cs, n_groups, n_groups <= K1_TABLE_G ? target_wgs : target_wgs_uniform, budget, have_spread);
+            cs->k1_layout_dirty = false; cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread;
+        }
+        unsigned first = 0;
+        const int n_tab = (int)cs->k1_tab_group.size();
+        for (int p = 0; p < n_tab; p++) {
+            a.tab_group[p] = (unsigned short)cs->k1_tab_group[(size_t)p];
+            a.wg_first[p] = first;
+            first += (unsigned)cs->k1_tab_nc[(size_t)p];
+        }
+        for (int p = 0; p < n_tab; p++)
+            for (unsigned w = a.wg_first[p]; w < a.wg_first[p] + (unsigned)cs->k1_tab_nc[(size_t)p]; w++) a.wg_pos[w] = (unsigned char)p;
+        for (int p = n_tab; p <= K1_TABLE_G; p++) a.wg_first[p] = first;
+        a.n_tab_wgs = (int)first;
+        a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
+        const int n_wgs = (int)first + cs->k1_uni_ng * cs->k1_uni_nc;
+        // 4 candidates per lane (few fat waves: fast start) while every workgroup runs at once, else 1 (throughput)
+        const int cpl = cpl_env > 0 ? cpl_env : (n_wgs <= 512 ? 4 : 1);
+        if (n_groups > cs->k1_cap_groups) {
+            if (cs->d_k1_tickets) (void)hipFree(cs->d_k1_tickets);
+            if (cs->d_k1_gkey) (void)hipFree(cs->d_k1_gkey);
+            cs->d_k1_tickets = nullptr; cs->d_k1_gkey = nullptr; cs->k1_cap_groups = 0;
+            const int cap = n_groups + n_groups / 4 + 16;
+            SH_HIP(hipMalloc(&cs->d_k1_tickets, sizeof(unsigned) * (size_t)(cap + 1)));
+            SH_HIP(hipMalloc(&cs->d_k1_gkey, sizeof(unsigned long long) * (size_t)cap));
+            if (cs->d_k1_acc) (void)hipFree(cs->d_k1_acc);
+            cs->d_k1_acc = nullptr;
+            SH_HIP(hipMalloc(&cs->d_k1_acc, sizeof(unsigned long long) * (size_t)cap * K1_GROUP));
+            SH_HIP(hipMemsetAsync(cs->d_k1_acc, 0, sizeof(unsigned long long) * (size_t)cap * K1_GROUP, ctx->stream));
+            cs->k1_cap_groups = cap;
+            cs->k1_tickets_groups = -1;
+        }
+        if (cs->k1_tickets_groups != n_groups) {
+            // tickets are zero between launches (the last arriver resets them); the group ticket lives at index
+            // n_groups, so a change of the group count (or a fresh buffer) zeroes the lot
+            SH_HIP(hipMemsetAsync(cs->d_k1_tickets, 0, sizeof(unsigned) * (size_t)(cs->k1_cap_groups + 1), ctx->stream));
+            cs->k1_tickets_groups = n_groups;
+        }
+        a.tickets = cs->d_k1_tickets; a.gkey = cs->d_k1_gkey; a.acc = cs->d_k1_acc;
+        {
+            sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
+#define K1_LAUNCH(M, V, C) hipLaunchKernelGGL((k1_search_tiled<M, V, C>), dim3(n_wgs), dim3(K1_GROUP / C), lds, ctx->stream, a)
+#define K1_LAUNCH_C(M, V) { if (cpl == 4) K1_LAUNCH(M, V, 4); else if (cpl == 2) K1_LAUNCH(M, V, 2); else K1_LAUNCH(M, V, 1); }
+            if (verify) { if (mode == 0) K1_LAUNCH_C(0, true) else if (mode == 1) K1_LAUNCH_C(1, true) else K1_LAUNCH_C(2, true) }
+            else        { if (mode == 0) K1_LAUNCH_C(0, false) else if (mode == 1) K1_LAUNCH_C(1, false) else K1_LAUNCH_C(2, false) }
+#undef K1_LAUNCH_C
+#undef K1_LAUNCH
+        }
+        SH_HIP(hipGetLastError());
+#ifdef K1_TIMES
+        {
+            static int calls = 0;
+            if (++calls == 8) {
+                (void)hipStreamSynchronize(ctx->stream);
+                const int nw = n_wgs < 4096 ? n_wgs : 4096;
+                std::vector<unsigned long long> h((size_t)nw * 16);
+                (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_k1_times), sizeof(unsigned long long) * h.size());
+                unsigned long long t0 = ~0ull, t1 = 0;
+                auto endof = [&](int i) { unsigned long long e = h[i * 16 + 8]; if (h[i * 16 + 9] > e) e = h[i * 16 + 9]; return e; };
+                for (int i = 0; i < nw; i++) { if (h[i * 16] < t0) t0 = h[i * 16]; if (endof(i) > t1) t1 = endof(i); }
+                static const char *nm[9] = { "q", "wred", "bnd", "boxes", "steps", "tile", "compute", "publish", "tail" };
+                double acc[9] = { 0 }; int nlast = 0;
+                for (int i = 0; i < nw; i++) {
+                    for (int k = 0; k < 8; k++) acc[k] += (double)(h[i * 16 + k + 1] - h[i * 16 + k]) * 0.01;
+                    if (h[i * 16 + 9] > h[i * 16 + 8]) { acc[8] += (double)(h[i * 16 + 9] - h[i * 16 + 8]) * 0.01; nlast++; }
+                }
+                fprintf(stderr, "[k1 times] WGs %d (groups %d: %d listed, %d x %d uniform; %d candidates per lane) span %.2f us; mean per WG:", n_wgs, n_groups, n_tab, cs->k1_uni_ng, cs->k1_uni_nc, cpl, (double)(t1 - t0) * 0.01);
+                for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.2f |", nm[k], acc[k] / nw);
+                fprintf(stderr, " reducers (%d) %.2f us\n", nlast, nlast ? acc[8] / nlast : 0.0);
+                {
+                    std::vector<unsigned long long> ws((size_t)nw * 16);
+                    (void)hipMemcpyFromSymbol(ws.data(), HIP_SYMBOL(g_k1_wstart), sizeof(unsigned long long) * ws.size());
+                    double skew = 0, mx = 0;
+                    for (int i = 0; i < nw; i++) {
+                        unsigned long long lo = ~0ull, hi = 0;
+                        for (int w = 0; w < K1_GROUP / cpl / 64; w++) { lo = std::min(lo, ws[i * 16 + w]); hi = std::max(hi, ws[i * 16 + w]); }
+                        skew += (double)(hi - lo) * 0.01; mx = std::max(mx, (double)(hi - lo) * 0.01);
+                    }
+                    fprintf(stderr, "[k1 times] wave start skew inside a workgroup: mean %.2f us, max %.2f us\n", skew / nw, mx);
+                }
+                std::vector<int> order((size_t)nw);
+                for (int i = 0; i < nw; i++) order[(size_t)i] = i;
+                std::sort(order.begin(), order.end(), [&](int x, int y) { return endof(x) > endof(y); });
+                for (int oi = 0; oi < nw; oi += (oi < 12 ? 1 : nw / 16 > 0 ? nw / 16 : 1)) {
+                    const int i = order[(size_t)oi];
+                    fprintf(stderr, "  wg %4d: start +%6.2f |", i, (double)(h[i * 16] - t0) * 0.01);
+                    for (int k = 0; k < 8; k++) fprintf(stderr, " %s %5.2f", nm[k], (double)(h[i * 16 + k + 1] - h[i * 16 + k]) * 0.01);
+                    fprintf(stderr, " tail %5.2f | end +%6.2f | g %2d nc %2d rays shared %d global %d band %d\n",
+                            h[i * 16 + 9] > h[i * 16 + 8] ? (double)(h[i * 16 + 9] - h[i * 16 + 8]) * 0.01 : 0.0,
+                            (double)(endof(i) - t0) * 0.01, (int)h[i * 16 + 14], (int)h[i * 16 + 15], (int)h[i * 16 + 11],
+                            (int)h[i * 16 + 12], (int)h[i * 16 + 13]);
+                }
+                // per group: chunks, ray-steps per kind, mean / max compute time
+                for (int g = 0; g < n_groups; g++) {
+                    double cs_ = 0, cm = 0; int n = 0; long long k4[4] = { 0, 0, 0, 0 };
+                    for (int i = 0; i < nw; i++) if ((int)h[i * 16 + 14] == g) {
+                        const double c = (double)(h[i * 16 + 7] - h[i * 16 + 6]) * 0.01;
+                        cs_ += c; cm = std::max(cm, c); n++;
+                        for (int k = 0; k < 4; k++) k4[k] += (long long)h[i * 16 + 10 + k];
+                    }
+                    fprintf(stderr, "  group %2d: chunks %2d | ray-steps own %lld shared %lld global %lld band %lld | compute mean %.2f max %.2f us\n",
+                            g, n, k4[0], k4[1], k4[2], k4[3], n ? cs_ / n : 0.0, cm);
+                }
+            }
+        }
+#endif
+        return SLAMHIP_OK;
+    }
+
+    // ---- fallback: candidate transform, bounds-checked global gathers, reduction -----------------------------------
     {
         sh_timer t(ctx, SLAMHIP_K_CS_PREP);
-        int *plans = tiled ? cs->d_plans : nullptr;
-#define K1_PREP(M) hipLaunchKernelGGL(k1_prep_plan<M>, dim3(n_groups), dim3(K1_WG), 0, ctx->stream, (const float *)cs->d_ev_off, \
-                       bx, by, bth, cs->hscale, cs->d_pxcs, count, key, (const float2 *)cs->d_pts_sorted, (const int *)cs->d_rb_start, \
-                       n_rb, cs->hs, budget_shared_eff, budget_sub, plans, tailp, bpc_t, n_chunks_t)
+        const dim3 grid(sh_div_up(count, K1_THREADS));
+#define K1_PREP(M) hipLaunchKernelGGL(k1_prep_pxcs<M>, grid, dim3(K1_THREADS), 0, ctx->stream, (const float *)cs->d_ev_off, \
+                       bx, by, bth, cs->hscale, cs->d_pxcs, count, key)
         if (mode == 0) K1_PREP(0); else if (mode == 1) K1_PREP(1); else K1_PREP(2);
 #undef K1_PREP
     }
-    static const int dump = env_int("SLAMHIP_K1_DUMP", 0);
-    if (dump && tiled) {                                           // debugging aid: histogram of plan kinds
-        std::vector<int> h((size_t)n_groups * n_rb * K1_PLAN_INTS + (size_t)n_groups * K1_NSUB * n_chunks_t);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipMemcpy(h.data(), cs->d_plans, sizeof(int) * h.size(), hipMemcpyDeviceToHost);
-        int kinds[4] = { 0, 0, 0, 0 }, tails = 0;
-        for (size_t i = 0; i < (size_t)n_groups * n_rb * 4; i++) kinds[h[i * 8 + 6] & 3]++;
-
-        fprintf(stderr, "[slamhip] K1 plans: count %d groups %d n_rb %d budgets %d/%d | own %d shared %d global %d (-) %d | tail (sub-batch,chunk) pairs %d\n",
-                count, n_groups, n_rb, budget_shared_eff, budget_sub, kinds[0], kinds[1], kinds[2], kinds[3], tails);
-        for (int b = 0; b < (n_rb < 3 ? n_rb : 3); b++)
-            for (int sb = 0; sb < 4; sb++) {
-                const int *r = &h[((size_t)0 * n_rb + b) * K1_PLAN_INTS + sb * 8];
-                fprintf(stderr, "   g0 b%d sb%d: x0a %d y0 %d w8 %d h %d lds %d shift %d kind %d\n", b, sb, r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
-            }
+    int bpc = (int)(((long long)sh_div_up(count, K1_THREADS) * n_rb) / 4096);
+    if (bpc < 1) bpc = 1;
+    if (bpc > n_rb) bpc = n_rb;
+    const int n_chunks = sh_div_up(n_rb, bpc);
+    SH_TRY(ensure_partial(cs, sizeof(uint2) * (size_t)n_chunks * count));
+    {
+        sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
+        dim3 grid(sh_div_up(count, K1_THREADS), n_chunks);
+        if (sane)
+            hipLaunchKernelGGL(k1_distance_global<false>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
+                               cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial);
+        else
+            hipLaunchKernelGGL(k1_distance_global<true>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
+                               cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial);
     }
-    const int rblocks = sh_div_up(count, 64) < 512 ? sh_div_up(count, 64) : 512;
-    if (tiled) {
-        int bpc = (int)(((long long)n_groups * n_rb) / target_wgs);
-        if (bpc < 1) bpc = 1;
-        if (bpc > n_rb) bpc = n_rb;
-        const int n_chunks = sh_div_up(n_rb, bpc);
-        SH_TRY(ensure_partial(cs, (size_t)(n_chunks + (use_tail_kernel ? n_chunks_t : 0)) * count));
-        const size_t lds = (size_t)K1_PTS_BYTES + (size_t)(budget_shared > K1_NSUB * budget_sub ? budget_shared : K1_NSUB * budget_sub);
-        {
-            sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
-            dim3 grid(n_groups * n_chunks);
-#define K1_LAUNCH(V, I) hipLaunchKernelGGL((k1_distance_tiled<V, I>), grid, dim3(K1_WG), lds, ctx->stream, cs->d_hole, cs->hs, \
-                       cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, cs->d_plans, (uint2 *)cs->d_partial, cs->d_verify, n_chunks)
-            if (verify) { if (use_tail_kernel) K1_LAUNCH(true, false); else K1_LAUNCH(true, true); }
-            else        { if (use_tail_kernel) K1_LAUNCH(false, false); else K1_LAUNCH(false, true); }
-#undef K1_LAUNCH
-            if (use_tail_kernel)
-                hipLaunchKernelGGL(k1_distance_global<false>, dim3(n_groups * K1_NSUB, n_chunks_t), dim3(K1_THREADS), 0, ctx->stream,
-                                   cs->d_hole, cs->hs, cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc_t, cs->d_pxcs, count,
-                                   (uint2 *)cs->d_partial + (size_t)n_chunks * count, (const int *)cs->d_plans, (const int *)tailp, K1_NSUB);
-        }
-        {
-            sh_timer t(ctx, SLAMHIP_K_CS_REDUCE);
-            hipLaunchKernelGGL(k1_reduce, dim3(rblocks), dim3(256), 0, ctx->stream, (const uint2 *)cs->d_partial, n_chunks,
-                               use_tail_kernel ? n_chunks_t : 0, (const int *)tailp, count, cs->n_points, cs->d_ev_idx, dist, key);
-        }
-    } else {
-        int bpc = (int)(((long long)sh_div_up(count, K1_THREADS) * n_rb) / 4096);
-        if (bpc < 1) bpc = 1;
-        if (bpc > n_rb) bpc = n_rb;
-        const int n_chunks = sh_div_up(n_rb, bpc);
-        SH_TRY(ensure_partial(cs, (size_t)n_chunks * count));
-        {
-            sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
-            dim3 grid(sh_div_up(count, K1_THREADS), n_chunks);
-            if (sane)
-                hipLaunchKernelGGL(k1_distance_global<false>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
-                                   cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial,
-                                   (const int *)nullptr, (const int *)nullptr, 1);
-            else
-                hipLaunchKernelGGL(k1_distance_global<true>, grid, dim3(K1_THREADS), 0, ctx->stream, cs->d_hole, cs->hs,
-                                   cs->d_pts_sorted, cs->d_rb_start, n_rb, bpc, cs->d_pxcs, count, (uint2 *)cs->d_partial,
-                                   (const int *)nullptr, (const int *)nullptr, 1);
-        }
-        {
-            sh_timer t(ctx, SLAMHIP_K_CS_REDUCE);
-            hipLaunchKernelGGL(k1_reduce, dim3(rblocks), dim3(256), 0, ctx->stream, (const uint2 *)cs->d_partial, n_chunks, 0,
-                               (const int *)nullptr, count, cs->n_points, cs->d_ev_idx, dist, key);
-        }
+    {
+        sh_timer t(ctx, SLAMHIP_K_CS_REDUCE);
+        const int rblocks = sh_div_up(count, 64) < 512 ? sh_div_up(count, 64) : 512;
+        hipLaunchKernelGGL(k1_reduce, dim3(rblocks), dim3(256), 0, ctx->stream, (const uint2 *)cs->d_partial, n_chunks,
+                           count, cs->n_points, cs->d_ev_idx, dist, key);
     }
     SH_HIP(hipGetLastError());
     return SLAMHIP_OK;

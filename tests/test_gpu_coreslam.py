@@ -172,15 +172,19 @@ def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
 
 def test_k1_tile_boxes_selfcheck():
     """Re-run the distance tests with SLAMHIP_K1_VERIFY=1 (every end point is checked against its LDS tile
-    box) and with SLAMHIP_K1_GLOBAL=1 (global-gather fallback kernel): both must stay bit-exact."""
+    box, every staged pixel against the map), with SLAMHIP_K1_GLOBAL=1 (global-gather fallback kernels) and
+    with tile budgets / layouts that force every step kind: all must stay bit-exact."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size"
-    for env_extra in ({"SLAMHIP_K1_VERIFY": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}, {"SLAMHIP_K1_TILE_KB": "8"},
-                      {"SLAMHIP_K1_TAIL_KERNEL_FROM": "1"}, {"SLAMHIP_K1_TAIL_KERNEL_FROM": "1", "SLAMHIP_K1_TILE_KB": "24"},
-                      {"SLAMHIP_K1_TAIL_KERNEL_FROM": "1000000000", "SLAMHIP_K1_VERIFY": "1"},
-                      {"SLAMHIP_K1_TARGET_WGS": "64"}, {"SLAMHIP_K1_TARGET_WGS": "100000"}):
+    for env_extra in ({"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "1"}, {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "2"},
+                      {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "4"}, {"SLAMHIP_K1_GLOBAL": "1"},
+                      {"SLAMHIP_K1_TILE_KB": "8", "SLAMHIP_K1_VERIFY": "1"},       # banded tiles and global gathers
+                      {"SLAMHIP_K1_TILE_KB": "24", "SLAMHIP_K1_CPL": "1"}, {"SLAMHIP_K1_TILE_KB": "1"},
+                      {"SLAMHIP_K1_NOTABLE": "1"},                                 # uniform chunk-major layout
+                      {"SLAMHIP_K1_TARGET_WGS": "64", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "64"},
+                      {"SLAMHIP_K1_TARGET_WGS": "100000", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "100000", "SLAMHIP_K1_CPL": "1"}):
         env = dict(os.environ); env.update(env_extra); env["SLAMHIP_EXPECT_SELFCHECK"] = "1"
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q",
                             "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
