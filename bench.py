@@ -3,10 +3,10 @@
 
 Workload (BASELINE.json `metric` / north_star): CoreSLAM Monte-Carlo search on a 2048^2 HoleMap with a
 1080-ray scan, --cands candidate poses per GPU per step (default 16384 = BASELINE.json configs[1]/[2]).
-One "step" = one full search over this rank's shard of the flat candidate list: candidate transform
-(pose + jitter -> px,py,c,s with device trig), K1 batched distance over all rays, K1r partial-sum +
-arg-min reduce; with N > 1 GPUs the per-rank packed (distance << 32 | index) keys are min-all-reduced
-over RCCL (one 8-byte all-reduce per step).  All inputs (map, scan, jitter list) are resident in HBM
+One "step" = one full search over this rank's shard of the flat candidate list = ONE launch of K1
+(k1_search_tiled: candidate transform pose + jitter -> px,py,c,s with device trig, batched distance over
+all rays from LDS-staged HoleMap tiles, per-candidate accumulation and arg-min); with N > 1 GPUs the
+per-rank packed (distance << 32 | index) keys are min-all-reduced over RCCL (one 8-byte all-reduce per step).  All inputs (map, scan, jitter list) are resident in HBM
 before the timed region.  Weak scaling: per-GPU candidates are fixed as N grows.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
@@ -135,7 +135,7 @@ def main():
             achieved = a.cands * bytes_per_eval / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a),
-                    "kernel": "k1_distance", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
+                    "kernel": "k1_search_tiled", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
                     "bytes_per_launch": a.cands * bytes_per_eval}
         out = {
             "metric": "candidate-pose distance evals/sec on 2048^2 map, 1080-ray scan, 1/2/4/8 GPU",

@@ -273,18 +273,17 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     const int n_rb = cs->n_rb;
     std::vector<int> rayblk((size_t)n * 4);
     cs->h_rb_start = rb;
-    cs->h_rb_ext.resize((size_t)n_rb); cs->h_rb_reach.resize((size_t)n_rb);
+    cs->h_rb_ex.resize((size_t)n_rb); cs->h_rb_ey.resize((size_t)n_rb); cs->h_rb_mx.resize((size_t)n_rb); cs->h_rb_my.resize((size_t)n_rb);
     for (int b = 0; b < n_rb; b++) {
         const int r0 = rb[(size_t)b], r1 = rb[(size_t)b + 1];
-        float x0 = sorted[2 * (size_t)r0], x1 = x0, y0 = sorted[2 * (size_t)r0 + 1], y1 = y0, reach = 0.0f;
+        float x0 = sorted[2 * (size_t)r0], x1 = x0, y0 = sorted[2 * (size_t)r0 + 1], y1 = y0;
         for (int r = r0; r < r1; r++) {
             const float X = sorted[2 * (size_t)r], Y = sorted[2 * (size_t)r + 1];
             x0 = fminf(x0, X); x1 = fmaxf(x1, X); y0 = fminf(y0, Y); y1 = fmaxf(y1, Y);
-            reach = fmaxf(reach, sqrtf(X * X + Y * Y));
             rayblk[4 * (size_t)r] = r0; rayblk[4 * (size_t)r + 1] = r1; rayblk[4 * (size_t)r + 2] = b; rayblk[4 * (size_t)r + 3] = 0;
         }
-        cs->h_rb_ext[(size_t)b] = fmaxf(x1 - x0, y1 - y0) * cs->hscale;
-        cs->h_rb_reach[(size_t)b] = reach * cs->hscale;
+        cs->h_rb_ex[(size_t)b] = (x1 - x0) * cs->hscale; cs->h_rb_ey[(size_t)b] = (y1 - y0) * cs->hscale;
+        cs->h_rb_mx[(size_t)b] = 0.5f * (x0 + x1) * cs->hscale; cs->h_rb_my[(size_t)b] = 0.5f * (y0 + y1) * cs->hscale;
     }
     cs->k1_layout_dirty = true;
     SH_HIP(hipMemcpyAsync(cs->d_ray_blk, rayblk.data(), sizeof(int) * rayblk.size(), hipMemcpyHostToDevice, cs->ctx->stream));

@@ -26,7 +26,7 @@ struct slamhip_cs {
     float2 *d_pts_sorted;         // spatially sorted copy for K1 (integer sum: any order is exact)
     int4 *d_ray_blk;              // per sorted ray: (first ray of its block, one past its last, block index, 0)
     std::vector<int> h_rb_start;  // host copy of the block table
-    std::vector<float> h_rb_ext, h_rb_reach;   // per ray block: pixel extent, reach (max |p| in pixels)
+    std::vector<float> h_rb_ex, h_rb_ey, h_rb_mx, h_rb_my;   // per ray block, scan frame, pixels: bounding box size and centre
     int n_rb;                     // ray blocks over d_pts_sorted
     int *d_rb_start;              // [n_rb + 1]
     bool pts_sane;                // all |coords| < 1e9: fast kernels need no NaN/overflow handling
@@ -50,7 +50,7 @@ struct slamhip_cs {
     // (pixels) -- from the offsets (ensure_shard) -- and the chunks per group derived from them and the scan
     std::vector<float> h_grp_dth, h_grp_dxy;
     std::vector<int> k1_tab_group, k1_tab_nc; int k1_uni_g0, k1_uni_ng, k1_uni_nc;
-    bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups;
+    bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups; float k1_layout_theta;
     float gen_sigma_xy, gen_sigma_theta;        // offsets generated on the device: their distribution
     bool offs_theta_small;        // every |dtheta| <= 1e4: the tiled kernel's trigonometry needs no huge-angle branch
     unsigned int *d_verify;       // [8] SLAMHIP_K1_VERIFY=1: [0] tile self-check failures (must stay 0), [1..4] unit counts per kind

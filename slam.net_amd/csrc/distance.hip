@@ -173,12 +173,10 @@ k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_poin
 
 // ---- the tiled search kernel -----------------------------------------------------------------------------------
 // Workgroup = one group of 1024 theta-consecutive candidates = LANES lanes x CPL candidates per lane (candidate
-// k*LANES + t of the group lives in slot k of lane t).  Two instantiations, chosen per launch (both measured on MI355X):
-//   CPL 1 (1024 lanes, 16 waves, 8 waves / SIMD): the VALU stays saturated by thread-level parallelism -- the
-//         throughput form, for launches of many workgroups per CU;
-//   CPL 4 (256 lanes, 4 waves): a wave costs ~0.15 us to launch, so a 16-wave workgroup starts over ~2.5 us; four
-//         fat waves start in ~0.3 us and share every ray point four ways -- the latency form, for launches whose
-//         workgroups all run at once.
+// k*LANES + t of the group lives in slot k of lane t).  Measured on MI355X: a wave costs ~0.15 us to launch and the
+// waves of a CU start one after the other, so 16-wave workgroups (CPL 1) start over ~2.5 us, two of them per CU over
+// ~5 us; with 4 waves (CPL 4: 2 waves / SIMD) the VALU starves, even with eight gathers in flight per lane.
+// CPL 2 (512 lanes, 8 waves, 4 waves / SIMD) is the default.
 #define K1_KIND_SHARED 1               // one tile holds the end points of the whole group: gathers need no test
 #define K1_KIND_GLOBAL 2               // no tile (box wider than 512 px or more than K1_MAXBANDS bands): global gathers
 #define K1_KIND_BAND 3                 // a row band of the group's box clipped to the map; gathers are range-tested
@@ -766,24 +764,28 @@ static int k1_legal_chunks(const slamhip_cs *cs, int nc)
 }
 
 // Estimated cost of a group in ray units (tile steps cost 1 per ray): from the theta range and the translation spread
-// of the group (ensure_shard) and the reach of each ray block (set_scan).  The end points of a block sweep a box of
-// about (extent + reach * dtheta + spread) pixels squared; a box beyond the tile budget is staged in bands with
-// range-tested gathers.  Only the balance of the launch depends on this estimate.
+// of the group (ensure_shard), the bounding box of each ray block (set_scan) and the search pose's heading.  A box
+// beyond the tile budget is staged in bands with range-tested gathers.  Only the balance of the launch depends on
+// this estimate.
 static double k1_group_cost(const slamhip_cs *cs, int g, int budget)
 {
-    const double dth = cs->h_grp_dth[(size_t)g], dxy = cs->h_grp_dxy[(size_t)g];
-    double c = 0.0;
+    const double dth = cs->h_grp_dth[(size_t)g], d = cs->h_grp_dxy[(size_t)g] + 4.0;
+    const double c = fabs(cos((double)cs->k1_layout_theta)), s = fabs(sin((double)cs->k1_layout_theta));
+    double cost = 0.0;
     for (int b = 0; b < cs->n_rb; b++) {
-        const double w = cs->h_rb_ext[(size_t)b] + cs->h_rb_reach[(size_t)b] * dth + dxy + 10.0;
-        const double bytes = 2.0 * w * w;
+        // the block's bounding box and centre turned into the map frame (search pose theta), grown by the translation
+        // spread and by the arc the centre sweeps over the group's theta range
+        const double ex = cs->h_rb_ex[(size_t)b], ey = cs->h_rb_ey[(size_t)b], mx = fabs(cs->h_rb_mx[(size_t)b]), my = fabs(cs->h_rb_my[(size_t)b]);
+        const double w = ex * c + ey * s + d + (mx * s + my * c) * dth, h = ex * s + ey * c + d + (mx * c + my * s) * dth;
+        const double bytes = 2.0 * (w + 8.0) * h;
         double f = 1.0;
         if (bytes > budget) {
             const double bands = ceil(bytes / budget);
-            f = bands <= K1_MAXBANDS && w <= 512.0 ? 2.5 * bands : 12.0;
+            f = bands <= K1_MAXBANDS && w <= 504.0 ? 1.9 * bands : 4.5;      // (measured cost per ray relative to a plain tile step)
         }
-        c += f * (cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b]);
+        cost += f * (cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b]);
     }
-    return c;
+    return cost;
 }
 
 // Launch layout (cs->k1_*): the groups whose estimated cost per ray is well above a plain group's get their own,
@@ -865,6 +867,20 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
         cs->k1_tab_nc[i] = res;
     }
     cs->k1_uni_nc = k1_legal_chunks(cs, cs->k1_uni_nc);
+    if (n_groups <= K1_TABLE_G && have_spread) {
+        // rounding and legalisation may overshoot the target: one workgroup too many starts a second round on a full
+        // chip.  Take the excess from the groups with the most chunks.
+        long long tot0 = 0;
+        for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot0 += cs->k1_tab_nc[i];
+        for (int guard = 0; tot0 > target_wgs && guard < 4096; guard++) {
+            size_t im = 0;
+            for (size_t i = 1; i < cs->k1_tab_nc.size(); i++) if (cs->k1_tab_nc[i] > cs->k1_tab_nc[im]) im = i;
+            if (cs->k1_tab_nc[im] <= 1) break;
+            const int lower = k1_legal_chunks(cs, 1);              // (smallest legal count)
+            if (cs->k1_tab_nc[im] - 1 < lower) break;
+            cs->k1_tab_nc[im]--; tot0--;
+        }
+    }
     long long tot = 0;
     for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
     if (tot > K1_TABLE_WGS) {                                      // (huge scans: legal chunk counts alone overflow the table)
@@ -910,9 +926,22 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 
         // launch layout
         const bool have_spread = mode == 1 && !no_table && (int)cs->h_grp_dth.size() == n_groups;
-        if (cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread) {
+        if (cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread ||
+            (have_spread && !(fabsf(bth - cs->k1_layout_theta) < 0.1f))) {
+            cs->k1_layout_theta = bth;
             k1_make_layout(cs, n_groups, n_groups <= K1_TABLE_G ? target_wgs : target_wgs_uniform, budget, have_spread);
             cs->k1_layout_dirty = false; cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread;
+        }
+        static const int dump = env_int("SLAMHIP_K1_DUMP", 0);
+        if (dump) {                                                // debugging aid: the launch layout and its cost estimates
+            fprintf(stderr, "[slamhip] K1 layout: %d groups, %zu listed, uniform [%d, %d) x %d chunks\n", n_groups, cs->k1_tab_group.size(),
+                    cs->k1_uni_g0, cs->k1_uni_g0 + cs->k1_uni_ng, cs->k1_uni_nc);
+            for (size_t i = 0; i < cs->k1_tab_group.size(); i++) {
+                const int g = cs->k1_tab_group[i];
+                fprintf(stderr, "   group %3d: chunks %3d, dtheta %.4f rad, spread %.1f px, cost %.0f ray units\n", g, cs->k1_tab_nc[i],
+                        have_spread ? cs->h_grp_dth[(size_t)g] : 0.f, have_spread ? cs->h_grp_dxy[(size_t)g] : 0.f,
+                        have_spread ? k1_group_cost(cs, g, budget) : 0.0);
+            }
         }
         unsigned first = 0;
         const int n_tab = (int)cs->k1_tab_group.size();
@@ -927,8 +956,9 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.n_tab_wgs = (int)first;
         a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
         const int n_wgs = (int)first + cs->k1_uni_ng * cs->k1_uni_nc;
-        // 4 candidates per lane (few fat waves: fast start) while every workgroup runs at once, else 1 (throughput)
-        const int cpl = cpl_env > 0 ? cpl_env : (n_wgs <= 512 ? 4 : 1);
+        // candidates per lane: 2 (512 lanes, 8 waves) measured best or equal from 16k to 256k candidates on MI355X;
+        // 1 (16 waves: slow start) and 4 (4 waves: the VALU starves at 2 waves / SIMD) stay selectable for experiments
+        const int cpl = cpl_env == 1 || cpl_env == 4 ? cpl_env : 2;
         if (n_groups > cs->k1_cap_groups) {
             if (cs->d_k1_tickets) (void)hipFree(cs->d_k1_tickets);
             if (cs->d_k1_gkey) (void)hipFree(cs->d_k1_gkey);
