@@ -60,12 +60,11 @@ struct slamhip_cs {
     float *d_grp_bounds; int cap_grp;          // per candidate group: min/max of px,py,c,s (8 floats)
     float *d_best_pose;           // winner's pose (theta normalised), device-resident for the fused path
 
-    // ---- K2 HoleMap update scratch ---------------------------------------------------------------
-    uint32_t *d_h_cnt;            // [hs*hs] fragments per pixel this scan (kept zero between calls)
-    int32_t *d_h_vmin, *d_h_vmax; // [hs*hs] min / max pixval per pixel this scan
-    cs_ray *d_rays; int cap_rays;
-    int *d_chunk_ray, *d_chunk_x0; int cap_chunks;   // fragment chunks: (ray, first step)
-    int *d_k2_counters;           // [0] n_chunks, [1] n_conflict_pixels, [2] total fragments (blended pixels)
+    // ---- K2 HoleMap update -----------------------------------------------------------------------------
+    cs_ray *d_rays; int cap_rays;               // per ray: clip / Bresenham / V-profile parameters
+    void *d_k2_cand;                            // rays as the pixel kernels test them, sorted by (direction class, slope bucket)
+    int *d_k2_start;                            // [4 x 1024 + 1] first table entry of every bucket
+    int *d_k2_counters;           // [0] longest ray, [1] conflict pixels, [2] blended pixels, [3] x1, [4] y1
     int *d_conflict_pix; int cap_conflict;
     int64_t last_hole_pixels;
 

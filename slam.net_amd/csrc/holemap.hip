@@ -3,20 +3,21 @@
 // Replaces UpdateHoleMap (CoreSLAM/CoreSLAMProcessor.cs:496-534), DrawLaserRayOnHoleMap (:359-443) and
 // ClipRay (:320-345).  The reference draws ray after ray with a read-modify-write blend
 //     pix = (ushort)(((256 - alpha) * pix + alpha * pixval) >> 8)                     (:431)
-// which does not commute for different pixval, so pixels touched by several rays must see their
-// fragments in ray order.  Design:
-//   setup    one thread per ray: literal float/int arithmetic of :519-530, :361-399 (clip, major
-//            axis, V-profile parameters) -> ray table; rays are cut into 64-step chunks
-//   count    one lane per fragment (closed-form Bresenham position, literal V-profile recurrence
-//            restarted at the edge of the hole zone): atomicAdd(cnt[pixel])
-//   minmax   fragments of multi-touched pixels: atomicMin / atomicMax of pixval
-//   apply    single-touched pixels: blend directly.  Multi-touched pixels: one elected fragment
-//            applies the blend cnt times if every fragment carried the same pixval (order-free),
-//            else queues the pixel on the conflict list
-//   resolve  one wavefront per conflict pixel: test all rays in ray order (closed form), apply the
-//            matching fragments' blends in that order
-// Closed form: after i iterations of the error recurrence (:394-396,:433-441) the walk has taken
-//   m(i) = min(i, max(0, ceil((2*dyc*i - dxc) / (2*dxc))))   minor steps     (tests/test_closed_forms.py)
+// which does not commute for different pixval, so a pixel touched by several rays must see their
+// fragments in ray order.  The update is PIXEL-centric (a gather, no atomics on the map,
+// no per-pixel scratch): a pixel asks which rays draw it, then blends their values in ray order.
+//   prepare  one workgroup: per ray the literal float/int arithmetic of :519-530, :361-399 (clip, major axis,
+//            V-profile parameters) -> ray table; rays are counting-sorted into 4 direction classes (major axis
+//            and its sign) x 1024 buckets of signed slope (minor / major)
+//   pixels   one lane per pixel of the scan's bounding square: step x of a ray lies at major offset x and minor
+//            offset m(x) = min(x, max(0, ceil((2*dyc*x - dxc) / (2*dxc)))) (closed form of the error
+//            recurrence :394-396,:433-441; tests/test_closed_forms.py), and |m(x) - slope*x| <= 1/2, so only
+//            rays of the pixel's class with slope in [(b-1)/a, (b+1)/a] can draw pixel (major a, minor b): a
+//            contiguous range of the sorted table, tested exactly.  Up to 4 hits are sorted by ray index in
+//            registers and blended; a pixel with more goes to the conflict list
+//   zone     one wavefront per pixel for the neighbourhood of the robot (every ray passes there) and the
+//            conflict list: lanes test the candidate rays, hits are rank-sorted by ray index and blended in
+//            that order; the few pixels with more than 64 candidates scan all rays in index order
 // All integer arithmetic wraps like C# unchecked int; float->int follows cvttss2si (sh_f2i).
 // Deviations from the reference (all in exception / platform-dependent territory; the oracle does the same):
 //   D1 non-representable pixel coordinates (NaN/inf, e.g. zero-range point) skip the ray;
@@ -24,10 +25,17 @@
 //   D4 a clipped endpoint outside the map (reachable only through int32 overflow in :329/:340) skips the ray.
 #include "cs_internal.h"
 #include "det_trig.h"
+#include <stdlib.h>
 
 #define TS_NO_OBSTACLE 65500
 #define TS_OBSTACLE 0
-#define K2_CHUNK 64
+#define K2_NBUCK 1024                  // slope buckets per direction class
+#define K2_ZONE 48                     // Chebyshev radius around the robot handled one wavefront per pixel
+#define K2_MAXHIT 4                    // hits a lane-per-pixel thread orders in registers
+
+// ray as the pixel kernels test it: clipped major length, signed clipped minor length (smin * dyc), the step beyond
+// which pixval leaves TS_NO_OBSTACLE (:406), ray index (= blend order)
+struct k2_cand { int dxc, sdyc, lim2, ray; };
 
 struct cs_ray {
     int valid;
@@ -40,7 +48,6 @@ struct cs_ray {
     int smaj, smin;           // coordinate signs along major / minor
     int derrorv, incv, incerrorv, sincv;   // :379/:386, :398, :399, :374
     int lim2, lim1;           // dx - 2*derrorv, dx - derrorv          (:406,:408)
-    int chunk0, nchunks;
 };
 
 __device__ static inline bool clip_ray(int size, int &xyc, int &yxc, int xy, int yx)
@@ -78,19 +85,13 @@ __device__ static inline float4 k2_pxcs(const float *d_pose, float4 h_pxcs, floa
     return q;
 }
 
-__global__ void __launch_bounds__(256)
-k2_setup(const float2 *__restrict__ pts, int n_points, int size, float scale, const float *d_pose, float4 h_pxcs,
-         float hole_width, cs_ray *__restrict__ rays)
+__device__ static inline cs_ray k2_make_ray(const float2 p, int size, const float4 q, float scale, float hole_width)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_points) return;
     cs_ray r;
     memset(&r, 0, sizeof(r));
-    const float4 q = k2_pxcs(d_pose, h_pxcs, scale);
     const float px = q.x, py = q.y, c = q.z, s = q.w;
     const int x1 = sh_f2i(px), y1 = sh_f2i(py);                            // :505-506
     bool ok = !(x1 < 0 || x1 >= size || y1 < 0 || y1 >= size);             // :509-512 robot out of map
-    const float2 p = pts[i];
     float x2p = c * p.x - s * p.y;                                         // :519
     float y2p = s * p.x + c * p.y;                                         // :520
     const int xp = sh_f2i(px + x2p);                                       // :521
@@ -142,56 +143,9 @@ k2_setup(const float2 *__restrict__ pts, int n_points, int size, float scale, co
             r.incerrorv = sh_wsub(TS_OBSTACLE - TS_NO_OBSTACLE, sh_wmul(derrorv, r.incv));   // :399
             r.lim2 = sh_wsub(dx, sh_wmul(2, derrorv));                     // :406
             r.lim1 = sh_wsub(dx, derrorv);                                 // :408
-            r.nchunks = (dxc + 1 + K2_CHUNK - 1) / K2_CHUNK;               // steps x = 0..dxc (:404)
         }
     }
-    rays[i] = r;
-}
-
-// exclusive prefix of nchunks over the rays (single workgroup; R is a few thousand)
-__global__ void __launch_bounds__(1024)
-k2_scan_chunks(cs_ray *__restrict__ rays, int n, int *__restrict__ counters)
-{
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    __shared__ int total_px;
-    if (threadIdx.x == 0) { carry = 0; total_px = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        int v = (i < n && rays[i].valid) ? rays[i].nchunks : 0;
-        // every step x = 0..dxc of a valid ray blends exactly one pixel (:404,:431): the blended-pixel statistic is
-        // a plain sum (a per-wave atomic on one address would serialise at ~12 ns each and dominate the update)
-        int px = (i < n && rays[i].valid) ? rays[i].dxc + 1 : 0;
-        for (int off = 32; off > 0; off >>= 1) px += __shfl_down(px, off, 64);
-        if (lane == 0 && px) atomicAdd(&total_px, px);
-        int incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
-        const int excl = carry + woff + incl - v;
-        if (i < n) rays[i].chunk0 = excl;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = excl + v;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { counters[0] = carry; counters[1] = 0; counters[2] = total_px; }
-}
-
-__global__ void __launch_bounds__(256)
-k2_fill_chunks(const cs_ray *__restrict__ rays, int n, int *__restrict__ chunk_ray, int *__restrict__ chunk_x0, int cap)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !rays[i].valid) return;
-    const int c0 = rays[i].chunk0, nc = rays[i].nchunks;
-    for (int k = 0; k < nc; k++)
-        if (c0 + k < cap) { chunk_ray[c0 + k] = i; chunk_x0[c0 + k] = k * K2_CHUNK; }
+    return r;
 }
 
 // minor steps taken before step x (closed form of :394-396,:433-441)
@@ -230,95 +184,269 @@ __device__ static inline uint16_t k2_blend(uint16_t pix, int pixval, int alpha)
     return (uint16_t)(sh_wadd(sh_wmul(256 - alpha, (int)pix), sh_wmul(alpha, pixval)) >> 8);   // :431
 }
 
-// One lane per fragment.  PASS 0: count, 1: min/max for multi-touched pixels, 2: apply.
-template <int PASS>
-__global__ void __launch_bounds__(256)
-k2_fragments(const cs_ray *__restrict__ rays, const int *__restrict__ chunk_ray, const int *__restrict__ chunk_x0,
-             int *__restrict__ counters, int npix, uint16_t *__restrict__ map, uint32_t *__restrict__ cnt,
-             int32_t *__restrict__ vmin, int32_t *__restrict__ vmax, int alpha,
-             int *__restrict__ conflict_pix, int cap_conflict)
+// does step x = a (major offset a >= 1) of the ray draw the pixel at signed minor offset b?  (closed form, no division;
+// T = int for maps up to 16384 pixels a side -- 2*dyc*a < 2^29 -- else long long: 64-bit multiplies are several
+// quarter-rate instructions each)
+template <typename T>
+__device__ static inline bool k2_hit(const k2_cand c, int a, int b)
 {
-    const int chunk = blockIdx.x * (256 / K2_CHUNK) + (threadIdx.x >> 6);
-    if (chunk >= counters[0]) return;                 // wave-uniform
-    const cs_ray r = rays[chunk_ray[chunk]];
-    const int x = chunk_x0[chunk] + (threadIdx.x & 63);
-    int ptr = -1;
-    if (x <= r.dxc) {
-        ptr = sh_wadd(sh_wadd(r.ptr0, sh_wmul(x, r.incmaj)), sh_wmul(k2_minor(r, x), r.incmin));
-        if (ptr < 0 || ptr >= npix) ptr = -1;         // cannot happen for a clipped ray; guards the array
-    }
-    if (PASS == 0) {
-        if (ptr >= 0) atomicAdd(&cnt[ptr], 1u);
-        return;
-    }
-    const uint32_t n = ptr >= 0 ? cnt[ptr] : 0u;
-    if (PASS == 1) {
-        if (n > 1) {
-            const int v = k2_pixval(r, x);
-            atomicMin(&vmin[ptr], v);
-            atomicMax(&vmax[ptr], v);
+    if (a > c.dxc) return false;
+    const int B = b < 0 ? -b : b, dyc = c.sdyc < 0 ? -c.sdyc : c.sdyc;
+    if (B > 0 && (c.sdyc == 0 || (b > 0) != (c.sdyc > 0))) return false;
+    const T N = (T)2 * dyc * a - c.dxc, D = (T)2 * c.dxc;
+    if (B == 0) return N <= 0;
+    if (B == a) return N > (T)(a - 1) * D;
+    return N > (T)(B - 1) * D && N <= (T)B * D;
+}
+
+// candidate range of pixel (a, b) in one class: rays whose signed slope lies in [(b-1)/a, (b+1)/a] (+- one bucket
+// for the float arithmetic of the bucket function; the exact test follows)
+__device__ static inline int k2_bucket(float t)
+{
+    int k = (int)floorf((t + 1.0f) * (K2_NBUCK / 2));
+    return k < 0 ? 0 : k > K2_NBUCK - 1 ? K2_NBUCK - 1 : k;
+}
+__device__ static inline void k2_range(const int *__restrict__ start, int cls, int a, int b, int &lo, int &hi)
+{
+    const float ra = 1.0f / (float)a;
+    int blo = k2_bucket((float)(b - 1) * ra) - 1, bhi = k2_bucket((float)(b + 1) * ra) + 1;
+    if (blo < 0) blo = 0;
+    if (bhi > K2_NBUCK - 1) bhi = K2_NBUCK - 1;
+    lo = start[cls * K2_NBUCK + blo];
+    hi = start[cls * K2_NBUCK + bhi + 1];
+}
+// classes of a pixel at offset (dx, dy) from the robot: 0 E, 1 W (x major), 2 S, 3 N (y major); a diagonal pixel has two
+__device__ static inline int k2_classes(int dx, int dy, int cls[2], int a[2], int b[2])
+{
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    int n = 0;
+    if (adx >= ady && adx > 0) { cls[n] = dx > 0 ? 0 : 1; a[n] = adx; b[n] = dy; n++; }
+    if (ady >= adx && ady > 0) { cls[n] = dy > 0 ? 2 : 3; a[n] = ady; b[n] = dx; n++; }
+    return n;
+}
+
+// counters: [0] R = longest clipped major length, [1] conflict pixels, [2] blended pixels (every step x = 0..dxc of
+// a valid ray blends exactly one pixel, :404,:431), [3] x1, [4] y1, [5] robot inside the map
+__global__ void __launch_bounds__(1024)
+k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
+           cs_ray *__restrict__ rays, k2_cand *__restrict__ cand, int *__restrict__ start, int *__restrict__ counters)
+{
+    __shared__ int hist[4 * K2_NBUCK];
+    __shared__ int wsum[16];
+    __shared__ int s_R, s_total;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    for (int i = t; i < 4 * K2_NBUCK; i += 1024) hist[i] = 0;
+    if (t == 0) { s_R = 0; s_total = 0; }
+    __syncthreads();
+    const float4 q = k2_pxcs(d_pose, h_pxcs, scale);
+    for (int i = t; i < n; i += 1024) {
+        const cs_ray r = k2_make_ray(pts[i], size, q, scale, hole_width);
+        rays[i] = r;
+        if (r.valid) {
+            const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
+            const float tt = r.dxc > 0 ? (float)(r.smin * r.dyc) / (float)r.dxc : 0.0f;
+            atomicAdd(&hist[cls * K2_NBUCK + k2_bucket(tt)], 1);
+            atomicMax(&s_R, r.dxc);
+            atomicAdd(&s_total, r.dxc + 1);
         }
-        return;
     }
-    // PASS 2
-    if (n == 1) {
-        map[ptr] = k2_blend(map[ptr], k2_pixval(r, x), alpha);
-        cnt[ptr] = 0;
-    } else if (n > 1) {
-        const uint32_t won = atomicExch(&cnt[ptr], 0u);      // elect one fragment per pixel
-        if (won != 0) {
-            const int lo = vmin[ptr], hi = vmax[ptr];
-            vmin[ptr] = INT32_MAX; vmax[ptr] = INT32_MIN;
-            if (lo == hi) {                                  // same pixval from every ray: order-free
-                uint16_t pix = map[ptr];
-                for (uint32_t k = 0; k < won; k++) pix = k2_blend(pix, lo, alpha);
-                map[ptr] = pix;
-            } else {
-                const int slot = atomicAdd(&counters[1], 1);
-                if (slot < cap_conflict) conflict_pix[slot] = ptr;
+    __syncthreads();
+    {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
+        int v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = hist[4 * t + k]; sum += v[k]; }
+        int incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int base = incl - sum;
+        for (int w = 0; w < wid; w++) base += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { start[4 * t + k] = base; hist[4 * t + k] = base; base += v[k]; }
+        if (t == 1023) start[4 * K2_NBUCK] = base;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const cs_ray r = rays[i];
+        if (r.valid) {
+            const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
+            const float tt = r.dxc > 0 ? (float)(r.smin * r.dyc) / (float)r.dxc : 0.0f;
+            const int pos = atomicAdd(&hist[cls * K2_NBUCK + k2_bucket(tt)], 1);
+            k2_cand c; c.dxc = r.dxc; c.sdyc = r.smin * r.dyc; c.lim2 = r.lim2; c.ray = i;
+            cand[pos] = c;
+        }
+    }
+    if (t == 0) {
+        counters[0] = s_R; counters[1] = 0; counters[2] = s_total;
+        counters[3] = sh_f2i(q.x); counters[4] = sh_f2i(q.y);
+    }
+}
+
+// lane per pixel over the bounding square of the scan (persistent grid; a wavefront takes 64 pixels of one row).
+// The bucket table and -- when it fits (LDS_TABLE) -- the candidate table live in LDS: a pixel's lookup is a chain of
+// dependent small reads (bucket bounds -> candidates -> map), which global-memory latency would dominate.
+#define K2_LDS_RAYS 3072
+template <bool LDS_TABLE, typename T>
+__global__ void __launch_bounds__(1024)
+k2_pixels(const cs_ray *__restrict__ rays, const k2_cand *__restrict__ cand_g, int n_rays, const int *__restrict__ start_g,
+          int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
+          int *__restrict__ conflict_pix, int cap_conflict, int exp_)
+{
+    __shared__ int start[4 * K2_NBUCK + 1];
+    __shared__ __attribute__((aligned(16))) k2_cand cand_s[LDS_TABLE ? K2_LDS_RAYS : 1];
+    const int R = counters[0], x1 = counters[3], y1 = counters[4];
+    if (R <= 0) return;
+    const int X0 = max(x1 - R, 0), X1 = min(x1 + R, size - 1), Y0 = max(y1 - R, 0), Y1 = min(y1 + R, size - 1);
+    if (X1 < X0 || Y1 < Y0) return;
+    for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
+    if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) cand_s[i] = cand_g[i];     // (entries past the valid rays are never addressed)
+    __syncthreads();
+    const k2_cand *cand = LDS_TABLE ? cand_s : cand_g;
+    const int tiles_x = (X1 - X0 + 64) / 64, items = tiles_x * (Y1 - Y0 + 1);
+    const int lane = threadIdx.x & 63;
+    for (int item = blockIdx.x * 16 + (threadIdx.x >> 6); item < items; item += gridDim.x * 16) {
+        const int row = item / tiles_x, tx = item - row * tiles_x;
+        const int X = X0 + tx * 64 + lane, Y = Y0 + row;
+        if (X > X1) continue;
+        const int dx = X - x1, dy = Y - y1;
+        if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K2_ZONE) continue;     // the zone kernel's pixels
+        if (exp_ == 1) continue;
+        int cls[2], a[2], b[2];
+        const int ncls = k2_classes(dx, dy, cls, a, b);
+        int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh = 0;
+        bool overflow = false;
+        for (int k = 0; k < ncls; k++) {
+            int lo, hi;
+            k2_range(start, cls[k], a[k], b[k], lo, hi);
+            if (exp_ == 2) { nh += (hi - lo) & 0; continue; }
+            for (int ci = lo; ci < hi; ci++) {
+                const k2_cand c = cand[ci];
+                if (exp_ == 3) { nh += c.dxc & 0; continue; }
+                if (!k2_hit<T>(c, a[k], b[k])) continue;
+                const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval(rays[c.ray], a[k]);
+                if (nh == K2_MAXHIT) { overflow = true; break; }
+                // insert by ray index (the list stays sorted; compile-time subscripts keep it in registers)
+                int posn = 0;
+#pragma unroll
+                for (int s = 0; s < K2_MAXHIT; s++) if (s < nh && hidx[s] < c.ray) posn++;
+#pragma unroll
+                for (int s = K2_MAXHIT - 1; s >= 1; s--) if (s > posn && s <= nh) { hidx[s] = hidx[s - 1]; hval[s] = hval[s - 1]; }
+#pragma unroll
+                for (int s = 0; s < K2_MAXHIT; s++) if (s == posn) { hidx[s] = c.ray; hval[s] = v; }
+                nh++;
             }
+            if (overflow) break;
+        }
+        const int ptr = Y * size + X;
+        if (overflow) {
+            const int slot = atomicAdd(&counters[1], 1);
+            if (slot < cap_conflict) conflict_pix[slot] = ptr;
+        } else if (nh > 0) {
+            uint16_t pix = map[ptr];
+#pragma unroll
+            for (int s = 0; s < K2_MAXHIT; s++) if (s < nh) pix = k2_blend(pix, hval[s], alpha);
+            map[ptr] = pix;
         }
     }
 }
 
-// One wavefront per conflict pixel: find the rays that touch it, in ray order, and blend in that order.
+// wavefront per pixel: the zone around the robot, then the conflict list
 __global__ void __launch_bounds__(256)
-k2_resolve(const cs_ray *__restrict__ rays, int n_rays, const int *__restrict__ counters, int size,
-           uint16_t *__restrict__ map, int alpha, const int *__restrict__ conflict_pix, int cap_conflict)
+k2_zone(const cs_ray *__restrict__ rays, int n_rays, const k2_cand *__restrict__ cand, const int *__restrict__ start,
+        const int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
+        const int *__restrict__ conflict_pix, int cap_conflict)
 {
-    int n = counters[1];
-    if (n > cap_conflict) n = cap_conflict;
-    const int lane = threadIdx.x & 63;
-    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
-    const int ptr = conflict_pix[w];
-    const int X = ptr % size, Y = ptr / size;
-    uint16_t pix = map[ptr];
-    for (int base = 0; base < n_rays; base += 64) {
-        const int i = base + lane;
-        bool hit = false;
-        int v = 0;
-        if (i < n_rays) {
-            const cs_ray r = rays[i];
-            if (r.valid) {
-                const int a = r.major_x ? X - r.x1 : Y - r.y1;
-                const int b = r.major_x ? Y - r.y1 : X - r.x1;
-                int x = -1;
-                if (r.smaj != 0) x = a * r.smaj; else if (a == 0) x = 0;
-                if (x >= 0 && x <= r.dxc) {
-                    const int m = k2_minor(r, x);
-                    if (m * r.smin == b) { hit = true; v = k2_pixval(r, x); }
+    __shared__ int sval[4][64];
+    const int R = counters[0], x1 = counters[3], y1 = counters[4];
+    if (R < 0 || x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;
+    int n_conf = counters[1];
+    if (n_conf > cap_conflict) n_conf = cap_conflict;
+    const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R;                       // zone = Chebyshev distance <= Z
+    const int side = 2 * Z + 1, n_zone = side * side;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int item = blockIdx.x * 4 + wv; item < n_zone + n_conf; item += gridDim.x * 4) {
+        int X, Y;
+        if (item < n_zone) { X = x1 - Z + item % side; Y = y1 - Z + item / side; }
+        else { const int ptr = conflict_pix[item - n_zone]; X = ptr % size; Y = ptr / size; }
+        if (X < 0 || X >= size || Y < 0 || Y >= size) continue;              // wave-uniform
+        const int ptr = Y * size + X;
+        const int dx = X - x1, dy = Y - y1;
+        int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
+        const int ncls = k2_classes(dx, dy, cls, a, b);
+        int nc = 0;
+        for (int k = 0; k < ncls; k++) { k2_range(start, cls[k], a[k], b[k], lo[k], hi[k]); nc += hi[k] - lo[k]; }
+        uint16_t pix = map[ptr];
+        bool stable = false;
+        int last_v = 0;
+        if (ncls == 0 || nc > 64) {
+            // the robot's pixel (step 0 of every ray) and its closest neighbours: all rays, in index order
+            for (int base = 0; base < n_rays; base += 64) {
+                const int i = base + lane;
+                bool hit = false;
+                int v = 0;
+                if (i < n_rays) {
+                    const cs_ray r = rays[i];
+                    if (r.valid) {
+                        const int aa = r.major_x ? dx : dy, bb = r.major_x ? dy : dx;
+                        int x = -1;
+                        if (r.smaj != 0) x = aa * r.smaj; else if (aa == 0) x = 0;
+                        if (x >= 0 && x <= r.dxc && k2_minor(r, x) * r.smin == bb) { hit = true; v = k2_pixval(r, x); }
+                    }
+                }
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    // the leading run of hits with one value (near the robot nearly every ray carries TS_NO_OBSTACLE): the
+                    // blend of a run converges -- once it no longer changes the pixel the rest of the run cannot either
+                    const int src = __ffsll((long long)mask) - 1;
+                    const int vv = __builtin_amdgcn_readlane(v, src);
+                    const unsigned long long same = __ballot(hit && v == vv) & mask, diff = mask & ~same;
+                    const unsigned long long run = diff ? (same & ((diff & (0ull - diff)) - 1ull)) : same;
+                    for (int k = __popcll(run); k > 0 && !(stable && vv == last_v); k--) {
+                        const uint16_t np = k2_blend(pix, vv, alpha);
+                        stable = np == pix; pix = np; last_v = vv;
+                    }
+                    mask &= ~run;
                 }
             }
+        } else if (nc > 0) {
+            // one candidate per lane, exact test, hits rank-sorted by ray index
+            int ci = -1, kk = 0;
+            if (lane < hi[0] - lo[0]) { ci = lo[0] + lane; kk = 0; }
+            else if (ncls > 1 && lane - (hi[0] - lo[0]) < hi[1] - lo[1]) { ci = lo[1] + lane - (hi[0] - lo[0]); kk = 1; }
+            bool hit = false;
+            int idx = 0x7fffffff, v = 0;
+            if (ci >= 0) {
+                const k2_cand c = cand[ci];
+                const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
+                if (k2_hit<long long>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval(rays[c.ray], aa); }
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                int rank = 0;
+                unsigned long long m = mask;
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    const int oi = __builtin_amdgcn_readlane(idx, src);
+                    rank += (hit && oi < idx) ? 1 : 0;
+                    m &= m - 1;
+                }
+                if (hit) sval[wv][rank] = v;
+                __builtin_amdgcn_wave_barrier();
+                const int nh = __popcll(mask);
+                for (int k = 0; k < nh; k++) {
+                    const int vv = sval[wv][k];
+                    if (!(stable && vv == last_v)) {
+                        const uint16_t np = k2_blend(pix, vv, alpha);
+                        stable = np == pix; pix = np; last_v = vv;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int src = __ffsll((long long)mask) - 1;
-            const int vv = __shfl(v, src, 64);
-            pix = k2_blend(pix, vv, alpha);
-            mask &= mask - 1;
-        }
-    }
-    if (lane == 0) map[ptr] = pix;
+        if (lane == 0) map[ptr] = pix;
     }
 }
 
@@ -326,26 +454,17 @@ k2_resolve(const cs_ray *__restrict__ rays, int n_rays, const int *__restrict__ 
 int32_t cs_holemap_alloc(slamhip_cs *cs)
 {
     const size_t npix = (size_t)cs->hs * cs->hs;
-    SH_HIP(hipMalloc(&cs->d_h_cnt, sizeof(uint32_t) * npix));
-    SH_HIP(hipMalloc(&cs->d_h_vmin, sizeof(int32_t) * npix));
-    SH_HIP(hipMalloc(&cs->d_h_vmax, sizeof(int32_t) * npix));
-    SH_HIP(hipMemsetAsync(cs->d_h_cnt, 0, sizeof(uint32_t) * npix, cs->ctx->stream));
-    // INT32_MAX = 0x7FFFFFFF / INT32_MIN = 0x80000000 are not byte patterns: fill with a kernel-free trick
-    std::vector<int32_t> tmp(npix, INT32_MAX);
-    SH_HIP(hipMemcpy(cs->d_h_vmin, tmp.data(), sizeof(int32_t) * npix, hipMemcpyHostToDevice));
-    std::fill(tmp.begin(), tmp.end(), INT32_MIN);
-    SH_HIP(hipMemcpy(cs->d_h_vmax, tmp.data(), sizeof(int32_t) * npix, hipMemcpyHostToDevice));
-    SH_HIP(hipMalloc(&cs->d_k2_counters, sizeof(int) * 4));
-    SH_HIP(hipMemsetAsync(cs->d_k2_counters, 0, sizeof(int) * 4, cs->ctx->stream));
-    cs->cap_conflict = (int)npix;
+    SH_HIP(hipMalloc(&cs->d_k2_counters, sizeof(int) * 8));
+    SH_HIP(hipMemsetAsync(cs->d_k2_counters, 0, sizeof(int) * 8, cs->ctx->stream));
+    SH_HIP(hipMalloc(&cs->d_k2_start, sizeof(int) * (4 * K2_NBUCK + 1)));
+    cs->cap_conflict = (int)(npix < (1u << 22) ? npix : (1u << 22));
     SH_HIP(hipMalloc(&cs->d_conflict_pix, sizeof(int) * (size_t)cs->cap_conflict));
     return SLAMHIP_OK;
 }
 
 void cs_holemap_free(slamhip_cs *cs)
 {
-    (void)hipFree(cs->d_h_cnt); (void)hipFree(cs->d_h_vmin); (void)hipFree(cs->d_h_vmax);
-    (void)hipFree(cs->d_rays); (void)hipFree(cs->d_chunk_ray); (void)hipFree(cs->d_chunk_x0);
+    (void)hipFree(cs->d_rays); (void)hipFree(cs->d_k2_cand); (void)hipFree(cs->d_k2_start);
     (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_conflict_pix);
 }
 
@@ -356,42 +475,25 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     if (n <= 0) return SLAMHIP_OK;
     if (n > cs->cap_rays) {
         if (cs->d_rays) (void)hipFree(cs->d_rays);
-        cs->d_rays = nullptr; cs->cap_rays = 0;
-        SH_HIP(hipMalloc(&cs->d_rays, sizeof(cs_ray) * (size_t)(n + n / 4 + 64)));
-        cs->cap_rays = n + n / 4 + 64;
+        if (cs->d_k2_cand) (void)hipFree(cs->d_k2_cand);
+        cs->d_rays = nullptr; cs->d_k2_cand = nullptr; cs->cap_rays = 0;
+        const int cap = n + n / 4 + 64;
+        SH_HIP(hipMalloc(&cs->d_rays, sizeof(cs_ray) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_k2_cand, sizeof(k2_cand) * (size_t)cap));
+        cs->cap_rays = cap;
     }
-    const int max_chunks_per_ray = (cs->hs + K2_CHUNK - 1) / K2_CHUNK;     // dxc + 1 <= Size
-    const long long want = (long long)n * max_chunks_per_ray;
-    if (want > cs->cap_chunks) {
-        if (cs->d_chunk_ray) (void)hipFree(cs->d_chunk_ray);
-        if (cs->d_chunk_x0) (void)hipFree(cs->d_chunk_x0);
-        cs->d_chunk_ray = cs->d_chunk_x0 = nullptr; cs->cap_chunks = 0;
-        SH_HIP(hipMalloc(&cs->d_chunk_ray, sizeof(int) * (size_t)want));
-        SH_HIP(hipMalloc(&cs->d_chunk_x0, sizeof(int) * (size_t)want));
-        cs->cap_chunks = (int)want;
-    }
-    const int npix = cs->hs * cs->hs;
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
-    hipLaunchKernelGGL(k2_setup, dim3(sh_div_up(n, 256)), dim3(256), 0, ctx->stream,
-                       cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs, hole_width, cs->d_rays);
-    hipLaunchKernelGGL(k2_scan_chunks, dim3(1), dim3(1024), 0, ctx->stream, cs->d_rays, n, cs->d_k2_counters);
-    hipLaunchKernelGGL(k2_fill_chunks, dim3(sh_div_up(n, 256)), dim3(256), 0, ctx->stream,
-                       cs->d_rays, n, cs->d_chunk_ray, cs->d_chunk_x0, cs->cap_chunks);
-    const dim3 fgrid(sh_div_up((int)want, 256 / K2_CHUNK));
-    hipLaunchKernelGGL(k2_fragments<0>, fgrid, dim3(256), 0, ctx->stream, cs->d_rays, cs->d_chunk_ray, cs->d_chunk_x0,
-                       cs->d_k2_counters, npix, cs->d_hole, cs->d_h_cnt, cs->d_h_vmin, cs->d_h_vmax, quality,
-                       cs->d_conflict_pix, cs->cap_conflict);
-    hipLaunchKernelGGL(k2_fragments<1>, fgrid, dim3(256), 0, ctx->stream, cs->d_rays, cs->d_chunk_ray, cs->d_chunk_x0,
-                       cs->d_k2_counters, npix, cs->d_hole, cs->d_h_cnt, cs->d_h_vmin, cs->d_h_vmax, quality,
-                       cs->d_conflict_pix, cs->cap_conflict);
-    hipLaunchKernelGGL(k2_fragments<2>, fgrid, dim3(256), 0, ctx->stream, cs->d_rays, cs->d_chunk_ray, cs->d_chunk_x0,
-                       cs->d_k2_counters, npix, cs->d_hole, cs->d_h_cnt, cs->d_h_vmin, cs->d_h_vmax, quality,
-                       cs->d_conflict_pix, cs->cap_conflict);
-    // conflict pixels are rare (0.015 % of touched pixels at 2048^2); the grid is sized for
-    // the worst case and exits on the device-side count
-    const int rgrid = sh_div_up(cs->cap_conflict < 16384 ? cs->cap_conflict : 16384, 4);
-    hipLaunchKernelGGL(k2_resolve, dim3(rgrid), dim3(256), 0, ctx->stream, cs->d_rays, n, cs->d_k2_counters, cs->hs,
-                       cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict);
+    hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
+                       hole_width, cs->d_rays, (k2_cand *)cs->d_k2_cand, cs->d_k2_start, cs->d_k2_counters);
+#define K2_PIXELS(L, T) hipLaunchKernelGGL((k2_pixels<L, T>), dim3(512), dim3(1024), 0, ctx->stream, cs->d_rays, (const k2_cand *)cs->d_k2_cand, n, \
+                           (const int *)cs->d_k2_start, cs->d_k2_counters, cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, exp_)
+    static const int exp_ = getenv("SLAMHIP_K2_EXP") ? atoi(getenv("SLAMHIP_K2_EXP")) : 0;
+    if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int); else K2_PIXELS(true, long long); }
+    else                  { if (cs->hs <= 16384) K2_PIXELS(false, int); else K2_PIXELS(false, long long); }
+#undef K2_PIXELS
+    hipLaunchKernelGGL(k2_zone, dim3(1024), dim3(256), 0, ctx->stream, cs->d_rays, n, (const k2_cand *)cs->d_k2_cand,
+                       (const int *)cs->d_k2_start, (const int *)cs->d_k2_counters, cs->hs, cs->d_hole, quality,
+                       (const int *)cs->d_conflict_pix, cs->cap_conflict);
     SH_HIP(hipGetLastError());
     return SLAMHIP_OK;
 }
