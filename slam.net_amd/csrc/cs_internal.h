@@ -63,6 +63,7 @@ struct slamhip_cs {
     // ---- K2 HoleMap update -----------------------------------------------------------------------------
     cs_ray *d_rays; int cap_rays;               // per ray: clip / Bresenham / V-profile parameters
     void *d_k2_cand;                            // rays as the pixel kernels test them, sorted by (direction class, slope bucket)
+    void *d_k2_vprof;                           // V-profile parameters by ray index
     int *d_k2_start;                            // [4 x 1024 + 1] first table entry of every bucket
     int *d_k2_counters;           // [0] longest ray, [1] conflict pixels, [2] blended pixels, [3] x1, [4] y1
     int *d_conflict_pix; int cap_conflict;

@@ -36,6 +36,8 @@
 // ray as the pixel kernels test it: clipped major length, signed clipped minor length (smin * dyc), the step beyond
 // which pixval leaves TS_NO_OBSTACLE (:406), ray index (= blend order)
 struct k2_cand { int dxc, sdyc, lim2, ray; };
+// V-profile of a ray, by ray index: derrorv (:379/:386), incv (:398), lim2 = dx - 2*derrorv, lim1 = dx - derrorv (:406,:408)
+struct k2_vprof { int derrorv, incv, lim2, lim1; };
 
 struct cs_ray {
     int valid;
@@ -179,6 +181,26 @@ __device__ static inline int k2_pixval(const cs_ray &r, int x)
     return pixval;
 }
 
+// The same value in closed form (tests/test_closed_forms.py).  TS_OBSTACLE < TS_NO_OBSTACLE makes incerrorv <= 0, so the
+// descending half (x <= lim1) never carries, and on the ascending half the carry fires on the first J steps only:
+// before-correction error of step i while every step carries = u0 + i*g + d*(i-1), negative iff i*(g+d) < d - u0.
+static_assert(TS_OBSTACLE < TS_NO_OBSTACLE, "k2_pixval_closed assumes a falling V-profile");
+__device__ static inline int k2_pixval_closed(const k2_vprof p, int x)
+{
+    if (x <= p.lim2) return TS_NO_OBSTACLE;
+    const int d = p.derrorv;
+    const int incerrorv = (TS_OBSTACLE - TS_NO_OBSTACLE) - d * p.incv;        // :399, in (-d, 0]
+    const int xs = p.lim2 < 0 ? 0 : p.lim2 + 1;
+    const int xm = x < p.lim1 ? x : p.lim1;
+    const int n1 = xm - xs + 1 > 0 ? xm - xs + 1 : 0;                          // steps of the descending half
+    const int j = (x - xs + 1) - n1;                                           // steps of the ascending half
+    const int u0 = d / 2 + n1 * incerrorv, g = -incerrorv;
+    int J = 0;
+    if (j > 0 && d - u0 > 0) J = (d - u0 + (g + d) - 1) / (g + d) - 1;
+    const int f = j < J ? j : J;
+    return TS_NO_OBSTACLE + (n1 - j) * p.incv + f;                             // sincv = -1 (:374)
+}
+
 __device__ static inline uint16_t k2_blend(uint16_t pix, int pixval, int alpha)
 {
     return (uint16_t)(sh_wadd(sh_wmul(256 - alpha, (int)pix), sh_wmul(alpha, pixval)) >> 8);   // :431
@@ -229,7 +251,8 @@ __device__ static inline int k2_classes(int dx, int dy, int cls[2], int a[2], in
 // a valid ray blends exactly one pixel, :404,:431), [3] x1, [4] y1, [5] robot inside the map
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
-           cs_ray *__restrict__ rays, k2_cand *__restrict__ cand, int *__restrict__ start, int *__restrict__ counters)
+           cs_ray *__restrict__ rays, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, int *__restrict__ start,
+           int *__restrict__ counters)
 {
     __shared__ int hist[4 * K2_NBUCK];
     __shared__ int wsum[16];
@@ -243,6 +266,8 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
         const cs_ray r = k2_make_ray(pts[i], size, q, scale, hole_width);
         rays[i] = r;
         if (r.valid) {
+            k2_vprof vp; vp.derrorv = r.derrorv; vp.incv = r.incv; vp.lim2 = r.lim2; vp.lim1 = r.lim1;
+            vprof[i] = vp;
             const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
             const float tt = r.dxc > 0 ? (float)(r.smin * r.dyc) / (float)r.dxc : 0.0f;
             atomicAdd(&hist[cls * K2_NBUCK + k2_bucket(tt)], 1);
@@ -291,9 +316,9 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
 #define K2_LDS_RAYS 3072
 template <bool LDS_TABLE, typename T>
 __global__ void __launch_bounds__(1024)
-k2_pixels(const cs_ray *__restrict__ rays, const k2_cand *__restrict__ cand_g, int n_rays, const int *__restrict__ start_g,
+k2_pixels(const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g, int n_rays, const int *__restrict__ start_g,
           int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
-          int *__restrict__ conflict_pix, int cap_conflict, int exp_)
+          int *__restrict__ conflict_pix, int cap_conflict)
 {
     __shared__ int start[4 * K2_NBUCK + 1];
     __shared__ __attribute__((aligned(16))) k2_cand cand_s[LDS_TABLE ? K2_LDS_RAYS : 1];
@@ -313,7 +338,6 @@ k2_pixels(const cs_ray *__restrict__ rays, const k2_cand *__restrict__ cand_g, i
         if (X > X1) continue;
         const int dx = X - x1, dy = Y - y1;
         if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K2_ZONE) continue;     // the zone kernel's pixels
-        if (exp_ == 1) continue;
         int cls[2], a[2], b[2];
         const int ncls = k2_classes(dx, dy, cls, a, b);
         int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh = 0;
@@ -321,12 +345,10 @@ k2_pixels(const cs_ray *__restrict__ rays, const k2_cand *__restrict__ cand_g, i
         for (int k = 0; k < ncls; k++) {
             int lo, hi;
             k2_range(start, cls[k], a[k], b[k], lo, hi);
-            if (exp_ == 2) { nh += (hi - lo) & 0; continue; }
             for (int ci = lo; ci < hi; ci++) {
                 const k2_cand c = cand[ci];
-                if (exp_ == 3) { nh += c.dxc & 0; continue; }
                 if (!k2_hit<T>(c, a[k], b[k])) continue;
-                const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval(rays[c.ray], a[k]);
+                const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], a[k]);
                 if (nh == K2_MAXHIT) { overflow = true; break; }
                 // insert by ray index (the list stays sorted; compile-time subscripts keep it in registers)
                 int posn = 0;
@@ -355,7 +377,8 @@ k2_pixels(const cs_ray *__restrict__ rays, const k2_cand *__restrict__ cand_g, i
 
 // wavefront per pixel: the zone around the robot, then the conflict list
 __global__ void __launch_bounds__(256)
-k2_zone(const cs_ray *__restrict__ rays, int n_rays, const k2_cand *__restrict__ cand, const int *__restrict__ start,
+k2_zone(const cs_ray *__restrict__ rays, const k2_vprof *__restrict__ vprof, int n_rays, const k2_cand *__restrict__ cand,
+        const int *__restrict__ start,
         const int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
         const int *__restrict__ conflict_pix, int cap_conflict)
 {
@@ -421,7 +444,7 @@ k2_zone(const cs_ray *__restrict__ rays, int n_rays, const k2_cand *__restrict__
             if (ci >= 0) {
                 const k2_cand c = cand[ci];
                 const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
-                if (k2_hit<long long>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval(rays[c.ray], aa); }
+                if (k2_hit<long long>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], aa); }
             }
             const unsigned long long mask = __ballot(hit);
             if (mask) {
@@ -464,7 +487,7 @@ int32_t cs_holemap_alloc(slamhip_cs *cs)
 
 void cs_holemap_free(slamhip_cs *cs)
 {
-    (void)hipFree(cs->d_rays); (void)hipFree(cs->d_k2_cand); (void)hipFree(cs->d_k2_start);
+    (void)hipFree(cs->d_rays); (void)hipFree(cs->d_k2_cand); (void)hipFree(cs->d_k2_vprof); (void)hipFree(cs->d_k2_start);
     (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_conflict_pix);
 }
 
@@ -476,22 +499,23 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     if (n > cs->cap_rays) {
         if (cs->d_rays) (void)hipFree(cs->d_rays);
         if (cs->d_k2_cand) (void)hipFree(cs->d_k2_cand);
-        cs->d_rays = nullptr; cs->d_k2_cand = nullptr; cs->cap_rays = 0;
+        if (cs->d_k2_vprof) (void)hipFree(cs->d_k2_vprof);
+        cs->d_rays = nullptr; cs->d_k2_cand = nullptr; cs->d_k2_vprof = nullptr; cs->cap_rays = 0;
         const int cap = n + n / 4 + 64;
         SH_HIP(hipMalloc(&cs->d_rays, sizeof(cs_ray) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_k2_cand, sizeof(k2_cand) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_vprof) * (size_t)cap));
         cs->cap_rays = cap;
     }
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
     hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                       hole_width, cs->d_rays, (k2_cand *)cs->d_k2_cand, cs->d_k2_start, cs->d_k2_counters);
-#define K2_PIXELS(L, T) hipLaunchKernelGGL((k2_pixels<L, T>), dim3(512), dim3(1024), 0, ctx->stream, cs->d_rays, (const k2_cand *)cs->d_k2_cand, n, \
-                           (const int *)cs->d_k2_start, cs->d_k2_counters, cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, exp_)
-    static const int exp_ = getenv("SLAMHIP_K2_EXP") ? atoi(getenv("SLAMHIP_K2_EXP")) : 0;
+                       hole_width, cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters);
+#define K2_PIXELS(L, T) hipLaunchKernelGGL((k2_pixels<L, T>), dim3(512), dim3(1024), 0, ctx->stream, (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, \
+                           (const int *)cs->d_k2_start, cs->d_k2_counters, cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict)
     if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int); else K2_PIXELS(true, long long); }
     else                  { if (cs->hs <= 16384) K2_PIXELS(false, int); else K2_PIXELS(false, long long); }
 #undef K2_PIXELS
-    hipLaunchKernelGGL(k2_zone, dim3(1024), dim3(256), 0, ctx->stream, cs->d_rays, n, (const k2_cand *)cs->d_k2_cand,
+    hipLaunchKernelGGL(k2_zone, dim3(1024), dim3(256), 0, ctx->stream, cs->d_rays, (const k2_vprof *)cs->d_k2_vprof, n, (const k2_cand *)cs->d_k2_cand,
                        (const int *)cs->d_k2_start, (const int *)cs->d_k2_counters, cs->hs, cs->d_hole, quality,
                        (const int *)cs->d_conflict_pix, cs->cap_conflict);
     SH_HIP(hipGetLastError());

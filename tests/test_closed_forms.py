@@ -58,3 +58,68 @@ def test_k5_minor_steps_closed_form():
             assert lit == [(da // 2 + i * db) // da for i in range(da)], (da, db)
     for da, db in ((2047, 2047), (2047, 1), (4095, 4094), (1023, 511)):
         assert k5_literal(da, db) == [(da // 2 + i * db) // da for i in range(da)]
+
+
+# ---- K2 V-profile (pixval) ------------------------------------------------------------------------------------
+TS_NO_OBSTACLE, TS_OBSTACLE = 65500, 0
+
+
+def _cs_div(a, b):
+    """C# integer division: truncation toward zero."""
+    q = abs(a) // abs(b)
+    return q if (a < 0) == (b < 0) else -q
+
+
+def k2_pixval_literal(dx, derrorv, x):
+    """csrc/holemap.hip k2_pixval == the pixval recurrence of DrawLaserRayOnHoleMap (:397-428) up to step x."""
+    incv = _cs_div(TS_OBSTACLE - TS_NO_OBSTACLE, derrorv)
+    incerrorv = (TS_OBSTACLE - TS_NO_OBSTACLE) - derrorv * incv
+    sincv = -1
+    lim2, lim1 = dx - 2 * derrorv, dx - derrorv
+    pixval, errorv = TS_NO_OBSTACLE, _cs_div(derrorv, 2)
+    if x <= lim2:
+        return pixval
+    xs = 0 if lim2 < 0 else lim2 + 1
+    for xi in range(xs, x + 1):
+        if xi <= lim1:
+            pixval += incv; errorv += incerrorv
+            if errorv > derrorv:
+                pixval += sincv; errorv -= derrorv
+        else:
+            pixval -= incv; errorv -= incerrorv
+            if errorv < 0:
+                pixval -= sincv; errorv += derrorv
+    return pixval
+
+
+def k2_pixval_closed(dx, derrorv, x):
+    """Closed form used by the pixel kernels (valid because incerrorv <= 0 for TS_OBSTACLE < TS_NO_OBSTACLE): the
+    descending half never carries; on the ascending half the carries fire on the first J steps only."""
+    d = derrorv
+    incv = _cs_div(TS_OBSTACLE - TS_NO_OBSTACLE, d)
+    incerrorv = (TS_OBSTACLE - TS_NO_OBSTACLE) - d * incv
+    sincv = -1
+    assert incerrorv <= 0
+    lim2, lim1 = dx - 2 * d, dx - d
+    if x <= lim2:
+        return TS_NO_OBSTACLE
+    xs = 0 if lim2 < 0 else lim2 + 1
+    n1 = max(0, min(x, lim1) - xs + 1)
+    j = (x - xs + 1) - n1
+    u0 = _cs_div(d, 2) + n1 * incerrorv
+    g = -incerrorv
+    J = 0
+    if d - u0 > 0:
+        J = (d - u0 + (g + d) - 1) // (g + d) - 1
+    f = min(j, max(J, 0))
+    return TS_NO_OBSTACLE + n1 * incv - j * incv - f * sincv
+
+
+def test_k2_pixval_closed_form():
+    for derrorv in list(range(1, 140)) + [255, 256, 257, 1000, 4097, 65499, 65500, 65501, 70000]:
+        for dx in sorted(set([0, 1, 2, derrorv - 1, derrorv, derrorv + 1, 2 * derrorv - 1, 2 * derrorv, 2 * derrorv + 1,
+                              3 * derrorv + 7, 5, 17, 100, 333])):
+            if dx < 0 or dx > 1500:
+                continue
+            for x in range(0, dx + 1):
+                assert k2_pixval_literal(dx, derrorv, x) == k2_pixval_closed(dx, derrorv, x), (dx, derrorv, x)
