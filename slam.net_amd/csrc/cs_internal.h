@@ -10,7 +10,6 @@
 #define CS_RB_EXTENT_PX 128.0f
 #define K1_GROUP 1024                  // theta-consecutive candidates per K1 workgroup ("group"): 256 lanes x 4
 
-struct cs_ray;      // K2 per-ray table entry (holemap.hip)
 
 struct slamhip_cs {
     slamhip_ctx *ctx;
@@ -61,7 +60,7 @@ struct slamhip_cs {
     float *d_best_pose;           // winner's pose (theta normalised), device-resident for the fused path
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------
-    cs_ray *d_rays; int cap_rays;               // per ray: clip / Bresenham / V-profile parameters
+    void *d_rays; int cap_rays;                 // rays by index (k2_byidx): clipped lengths, flags
     void *d_k2_cand;                            // rays as the pixel kernels test them, sorted by (direction class, slope bucket)
     void *d_k2_vprof;                           // V-profile parameters by ray index
     int *d_k2_start;                            // [4 x 1024 + 1] first table entry of every bucket

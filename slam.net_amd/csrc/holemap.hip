@@ -15,9 +15,10 @@
 //            rays of the pixel's class with slope in [(b-1)/a, (b+1)/a] can draw pixel (major a, minor b): a
 //            contiguous range of the sorted table, tested exactly.  Up to 4 hits are sorted by ray index in
 //            registers and blended; a pixel with more goes to the conflict list
-//   zone     one wavefront per pixel for the neighbourhood of the robot (every ray passes there) and the
-//            conflict list: lanes test the candidate rays, hits are rank-sorted by ray index and blended in
-//            that order; the few pixels with more than 64 candidates scan all rays in index order
+//            (same launch) one wavefront per pixel for the neighbourhood of the robot (every ray passes there) and,
+//            in the last workgroup to finish, for the conflict list: lanes test the candidate rays, hits are
+//            rank-sorted by ray index and blended in that order; the few pixels with more than 64 candidates scan
+//            all rays in index order
 // All integer arithmetic wraps like C# unchecked int; float->int follows cvttss2si (sh_f2i).
 // Deviations from the reference (all in exception / platform-dependent territory; the oracle does the same):
 //   D1 non-representable pixel coordinates (NaN/inf, e.g. zero-range point) skip the ray;
@@ -38,6 +39,8 @@
 struct k2_cand { int dxc, sdyc, lim2, ray; };
 // V-profile of a ray, by ray index: derrorv (:379/:386), incv (:398), lim2 = dx - 2*derrorv, lim1 = dx - derrorv (:406,:408)
 struct k2_vprof { int derrorv, incv, lim2, lim1; };
+// ray by index, for the pixels that scan all rays: flags = valid | major_x << 1 | (smaj + 1) << 2
+struct k2_byidx { int dxc, sdyc, lim2, flags; };
 
 struct cs_ray {
     int valid;
@@ -150,38 +153,9 @@ __device__ static inline cs_ray k2_make_ray(const float2 p, int size, const floa
     return r;
 }
 
-// minor steps taken before step x (closed form of :394-396,:433-441)
-__device__ static inline int k2_minor(const cs_ray &r, int x)
-{
-    if (r.dxc <= 0) return 0;
-    long long num = 2ll * r.dyc * x - r.dxc;
-    if (num <= 0) return 0;
-    long long den = 2ll * r.dxc;
-    long long m = (num + den - 1) / den;
-    return m > x ? x : (int)m;
-}
-
-// pixval at step x: literal recurrence of :406-428 restarted where it starts to change
-__device__ static inline int k2_pixval(const cs_ray &r, int x)
-{
-    int pixval = TS_NO_OBSTACLE, errorv = r.derrorv / 2;                   // :402,:397
-    if (x <= r.lim2) return pixval;                                        // :406
-    int xs = r.lim2 < 0 ? 0 : r.lim2 + 1;
-    for (int xi = xs; xi <= x; xi++) {
-        if (xi <= r.lim1) {                                                // :408
-            pixval = sh_wadd(pixval, r.incv);
-            errorv = sh_wadd(errorv, r.incerrorv);
-            if (errorv > r.derrorv) { pixval = sh_wadd(pixval, r.sincv); errorv = sh_wsub(errorv, r.derrorv); }
-        } else {
-            pixval = sh_wsub(pixval, r.incv);
-            errorv = sh_wsub(errorv, r.incerrorv);
-            if (errorv < 0) { pixval = sh_wsub(pixval, r.sincv); errorv = sh_wadd(errorv, r.derrorv); }
-        }
-    }
-    return pixval;
-}
-
-// The same value in closed form (tests/test_closed_forms.py).  TS_OBSTACLE < TS_NO_OBSTACLE makes incerrorv <= 0, so the
+// pixval at step x is the recurrence of :406-428 (oracle/coreslam_oracle.c draws it literally); here it is evaluated
+// in closed form (tests/test_closed_forms.py checks it against the literal recurrence).  TS_OBSTACLE < TS_NO_OBSTACLE
+// makes incerrorv <= 0, so the
 // descending half (x <= lim1) never carries, and on the ascending half the carry fires on the first J steps only:
 // before-correction error of step i while every step carries = u0 + i*g + d*(i-1), negative iff i*(g+d) < d - u0.
 static_assert(TS_OBSTACLE < TS_NO_OBSTACLE, "k2_pixval_closed assumes a falling V-profile");
@@ -251,7 +225,7 @@ __device__ static inline int k2_classes(int dx, int dy, int cls[2], int a[2], in
 // a valid ray blends exactly one pixel, :404,:431), [3] x1, [4] y1, [5] robot inside the map
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
-           cs_ray *__restrict__ rays, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, int *__restrict__ start,
+           k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, int *__restrict__ start,
            int *__restrict__ counters)
 {
     __shared__ int hist[4 * K2_NBUCK];
@@ -262,19 +236,27 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     if (t == 0) { s_R = 0; s_total = 0; }
     __syncthreads();
     const float4 q = k2_pxcs(d_pose, h_pxcs, scale);
+    int my_R = 0, my_total = 0;
     for (int i = t; i < n; i += 1024) {
         const cs_ray r = k2_make_ray(pts[i], size, q, scale, hole_width);
-        rays[i] = r;
+        k2_byidx e; e.dxc = r.dxc; e.sdyc = r.smin * r.dyc; e.lim2 = r.lim2;
+        e.flags = (r.valid ? 1 : 0) | (r.major_x ? 2 : 0) | ((r.smaj + 1) << 2);
+        byidx[i] = e;
         if (r.valid) {
             k2_vprof vp; vp.derrorv = r.derrorv; vp.incv = r.incv; vp.lim2 = r.lim2; vp.lim1 = r.lim1;
             vprof[i] = vp;
             const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
-            const float tt = r.dxc > 0 ? (float)(r.smin * r.dyc) / (float)r.dxc : 0.0f;
+            const float tt = r.dxc > 0 ? (float)e.sdyc / (float)r.dxc : 0.0f;
             atomicAdd(&hist[cls * K2_NBUCK + k2_bucket(tt)], 1);
-            atomicMax(&s_R, r.dxc);
-            atomicAdd(&s_total, r.dxc + 1);
+            my_R = max(my_R, r.dxc);
+            my_total += r.dxc + 1;
         }
     }
+    for (int off = 32; off > 0; off >>= 1) {                       // one LDS atomic per wave, not per ray (same address)
+        my_R = max(my_R, __shfl_down(my_R, off, 64));
+        my_total += __shfl_down(my_total, off, 64);
+    }
+    if (lane == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_total, my_total); }
     __syncthreads();
     {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
         int v[4], sum = 0;
@@ -295,12 +277,13 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     }
     __syncthreads();
     for (int i = t; i < n; i += 1024) {
-        const cs_ray r = rays[i];
-        if (r.valid) {
-            const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
-            const float tt = r.dxc > 0 ? (float)(r.smin * r.dyc) / (float)r.dxc : 0.0f;
+        const k2_byidx e = byidx[i];
+        if (e.flags & 1) {
+            const int smaj = ((e.flags >> 2) & 3) - 1;
+            const int cls = (e.flags & 2) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3);
+            const float tt = e.dxc > 0 ? (float)e.sdyc / (float)e.dxc : 0.0f;
             const int pos = atomicAdd(&hist[cls * K2_NBUCK + k2_bucket(tt)], 1);
-            k2_cand c; c.dxc = r.dxc; c.sdyc = r.smin * r.dyc; c.lim2 = r.lim2; c.ray = i;
+            k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
             cand[pos] = c;
         }
     }
@@ -310,34 +293,136 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     }
 }
 
+// One wavefront draws one pixel: lanes test the candidate rays, hits are rank-sorted by ray index and blended in that
+// order; the robot's pixel (step 0 of every ray) and its closest neighbours (more than 64 candidates) scan all rays in
+// index order.  `sval` is 64 ints of LDS private to the wavefront.
+template <typename CT>
+__device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int size, const k2_byidx *__restrict__ byidx,
+                                            const k2_vprof *__restrict__ vprof, int n_rays, CT cand, const int *start,
+                                            uint16_t *__restrict__ map, int alpha, int *sval)
+{
+    const int lane = threadIdx.x & 63;
+    const int ptr = Y * size + X;
+    const int dx = X - x1, dy = Y - y1;
+    int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
+    const int ncls = k2_classes(dx, dy, cls, a, b);
+    int nc = 0;
+    for (int k = 0; k < ncls; k++) { k2_range(start, cls[k], a[k], b[k], lo[k], hi[k]); nc += hi[k] - lo[k]; }
+    uint16_t pix = map[ptr];
+    bool stable = false;
+    int last_v = 0;
+    if (ncls == 0 || nc > 64) {
+        k2_byidx e_next = byidx[lane < n_rays ? lane : 0];             // (the table is read one iteration ahead)
+        for (int base = 0; base < n_rays; base += 64) {
+            const int i = base + lane;
+            bool hit = false;
+            int v = 0;
+            const k2_byidx e = e_next;
+            e_next = byidx[i + 64 < n_rays ? i + 64 : 0];
+            if (i < n_rays) {
+                if (e.flags & 1) {
+                    const int smaj = ((e.flags >> 2) & 3) - 1;
+                    const int aa = (e.flags & 2) ? dx : dy, bb = (e.flags & 2) ? dy : dx;
+                    int x = -1;
+                    if (smaj != 0) x = aa * smaj; else if (aa == 0) x = 0;
+                    k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
+                    if (x == 0 ? bb == 0 : (x > 0 && k2_hit<long long>(c, x, bb))) {
+                        hit = true;
+                        v = x <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[i], x);
+                    }
+                }
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                // the leading run of hits with one value (near the robot nearly every ray carries TS_NO_OBSTACLE): the
+                // blend of a run converges -- once it no longer changes the pixel the rest of the run cannot either
+                const int src = __ffsll((long long)mask) - 1;
+                const int vv = __builtin_amdgcn_readlane(v, src);
+                const unsigned long long same = __ballot(hit && v == vv) & mask, diff = mask & ~same;
+                const unsigned long long run = diff ? (same & ((diff & (0ull - diff)) - 1ull)) : same;
+                for (int k = __popcll(run); k > 0 && !(stable && vv == last_v); k--) {
+                    const uint16_t np = k2_blend(pix, vv, alpha);
+                    stable = np == pix; pix = np; last_v = vv;
+                }
+                mask &= ~run;
+            }
+        }
+    } else if (nc > 0) {
+        int ci = -1, kk = 0;
+        if (lane < hi[0] - lo[0]) { ci = lo[0] + lane; kk = 0; }
+        else if (ncls > 1 && lane - (hi[0] - lo[0]) < hi[1] - lo[1]) { ci = lo[1] + lane - (hi[0] - lo[0]); kk = 1; }
+        bool hit = false;
+        int idx = 0x7fffffff, v = 0;
+        if (ci >= 0) {
+            const k2_cand c = cand[ci];
+            const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
+            if (k2_hit<long long>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], aa); }
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            int rank = 0;
+            unsigned long long m = mask;
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                const int oi = __builtin_amdgcn_readlane(idx, src);
+                rank += (hit && oi < idx) ? 1 : 0;
+                m &= m - 1;
+            }
+            if (hit) sval[rank] = v;
+            __builtin_amdgcn_wave_barrier();
+            const int nh = __popcll(mask);
+            for (int k = 0; k < nh; k++) {
+                const int vv = sval[k];
+                if (!(stable && vv == last_v)) {
+                    const uint16_t np = k2_blend(pix, vv, alpha);
+                    stable = np == pix; pix = np; last_v = vv;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) map[ptr] = pix;
+}
+
 // lane per pixel over the bounding square of the scan (persistent grid; a wavefront takes 64 pixels of one row).
 // The bucket table and -- when it fits (LDS_TABLE) -- the candidate table live in LDS: a pixel's lookup is a chain of
 // dependent small reads (bucket bounds -> candidates -> map), which global-memory latency would dominate.
 #define K2_LDS_RAYS 3072
 template <bool LDS_TABLE, typename T>
 __global__ void __launch_bounds__(1024)
-k2_pixels(const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g, int n_rays, const int *__restrict__ start_g,
-          int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
+k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g, int n_rays,
+          const int *__restrict__ start_g, int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
           int *__restrict__ conflict_pix, int cap_conflict)
 {
     __shared__ int start[4 * K2_NBUCK + 1];
     __shared__ __attribute__((aligned(16))) k2_cand cand_s[LDS_TABLE ? K2_LDS_RAYS : 1];
+    __shared__ int sval[16][64];
+    __shared__ int s_last;
     const int R = counters[0], x1 = counters[3], y1 = counters[4];
-    if (R <= 0) return;
+    if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;       // robot outside the map: nothing is drawn (:509-512)
     const int X0 = max(x1 - R, 0), X1 = min(x1 + R, size - 1), Y0 = max(y1 - R, 0), Y1 = min(y1 + R, size - 1);
-    if (X1 < X0 || Y1 < Y0) return;
     for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
     if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) cand_s[i] = cand_g[i];     // (entries past the valid rays are never addressed)
     __syncthreads();
     const k2_cand *cand = LDS_TABLE ? cand_s : cand_g;
-    const int tiles_x = (X1 - X0 + 64) / 64, items = tiles_x * (Y1 - Y0 + 1);
-    const int lane = threadIdx.x & 63;
-    for (int item = blockIdx.x * 16 + (threadIdx.x >> 6); item < items; item += gridDim.x * 16) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 16 + wv, nw = gridDim.x * 16;
+    // (1) the zone around the robot (Chebyshev distance <= Z): one wavefront per pixel
+    const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R;
+    const int side = 2 * Z + 1, n_zone = side * side;
+    for (int item = gw; item < n_zone; item += nw) {
+        const int X = x1 - Z + item % side, Y = y1 - Z + item / side;
+        if (X < 0 || X >= size || Y < 0 || Y >= size) continue;              // wave-uniform
+        k2_wave_pixel(X, Y, x1, y1, size, byidx, vprof, n_rays, cand, start, map, alpha, sval[wv]);
+    }
+    // (2) the rest of the bounding square: one lane per pixel, a wavefront takes 64 pixels of one row
+    const int tiles_x = (X1 - X0 + 64) / 64, items = R > 0 ? tiles_x * (Y1 - Y0 + 1) : 0;
+    for (int item = gw; item < items; item += nw) {
         const int row = item / tiles_x, tx = item - row * tiles_x;
         const int X = X0 + tx * 64 + lane, Y = Y0 + row;
         if (X > X1) continue;
         const int dx = X - x1, dy = Y - y1;
-        if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K2_ZONE) continue;     // the zone kernel's pixels
+        if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K2_ZONE) continue;     // (1)'s pixels
         int cls[2], a[2], b[2];
         const int ncls = k2_classes(dx, dy, cls, a, b);
         int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh = 0;
@@ -364,8 +449,8 @@ k2_pixels(const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g
         }
         const int ptr = Y * size + X;
         if (overflow) {
-            const int slot = atomicAdd(&counters[1], 1);
-            if (slot < cap_conflict) conflict_pix[slot] = ptr;
+            const int slot = __hip_atomic_fetch_add(&counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (slot < cap_conflict) __hip_atomic_store(&conflict_pix[slot], ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (nh > 0) {
             uint16_t pix = map[ptr];
 #pragma unroll
@@ -373,103 +458,23 @@ k2_pixels(const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g
             map[ptr] = pix;
         }
     }
-}
-
-// wavefront per pixel: the zone around the robot, then the conflict list
-__global__ void __launch_bounds__(256)
-k2_zone(const cs_ray *__restrict__ rays, const k2_vprof *__restrict__ vprof, int n_rays, const k2_cand *__restrict__ cand,
-        const int *__restrict__ start,
-        const int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
-        const int *__restrict__ conflict_pix, int cap_conflict)
-{
-    __shared__ int sval[4][64];
-    const int R = counters[0], x1 = counters[3], y1 = counters[4];
-    if (R < 0 || x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;
-    int n_conf = counters[1];
+    // (3) pixels with more than K2_MAXHIT hits, queued by (2): the last workgroup to finish draws them, one wavefront
+    //     per pixel.  Queue entries are published write-through and the count is an agent-scope atomic; every wave
+    //     drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(&counters[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (int)gridDim.x - 1;
+        if (s_last) __hip_atomic_store(&counters[6], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    int n_conf = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n_conf > cap_conflict) n_conf = cap_conflict;
-    const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R;                       // zone = Chebyshev distance <= Z
-    const int side = 2 * Z + 1, n_zone = side * side;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int item = blockIdx.x * 4 + wv; item < n_zone + n_conf; item += gridDim.x * 4) {
-        int X, Y;
-        if (item < n_zone) { X = x1 - Z + item % side; Y = y1 - Z + item / side; }
-        else { const int ptr = conflict_pix[item - n_zone]; X = ptr % size; Y = ptr / size; }
-        if (X < 0 || X >= size || Y < 0 || Y >= size) continue;              // wave-uniform
-        const int ptr = Y * size + X;
-        const int dx = X - x1, dy = Y - y1;
-        int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
-        const int ncls = k2_classes(dx, dy, cls, a, b);
-        int nc = 0;
-        for (int k = 0; k < ncls; k++) { k2_range(start, cls[k], a[k], b[k], lo[k], hi[k]); nc += hi[k] - lo[k]; }
-        uint16_t pix = map[ptr];
-        bool stable = false;
-        int last_v = 0;
-        if (ncls == 0 || nc > 64) {
-            // the robot's pixel (step 0 of every ray) and its closest neighbours: all rays, in index order
-            for (int base = 0; base < n_rays; base += 64) {
-                const int i = base + lane;
-                bool hit = false;
-                int v = 0;
-                if (i < n_rays) {
-                    const cs_ray r = rays[i];
-                    if (r.valid) {
-                        const int aa = r.major_x ? dx : dy, bb = r.major_x ? dy : dx;
-                        int x = -1;
-                        if (r.smaj != 0) x = aa * r.smaj; else if (aa == 0) x = 0;
-                        if (x >= 0 && x <= r.dxc && k2_minor(r, x) * r.smin == bb) { hit = true; v = k2_pixval(r, x); }
-                    }
-                }
-                unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    // the leading run of hits with one value (near the robot nearly every ray carries TS_NO_OBSTACLE): the
-                    // blend of a run converges -- once it no longer changes the pixel the rest of the run cannot either
-                    const int src = __ffsll((long long)mask) - 1;
-                    const int vv = __builtin_amdgcn_readlane(v, src);
-                    const unsigned long long same = __ballot(hit && v == vv) & mask, diff = mask & ~same;
-                    const unsigned long long run = diff ? (same & ((diff & (0ull - diff)) - 1ull)) : same;
-                    for (int k = __popcll(run); k > 0 && !(stable && vv == last_v); k--) {
-                        const uint16_t np = k2_blend(pix, vv, alpha);
-                        stable = np == pix; pix = np; last_v = vv;
-                    }
-                    mask &= ~run;
-                }
-            }
-        } else if (nc > 0) {
-            // one candidate per lane, exact test, hits rank-sorted by ray index
-            int ci = -1, kk = 0;
-            if (lane < hi[0] - lo[0]) { ci = lo[0] + lane; kk = 0; }
-            else if (ncls > 1 && lane - (hi[0] - lo[0]) < hi[1] - lo[1]) { ci = lo[1] + lane - (hi[0] - lo[0]); kk = 1; }
-            bool hit = false;
-            int idx = 0x7fffffff, v = 0;
-            if (ci >= 0) {
-                const k2_cand c = cand[ci];
-                const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
-                if (k2_hit<long long>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], aa); }
-            }
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                int rank = 0;
-                unsigned long long m = mask;
-                while (m) {
-                    const int src = __ffsll((long long)m) - 1;
-                    const int oi = __builtin_amdgcn_readlane(idx, src);
-                    rank += (hit && oi < idx) ? 1 : 0;
-                    m &= m - 1;
-                }
-                if (hit) sval[wv][rank] = v;
-                __builtin_amdgcn_wave_barrier();
-                const int nh = __popcll(mask);
-                for (int k = 0; k < nh; k++) {
-                    const int vv = sval[wv][k];
-                    if (!(stable && vv == last_v)) {
-                        const uint16_t np = k2_blend(pix, vv, alpha);
-                        stable = np == pix; pix = np; last_v = vv;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (lane == 0) map[ptr] = pix;
+    for (int item = wv; item < n_conf; item += 16) {
+        const int ptr = __hip_atomic_load(&conflict_pix[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k2_wave_pixel(ptr % size, ptr / size, x1, y1, size, byidx, vprof, n_rays, cand, start, map, alpha, sval[wv]);
     }
 }
 
@@ -502,22 +507,20 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         if (cs->d_k2_vprof) (void)hipFree(cs->d_k2_vprof);
         cs->d_rays = nullptr; cs->d_k2_cand = nullptr; cs->d_k2_vprof = nullptr; cs->cap_rays = 0;
         const int cap = n + n / 4 + 64;
-        SH_HIP(hipMalloc(&cs->d_rays, sizeof(cs_ray) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_rays, sizeof(k2_byidx) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_k2_cand, sizeof(k2_cand) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_vprof) * (size_t)cap));
         cs->cap_rays = cap;
     }
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
     hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                       hole_width, cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters);
-#define K2_PIXELS(L, T) hipLaunchKernelGGL((k2_pixels<L, T>), dim3(512), dim3(1024), 0, ctx->stream, (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, \
-                           (const int *)cs->d_k2_start, cs->d_k2_counters, cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict)
+                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters);
+#define K2_PIXELS(L, T) hipLaunchKernelGGL((k2_pixels<L, T>), dim3(512), dim3(1024), 0, ctx->stream, (const k2_byidx *)cs->d_rays, \
+                           (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
+                           cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict)
     if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int); else K2_PIXELS(true, long long); }
     else                  { if (cs->hs <= 16384) K2_PIXELS(false, int); else K2_PIXELS(false, long long); }
 #undef K2_PIXELS
-    hipLaunchKernelGGL(k2_zone, dim3(1024), dim3(256), 0, ctx->stream, cs->d_rays, (const k2_vprof *)cs->d_k2_vprof, n, (const k2_cand *)cs->d_k2_cand,
-                       (const int *)cs->d_k2_start, (const int *)cs->d_k2_counters, cs->hs, cs->d_hole, quality,
-                       (const int *)cs->d_conflict_pix, cs->cap_conflict);
     SH_HIP(hipGetLastError());
     return SLAMHIP_OK;
 }
