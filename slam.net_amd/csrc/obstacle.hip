@@ -6,17 +6,21 @@
 //   - the endpoint cell does a saturating ++ below MaxObstacleHits (:474-477): k hits on a cell with
 //     value v give v + min(k, max(0, Max - v)), so hits are counted with integer atomics and applied once;
 //   - the decay pass (:576-592) runs after all rays, on the value that already includes the hits.
-// One thread per ray walks the literal Rosetta-style Bresenham (:458-488); one thread per cell then
-// applies hits + decay and clears the per-scan scratch.
+// One wavefront per (ray, 64 iterations of the walk), one lane per iteration: after i iterations of the Rosetta-style
+// walk (:458-488) the position is i steps along the major axis and max(0, ceil((i*minor - major/2) / major)) along
+// the minor one (tests/test_closed_forms.py checks this against the literal loop); the walk is monotone in x and
+// y, so the cells inside the map are a prefix of it (:465-469 breaks at the first one outside).  One thread per cell
+// then applies hits + decay and clears the per-scan scratch.
 #include "cs_internal.h"
 #include "det_trig.h"
 
 __global__ void __launch_bounds__(256)
 k3_rays(const float2 *__restrict__ pts, int n_points, int size, float scale, const float *d_pose, float4 h_pxcs,
-        uint32_t *__restrict__ hits, uint8_t *__restrict__ nohit)
+        uint32_t *__restrict__ hits, uint8_t *__restrict__ nohit, int chunks_per_ray)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_points) return;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);             // (ray, chunk), wave-uniform
+    const int ray = w / chunks_per_ray, chunk = w - ray * chunks_per_ray;
+    if (ray >= n_points) return;
     float4 q = h_pxcs;
     if (d_pose) {
         float s, c;
@@ -26,9 +30,9 @@ k3_rays(const float2 *__restrict__ pts, int n_points, int size, float scale, con
         q.z = c * scale;                                                   // :547
         q.w = s * scale;                                                   // :548
     }
-    int x1 = sh_f2i(q.x), y1 = sh_f2i(q.y);                                // :553-554
+    const int x1 = sh_f2i(q.x), y1 = sh_f2i(q.y);                          // :553-554
     if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;              // :557-560
-    const float2 p = pts[i];
+    const float2 p = pts[ray];
     float fx = q.x + q.z * p.x;  fx = fx - q.w * p.y;                      // :566
     float fy = q.y + q.w * p.x;  fy = fy + q.z * p.y;                      // :567
     const int x2 = sh_f2i(fx), y2 = sh_f2i(fy);
@@ -36,19 +40,23 @@ k3_rays(const float2 *__restrict__ pts, int n_points, int size, float scale, con
     if (ddx == INT32_MIN || ddy == INT32_MIN) return;                      // Math.Abs overflow (throws in C#)
     const int dx = sh_abs(ddx), sx = sh_sign(ddx);                         // :458
     const int dy = sh_abs(ddy), sy = sh_sign(ddy);                         // :459
-    int err = (dx > dy ? dx : -dy) / 2, e2;                                // :460
-    for (;;) {                                                             // :462
-        if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) break;           // :465-469
-        const int idx = y1 * size + x1;
-        if (x1 == x2 && y1 == y2) {                                        // :471
-            atomicAdd(&hits[idx], 1u);                                     // :474-477 (applied in k3_apply)
-            break;
-        }
-        nohit[idx] = 1;                                                    // :483
-        e2 = err;                                                          // :486
-        if (e2 > -dx) { err = sh_wsub(err, dy); x1 = sh_wadd(x1, sx); }    // :487
-        if (e2 < dy)  { err = sh_wadd(err, dx); y1 = sh_wadd(y1, sy); }    // :488
+    const long long n = dx > dy ? dx : dy;                                 // iterations to the end point
+    const long long i = (long long)chunk * 64 + (threadIdx.x & 63);
+    // the part of the walk that can lie in the map is shorter than 2 * size iterations (host: chunks_per_ray)
+    if (i > n) return;
+    long long ax, ay;                                                      // steps taken along x / y before iteration i
+    if (dx > dy) {
+        const long long num = i * dy - dx / 2;                             // err0 = dx / 2 (:460)
+        ax = i; ay = num <= 0 ? 0 : (num + dx - 1) / dx;
+    } else {
+        const long long num = i * dx - dy / 2;                             // err0 = -dy / 2 = -(dy / 2) in C#
+        ay = i; ax = (num <= 0 || dy == 0) ? 0 : (num + dy - 1) / dy;
     }
+    const long long X = x1 + sx * ax, Y = y1 + sy * ay;
+    if (X < 0 || X >= size || Y < 0 || Y >= size) return;                  // :465-469 (everything after it is outside too)
+    const int idx = (int)Y * size + (int)X;
+    if (i == n) atomicAdd(&hits[idx], 1u);                                 // :471-477 (applied in k3_apply)
+    else nohit[idx] = 1;                                                   // :483
 }
 
 __global__ void __launch_bounds__(256)
@@ -96,8 +104,10 @@ int32_t cs_launch_obstacle_update(slamhip_cs *cs, const float *d_pose, float4 h_
     if (n <= 0) return SLAMHIP_OK;
     const int cells = cs->os * cs->os;
     sh_timer t(ctx, SLAMHIP_K_CS_OBSTACLE);
-    hipLaunchKernelGGL(k3_rays, dim3(sh_div_up(n, 256)), dim3(256), 0, ctx->stream,
-                       cs->d_pts, n, cs->os, cs->oscale, d_pose, h_pxcs, cs->d_o_hits, cs->d_o_nohit);
+    // a walk stays in the map for at most `size` iterations (one major-axis step each): iterations 0 .. size
+    const int chunks_per_ray = sh_div_up(cs->os + 1, 64);
+    hipLaunchKernelGGL(k3_rays, dim3(sh_div_up(n * chunks_per_ray, 4)), dim3(256), 0, ctx->stream,
+                       cs->d_pts, n, cs->os, cs->oscale, d_pose, h_pxcs, cs->d_o_hits, cs->d_o_nohit, chunks_per_ray);
     hipLaunchKernelGGL(k3_apply, dim3(sh_div_up(cells, 256)), dim3(256), 0, ctx->stream,
                        cs->d_obst, cells, cs->d_o_hits, cs->d_o_nohit, max_hits);
     SH_HIP(hipGetLastError());

@@ -123,3 +123,45 @@ def test_k2_pixval_closed_form():
                 continue
             for x in range(0, dx + 1):
                 assert k2_pixval_literal(dx, derrorv, x) == k2_pixval_closed(dx, derrorv, x), (dx, derrorv, x)
+
+
+# ---- K3 ObstacleMap line (DrawLaserRayOnObstacleMap, CoreSLAMProcessor.cs:456-490) -----------------------------------
+def k3_literal(dx, dy):
+    """(x steps, y steps) taken before each iteration of the Rosetta-style walk, up to and including the end point."""
+    err = _cs_div(dx if dx > dy else -dy, 2)
+    ax = ay = 0
+    out = []
+    for _ in range(max(dx, dy) + 1):
+        out.append((ax, ay))
+        if ax == dx and ay == dy:
+            break
+        e2 = err
+        if e2 > -dx:
+            err -= dy; ax += 1
+        if e2 < dy:
+            err += dx; ay += 1
+    return out
+
+
+def _ceil_div(a, b):
+    return -((-a) // b)
+
+
+def k3_closed(dx, dy, i):
+    """csrc/obstacle.hip: after i iterations the walk has taken i steps along the major axis and
+    max(0, ceil((i*minor - e0) / major)) along the minor one, e0 = major / 2 (C# division: floor for major >= 0)."""
+    if dx > dy:
+        return (i, max(0, _ceil_div(i * dy - dx // 2, dx)))
+    if dy == 0:
+        return (0, 0)
+    return (max(0, _ceil_div(i * dx - dy // 2, dy)), i)
+
+
+def test_k3_walk_closed_form():
+    for dx in range(0, 70):
+        for dy in range(0, 70):
+            lit = k3_literal(dx, dy)
+            assert len(lit) == max(dx, dy) + 1 and lit[-1] == (dx, dy), (dx, dy)
+            assert lit == [k3_closed(dx, dy, i) for i in range(max(dx, dy) + 1)], (dx, dy)
+    for dx, dy in ((511, 1), (511, 510), (511, 511), (1023, 777), (2, 1023), (1023, 1022), (8191, 4097)):
+        assert k3_literal(dx, dy) == [k3_closed(dx, dy, i) for i in range(max(dx, dy) + 1)]
