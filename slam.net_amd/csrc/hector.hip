@@ -84,10 +84,31 @@ __device__ static inline void hs_interp(const hs_level_dev &L, float cx, float c
     gy = -((dy1 * yi) + (dy2 * fy));                                       // :248
 }
 
+// wave-wide sum of a double in six DPP steps (no LDS permutes: a ds_bpermute costs ~100 cycles of latency, and nine
+// sums x six steps of them dominated an iteration): butterfly inside each row of 16 lanes, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3 -- the total is valid in lane 63.  Lanes a step's row mask excludes
+// add zero (update_dpp's `old`).
+template <int CTRL, int ROWS> __device__ static inline double hs_dpp_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xf, false));
+}
+__device__ static inline double hs_wave_sum(double v)
+{
+    v += hs_dpp_f64<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
+    v += hs_dpp_f64<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
+    v += hs_dpp_f64<0x124, 0xf>(v);         // row_ror:4
+    v += hs_dpp_f64<0x128, 0xf>(v);         // row_ror:8
+    v += hs_dpp_f64<0x142, 0xa>(v);         // row_bcast:15 -> rows 1, 3
+    v += hs_dpp_f64<0x143, 0xc>(v);         // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) broadcast in sums[].
 // order: dTr.x, dTr.y, dTr.z, H11, H22, H33, H12, H13, H23
 __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__restrict__ pts, int n, const float pose[3],
-                                        double *red /* [nwaves*9] LDS */, float sums[9])
+                                        double *red /* [16*9 + 9] LDS */, float sums[9])
 {
     const sh_m3x2 t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]),
                                               sh_m3x2_translation(pose[0] * L.cell, pose[1] * L.cell)),
@@ -109,18 +130,22 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int k = 0; k < 9; k++) {
-        double v = (double)acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wid * 9 + k] = v;
+        const double v = hs_wave_sum((double)acc[k]);
+        if (lane == 63) red[k * 16 + wid] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9) {
-        double v = 0.0;
-        for (int w = 0; w < nw; w++) v += red[w * 9 + threadIdx.x];
-        red[threadIdx.x] = v;                  // wave 0's own slots: safe, every read of them is by this thread
+    // nine sums over (up to) 16 wave partials: lane k*16 + w holds partial w of sum k, so each sum is one DPP row
+    if (threadIdx.x < 9 * 16) {
+        const int w = threadIdx.x & 15;
+        double v = w < nw ? red[threadIdx.x] : 0.0;
+        v += hs_dpp_f64<0xB1, 0xf>(v);
+        v += hs_dpp_f64<0x4E, 0xf>(v);
+        v += hs_dpp_f64<0x124, 0xf>(v);
+        v += hs_dpp_f64<0x128, 0xf>(v);
+        if (w == 0) red[9 * 16 + (threadIdx.x >> 4)] = v;
     }
     __syncthreads();
-    for (int k = 0; k < 9; k++) sums[k] = (float)red[k];
+    for (int k = 0; k < 9; k++) sums[k] = (float)red[9 * 16 + k];
     __syncthreads();
 }
 
@@ -143,11 +168,11 @@ __device__ static inline void hs_step(const float sums[9], float est[3])
 
 // MatchData(MapRepMultiMap) (:41-54): one workgroup per hint; levels coarse -> fine.
 // only_level >= 0 restricts to one level with `iters_override` iterations (MatchData(OccGridMap), :64-84).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float *__restrict__ out,
          int only_level, int iters_override)
 {
-    __shared__ double red[4 * 9];
+    __shared__ double red[16 * 9 + 9];
     const int b = blockIdx.x;
     float est_w[3] = { hints[3 * b], hints[3 * b + 1], hints[3 * b + 2] };  // :43
     if (n > 0) {                                                           // :66 (else: hint returned, :83)
@@ -176,7 +201,7 @@ __global__ void __launch_bounds__(256)
 k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, const float *__restrict__ pose_in,
            float *__restrict__ out12)
 {
-    __shared__ double red[4 * 9];
+    __shared__ double red[16 * 9 + 9];
     float pose[3] = { pose_in[0], pose_in[1], pose_in[2] };
     float sums[9];
     hs_hessian_block(A.lv[level], pts, n, pose, red, sums);
@@ -578,7 +603,10 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     SH_HIP(hipMemcpyAsync(d_in, hs->h_io, sizeof(float) * 3 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
     {
         sh_timer t(ctx, SLAMHIP_K_HS_MATCH);
-        hipLaunchKernelGGL(k4_match, dim3(B), dim3(256), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
+        // a single match is a latency chain (levels x iterations): 1024 lanes leave one or two scan points per lane;
+        // batches keep 256 lanes per hint (throughput: many workgroups per CU)
+        const int lanes = B <= 64 ? 1024 : 256;
+        hipLaunchKernelGGL(k4_match, dim3(B), dim3(lanes), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
                            (const float *)d_in, d_out, only_level, iters);
     }
     SH_HIP(hipGetLastError());
