@@ -17,6 +17,7 @@
 // transitions literally -- bit-exact fp32 cell values.
 #include "common.h"
 #include "m3x2.h"
+#include "raster.h"
 #include <vector>
 #include <chrono>
 #include <stdlib.h>
@@ -28,7 +29,6 @@ struct hs_level {
     int w, h; float cell, stm;             // MapProperties: Dimensions, CellLength, ScaleToMap (MapProperties.cs:22-32)
     sh_m3x2 map_t_world, world_t_map;      // GridMap.cs:46-47
     float *d_value; int32_t *d_upd;        // LogOddsCell SoA (GridMap.cs:13)
-    uint32_t *d_minkey; uint8_t *d_occ;    // K5 per-scan scratch (kept clean between calls)
     int curr_update_index;                 // OccGridMap.cs:20
     int iterations;                        // EstimateIterations (OccGridMap.cs:53)
 };
@@ -48,10 +48,8 @@ struct slamhip_hs {
     int n_points, cap_points;
     float2 *d_pts; float origin[2];
     float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
-    // K5 scratch: per (level, ray) line records, 64-fragment chunks, per-level chunk counts
-    struct k5_ray *d_rays; int cap_rays;
-    int *d_chunk_ray, *d_chunk_i0; int cap_chunks_per_level;
-    int *d_k5_counters;
+    // K5 line tables, per level: lines by index, lines sorted by (direction class, slope bucket), bucket starts, header
+    void *d_k5_byidx, *d_k5_cand; int *d_k5_start, *d_k5_hdr; int cap_lines;
 };
 
 struct hs_levels_arg { hs_level_dev lv[HS_MAX_LEVELS]; int n; };
@@ -214,141 +212,225 @@ k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, co
 }
 
 // ---- K5 device code --------------------------------------------------------------------------------------------
-struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; uint32_t *minkey; uint8_t *occ; int mark_free, mark_occ; };
-struct k5_arg { k5_level lv[HS_MAX_LEVELS]; int n; };
-
 // One line of OccGridMap.UpdateByScan on one level: UpdateLineBresenhami (:155-190) + Bresenham2D (:220-239).
-// The line has da "free" cells (steps i = 0..da-1, the end point excluded, :224-238) plus the occupied end cell.
-// Closed form of the error recurrence (:228-235): after i steps the walk has taken (e0 + i*db) / da minor steps
-// (db <= da, so at most one per step), which makes every cell of every ray an independent fragment.
-struct k5_ray {
-    int valid;
-    int start;            // begin.Y * W + begin.X                     (:172)
-    int da, db, e0;       // dominant / minor extent, initial error     (:175-185)
-    int oa, ob;           // index increments along dominant / minor    (:169-170)
-    int end_cell;         // end.Y * W + end.X                          (:187)
-    int chunk0, nchunks;  // 64-fragment chunks of the da + 1 fragments
-};
-#define K5_CHUNK 64
+// The line has da "free" cells (steps i = 0..da-1, the end point excluded, :224-238) plus the occupied end cell; after
+// i steps the walk has taken (e0 + i*db) / da minor steps, e0 = da / 2 (closed form of :228-235, db <= da;
+// tests/test_closed_forms.py).  The update is CELL-centric (raster.h): a cell asks which lines draw it.  Lines are
+// processed in index order by the reference, and a cell changes at most twice per update (BresenhamCellFree marks it,
+// BresenhamCellOcc overrides the mark), so all a cell needs is the smallest index of a line that crosses it as "free",
+// the smallest index of a line that ends in it, and their order -- no atomics, no per-cell scratch, coalesced rows.
+struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; int mark_free, mark_occ; int wg0, wgn; };
+struct k5_arg { k5_level lv[HS_MAX_LEVELS]; int n; };
+struct k5_line { int da, sdb, ray, flags; };      // major length, signed minor length, line index, valid | major_x << 1 | (smaj + 1) << 2
+#define K5_ZONE 16                     // Chebyshev radius around the begin cell handled one wavefront per cell
+#define K5_LDS_LINES 3072
+#define K5_HDR 8                       // ints per level: [0] begin x, [1] begin y, [2] longest line, [3] valid lines, [4] first valid line
 
-__global__ void __launch_bounds__(256)
-k5_setup(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, k5_ray *__restrict__ rays, int cap_rays)
+// does the line draw cell (major offset a >= 1, signed minor offset b)?  1: as a free cell, 2: as its end cell, 0: no
+__device__ static inline int k5_hit(const k5_line c, int a, int b)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const k5_level &L = A.lv[blockIdx.y];
-    k5_ray r;
-    memset(&r, 0, sizeof(r));
-    float bxf, byf, exf, eyf;
-    sh_v2_transform(ox, oy, L.t, &bxf, &byf);                              // :126
-    sh_v2_transform(pts[i].x, pts[i].y, L.t, &exf, &eyf);                  // :133
-    const int bx = sh_f2i(rintf(bxf)), by = sh_f2i(rintf(byf));            // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
-    const int ex = sh_f2i(rintf(exf)), ey = sh_f2i(rintf(eyf));            // :134
-    const bool same = (bx == ex) & (by == ey);                             // :137
-    const bool inside = (bx >= 0) & (by >= 0) & (bx < L.w) & (by < L.h) & (ex >= 0) & (ey >= 0) & (ex < L.w) & (ey < L.h);   // :158-161
-    if (!same && inside) {
-        const int dx = ex - bx, dy = ey - by;
-        const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-        const int odx = sh_sign(dx), ody = sh_sign(dy) * L.w;              // :169-170
-        r.valid = 1;
-        r.start = by * L.w + bx;                                           // :172
-        if (adx >= ady) { r.da = adx; r.db = ady; r.e0 = adx / 2; r.oa = odx; r.ob = ody; }      // :175-179
-        else            { r.da = ady; r.db = adx; r.e0 = ady / 2; r.oa = ody; r.ob = odx; }      // :180-185
-        r.end_cell = ey * L.w + ex;                                        // :187
-        r.nchunks = (r.da + 1 + K5_CHUNK - 1) / K5_CHUNK;
-    }
-    rays[(size_t)blockIdx.y * cap_rays + i] = r;
+    if (a > c.da) return 0;
+    const int B = b < 0 ? -b : b, db = c.sdb < 0 ? -c.sdb : c.sdb;
+    if (B > 0 && (c.sdb == 0 || (b > 0) != (c.sdb > 0))) return 0;
+    if (a == c.da) return B == db ? 2 : 0;                                 // the end cell (:187), excluded from the free steps
+    const int e = c.da / 2 + a * db;                                       // minor steps = e / da (maps <= 32768 a side: < 2^31)
+    return (e >= B * c.da && e < (B + 1) * c.da) ? 1 : 0;
 }
 
-// exclusive prefix of nchunks over the rays of one level (one workgroup per level)
+// per level (blockIdx.x): the lines of the scan, counting-sorted by (direction class, slope bucket)
 __global__ void __launch_bounds__(1024)
-k5_scan_chunks(k5_ray *__restrict__ rays_all, int n, int cap_rays, int *__restrict__ counters)
+k5_prepare(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, int cap, k5_line *__restrict__ byidx_all,
+           k5_line *__restrict__ cand_all, int *__restrict__ start_all, int *__restrict__ hdr_all)
 {
+    __shared__ int hist[4 * RS_NBUCK];
     __shared__ int wsum[16];
-    __shared__ int carry;
-    k5_ray *rays = rays_all + (size_t)blockIdx.x * cap_rays;
-    if (threadIdx.x == 0) carry = 0;
+    __shared__ int s_R, s_nv, s_first;
+    const k5_level &L = A.lv[blockIdx.x];
+    k5_line *byidx = byidx_all + (size_t)blockIdx.x * cap, *cand = cand_all + (size_t)blockIdx.x * cap;
+    int *start = start_all + (size_t)blockIdx.x * (4 * RS_NBUCK + 1), *hdr = hdr_all + blockIdx.x * K5_HDR;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    for (int i = t; i < 4 * RS_NBUCK; i += 1024) hist[i] = 0;
+    if (t == 0) { s_R = 0; s_nv = 0; s_first = 0x7fffffff; }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = (i < n && rays[i].valid) ? rays[i].nchunks : 0;
-        int incl = v;
+    float bxf, byf;
+    sh_v2_transform(ox, oy, L.t, &bxf, &byf);                              // :126
+    const int bx = sh_f2i(rintf(bxf)), by = sh_f2i(rintf(byf));            // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
+    int my_R = 0, my_nv = 0, my_first = 0x7fffffff;
+    for (int i = t; i < n; i += 1024) {
+        float exf, eyf;
+        sh_v2_transform(pts[i].x, pts[i].y, L.t, &exf, &eyf);              // :133
+        const int ex = sh_f2i(rintf(exf)), ey = sh_f2i(rintf(eyf));        // :134
+        const bool same = (bx == ex) & (by == ey);                         // :137
+        const bool inside = (bx >= 0) & (by >= 0) & (bx < L.w) & (by < L.h) & (ex >= 0) & (ey >= 0) & (ex < L.w) & (ey < L.h);   // :158-161
+        k5_line e; e.da = 0; e.sdb = 0; e.ray = i; e.flags = 0;
+        if (!same && inside) {
+            const int dx = ex - bx, dy = ey - by;
+            const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+            const bool major_x = adx >= ady;                               // :175
+            e.da = major_x ? adx : ady;
+            e.sdb = major_x ? dy : dx;                                     // minor extent with its sign (:169-170)
+            const int smaj = sh_sign(major_x ? dx : dy);
+            e.flags = 1 | (major_x ? 2 : 0) | ((smaj + 1) << 2);
+            atomicAdd(&hist[rs_class(major_x, smaj) * RS_NBUCK + rs_bucket((float)e.sdb / (float)e.da)], 1);
+            my_R = max(my_R, e.da);
+            my_nv++;
+            my_first = min(my_first, i);
+        }
+        byidx[i] = e;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        my_R = max(my_R, __shfl_down(my_R, off, 64)); my_nv += __shfl_down(my_nv, off, 64); my_first = min(my_first, __shfl_down(my_first, off, 64));
+    }
+    if (lane == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_nv, my_nv); atomicMin(&s_first, my_first); }
+    __syncthreads();
+    {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
+        int v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = hist[4 * t + k]; sum += v[k]; }
+        int incl = sum;
         for (int off = 1; off < 64; off <<= 1) {
             const int o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
         if (lane == 63) wsum[wid] = incl;
         __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
-        const int excl = carry + woff + incl - v;
-        if (i < n) rays[i].chunk0 = excl;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = excl + v;
-        __syncthreads();
+        int base = incl - sum;
+        for (int w = 0; w < wid; w++) base += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { start[4 * t + k] = base; hist[4 * t + k] = base; base += v[k]; }
+        if (t == 1023) start[4 * RS_NBUCK] = base;
     }
-    if (threadIdx.x == 0) counters[blockIdx.x] = carry;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const k5_line e = byidx[i];
+        if (e.flags & 1) {
+            const int smaj = ((e.flags >> 2) & 3) - 1;
+            const int pos = atomicAdd(&hist[rs_class((e.flags & 2) != 0, smaj) * RS_NBUCK + rs_bucket((float)e.sdb / (float)e.da)], 1);
+            cand[pos] = e;
+        }
+    }
+    if (t == 0) { hdr[0] = bx; hdr[1] = by; hdr[2] = s_R; hdr[3] = s_nv; hdr[4] = s_first; }
 }
 
-__global__ void __launch_bounds__(256)
-k5_fill_chunks(const k5_ray *__restrict__ rays_all, int n, int cap_rays, int *__restrict__ chunk_ray, int *__restrict__ chunk_i0,
-               int cap_chunks)
+// the state transitions of one cell: BresenhamCellFree (:192-199) by the first line that crosses it, then
+// BresenhamCellOcc (:201-218) by the first line that ends in it; a cell first touched by an end point is not
+// marked free any more (the mark_occ update index is above mark_free)
+__device__ static inline void k5_transition(const k5_level &L, float &v, int &u, int first_free, int first_occ, float lo_free, float lo_occ)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const k5_ray r = rays_all[(size_t)blockIdx.y * cap_rays + i];
-    if (!r.valid) return;
-    int *cr = chunk_ray + (size_t)blockIdx.y * cap_chunks, *ci = chunk_i0 + (size_t)blockIdx.y * cap_chunks;
-    for (int k = 0; k < r.nchunks; k++)
-        if (r.chunk0 + k < cap_chunks) { cr[r.chunk0 + k] = i; ci[r.chunk0 + k] = k * K5_CHUNK; }
-}
-
-// One lane per fragment.  PASS 0 records, per cell, the earliest touch in ray order as atomicMin(2*ray + isOcc)
-// plus an end-point flag; PASS 1 elects one fragment per touched cell and replays the (at most two) state
-// transitions of BresenhamCellFree / BresenhamCellOcc literally.
-template <int PASS>
-__global__ void __launch_bounds__(256)
-k5_fragments(k5_arg A, const k5_ray *__restrict__ rays_all, int cap_rays, const int *__restrict__ chunk_ray,
-             const int *__restrict__ chunk_i0, int cap_chunks, const int *__restrict__ counters, float lo_free, float lo_occ)
-{
-    const int chunk = blockIdx.x * (256 / K5_CHUNK) + (threadIdx.x >> 6);
-    if (chunk >= counters[blockIdx.y]) return;                             // wave-uniform
-    const k5_level &L = A.lv[blockIdx.y];
-    const int ray = chunk_ray[(size_t)blockIdx.y * cap_chunks + chunk];
-    const k5_ray r = rays_all[(size_t)blockIdx.y * cap_rays + ray];
-    const int i = chunk_i0[(size_t)blockIdx.y * cap_chunks + chunk] + (threadIdx.x & 63);
-    if (i > r.da) return;
-    const int is_occ = i == r.da;
-    const int cell = is_occ ? r.end_cell : r.start + i * r.oa + ((r.e0 + i * r.db) / r.da) * r.ob;
-    if (PASS == 0) {
-        atomicMin(&L.minkey[cell], 2u * (uint32_t)ray + (uint32_t)is_occ);
-        if (is_occ) L.occ[cell] = 1;
-        return;
-    }
-    const uint32_t k = atomicExch(&L.minkey[cell], HS_NONE);               // elect one fragment per cell
-    if (k == HS_NONE) return;
-    const bool has_occ = L.occ[cell] != 0;
-    L.occ[cell] = 0;
-    float v = L.value[cell];
-    int u = L.upd[cell];
-    if ((k & 1u) == 0u) {                                                  // first touch in ray order is "free"
-        if (u < L.mark_free) { v += lo_free; u = L.mark_free; }            // BresenhamCellFree :192-199
-    }
-    if (has_occ && u < L.mark_occ) {                                       // BresenhamCellOcc :201-218
+    if (first_free < first_occ && u < L.mark_free) { v += lo_free; u = L.mark_free; }     // :192-199
+    if (first_occ != 0x7fffffff && u < L.mark_occ) {                       // :201-218
         if (u == L.mark_free) v -= lo_free;                                // :206-209
         if (v < 50.0f) v += lo_occ;                                        // :211-214
         u = L.mark_occ;                                                    // :216
     }
+}
+__device__ static inline void k5_apply(const k5_level &L, int cell, int first_free, int first_occ, float lo_free, float lo_occ)
+{
+    float v = L.value[cell];
+    int u = L.upd[cell];
+    k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
     L.value[cell] = v;
     L.upd[cell] = u;
 }
 
-__global__ void k5_fill_cells(float *value, int32_t *upd, uint32_t *minkey, uint8_t *occ, size_t n)
+// wave-wide minimum by DPP (butterfly in rows of 16, row_bcast:15 / :31): valid in lane 63
+template <int CTRL, int ROWS> __device__ static inline int k5_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }
+__device__ static inline int k5_wave_min(int x)
+{
+    x = min(x, (k5_dpp<0xB1, 0xf>(x))); x = min(x, (k5_dpp<0x4E, 0xf>(x)));
+    x = min(x, (k5_dpp<0x124, 0xf>(x))); x = min(x, (k5_dpp<0x128, 0xf>(x)));
+    x = min(x, (k5_dpp<0x142, 0xa>(x))); x = min(x, (k5_dpp<0x143, 0xc>(x)));
+    return x;
+}
+
+// persistent grid over the bounding squares of the lines of all levels
+template <bool LDS_TABLE>
+__global__ void __launch_bounds__(1024)
+k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
+         const int *__restrict__ start_all, const int *__restrict__ hdr_all, float lo_free, float lo_occ)
+{
+    __shared__ int start[4 * RS_NBUCK + 1];
+    __shared__ __attribute__((aligned(16))) k5_line cand_s[LDS_TABLE ? K5_LDS_LINES : 1];
+    // workgroups are shared out over the levels in proportion to their cell counts (host: wg0, wgn)
+    int lvl = 0;
+    for (int l = 1; l < A.n; l++) if ((int)blockIdx.x >= A.lv[l].wg0) lvl = l;
+    const k5_level &L = A.lv[lvl];
+    const k5_line *cand_g = cand_all + (size_t)lvl * cap;
+    const int *start_g = start_all + (size_t)lvl * (4 * RS_NBUCK + 1), *hdr = hdr_all + lvl * K5_HDR;
+    const int bx = hdr[0], by = hdr[1], R = hdr[2], nv = hdr[3];
+    if (nv == 0) return;
+    for (int i = threadIdx.x; i <= 4 * RS_NBUCK; i += 1024) start[i] = start_g[i];
+    if (LDS_TABLE) for (int i = threadIdx.x; i < nv; i += 1024) cand_s[i] = cand_g[i];
+    __syncthreads();
+    const k5_line *cand = LDS_TABLE ? cand_s : cand_g;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = ((int)blockIdx.x - L.wg0) * 16 + wv, nw = L.wgn * 16;
+    // (1) the zone around the begin cell, where a cell has many candidate lines: one wavefront per cell, one candidate
+    //     per lane and trip, the smallest indices by wave reduction.  The begin cell itself is step 0 of every line.
+    const int Z = K5_ZONE - 1 < R ? K5_ZONE - 1 : R;
+    const int side = 2 * Z + 1;
+    for (int item = gw; item < side * side; item += nw) {
+        const int X = bx - Z + item % side, Y = by - Z + item / side;
+        if (X < 0 || X >= L.w || Y < 0 || Y >= L.h) continue;              // wave-uniform
+        const int dx = X - bx, dy = Y - by;
+        const int cell = Y * L.w + X;
+        float v = L.value[cell];                                           // (requested now, needed after the search)
+        int u = L.upd[cell];
+        int first_free = 0x7fffffff, first_occ = 0x7fffffff;
+        if (dx == 0 && dy == 0) first_free = hdr[4];
+        else {
+            int cls[2], a[2], b[2];
+            const int ncls = rs_classes(dx, dy, cls, a, b);
+            for (int k = 0; k < ncls; k++) {
+                int lo, hi;
+                rs_range(start, cls[k], a[k], b[k], lo, hi);
+                for (int ci = lo + lane; ci < hi; ci += 64) {
+                    const k5_line c = cand[ci];
+                    const int h = k5_hit(c, a[k], b[k]);
+                    if (h == 1) first_free = min(first_free, c.ray);
+                    else if (h == 2) first_occ = min(first_occ, c.ray);
+                }
+            }
+            first_free = k5_wave_min(first_free);                          // valid in lane 63
+            first_occ = k5_wave_min(first_occ);
+        }
+        if (lane == 63 && (first_free != 0x7fffffff || first_occ != 0x7fffffff)) {
+            k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
+            L.value[cell] = v;
+            L.upd[cell] = u;
+        }
+    }
+    // (2) the rest of the bounding square: one lane per cell, a wavefront takes 64 cells of one row
+    const int X0 = max(bx - R, 0), X1 = min(bx + R, L.w - 1), Y0 = max(by - R, 0), Y1 = min(by + R, L.h - 1);
+    const int tiles_x = (X1 - X0 + 64) / 64, items = (R > 0 && X1 >= X0 && Y1 >= Y0) ? tiles_x * (Y1 - Y0 + 1) : 0;
+    for (int item = gw; item < items; item += nw) {
+        const int row = item / tiles_x, tx = item - row * tiles_x;
+        const int X = X0 + tx * 64 + lane, Y = Y0 + row;
+        if (X > X1) continue;
+        const int dx = X - bx, dy = Y - by;
+        if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K5_ZONE) continue;     // (1)'s cells
+        int cls[2], a[2], b[2];
+        const int ncls = rs_classes(dx, dy, cls, a, b);
+        int first_free = 0x7fffffff, first_occ = 0x7fffffff;
+        for (int k = 0; k < ncls; k++) {
+            int lo, hi;
+            rs_range(start, cls[k], a[k], b[k], lo, hi);
+            for (int ci = lo; ci < hi; ci++) {
+                const k5_line c = cand[ci];
+                const int h = k5_hit(c, a[k], b[k]);
+                if (h == 1) first_free = min(first_free, c.ray);
+                else if (h == 2) first_occ = min(first_occ, c.ray);
+            }
+        }
+        if (first_free != 0x7fffffff || first_occ != 0x7fffffff) k5_apply(L, Y * L.w + X, first_free, first_occ, lo_free, lo_occ);
+    }
+}
+
+__global__ void k5_fill_cells(float *value, int32_t *upd, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) { value[i] = 0.0f; upd[i] = -1; minkey[i] = HS_NONE; occ[i] = 0; }   // LogOddsCell.Reset :38-42
+    for (; i < n; i += stride) { value[i] = 0.0f; upd[i] = -1; }   // LogOddsCell.Reset :38-42
 }
 
 __global__ void k5_pack_cells(const float *value, const int32_t *upd, slamhip_cell *out, size_t n)
@@ -400,10 +482,9 @@ extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
     (void)hipStreamSynchronize(hs->ctx->stream);
     for (int l = 0; l < hs->n_levels; l++) {
         (void)hipFree(hs->lv[l].d_value); (void)hipFree(hs->lv[l].d_upd);
-        (void)hipFree(hs->lv[l].d_minkey); (void)hipFree(hs->lv[l].d_occ);
     }
     (void)hipFree(hs->d_pts); (void)hipFree(hs->d_io);
-    (void)hipFree(hs->d_rays); (void)hipFree(hs->d_chunk_ray); (void)hipFree(hs->d_chunk_i0); (void)hipFree(hs->d_k5_counters);
+    (void)hipFree(hs->d_k5_byidx); (void)hipFree(hs->d_k5_cand); (void)hipFree(hs->d_k5_start); (void)hipFree(hs->d_k5_hdr);
     if (hs->h_io) (void)hipHostFree(hs->h_io);
     free(hs);
     return SLAMHIP_OK;
@@ -415,8 +496,7 @@ extern "C" int32_t slamhip_hs_reset(slamhip_hs *hs)
     SH_HIP(hipSetDevice(hs->ctx->device));
     for (int l = 0; l < hs->n_levels; l++) {
         hs_level &L = hs->lv[l];
-        hipLaunchKernelGGL(k5_fill_cells, dim3(1024), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, L.d_minkey, L.d_occ,
-                           (size_t)L.w * L.h);                             // GridMap.Reset :56-62
+        hipLaunchKernelGGL(k5_fill_cells, dim3(1024), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, (size_t)L.w * L.h);                             // GridMap.Reset :56-62
         L.curr_update_index = 0;                                           // OccGridMap.Reset :244-252
     }
     SH_HIP(hipStreamSynchronize(hs->ctx->stream));
@@ -444,8 +524,7 @@ extern "C" int32_t slamhip_hs_create(slamhip_ctx *ctx, float cell_length, int32_
         L.map_t_world = sh_m3x2_mul(sh_m3x2_scale(L.stm), sh_m3x2_translation(0.0f, 0.0f));   // GridMap.cs:46 (offset = 0)
         if (!sh_m3x2_invert(L.map_t_world, &L.world_t_map)) { slamhip_set_error("Map to world matrix is not invertible"); rc = SLAMHIP_ERR_INVALID; break; }  // :47-50
         const size_t n = (size_t)w * h;
-        if (hipMalloc(&L.d_value, sizeof(float) * n) != hipSuccess || hipMalloc(&L.d_upd, sizeof(int32_t) * n) != hipSuccess ||
-            hipMalloc(&L.d_minkey, sizeof(uint32_t) * n) != hipSuccess || hipMalloc(&L.d_occ, n) != hipSuccess) {
+        if (hipMalloc(&L.d_value, sizeof(float) * n) != hipSuccess || hipMalloc(&L.d_upd, sizeof(int32_t) * n) != hipSuccess) {
             slamhip_set_error("device allocation failed (level %d)", l); rc = SLAMHIP_ERR_NOMEM; break;
         }
         w /= 2; h /= 2;                                                   // :55
@@ -666,42 +745,45 @@ extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3]
         A.lv[l].w = L.w; A.lv[l].h = L.h;
         A.lv[l].t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]), sh_m3x2_translation(pose[0], pose[1])),
                                 sh_m3x2_scale(L.stm));                    // OccGridMap.cs:120-123
-        A.lv[l].value = L.d_value; A.lv[l].upd = L.d_upd; A.lv[l].minkey = L.d_minkey; A.lv[l].occ = L.d_occ;
+        A.lv[l].value = L.d_value; A.lv[l].upd = L.d_upd;
         A.lv[l].mark_free = L.curr_update_index + 1;                      // :116
         A.lv[l].mark_occ = L.curr_update_index + 2;                       // :117
     }
     if (n > 0) {
-        if (n > hs->cap_rays || !hs->d_k5_counters) {
-            (void)hipFree(hs->d_rays); (void)hipFree(hs->d_chunk_ray); (void)hipFree(hs->d_chunk_i0);
-            hs->d_rays = nullptr; hs->d_chunk_ray = hs->d_chunk_i0 = nullptr; hs->cap_rays = 0;
+        if (n > hs->cap_lines || !hs->d_k5_hdr) {
+            (void)hipFree(hs->d_k5_byidx); (void)hipFree(hs->d_k5_cand); (void)hipFree(hs->d_k5_start); (void)hipFree(hs->d_k5_hdr);
+            hs->d_k5_byidx = hs->d_k5_cand = nullptr; hs->d_k5_start = hs->d_k5_hdr = nullptr; hs->cap_lines = 0;
             const int cap = n + n / 4 + 64;
-            int maxdim = 0;
-            for (int l = 0; l < hs->n_levels; l++) { if (hs->lv[l].w > maxdim) maxdim = hs->lv[l].w; if (hs->lv[l].h > maxdim) maxdim = hs->lv[l].h; }
-            const long long cpl = (long long)cap * ((maxdim + 1 + K5_CHUNK - 1) / K5_CHUNK + 1);      // da + 1 <= max(w, h)
-            SH_HIP(hipMalloc(&hs->d_rays, sizeof(k5_ray) * (size_t)cap * HS_MAX_LEVELS));
-            SH_HIP(hipMalloc(&hs->d_chunk_ray, sizeof(int) * (size_t)cpl * hs->n_levels));
-            SH_HIP(hipMalloc(&hs->d_chunk_i0, sizeof(int) * (size_t)cpl * hs->n_levels));
-            if (!hs->d_k5_counters) SH_HIP(hipMalloc(&hs->d_k5_counters, sizeof(int) * HS_MAX_LEVELS));
-            hs->cap_rays = cap; hs->cap_chunks_per_level = (int)cpl;
+            SH_HIP(hipMalloc(&hs->d_k5_byidx, sizeof(k5_line) * (size_t)cap * HS_MAX_LEVELS));
+            SH_HIP(hipMalloc(&hs->d_k5_cand, sizeof(k5_line) * (size_t)cap * HS_MAX_LEVELS));
+            SH_HIP(hipMalloc(&hs->d_k5_start, sizeof(int) * (4 * RS_NBUCK + 1) * HS_MAX_LEVELS));
+            SH_HIP(hipMalloc(&hs->d_k5_hdr, sizeof(int) * K5_HDR * HS_MAX_LEVELS));
+            hs->cap_lines = cap;
         }
+        int cgrid_x = 0;
         sh_timer t(ctx, SLAMHIP_K_HS_UPDATE);
-        const dim3 rgrid(sh_div_up(n, 256), hs->n_levels);                // all levels in every launch (MapRepMultiMap.cs:76)
-        hipLaunchKernelGGL(k5_setup, rgrid, dim3(256), 0, ctx->stream, A, hs->d_pts, n, hs->origin[0], hs->origin[1], hs->d_rays, hs->cap_rays);
-        hipLaunchKernelGGL(k5_scan_chunks, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, hs->d_rays, n, hs->cap_rays, hs->d_k5_counters);
-        hipLaunchKernelGGL(k5_fill_chunks, rgrid, dim3(256), 0, ctx->stream, (const k5_ray *)hs->d_rays, n, hs->cap_rays,
-                           hs->d_chunk_ray, hs->d_chunk_i0, hs->cap_chunks_per_level);
-        // upper bound of chunks per level for the grid: every ray at the longest line of the finest level
-        int maxdim = 0;
-        for (int l = 0; l < hs->n_levels; l++) { if (hs->lv[l].w > maxdim) maxdim = hs->lv[l].w; if (hs->lv[l].h > maxdim) maxdim = hs->lv[l].h; }
-        long long bound = (long long)n * ((maxdim + 1 + K5_CHUNK - 1) / K5_CHUNK);
-        if (bound > hs->cap_chunks_per_level) bound = hs->cap_chunks_per_level;
-        const dim3 fgrid(sh_div_up((int)bound, 256 / K5_CHUNK), hs->n_levels);
-        hipLaunchKernelGGL(k5_fragments<0>, fgrid, dim3(256), 0, ctx->stream, A, (const k5_ray *)hs->d_rays, hs->cap_rays,
-                           (const int *)hs->d_chunk_ray, (const int *)hs->d_chunk_i0, hs->cap_chunks_per_level,
-                           (const int *)hs->d_k5_counters, hs->lo_free, hs->lo_occ);
-        hipLaunchKernelGGL(k5_fragments<1>, fgrid, dim3(256), 0, ctx->stream, A, (const k5_ray *)hs->d_rays, hs->cap_rays,
-                           (const int *)hs->d_chunk_ray, (const int *)hs->d_chunk_i0, hs->cap_chunks_per_level,
-                           (const int *)hs->d_k5_counters, hs->lo_free, hs->lo_occ);
+        // all levels in every launch (MapRepMultiMap.cs:76)
+        hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
+                           hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);
+        {   // 512 workgroups (two per CU), shared out over the levels by cell count
+            double tot = 0.0;
+            for (int l = 0; l < hs->n_levels; l++) tot += (double)hs->lv[l].w * hs->lv[l].h;
+            int first = 0;
+            for (int l = 0; l < hs->n_levels; l++) {
+                int k = (int)(512.0 * ((double)hs->lv[l].w * hs->lv[l].h) / tot);
+                if (k < 64) k = 64;
+                A.lv[l].wg0 = first; A.lv[l].wgn = k;
+                first += k;
+            }
+            cgrid_x = first;
+        }
+        const dim3 cgrid(cgrid_x);
+        if (n <= K5_LDS_LINES)
+            hipLaunchKernelGGL(k5_cells<true>, cgrid, dim3(1024), 0, ctx->stream, A, hs->cap_lines,
+                               (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start, (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
+        else
+            hipLaunchKernelGGL(k5_cells<false>, cgrid, dim3(1024), 0, ctx->stream, A, hs->cap_lines,
+                               (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start, (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
     }
     SH_HIP(hipGetLastError());
     for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144

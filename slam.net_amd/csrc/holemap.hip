@@ -26,11 +26,12 @@
 //   D4 a clipped endpoint outside the map (reachable only through int32 overflow in :329/:340) skips the ray.
 #include "cs_internal.h"
 #include "det_trig.h"
+#include "raster.h"
 #include <stdlib.h>
 
 #define TS_NO_OBSTACLE 65500
 #define TS_OBSTACLE 0
-#define K2_NBUCK 1024                  // slope buckets per direction class
+#define K2_NBUCK RS_NBUCK
 #define K2_ZONE 48                     // Chebyshev radius around the robot handled one wavefront per pixel
 #define K2_MAXHIT 4                    // hits a lane-per-pixel thread orders in registers
 
@@ -195,32 +196,6 @@ __device__ static inline bool k2_hit(const k2_cand c, int a, int b)
     return N > (T)(B - 1) * D && N <= (T)B * D;
 }
 
-// candidate range of pixel (a, b) in one class: rays whose signed slope lies in [(b-1)/a, (b+1)/a] (+- one bucket
-// for the float arithmetic of the bucket function; the exact test follows)
-__device__ static inline int k2_bucket(float t)
-{
-    int k = (int)floorf((t + 1.0f) * (K2_NBUCK / 2));
-    return k < 0 ? 0 : k > K2_NBUCK - 1 ? K2_NBUCK - 1 : k;
-}
-__device__ static inline void k2_range(const int *__restrict__ start, int cls, int a, int b, int &lo, int &hi)
-{
-    const float ra = 1.0f / (float)a;
-    int blo = k2_bucket((float)(b - 1) * ra) - 1, bhi = k2_bucket((float)(b + 1) * ra) + 1;
-    if (blo < 0) blo = 0;
-    if (bhi > K2_NBUCK - 1) bhi = K2_NBUCK - 1;
-    lo = start[cls * K2_NBUCK + blo];
-    hi = start[cls * K2_NBUCK + bhi + 1];
-}
-// classes of a pixel at offset (dx, dy) from the robot: 0 E, 1 W (x major), 2 S, 3 N (y major); a diagonal pixel has two
-__device__ static inline int k2_classes(int dx, int dy, int cls[2], int a[2], int b[2])
-{
-    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-    int n = 0;
-    if (adx >= ady && adx > 0) { cls[n] = dx > 0 ? 0 : 1; a[n] = adx; b[n] = dy; n++; }
-    if (ady >= adx && ady > 0) { cls[n] = dy > 0 ? 2 : 3; a[n] = ady; b[n] = dx; n++; }
-    return n;
-}
-
 // counters: [0] R = longest clipped major length, [1] conflict pixels, [2] blended pixels (every step x = 0..dxc of
 // a valid ray blends exactly one pixel, :404,:431), [3] x1, [4] y1, [5] robot inside the map
 __global__ void __launch_bounds__(1024)
@@ -247,7 +222,7 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
             vprof[i] = vp;
             const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
             const float tt = r.dxc > 0 ? (float)e.sdyc / (float)r.dxc : 0.0f;
-            atomicAdd(&hist[cls * K2_NBUCK + k2_bucket(tt)], 1);
+            atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
             my_R = max(my_R, r.dxc);
             my_total += r.dxc + 1;
         }
@@ -282,7 +257,7 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
             const int smaj = ((e.flags >> 2) & 3) - 1;
             const int cls = (e.flags & 2) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3);
             const float tt = e.dxc > 0 ? (float)e.sdyc / (float)e.dxc : 0.0f;
-            const int pos = atomicAdd(&hist[cls * K2_NBUCK + k2_bucket(tt)], 1);
+            const int pos = atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
             k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
             cand[pos] = c;
         }
@@ -305,9 +280,9 @@ __device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int si
     const int ptr = Y * size + X;
     const int dx = X - x1, dy = Y - y1;
     int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
-    const int ncls = k2_classes(dx, dy, cls, a, b);
+    const int ncls = rs_classes(dx, dy, cls, a, b);
     int nc = 0;
-    for (int k = 0; k < ncls; k++) { k2_range(start, cls[k], a[k], b[k], lo[k], hi[k]); nc += hi[k] - lo[k]; }
+    for (int k = 0; k < ncls; k++) { rs_range(start, cls[k], a[k], b[k], lo[k], hi[k]); nc += hi[k] - lo[k]; }
     uint16_t pix = map[ptr];
     bool stable = false;
     int last_v = 0;
@@ -424,12 +399,12 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
         const int dx = X - x1, dy = Y - y1;
         if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K2_ZONE) continue;     // (1)'s pixels
         int cls[2], a[2], b[2];
-        const int ncls = k2_classes(dx, dy, cls, a, b);
+        const int ncls = rs_classes(dx, dy, cls, a, b);
         int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh = 0;
         bool overflow = false;
         for (int k = 0; k < ncls; k++) {
             int lo, hi;
-            k2_range(start, cls[k], a[k], b[k], lo, hi);
+            rs_range(start, cls[k], a[k], b[k], lo, hi);
             for (int ci = lo; ci < hi; ci++) {
                 const k2_cand c = cand[ci];
                 if (!k2_hit<T>(c, a[k], b[k])) continue;

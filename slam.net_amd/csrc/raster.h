@@ -1,0 +1,39 @@
+// raster.h -- shared pieces of the pixel-centric line rasterisers (K2 HoleMap update, K5 Hector grid update).
+//
+// A Bresenham-type walk from a common start cell takes, at its i-th step, i cells along its major axis and
+// m(i) cells along the minor one with |m(i) - slope * i| <= 1/2 (slope = minor length / major length): a cell at
+// major offset a and signed minor offset b can only be drawn by lines of its direction class (major axis and its
+// sign) whose signed slope lies in [(b - 1) / a, (b + 1) / a].  Lines are counting-sorted by (class, slope bucket),
+// so the candidates of a cell are one contiguous range of that table; the exact closed-form test follows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define RS_NBUCK 1024                  // slope buckets per direction class
+
+__device__ static inline int rs_bucket(float t)
+{
+    int k = (int)floorf((t + 1.0f) * (RS_NBUCK / 2));
+    return k < 0 ? 0 : k > RS_NBUCK - 1 ? RS_NBUCK - 1 : k;
+}
+// direction class of a line: 0 E, 1 W (x major), 2 S, 3 N (y major)
+__device__ static inline int rs_class(bool major_x, int smaj) { return major_x ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3); }
+
+// candidate range of cell (a, b) in one class (+- one bucket for the float arithmetic of the bucket function)
+__device__ static inline void rs_range(const int *start, int cls, int a, int b, int &lo, int &hi)
+{
+    const float ra = 1.0f / (float)a;
+    int blo = rs_bucket((float)(b - 1) * ra) - 1, bhi = rs_bucket((float)(b + 1) * ra) + 1;
+    if (blo < 0) blo = 0;
+    if (bhi > RS_NBUCK - 1) bhi = RS_NBUCK - 1;
+    lo = start[cls * RS_NBUCK + blo];
+    hi = start[cls * RS_NBUCK + bhi + 1];
+}
+// classes of a cell at offset (dx, dy) from the start cell; a diagonal cell has two; the start cell itself none
+__device__ static inline int rs_classes(int dx, int dy, int cls[2], int a[2], int b[2])
+{
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    int n = 0;
+    if (adx >= ady && adx > 0) { cls[n] = dx > 0 ? 0 : 1; a[n] = adx; b[n] = dy; n++; }
+    if (ady >= adx && ady > 0) { cls[n] = dy > 0 ? 2 : 3; a[n] = ady; b[n] = dx; n++; }
+    return n;
+}
