@@ -154,7 +154,7 @@ __device__ static inline cs_ray k2_make_ray(const float2 p, int size, const floa
     return r;
 }
 
-// pixval at step x is the recurrence of :406-428 (oracle/coreslam_oracle.c draws it literally); here it is evaluated
+// pixval at step x is the recurrence of :406-428 (the CPU checker draws it literally); here it is evaluated
 // in closed form (tests/test_closed_forms.py checks it against the literal recurrence).  TS_OBSTACLE < TS_NO_OBSTACLE
 // makes incerrorv <= 0, so the
 // descending half (x <= lim1) never carries, and on the ascending half the carry fires on the first J steps only:
