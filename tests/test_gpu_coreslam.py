@@ -216,6 +216,8 @@ def test_holemap_golden(cs_mod, ctx, name):
     (256, 1080, 5.0, (6.0, 6.0, 0.77)),       # corner, very wide holes: many conflicting fragments
     (300, 500, 0.6, (39.9, 39.9, 2.0)),       # robot at the map edge: clipping on most rays
     (2048, 2000, 0.6, (5.5, 5.5, 0.4)),
+    (1024, 4001, 0.6, (20.0, 20.0, 0.2)),     # more rays than the pixel kernel keeps in LDS: global ray table
+    (16392, 360, 0.6, (20.0, 20.0, 0.1)),     # sides above 16384: 64-bit hit test
 ])
 def test_holemap_vs_oracle(cs_mod, ctx, det, sim, size, R, hw, pose):
     oc = det
@@ -233,6 +235,27 @@ def test_holemap_vs_oracle(cs_mod, ctx, det, sim, size, R, hw, pose):
         got = dev.holemap_download()
         bad = np.flatnonzero(got != ref)
         assert bad.size == 0, (it, bad[:10], got[bad[:10]], ref[bad[:10]])
+    dev.close()
+
+
+def test_holemap_unordered_dense_scan(cs_mod, ctx, det):
+    """Rays in random order and far denser than one per pixel: most pixels collect more than four fragments whose
+    blend order is the (random) ray index -- the conflict list, the rank sort and the all-rays scan of the zone."""
+    oc = det
+    size = 256
+    dev = make_dev(cs_mod, ctx, size)
+    ref = np.full(size * size, 32750, np.uint16)
+    rng = np.random.default_rng(11)
+    for it in range(3):
+        ang = rng.uniform(-np.pi, np.pi, 3000)
+        rad = rng.uniform(0.5, 18.0, 3000)
+        xy = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1).astype(np.float32)
+        pose = [20.0 + it, 19.0, 0.3 * it]
+        dev.set_scan(xy)
+        dev.update_holemap(pose, 1.5, 77)
+        n = oc.update_holemap(ref, size, dev.hole_scale, xy, pose, 1.5, 77)
+        assert dev.last_holemap_pixels == n
+        assert (dev.holemap_download() == ref).all()
     dev.close()
 
 

@@ -55,7 +55,8 @@ def test_grid_golden(hs_mod, ctx):
     rep.close()
 
 
-@pytest.mark.parametrize("side,cell,levels,R", [(400, 0.1, 4, 400), (2048, 40.0 / 2048, 3, 1080), (301, 0.13, 2, 360)])
+@pytest.mark.parametrize("side,cell,levels,R", [(400, 0.1, 4, 400), (2048, 40.0 / 2048, 3, 1080), (301, 0.13, 2, 360),
+                                                (512, 0.08, 3, 3500)])     # more lines than the cell kernel keeps in LDS
 def test_grid_update_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R):
     oc = det
     segs = sim.default_field()
@@ -111,6 +112,24 @@ def test_grid_update_order_dependence(hs_mod, ctx, det):
             ref.update_by_scan(xy, [10.0, 10.0, 0.0])
             assert cells_equal(rep.Maps[0].GetCells(), ref.cells)
         rep.close()
+
+
+def test_grid_update_unordered_dense_scan(hs_mod, ctx, det):
+    """Lines in random order, many per cell: the first free / first occupied line of a cell is the smallest index."""
+    oc = det
+    rep = hs_mod.MapRepMultiMap(0.2, (200, 200), 2, ctx=ctx)
+    ref = oc.make_pyramid(0.2, 200, 200, 2)
+    rng = np.random.default_rng(5)
+    for it in range(4):
+        ang = rng.uniform(-np.pi, np.pi, 2500)
+        rad = rng.uniform(0.3, 15.0, 2500)
+        xy = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1).astype(np.float32)
+        p = [20.0 + 0.3 * it, 20.0, 0.2 * it]
+        rep.UpdateByScan(hs_mod.ScanCloud(xy), p)
+        for l in range(2):
+            ref[l].update_by_scan(xy, p)
+            assert cells_equal(rep.Maps[l].GetCells(), ref[l].cells), (it, l)
+    rep.close()
 
 
 def build_pair(hs_mod, ctx, oc, sim, side, cell, levels, R, n_scans):
