@@ -402,3 +402,42 @@ def test_processor_vs_oracle(cs_mod, ctx, det, sim):
         proc2.Update([cs_mod.ScanSegment(rays, proc2.Pose)])
     assert np.isfinite(proc2.Pose).all()
     proc2.Dispose(); proc.Dispose()
+
+
+def test_group_single_gpu(cs_mod, ctx, det, sim):
+    """slamhip_group_* (the single-process multi-GPU form: RCCL communicator, sharded search, replicated updates) with a
+    one-GPU group: the same answers as the plain operator object and the oracle."""
+    import ctypes as C
+    import slam.net_amd.capi as capi
+    oc = det
+    size, R, K = 512, 720, 5000
+    segs = sim.default_field()
+    rng = sim.PCG32(77)
+    g = C.c_void_p()
+    dev_ids = (C.c_int32 * 1)(0)
+    capi.call("slamhip_group_create", dev_ids, 1, C.c_float(40.0), size, 64, C.byref(g))
+    try:
+        n = C.c_int32()
+        capi.call("slamhip_group_size", g, C.byref(n))
+        assert n.value == 1
+        capi.call("slamhip_group_reset", g, -5)
+        ref = np.full(size * size, 32750, np.uint16)
+        scale = size / 40.0
+        for p in sim.trajectory(6)[:-1]:
+            _, xy = sim.make_scan(segs, p, R, rng)
+            capi.call("slamhip_group_set_scan", g, capi.fptr(capi.f32(xy)), xy.shape[0])
+            capi.call("slamhip_group_update_maps", g, capi.fptr(capi.f32(p)), C.c_float(0.6), 50, 60)
+            oc.update_holemap(ref, size, scale, xy, p, 0.6, 50)
+        pose = sim.trajectory(6)[-1]
+        _, xy = sim.make_scan(segs, pose, R, rng)
+        base = (pose + np.array([0.02, -0.03, 0.01], np.float32)).astype(np.float32)
+        offs = sim.gaussian_offsets(K - 1)
+        capi.call("slamhip_group_set_scan", g, capi.fptr(capi.f32(xy)), xy.shape[0])
+        capi.call("slamhip_group_set_offsets", g, capi.fptr(capi.f32(offs)), offs.shape[0])
+        out_pose = np.zeros(3, np.float32)
+        dist, idx = C.c_int32(), C.c_int32()
+        capi.call("slamhip_group_search", g, capi.fptr(base), capi.fptr(out_pose), C.byref(dist), C.byref(idx))
+        rbi, rpose, rbd, _ = oc.search(ref, size, scale, xy, base, offs)
+        assert idx.value == rbi and dist.value == rbd and (out_pose == rpose).all()
+    finally:
+        capi.call("slamhip_group_destroy", g)
