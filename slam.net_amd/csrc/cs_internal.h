@@ -48,7 +48,7 @@ struct slamhip_cs {
     // K1 launch layout: per group of 1024 evaluation-order candidates the theta range (rad) and translation spread
     // (pixels) -- from the offsets (ensure_shard) -- and the chunks per group derived from them and the scan
     std::vector<float> h_grp_dth, h_grp_dxy;
-    std::vector<int> k1_tab_group, k1_tab_nc; int k1_uni_g0, k1_uni_ng, k1_uni_nc;
+    std::vector<int> k1_tab_group, k1_tab_nc, k1_tab_nbp; int k1_uni_g0, k1_uni_ng, k1_uni_nc;
     bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups; float k1_layout_theta;
     float gen_sigma_xy, gen_sigma_theta;        // offsets generated on the device: their distribution
     bool offs_theta_small;        // every |dtheta| <= 1e4: the tiled kernel's trigonometry needs no huge-angle branch

@@ -215,6 +215,7 @@ struct k1_args {
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
     int n_tab_wgs, uni_g0, uni_ng, uni_nc;
     unsigned short tab_group[K1_TABLE_G];
+    unsigned char tab_nbp[K1_TABLE_G];  // band parts: the chunks of a listed group come in sets of nbp that share a ray range and split its bands
     unsigned wg_first[K1_TABLE_G + 1]; // dispatch position p -> first workgroup
     unsigned char wg_pos[K1_TABLE_WGS];// workgroup -> dispatch position
 };
@@ -319,13 +320,14 @@ k1_search_tiled(const k1_args a)
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));                   // opaque zero (see k1_point_lds)
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);         // wave index in the workgroup
     const int ng = a.n_groups;
-    int g, chunk, nc, rowbase;
+    int g, chunk, nc, rowbase, nbp = 1;
     if ((int)blockIdx.x < a.n_tab_wgs) {
         const int p = a.wg_pos[blockIdx.x];
         rowbase = (int)a.wg_first[p];
         nc = (int)a.wg_first[p + 1] - rowbase;
         chunk = blockIdx.x - rowbase;
         g = a.tab_group[p];
+        nbp = a.tab_nbp[p];
     } else {
         const int b = blockIdx.x - a.n_tab_wgs;
         nc = a.uni_nc;
@@ -341,7 +343,10 @@ k1_search_tiled(const k1_args a)
 #endif
     // the chunk = rays [rlo, rhi) of the sorted scan, cut into pieces at ray block boundaries (host: <= K1_MAXR
     // rays, <= K1_MAXP pieces)
-    const int rlo = (int)(((long long)chunk * a.n_rays) / nc), rhi = (int)(((long long)(chunk + 1) * a.n_rays) / nc);
+    // (theta-tail groups: nbp workgroups share a ray range and take every nbp-th band of its banded tiles -- their
+    // run time is the number of tile steps, which more ray ranges would not reduce)
+    const int rc = chunk / nbp, bp = chunk - rc * nbp, nrc = nc / nbp;
+    const int rlo = (int)(((long long)rc * a.n_rays) / nrc), rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc);
     const int nrays = rhi - rlo;
     const int blk_first = a.ray_blk[rlo].z;
     const int npieces = a.ray_blk[rhi - 1].z - blk_first + 1;
@@ -450,7 +455,7 @@ k1_search_tiled(const k1_args a)
                 if (h <= 0) nsteps = 0;                            // (rounding can leave the last band empty)
             }
         }
-        if (band < nsteps) {
+        if (band < nsteps && (kind == K1_KIND_BAND ? band % nbp == bp : bp == 0)) {
             int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
             dst[0] = make_int4(x0a, y0, w8, h);
             dst[1] = make_int4(shift, kind, prec, 0);
@@ -790,10 +795,10 @@ static double k1_group_cost(const slamhip_cs *cs, int g, int budget)
 
 // Launch layout (cs->k1_*): the groups whose estimated cost per ray is well above a plain group's get their own,
 // larger chunk counts (at most K1_TABLE_G groups, the most expensive first); the rest share one count.
-static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int budget, bool have_spread)
+static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int budget, bool have_spread, int band_parts)
 {
     const int R = cs->n_points;
-    cs->k1_tab_group.clear(); cs->k1_tab_nc.clear();
+    cs->k1_tab_group.clear(); cs->k1_tab_nc.clear(); cs->k1_tab_nbp.clear();
     int uni_target = (int)((double)target_wgs / n_groups + 0.5);
     if (have_spread) {
         // candidates for the table: all groups if few, else the theta tails (the only ones that can be expensive)
@@ -860,11 +865,17 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
                 if (cs->k1_tab_nc[i] < 1) cs->k1_tab_nc[i] = 1;
             }
     }
+    // band parts: groups whose tiles are banded (estimated cost per ray of two bands or more) get their chunks in pairs
+    cs->k1_tab_nbp.assign(cs->k1_tab_nc.size(), 1);
+    if (have_spread && band_parts > 1)
+        for (size_t i = 0; i < cs->k1_tab_group.size(); i++)
+            if (k1_group_cost(cs, cs->k1_tab_group[i], budget) >= 2.0 * 1.9 * R && cs->k1_tab_nc[i] >= 2 * band_parts) cs->k1_tab_nbp[i] = band_parts;
     // legal chunk counts (rays and pieces per chunk); identical requests share the search
     int req = -1, res = -1;
     for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) {
-        if (cs->k1_tab_nc[i] != req) { req = cs->k1_tab_nc[i]; res = k1_legal_chunks(cs, req); }
-        cs->k1_tab_nc[i] = res;
+        const int nbp = cs->k1_tab_nbp[i], want = cs->k1_tab_nc[i] / nbp > 0 ? cs->k1_tab_nc[i] / nbp : 1;
+        if (want != req) { req = want; res = k1_legal_chunks(cs, req); }
+        cs->k1_tab_nc[i] = res * nbp;
     }
     cs->k1_uni_nc = k1_legal_chunks(cs, cs->k1_uni_nc);
     if (n_groups <= K1_TABLE_G && have_spread) {
@@ -877,14 +888,15 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
             for (size_t i = 1; i < cs->k1_tab_nc.size(); i++) if (cs->k1_tab_nc[i] > cs->k1_tab_nc[im]) im = i;
             if (cs->k1_tab_nc[im] <= 1) break;
             const int lower = k1_legal_chunks(cs, 1);              // (smallest legal count)
-            if (cs->k1_tab_nc[im] - 1 < lower) break;
-            cs->k1_tab_nc[im]--; tot0--;
+            const int step = cs->k1_tab_nbp[im];
+            if (cs->k1_tab_nc[im] - step < lower * step) break;
+            cs->k1_tab_nc[im] -= step; tot0 -= step;
         }
     }
     long long tot = 0;
     for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
     if (tot > K1_TABLE_WGS) {                                      // (huge scans: legal chunk counts alone overflow the table)
-        cs->k1_tab_group.clear(); cs->k1_tab_nc.clear();
+        cs->k1_tab_group.clear(); cs->k1_tab_nc.clear(); cs->k1_tab_nbp.clear();
         cs->k1_uni_g0 = 0; cs->k1_uni_ng = n_groups;
         cs->k1_uni_nc = k1_legal_chunks(cs, uni_target > 0 ? uni_target : 1);
     }
@@ -904,6 +916,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     static const int target_wgs = env_int("SLAMHIP_K1_TARGET_WGS", 512);
     static const int target_wgs_uniform = env_int("SLAMHIP_K1_TARGET_WGS_UNIFORM", 768);
     static const int cpl_env = env_int("SLAMHIP_K1_CPL", 0);           // candidates per lane: 0 = by launch size
+    static const int band_parts = env_int("SLAMHIP_K1_BAND_PARTS", 2);
     static const int no_table = env_int("SLAMHIP_K1_NOTABLE", 0);
     const bool sane = cs->pts_sane && cand_sane;
     const bool tiled = sane && (cs->hs % 8 == 0) && !force_global;
@@ -929,7 +942,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         if (cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread ||
             (have_spread && !(fabsf(bth - cs->k1_layout_theta) < 0.1f))) {
             cs->k1_layout_theta = bth;
-            k1_make_layout(cs, n_groups, n_groups <= K1_TABLE_G ? target_wgs : target_wgs_uniform, budget, have_spread);
+            k1_make_layout(cs, n_groups, n_groups <= K1_TABLE_G ? target_wgs : target_wgs_uniform, budget, have_spread, band_parts);
             cs->k1_layout_dirty = false; cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread;
         }
         static const int dump = env_int("SLAMHIP_K1_DUMP", 0);
@@ -947,6 +960,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         const int n_tab = (int)cs->k1_tab_group.size();
         for (int p = 0; p < n_tab; p++) {
             a.tab_group[p] = (unsigned short)cs->k1_tab_group[(size_t)p];
+            a.tab_nbp[p] = (unsigned char)cs->k1_tab_nbp[(size_t)p];
             a.wg_first[p] = first;
             first += (unsigned)cs->k1_tab_nc[(size_t)p];
         }
