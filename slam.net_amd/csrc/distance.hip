@@ -329,12 +329,14 @@ k1_search_tiled(const k1_args a)
         g = a.tab_group[p];
         nbp = a.tab_nbp[p];
     } else {
+        // the uniform part runs chunk-major: the workgroups in flight work on the SAME rays for neighbouring theta groups,
+        // whose tiles overlap almost completely (L2 reuse).  (Sending ray chunk c of every group to XCD c % 8 -- one
+        // fabric fetch per tile instead of one per XCD -- was measured 1.2x to 2x SLOWER.)
         const int b = blockIdx.x - a.n_tab_wgs;
         nc = a.uni_nc;
         chunk = b / (unsigned)a.uni_ng;
-        const int gi = b - chunk * a.uni_ng;
-        g = a.uni_g0 + gi;
-        rowbase = a.n_tab_wgs + gi * nc;
+        g = a.uni_g0 + (b - chunk * a.uni_ng);
+        rowbase = 0;
     }
     K1_STAMP(0)
 #ifdef K1_TIMES
@@ -697,15 +699,27 @@ k1_search_tiled(const k1_args a)
         __hip_atomic_store(a.gkey + g, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned old = __hip_atomic_fetch_add(a.tickets + ng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)ng - 1u) {                            // the last group: minimum over the groups
-            __hip_atomic_store(a.tickets + ng, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            u64 best = ~0ull;
-            for (int i = 0; i < ng; i++) {
-                const u64 k = __hip_atomic_load(a.gkey + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                best = k < best ? k : best;
-            }
-            *a.key_out = best;
-        }
+        s_last = old == (unsigned)ng - 1u;
+        if (s_last) __hip_atomic_store(a.tickets + ng, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last group: minimum over the groups, by the whole workgroup (a single lane would walk hundreds of dependent
+    // loads at large candidate counts)
+    u64 best = ~0ull;
+    for (int i = t; i < ng; i += LANES) {
+        const u64 k = __hip_atomic_load(a.gkey + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        best = k < best ? k : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_down(best, off, 64);
+        best = o < best ? o : best;
+    }
+    if (lane == 0) wkey[wv] = best;
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < NW; w++) best = wkey[w] < best ? wkey[w] : best;
+        *a.key_out = best;
     }
     K1_STAMP(9)
 }
@@ -799,106 +813,69 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
 {
     const int R = cs->n_points;
     cs->k1_tab_group.clear(); cs->k1_tab_nc.clear(); cs->k1_tab_nbp.clear();
-    int uni_target = (int)((double)target_wgs / n_groups + 0.5);
+    cs->k1_uni_g0 = 0; cs->k1_uni_ng = n_groups;
+    int uni_want = (int)((double)target_wgs / n_groups + 0.5);
     if (have_spread) {
-        // candidates for the table: all groups if few, else the theta tails (the only ones that can be expensive)
-        std::vector<std::pair<double, int>> cand;
+        // Groups in the middle of the theta order cost the same and form the uniform part; groups that cost clearly
+        // more (theta tails: banded tiles) are listed with their own chunk counts.  With many groups only the outer
+        // K1_TABLE_G / 2 on each side are examined.
         const int side = n_groups <= K1_TABLE_G ? n_groups : K1_TABLE_G / 2;
-        for (int g = 0; g < n_groups; g++) {
-            if (n_groups > K1_TABLE_G && g >= side && g < n_groups - side) continue;
-            cand.push_back(std::make_pair(k1_group_cost(cs, g, budget), g));
+        const double ref = k1_group_cost(cs, n_groups / 2, budget);
+        std::vector<double> cost((size_t)n_groups, ref);
+        for (int g = 0; g < n_groups; g++)
+            if (g < side || g >= n_groups - side) cost[(size_t)g] = k1_group_cost(cs, g, budget);
+        int lo = n_groups / 2, hi = n_groups / 2 + 1;
+        while (lo > 0 && cost[(size_t)lo - 1] <= 1.15 * ref && (n_groups <= K1_TABLE_G || lo - 1 >= 0)) lo--;
+        while (hi < n_groups && cost[(size_t)hi] <= 1.15 * ref) hi++;
+        if (lo > K1_TABLE_G / 2) lo = K1_TABLE_G / 2;              // (at most K1_TABLE_G listed groups)
+        if (n_groups - hi > K1_TABLE_G / 2) hi = n_groups - K1_TABLE_G / 2;
+        double total = (double)(hi - lo) * ref;
+        for (int g = 0; g < lo; g++) total += cost[(size_t)g];
+        for (int g = hi; g < n_groups; g++) total += cost[(size_t)g];
+        const double per_cost = (double)target_wgs / total;
+        uni_want = (int)floor(ref * per_cost + 0.5);
+        const int n_list = lo + (n_groups - hi);
+        for (int p = 0; p < 2 * std::max(lo, n_groups - hi); p++) {    // dispatch order: theta extremes first
+            const int k = p >> 1, g = (p & 1) ? n_groups - 1 - k : k;
+            if ((p & 1) ? k >= n_groups - hi : k >= lo) continue;
+            int v = (int)floor(cost[(size_t)g] * per_cost + 0.5);
+            if (v < 1) v = 1;
+            if (v > R / 4) v = R / 4 > 0 ? R / 4 : 1;
+            int nbp = 1;                                           // banded tiles (two bands or more on average): chunks in sets
+            if (band_parts > 1 && cost[(size_t)g] >= 2.0 * 1.9 * R && v >= 2 * band_parts) nbp = band_parts;
+            cs->k1_tab_group.push_back(g); cs->k1_tab_nc.push_back(v); cs->k1_tab_nbp.push_back(nbp);
         }
-        if (n_groups <= K1_TABLE_G) {
-            double total = 0.0;
-            for (size_t i = 0; i < cand.size(); i++) total += cand[i].first;
-            for (size_t i = 0; i < cand.size(); i++) {
-                int v = (int)floor(cand[i].first / total * target_wgs + 0.5);
-                if (v < 1) v = 1;
-                if (v > R / 4) v = R / 4 > 0 ? R / 4 : 1;
-                cs->k1_tab_group.push_back(cand[i].second);
-                cs->k1_tab_nc.push_back(v);
-            }
-            // dispatch order: theta extremes first (0, n-1, 1, n-2, ...): the expensive groups start first
-            std::vector<int> og, on;
-            for (int p = 0; p < n_groups; p++) {
-                const int g = (p & 1) ? n_groups - 1 - (p >> 1) : (p >> 1);
-                og.push_back(g); on.push_back(cs->k1_tab_nc[(size_t)g]);
-            }
-            cs->k1_tab_group = og; cs->k1_tab_nc = on;
-            cs->k1_uni_g0 = 0; cs->k1_uni_ng = 0; cs->k1_uni_nc = 1;
-        } else {
-            // many groups: a plain group costs R ray units and gets uni_target chunks; tail groups in proportion
-            int lo = 0, hi = n_groups;                             // uniform range [lo, hi)
-            std::vector<std::pair<double, int>> tail;
-            for (size_t i = 0; i < cand.size(); i++) if (cand[i].first > 1.25 * R) tail.push_back(cand[i]);
-            std::sort(tail.begin(), tail.end());
-            // the table must be a prefix and a suffix of the group range: extend to the outermost cheap group
-            int left = 0, right = 0;
-            for (size_t i = 0; i < tail.size(); i++) {
-                if (tail[i].second < side) left = std::max(left, tail[i].second + 1);
-                else right = std::max(right, n_groups - tail[i].second);
-            }
-            lo = left; hi = n_groups - right;
-            for (int p = 0; p < left + right; p++) {               // extremes first
-                const int g = (p & 1) ? (n_groups - 1 - (p >> 1)) : (p >> 1);
-                const int gg = (p >> 1) < ((p & 1) ? right : left) ? g : -1;
-                if (gg < 0) continue;
-                double c = 0.0;
-                for (size_t i = 0; i < cand.size(); i++) if (cand[i].second == gg) c = cand[i].first;
-                int v = (int)floor(c / R * (uni_target > 0 ? uni_target : 1) + 0.5);
-                if (v < 1) v = 1;
-                if (v > R / 4) v = R / 4 > 0 ? R / 4 : 1;
-                cs->k1_tab_group.push_back(gg); cs->k1_tab_nc.push_back(v);
-            }
-            cs->k1_uni_g0 = lo; cs->k1_uni_ng = hi - lo; cs->k1_uni_nc = uni_target > 0 ? uni_target : 1;
-        }
-    } else {
-        cs->k1_uni_g0 = 0; cs->k1_uni_ng = n_groups; cs->k1_uni_nc = uni_target > 0 ? uni_target : 1;
+        (void)n_list;
+        cs->k1_uni_g0 = lo; cs->k1_uni_ng = hi - lo;
     }
-    // the listed part is addressed through a K1_TABLE_WGS-entry table: scale oversized requests down
-    {
-        long long tot = 0;
-        for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
-        if (tot > K1_TABLE_WGS / 2)
-            for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) {
-                cs->k1_tab_nc[i] = (int)((long long)cs->k1_tab_nc[i] * (K1_TABLE_WGS / 2) / tot);
-                if (cs->k1_tab_nc[i] < 1) cs->k1_tab_nc[i] = 1;
-            }
-    }
-    // band parts: groups whose tiles are banded (estimated cost per ray of two bands or more) get their chunks in pairs
-    cs->k1_tab_nbp.assign(cs->k1_tab_nc.size(), 1);
-    if (have_spread && band_parts > 1)
-        for (size_t i = 0; i < cs->k1_tab_group.size(); i++)
-            if (k1_group_cost(cs, cs->k1_tab_group[i], budget) >= 2.0 * 1.9 * R && cs->k1_tab_nc[i] >= 2 * band_parts) cs->k1_tab_nbp[i] = band_parts;
+    if (uni_want < 1) uni_want = 1;
     // legal chunk counts (rays and pieces per chunk); identical requests share the search
+    cs->k1_uni_nc = k1_legal_chunks(cs, uni_want);
     int req = -1, res = -1;
     for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) {
         const int nbp = cs->k1_tab_nbp[i], want = cs->k1_tab_nc[i] / nbp > 0 ? cs->k1_tab_nc[i] / nbp : 1;
         if (want != req) { req = want; res = k1_legal_chunks(cs, req); }
         cs->k1_tab_nc[i] = res * nbp;
     }
-    cs->k1_uni_nc = k1_legal_chunks(cs, cs->k1_uni_nc);
-    if (n_groups <= K1_TABLE_G && have_spread) {
-        // rounding and legalisation may overshoot the target: one workgroup too many starts a second round on a full
-        // chip.  Take the excess from the groups with the most chunks.
-        long long tot0 = 0;
-        for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot0 += cs->k1_tab_nc[i];
-        for (int guard = 0; tot0 > target_wgs && guard < 4096; guard++) {
+    // one workgroup too many starts a second round on a full chip: take an excess over the target from the listed
+    // groups with the most chunks (small launches only)
+    long long tot = (long long)cs->k1_uni_ng * cs->k1_uni_nc;
+    for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
+    if (n_groups <= K1_TABLE_G) {
+        const int lower = k1_legal_chunks(cs, 1);
+        for (int guard = 0; tot > target_wgs && guard < 4096 && !cs->k1_tab_nc.empty(); guard++) {
             size_t im = 0;
             for (size_t i = 1; i < cs->k1_tab_nc.size(); i++) if (cs->k1_tab_nc[i] > cs->k1_tab_nc[im]) im = i;
-            if (cs->k1_tab_nc[im] <= 1) break;
-            const int lower = k1_legal_chunks(cs, 1);              // (smallest legal count)
             const int step = cs->k1_tab_nbp[im];
             if (cs->k1_tab_nc[im] - step < lower * step) break;
-            cs->k1_tab_nc[im] -= step; tot0 -= step;
+            cs->k1_tab_nc[im] -= step; tot -= step;
         }
     }
-    long long tot = 0;
-    for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
-    if (tot > K1_TABLE_WGS) {                                      // (huge scans: legal chunk counts alone overflow the table)
+    long long tab = 0;
+    for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tab += cs->k1_tab_nc[i];
+    if (tab > K1_TABLE_WGS) {                                      // (huge scans: legal chunk counts alone overflow the table)
         cs->k1_tab_group.clear(); cs->k1_tab_nc.clear(); cs->k1_tab_nbp.clear();
         cs->k1_uni_g0 = 0; cs->k1_uni_ng = n_groups;
-        cs->k1_uni_nc = k1_legal_chunks(cs, uni_target > 0 ? uni_target : 1);
     }
 }
 
@@ -969,7 +946,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         for (int p = n_tab; p <= K1_TABLE_G; p++) a.wg_first[p] = first;
         a.n_tab_wgs = (int)first;
         a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
-        const int n_wgs = (int)first + cs->k1_uni_ng * cs->k1_uni_nc;
+        const int n_wgs = (int)first + cs->k1_uni_nc * cs->k1_uni_ng;
         // candidates per lane: 2 (512 lanes, 8 waves) measured best or equal from 16k to 256k candidates on MI355X;
         // 1 (16 waves: slow start) and 4 (4 waves: the VALU starves at 2 waves / SIMD) stay selectable for experiments
         const int cpl = cpl_env == 1 || cpl_env == 4 ? cpl_env : 2;

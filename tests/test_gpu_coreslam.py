@@ -126,7 +126,9 @@ def test_empty_scan_is_state_error(cs_mod, ctx):
     dev.close()
 
 
-@pytest.mark.parametrize("size,R,K", [(400, 360, 4001), (1024, 1080, 16384), (2048, 1080, 16384)])
+@pytest.mark.parametrize("size,R,K", [(400, 360, 4001), (1024, 1080, 16384), (2048, 1080, 16384),
+                                      (512, 360, 70001),       # more than 64 candidate groups: listed theta tails + uniform middle
+                                      (1024, 500, 140000)])
 def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
     """BASELINE configs C1/C2/C3 sizes: every candidate's distance and the arg-min vs the C oracle."""
     oc = det
