@@ -168,6 +168,10 @@ def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
     pose, dist, idx = dev.search(base)
     rbi, rpose, rbd, _ = oc.search(pix, size, scale, xy, base, goffs)
     assert idx == rbi and dist == rbd and (pose == rpose).all()
+    for n in (2, 5):                               # shards of the device-sorted list (the base pose sits mid-list in shard 0)
+        keys = [dev.search_shard(base, K * r // n, K * (r + 1) // n - K * r // n) for r in range(n)]
+        p2, d2, i2 = dev.pose_from_key(base, min(keys))
+        assert i2 == rbi and d2 == rbd and (p2 == rpose).all()
     assert dev.selfcheck_failures == 0
     dev.close()
 
