@@ -9,18 +9,19 @@
 // candidates in theta-sorted order; the arg-min key (distance << 32 | flat index) restores the
 // reference tie-break (first strictly smaller wins, :644,:700).
 //
-// One launch per search (k1_search_tiled).  A workgroup owns 1024 theta-consecutive candidates (a "group",
-// one per lane) and a chunk of ray blocks:
+// One launch per search (k1_search_tiled).  A workgroup owns 1024 theta-consecutive candidates (a "group") and a
+// chunk = a range of the spatially sorted rays, cut into pieces at ray block boundaries:
 //   prologue  (px,py,c,s) of its candidates (deterministic trigonometry), their min/max bounds, and -- by interval
 //             arithmetic on the reference's very float operations (rounding is monotone, so the box is rigorous)
-//             -- the pixel box every candidate's end points of a ray block fall into; from the boxes a list
-//             of STEPS: one HoleMap tile in LDS per ray block when the box fits (SHARED), one tile per 256-
-//             candidate sub-batch (OWN), or the box cut into row BANDs that are staged one after the other
-//             with a per-gather range test (theta tails, long rays, boxes clipped at the map border);
+//             -- the pixel box every candidate's end points of a piece fall into; from the boxes a list of STEPS:
+//             one HoleMap tile in LDS per piece when the box fits (SHARED), else the box, clipped to the map, cut
+//             into row BANDs that are staged one after the other with a per-gather range test (theta tails, long
+//             rays, boxes at the map border), else bounds-checked global gathers (GLOBAL);
 //   steps     the tile is staged with coalesced 16-byte loads that were issued one step ahead (registers),
-//             then ~14 VALU + 1 ds_read_u16 per point evaluation, no bounds test for SHARED / OWN;
-//   epilogue  the partial row is published write-through, the last workgroup of the group to arrive (ticket)
-//             sums the group's rows and takes the group arg-min, the last group the overall arg-min.
+//             then ~14 VALU + 1 ds_read_u16 per point evaluation, no bounds test for SHARED;
+//   epilogue  partial sums are added to per-candidate accumulators with agent-scope atomics; the last workgroup of the
+//             group to arrive (ticket) reads them back, finishes the distances and takes the group arg-min, the
+//             last group the overall arg-min.
 // Inputs the fast path cannot take (NaN / huge coordinates, map sides that are not a multiple of 8) run the
 // bounds-checked global-gather kernels (k1_prep_pxcs, k1_distance_global, k1_reduce).
 #include "cs_internal.h"
@@ -320,12 +321,11 @@ k1_search_tiled(const k1_args a)
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));                   // opaque zero (see k1_point_lds)
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);         // wave index in the workgroup
     const int ng = a.n_groups;
-    int g, chunk, nc, rowbase, nbp = 1;
+    int g, chunk, nc, nbp = 1;
     if ((int)blockIdx.x < a.n_tab_wgs) {
         const int p = a.wg_pos[blockIdx.x];
-        rowbase = (int)a.wg_first[p];
-        nc = (int)a.wg_first[p + 1] - rowbase;
-        chunk = blockIdx.x - rowbase;
+        nc = (int)(a.wg_first[p + 1] - a.wg_first[p]);
+        chunk = blockIdx.x - (int)a.wg_first[p];
         g = a.tab_group[p];
         nbp = a.tab_nbp[p];
     } else {
@@ -336,7 +336,6 @@ k1_search_tiled(const k1_args a)
         nc = a.uni_nc;
         chunk = b / (unsigned)a.uni_ng;
         g = a.uni_g0 + (b - chunk * a.uni_ng);
-        rowbase = 0;
     }
     K1_STAMP(0)
 #ifdef K1_TIMES
