@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--cands", type=int, default=16384, help="candidate poses per GPU per step")
     ap.add_argument("--map-updates", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP-event timing of K1 (no roofline object)")
     return ap.parse_args()
 
