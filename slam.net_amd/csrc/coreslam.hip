@@ -252,7 +252,19 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     rb.push_back(0);
     int cur = 0;
     float bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
-    const float ext = CS_RB_EXTENT_PX / cs->hscale;            // block extent limit in metres
+    // Block extent: the tile of a (candidate group, block) is about (extent + translation spread of the candidates + arc)
+    // pixels square and should fit the 60 KB LDS tile (~173 px square) -- at fine map scales the spread (known from the
+    // last candidate list, else the reference's default sigma of 0.1 m: ~0.7 m) takes a large part of that.  Measured on
+    // MI355X at 4096^2 / 32768 candidates: 96 px blocks are 1.28x faster than 128 px ones.
+    static const int ext_env = getenv("SLAMHIP_RB_EXTENT") ? atoi(getenv("SLAMHIP_RB_EXTENT")) : 0;   // (tuning override)
+    float spread_px = 0.7f * cs->hscale;
+    for (size_t g = 0; g < cs->h_grp_dxy.size(); g++) if (g == 0 || cs->h_grp_dxy[g] > spread_px) spread_px = g == 0 ? cs->h_grp_dxy[0] : cs->h_grp_dxy[g];
+    float ext_px = 165.0f - spread_px;
+    if (!(ext_px <= CS_RB_EXTENT_PX)) ext_px = CS_RB_EXTENT_PX;
+    if (ext_px < 64.0f) ext_px = 64.0f;
+    if (cs->n_offs + 1 >= 131072) ext_px = CS_RB_EXTENT_PX;   // (very many candidates: two bands of a big block beat more, smaller blocks -- measured)
+    if (ext_env > 0) ext_px = (float)ext_env;
+    const float ext = ext_px / cs->hscale;                     // block extent limit in metres
     for (int j = 0; j < n; j++) {
         const int i = (int)(uint32_t)keys[j];
         const float X = xy[2 * i], Y = xy[2 * i + 1];

@@ -7,7 +7,7 @@
 // limited to CS_RB_EXTENT_PX map pixels); a workgroup of the distance kernel handles
 // (1024 candidates) x (a chunk of ray blocks) and stages one HoleMap tile in LDS per ray block.
 #define CS_RB_MAX 64
-#define CS_RB_EXTENT_PX 128.0f
+#define CS_RB_EXTENT_PX 128.0f         // upper limit; set_scan lowers it at fine map scales (coreslam.hip)
 #define K1_GROUP 1024                  // theta-consecutive candidates per K1 workgroup ("group"): 256 lanes x 4
 
 
