@@ -94,7 +94,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start); (void)hipFree(cs->d_ray_blk);
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
-    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_best_pose); (void)hipFree(cs->d_verify);
+    (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_verify);
     (void)hipFree(cs->d_k1_tickets); (void)hipFree(cs->d_k1_gkey); (void)hipFree(cs->d_k1_acc);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
     cs_holemap_free(cs);
@@ -120,10 +120,11 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
     do {
         if (hipMalloc(&cs->d_hole, sizeof(uint16_t) * (size_t)hole_size * hole_size) != hipSuccess ||
             hipMalloc(&cs->d_obst, (size_t)obst_size * obst_size) != hipSuccess ||
-            hipMalloc(&cs->d_key, sizeof(uint64_t)) != hipSuccess ||
-            hipMalloc(&cs->d_best_pose, sizeof(float) * 4) != hipSuccess ||
+            hipMalloc(&cs->d_key, 64) != hipSuccess ||          // result block: key (8 B) | winner pose (16 B) | blended pixels (4 B)
+
             hipMalloc(&cs->d_verify, sizeof(unsigned int) * 8) != hipSuccess ||
             hipHostMalloc(&cs->h_key, 128) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
+        cs->d_best_pose = (float *)cs->d_key + 2;
         if (hipMemset(cs->d_verify, 0, sizeof(unsigned int) * 8) != hipSuccess) { slamhip_set_error("hipMemset failed"); rc = SLAMHIP_ERR_HIP; break; }
         if ((rc = cs_holemap_alloc(cs)) != SLAMHIP_OK) break;
         if ((rc = cs_obstacle_alloc(cs)) != SLAMHIP_OK) break;
@@ -644,15 +645,21 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     SH_CHECK_ARG(cs && pose);
     SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
     slamhip_ctx *ctx = cs->ctx;
-    SH_TRY(search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key));         // :732
-    hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
-                       cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);   // :746-747
+    // search (:732) -- the launch also leaves the winner's pose, theta normalised (:746-747), on the device -- then both
+    // map updates from that pose (:750-751); one 32-byte result block comes back
+    cs->k1_want_pose = true;
+    const int32_t rc_s = search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key);
+    cs->k1_want_pose = false;
+    SH_TRY(rc_s);
+    if (!cs->k1_pose_written)                                    // (fallback search kernels: decode the key in a launch of its own)
+        hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
+                           cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);
     SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality));   // :750
     SH_TRY(cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits));             // :751
-    float *hp = (float *)(cs->h_key + 4);
-    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SH_HIP(hipMemcpyAsync(hp, cs->d_best_pose, sizeof(float) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SH_TRY(finish_holemap(cs));
+    float *hp = (float *)(cs->h_key + 1);
+    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, 32, hipMemcpyDeviceToHost, ctx->stream));
+    SH_HIP(hipStreamSynchronize(ctx->stream));
+    cs->last_hole_pixels = ((int *)cs->h_key)[6];
     const uint64_t key = *cs->h_key;
     if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
     if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);

@@ -57,7 +57,9 @@ struct slamhip_cs {
     uint64_t *d_key;              // packed (dist << 32 | flat index) arg-min
     uint64_t *h_key;              // pinned
     float *d_grp_bounds; int cap_grp;          // per candidate group: min/max of px,py,c,s (8 floats)
-    float *d_best_pose;           // winner's pose (theta normalised), device-resident for the fused path
+    float *d_best_pose;           // winner's pose (theta normalised), device-resident for the fused path (inside d_key's block)
+    bool k1_want_pose;            // the next search launch also writes d_best_pose (fused search + update)
+    bool k1_pose_written;         // ... and it did (tiled kernel); the fallback kernels do not
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------
     void *d_rays; int cap_rays;                 // rays by index (k2_byidx): clipped lengths, flags

@@ -211,6 +211,7 @@ struct k1_args {
     int32_t *dist_out;
     unsigned long long *key_out;
     unsigned *verify;
+    const float *offs_flat; float *best_pose;   // fused search + update: the winner's pose (theta normalised) for the map updates
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
@@ -719,6 +720,13 @@ k1_search_tiled(const k1_args a)
     if (t == 0) {
         for (int w = 1; w < NW; w++) best = wkey[w] < best ? wkey[w] : best;
         *a.key_out = best;
+        if (a.best_pose) {                                         // search_pose + offs[index - 1] (:635-637), theta normalised (:746)
+            const uint32_t flat = (uint32_t)best;
+            float x = a.bx, y = a.by, th = a.bth;
+            if (flat > 0) { x = a.bx + a.offs_flat[3 * (flat - 1)]; y = a.by + a.offs_flat[3 * (flat - 1) + 1]; th = a.bth + a.offs_flat[3 * (flat - 1) + 2]; }
+            a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
+            a.best_pose[3] = th;                                   // un-normalised, as MonteCarloSearch returns it
+        }
     }
     K1_STAMP(9)
 }
@@ -912,6 +920,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.pxcs = cs->d_pxcs; a.src3 = cs->d_ev_off; a.bx = bx; a.by = by; a.bth = bth; a.scale = cs->hscale;
         a.count = count; a.n_groups = n_groups; a.budget = budget;
         a.ev_idx = cs->d_ev_idx; a.dist_out = dist; a.key_out = key; a.verify = cs->d_verify;
+        a.offs_flat = cs->d_offs_flat; a.best_pose = (mode == 1 && cs->k1_want_pose) ? cs->d_best_pose : nullptr;
+        cs->k1_pose_written = a.best_pose != nullptr;
 
         // launch layout
         const bool have_spread = mode == 1 && !no_table && (int)cs->h_grp_dth.size() == n_groups;
@@ -1041,6 +1051,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     }
 
     // ---- fallback: candidate transform, bounds-checked global gathers, reduction -----------------------------------
+    cs->k1_pose_written = false;
     {
         sh_timer t(ctx, SLAMHIP_K_CS_PREP);
         const dim3 grid(sh_div_up(count, K1_THREADS));

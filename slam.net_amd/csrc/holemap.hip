@@ -201,7 +201,7 @@ __device__ static inline bool k2_hit(const k2_cand c, int a, int b)
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
            k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, int *__restrict__ start,
-           int *__restrict__ counters)
+           int *__restrict__ counters, int *__restrict__ total_out)
 {
     __shared__ int hist[4 * K2_NBUCK];
     __shared__ int wsum[16];
@@ -264,6 +264,7 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     }
     if (t == 0) {
         counters[0] = s_R; counters[1] = 0; counters[2] = s_total;
+        if (total_out) *total_out = s_total;
         counters[3] = sh_f2i(q.x); counters[4] = sh_f2i(q.y);
     }
 }
@@ -489,7 +490,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     }
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
     hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters);
+                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6);
 #define K2_PIXELS(L, T) hipLaunchKernelGGL((k2_pixels<L, T>), dim3(512), dim3(1024), 0, ctx->stream, (const k2_byidx *)cs->d_rays, \
                            (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
                            cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict)
