@@ -91,7 +91,8 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipSetDevice(cs->ctx->device);
     (void)hipStreamSynchronize(cs->ctx->stream);
     (void)hipFree(cs->d_hole); (void)hipFree(cs->d_obst);
-    (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start); (void)hipFree(cs->d_ray_blk);
+    (void)hipFree(cs->d_scan_blob); if (cs->h_scan_blob) (void)hipHostFree(cs->h_scan_blob);
+    if (cs->ev_scan) (void)hipEventDestroy(cs->ev_scan);
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
     (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_verify);
@@ -224,15 +225,31 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     cs->n_rb = 0;
     if (n == 0) return SLAMHIP_OK;
     if (n > cs->cap_points) {
-        (void)hipFree(cs->d_pts); (void)hipFree(cs->d_pts_sorted); (void)hipFree(cs->d_rb_start); (void)hipFree(cs->d_ray_blk);
-        cs->d_pts = cs->d_pts_sorted = nullptr; cs->d_rb_start = nullptr; cs->d_ray_blk = nullptr; cs->cap_points = 0;
+        // one device block and one pinned staging block for everything a scan uploads: rays (original order: K2/K3 are
+        // ray-order dependent), rays sorted for K1, K1's per-ray block table, the block starts -- one copy per scan
+        SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+        (void)hipFree(cs->d_scan_blob); if (cs->h_scan_blob) (void)hipHostFree(cs->h_scan_blob);
+        cs->d_scan_blob = nullptr; cs->h_scan_blob = nullptr; cs->cap_points = 0;
         const int cap = n + n / 4 + 64;
-        SH_HIP(hipMalloc(&cs->d_ray_blk, sizeof(int4) * (size_t)cap));
-        SH_HIP(hipMalloc(&cs->d_pts, sizeof(float2) * (size_t)cap));
-        SH_HIP(hipMalloc(&cs->d_pts_sorted, sizeof(float2) * (size_t)cap));
-        SH_HIP(hipMalloc(&cs->d_rb_start, sizeof(int) * (size_t)(cap + 2)));
+        const size_t bytes = (size_t)cap * (16 + 8 + 8) + sizeof(int) * (size_t)(cap + 2);
+        SH_HIP(hipMalloc(&cs->d_scan_blob, bytes));
+        SH_HIP(hipHostMalloc(&cs->h_scan_blob, bytes));
+        if (!cs->ev_scan) SH_HIP(hipEventCreateWithFlags(&cs->ev_scan, hipEventDisableTiming));
+        char *d = (char *)cs->d_scan_blob;
+        cs->d_ray_blk = (int4 *)d;                     d += (size_t)cap * 16;
+        cs->d_pts = (float2 *)d;                       d += (size_t)cap * 8;
+        cs->d_pts_sorted = (float2 *)d;                d += (size_t)cap * 8;
+        cs->d_rb_start = (int *)d;
         cs->cap_points = cap;
+        cs->scan_in_flight = false;
     }
+    if (cs->scan_in_flight) { SH_HIP(hipEventSynchronize(cs->ev_scan)); cs->scan_in_flight = false; }   // the previous copy has left the staging block
+    const int cap_ = cs->cap_points;
+    int *h_rayblk = (int *)cs->h_scan_blob;
+    float *h_pts = (float *)((char *)cs->h_scan_blob + (size_t)cap_ * 16);
+    float *sorted = (float *)((char *)cs->h_scan_blob + (size_t)cap_ * 24);
+    int *h_rb = (int *)((char *)cs->h_scan_blob + (size_t)cap_ * 32);
+    memcpy(h_pts, xy, sizeof(float) * 2 * (size_t)n);
     // K1 sums integers, so it may visit the rays in any order: sort them along a Z-order curve at
     // 64-pixel granularity so that a ray block's end points stay close together in the map (the rigid
     // candidate transform preserves distances), then cut the sorted list into blocks of <= CS_RB_MAX.
@@ -247,9 +264,24 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         uint32_t uy = gy > 0.0f ? (gy < 65535.0f ? (uint32_t)gy : 65535u) : 0u;
         keys[i] = ((uint64_t)(part1by1(ux) | (part1by1(uy) << 1)) << 32) | (uint32_t)i;
     }
-    std::sort(keys.begin(), keys.end());
-    std::vector<float> sorted((size_t)n * 2);
-    std::vector<int> rb;
+    {   // LSD radix sort on the 32-bit Morton code (3 stable passes of 11 bits; ties keep ray order): std::sort was
+        // most of this function's time at ~1000 rays
+        std::vector<uint64_t> tmp((size_t)n);
+        uint64_t *src = keys.data(), *dst = tmp.data();
+        for (int pass = 0; pass < 3; pass++) {
+            const int shift = 32 + 11 * pass;
+            unsigned cnt[2048];
+            memset(cnt, 0, sizeof(cnt));
+            for (int i = 0; i < n; i++) cnt[(src[i] >> shift) & 2047u]++;
+            unsigned sum = 0;
+            for (int k = 0; k < 2048; k++) { const unsigned c = cnt[k]; cnt[k] = sum; sum += c; }
+            for (int i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
+            uint64_t *t = src; src = dst; dst = t;
+        }
+        if (src != keys.data()) memcpy(keys.data(), src, sizeof(uint64_t) * (size_t)n);
+    }
+    std::vector<int> &rb = cs->h_rb_start;
+    rb.clear();
     rb.push_back(0);
     int cur = 0;
     float bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
@@ -284,8 +316,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     // K1's view: per sorted ray its block (a workgroup's chunk is a ray range, cut into pieces at block
     // boundaries), and per block the figures the launch layout is balanced with
     const int n_rb = cs->n_rb;
-    std::vector<int> rayblk((size_t)n * 4);
-    cs->h_rb_start = rb;
+    int *rayblk = h_rayblk;
     cs->h_rb_ex.resize((size_t)n_rb); cs->h_rb_ey.resize((size_t)n_rb); cs->h_rb_mx.resize((size_t)n_rb); cs->h_rb_my.resize((size_t)n_rb);
     for (int b = 0; b < n_rb; b++) {
         const int r0 = rb[(size_t)b], r1 = rb[(size_t)b + 1];
@@ -299,11 +330,11 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->h_rb_mx[(size_t)b] = 0.5f * (x0 + x1) * cs->hscale; cs->h_rb_my[(size_t)b] = 0.5f * (y0 + y1) * cs->hscale;
     }
     cs->k1_layout_dirty = true;
-    SH_HIP(hipMemcpyAsync(cs->d_ray_blk, rayblk.data(), sizeof(int) * rayblk.size(), hipMemcpyHostToDevice, cs->ctx->stream));
-    SH_HIP(hipMemcpyAsync(cs->d_pts, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, cs->ctx->stream));
-    SH_HIP(hipMemcpyAsync(cs->d_pts_sorted, sorted.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, cs->ctx->stream));
-    SH_HIP(hipMemcpyAsync(cs->d_rb_start, rb.data(), sizeof(int) * rb.size(), hipMemcpyHostToDevice, cs->ctx->stream));
-    SH_HIP(hipStreamSynchronize(cs->ctx->stream));     // host staging buffers die here
+    memcpy(h_rb, rb.data(), sizeof(int) * rb.size());
+    const size_t used = (size_t)cap_ * 32 + sizeof(int) * rb.size();
+    SH_HIP(hipMemcpyAsync(cs->d_scan_blob, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
+    SH_HIP(hipEventRecord(cs->ev_scan, cs->ctx->stream));
+    cs->scan_in_flight = true;
     return SLAMHIP_OK;
 }
 

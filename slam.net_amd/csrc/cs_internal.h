@@ -21,6 +21,8 @@ struct slamhip_cs {
 
     // ---- scan -------------------------------------------------------------------------------
     int n_points, cap_points;
+    void *d_scan_blob, *h_scan_blob;  // one device block / one pinned staging block for all per-scan uploads
+    hipEvent_t ev_scan; bool scan_in_flight;
     float2 *d_pts;                // original order: K2/K3 are ray-order dependent
     float2 *d_pts_sorted;         // spatially sorted copy for K1 (integer sum: any order is exact)
     int4 *d_ray_blk;              // per sorted ray: (first ray of its block, one past its last, block index, 0)
