@@ -167,12 +167,13 @@ __device__ static inline void hs_step(const float sums[9], float est[3])
 // MatchData(MapRepMultiMap) (:41-54): one workgroup per hint; levels coarse -> fine.
 // only_level >= 0 restricts to one level with `iters_override` iterations (MatchData(OccGridMap), :64-84).
 __global__ void __launch_bounds__(1024)
-k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float *__restrict__ out,
-         int only_level, int iters_override)
+k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float3 hint1,
+         float *__restrict__ out, int only_level, int iters_override)
 {
     __shared__ double red[16 * 9 + 9];
     const int b = blockIdx.x;
-    float est_w[3] = { hints[3 * b], hints[3 * b + 1], hints[3 * b + 2] };  // :43
+    float est_w[3] = { hint1.x, hint1.y, hint1.z };                         // :43 (a single hint travels in the launch arguments)
+    if (hints) { est_w[0] = hints[3 * b]; est_w[1] = hints[3 * b + 1]; est_w[2] = hints[3 * b + 2]; }
     if (n > 0) {                                                           // :66 (else: hint returned, :83)
         const int l_hi = only_level >= 0 ? only_level : A.n - 1;
         const int l_lo = only_level >= 0 ? only_level : 0;
@@ -678,15 +679,17 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     slamhip_ctx *ctx = hs->ctx;
     SH_TRY(ensure_io(hs, 6 * B));
     float *d_in = hs->d_io, *d_out = hs->d_io + 3 * (size_t)B;
-    memcpy(hs->h_io, hints, sizeof(float) * 3 * (size_t)B);
-    SH_HIP(hipMemcpyAsync(d_in, hs->h_io, sizeof(float) * 3 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+    if (B > 1) {
+        memcpy(hs->h_io, hints, sizeof(float) * 3 * (size_t)B);
+        SH_HIP(hipMemcpyAsync(d_in, hs->h_io, sizeof(float) * 3 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+    }
     {
         sh_timer t(ctx, SLAMHIP_K_HS_MATCH);
         // a single match is a latency chain (levels x iterations): 1024 lanes leave one or two scan points per lane;
         // batches keep 256 lanes per hint (throughput: many workgroups per CU)
         const int lanes = B <= 64 ? 1024 : 256;
         hipLaunchKernelGGL(k4_match, dim3(B), dim3(lanes), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
-                           (const float *)d_in, d_out, only_level, iters);
+                           B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters);
     }
     SH_HIP(hipGetLastError());
     SH_HIP(hipMemcpyAsync(hs->h_io + 3 * (size_t)B, d_out, sizeof(float) * 3 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
