@@ -164,7 +164,24 @@ __device__ static inline int k2_pixval_closed(const k2_vprof p, int x)
 {
     if (x <= p.lim2) return TS_NO_OBSTACLE;
     const int d = p.derrorv;
-    const int incerrorv = (TS_OBSTACLE - TS_NO_OBSTACLE) - d * p.incv;        // :399, in (-d, 0]
+    const int incerrorv = sh_wsub(TS_OBSTACLE - TS_NO_OBSTACLE, sh_wmul(d, p.incv));   // :399, in (-d, 0]
+    if (d > (1 << 24)) {
+        // absurd hole widths (half-width beyond 16M pixels): the closed form's intermediates could leave int32, where the
+        // reference's unchecked arithmetic wraps -- walk the recurrence (:406-428) literally instead
+        int pixval = TS_NO_OBSTACLE, errorv = d / 2;                       // :402,:397
+        for (int xi = p.lim2 < 0 ? 0 : p.lim2 + 1; xi <= x; xi++) {
+            if (xi <= p.lim1) {                                            // :408
+                pixval = sh_wadd(pixval, p.incv);
+                errorv = sh_wadd(errorv, incerrorv);
+                if (errorv > d) { pixval = sh_wadd(pixval, -1); errorv = sh_wsub(errorv, d); }
+            } else {
+                pixval = sh_wsub(pixval, p.incv);
+                errorv = sh_wsub(errorv, incerrorv);
+                if (errorv < 0) { pixval = sh_wsub(pixval, -1); errorv = sh_wadd(errorv, d); }
+            }
+        }
+        return pixval;
+    }
     const int xs = p.lim2 < 0 ? 0 : p.lim2 + 1;
     const int xm = x < p.lim1 ? x : p.lim1;
     const int n1 = xm - xs + 1 > 0 ? xm - xs + 1 : 0;                          // steps of the descending half

@@ -224,6 +224,8 @@ def test_holemap_golden(cs_mod, ctx, name):
     (2048, 2000, 0.6, (5.5, 5.5, 0.4)),
     (1024, 4001, 0.6, (20.0, 20.0, 0.2)),     # more rays than the pixel kernel keeps in LDS: global ray table
     (16392, 360, 0.6, (20.0, 20.0, 0.1)),     # sides above 16384: 64-bit hit test
+    (128, 90, 3.0e7, (20.0, 20.0, 0.5)),      # absurd hole width (half-width > 2^24 px): literal wrapping recurrence
+    (128, 90, 2.0e9, (21.0, 20.0, 0.5)),      # extension end beyond the int32 range
 ])
 def test_holemap_vs_oracle(cs_mod, ctx, det, sim, size, R, hw, pose):
     oc = det
