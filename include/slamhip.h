@@ -224,6 +224,9 @@ int32_t slamhip_hs_cells_upload(slamhip_hs *hs, int32_t level, const slamhip_cel
 int32_t slamhip_hs_cells_download(slamhip_hs *hs, int32_t level, slamhip_cell *cells, size_t n_cells);
 /* GridMap.GetBitmapData (GridMap.cs:104-115) computed on the device */
 int32_t slamhip_hs_bitmap_download(slamhip_hs *hs, int32_t level, uint8_t *out, size_t n_cells);
+/* GridMap.GetMapExtends (GridMap.cs:147-207) reduced on the device: extends = {xMax, yMax, xMin, yMin} of the cells with
+ * Value != 0, *found = 1; or all zeros and *found = 0 (also when a minimum never left the reference's start value 10000) */
+int32_t slamhip_hs_map_extends(slamhip_hs *hs, int32_t level, int32_t extends[4], int32_t *found);
 /* OccGridMap.GetCachedProbability (OccGridMap.cs:97-107) for a list of cell indices */
 int32_t slamhip_hs_probability(slamhip_hs *hs, int32_t level, const int32_t *indices, int32_t n, float *out);
 

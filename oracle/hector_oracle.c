@@ -265,6 +265,28 @@ void oracle_grid_bitmap(const oracle_grid *g, uint8_t *out)
     }
 }
 
+/* GridMap.cs:147-207 GetMapExtends: out = {xMax, yMax, xMin, yMin}; the minima start at 10000 (:150), so on maps wider
+ * than that a populated region entirely beyond column / row 10000 reports "nothing found" exactly as the reference does */
+int oracle_grid_map_extends(const oracle_grid *g, int out[4])
+{
+    const int lower_start = -1, upper_start = 10000;                        /* :149-150 */
+    int xmax = lower_start, ymax = lower_start, xmin = upper_start, ymin = upper_start;
+    for (int x = 0; x < g->w; ++x)                                          /* :157-184 */
+        for (int y = 0; y < g->h; ++y)
+            if (g->cells[(size_t)y * g->w + x].value != 0.0f) {
+                if (x > xmax) xmax = x;
+                if (x < xmin) xmin = x;
+                if (y > ymax) ymax = y;
+                if (y < ymin) ymin = y;
+            }
+    if (xmax != lower_start && ymax != lower_start && xmin != upper_start && ymin != upper_start) {   /* :186-197 */
+        out[0] = xmax; out[1] = ymax; out[2] = xmin; out[3] = ymin;
+        return 1;
+    }
+    out[0] = out[1] = out[2] = out[3] = 0;                                  /* :199-205 */
+    return 0;
+}
+
 /* ---- matcher ---------------------------------------------------------------------------- */
 /* ScanMatcher.cs:211-249 InterpMapValueWithDerivatives */
 void oracle_hs_interp(oracle_grid *g, float cx, float cy, float out[3])

@@ -137,6 +137,7 @@ void   oracle_grid_world_pose(const oracle_grid *g, const float map[3], float ou
 void   oracle_grid_update_by_scan(oracle_grid *g, const float *xy, int n_points,
                                   const float scan_origin[2], const float pose_world[3]);
 void   oracle_grid_bitmap(const oracle_grid *g, uint8_t *out);  /* GridMap.cs:104-115 */
+int    oracle_grid_map_extends(const oracle_grid *g, int out[4]);  /* GridMap.cs:147-207: {xMax,yMax,xMin,yMin}, returns found */
 
 /* ScanMatcher.cs:211-249: out = (P, dPdx, dPdy) */
 void   oracle_hs_interp(oracle_grid *g, float cx, float cy, float out[3]);

@@ -99,6 +99,7 @@ def _declare(L):
     L.oracle_grid_world_pose.argtypes = [vp, fp, fp]
     L.oracle_grid_update_by_scan.argtypes = [vp, fp, C.c_int, fp, fp]
     L.oracle_grid_bitmap.argtypes = [vp, u8p]
+    L.oracle_grid_map_extends.argtypes = [vp, C.POINTER(C.c_int)]; L.oracle_grid_map_extends.restype = C.c_int
     L.oracle_hs_interp.argtypes = [vp, f, f, fp]
     L.oracle_hs_hessian.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, fp]
     L.oracle_hs_estimate_step.argtypes = [vp, fp, C.c_int, fp, C.c_int]; L.oracle_hs_estimate_step.restype = C.c_int
@@ -344,6 +345,12 @@ class Grid:
     def bitmap(self):
         out = np.empty(self.w * self.h, np.uint8)
         lib().oracle_grid_bitmap(self._h, _p(out, C.c_uint8)); return out
+
+    def map_extends(self):
+        """(found, xMax, yMax, xMin, yMin) -- GridMap.cs:147-207"""
+        o = (C.c_int * 4)()
+        f = lib().oracle_grid_map_extends(self._h, o)
+        return (bool(f), o[0], o[1], o[2], o[3])
 
     def interp(self, cx, cy):
         o = np.empty(3, np.float32)

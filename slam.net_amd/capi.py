@@ -107,6 +107,7 @@ def _declare(L):
         "slamhip_hs_cells_upload": (i32, [vp, i32, vp, sz]),
         "slamhip_hs_cells_download": (i32, [vp, i32, vp, sz]),
         "slamhip_hs_bitmap_download": (i32, [vp, i32, u8p, sz]),
+        "slamhip_hs_map_extends": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "slamhip_hs_probability": (i32, [vp, i32, ip, i32, fp]),
         "slamhip_hs_set_scan": (i32, [vp, fp, i32, fp]),
         "slamhip_hs_match": (i32, [vp, fp, fp]),

@@ -453,6 +453,32 @@ __global__ void k5_bitmap(const float *value, uint8_t *out, size_t n)
     const int sgn = (v > 0.0f) - (v < 0.0f);
     out[i] = (uint8_t)(127 - sgn * 127);                                   // :111
 }
+// GridMap.GetMapExtends (GridMap.cs:147-207): bounding rectangle of the cells whose Value != 0.  ext = {xMax, yMax, xMin, yMin},
+// preset to {-1, -1, 10000, 10000} (:149-150 -- the reference's minima start at 10000 whatever the map size).
+__global__ void k5_extends_init(int32_t *ext)
+{
+    if (threadIdx.x < 4) ext[threadIdx.x] = threadIdx.x < 2 ? -1 : 10000;
+}
+__global__ __launch_bounds__(256) void k5_extends(const float *value, int w, int h, int32_t *ext)
+{
+    int xmax = -1, ymax = -1, xmin = 10000, ymin = 10000;
+    for (int y = blockIdx.x; y < h; y += gridDim.x) {                      // one row per workgroup pass: coalesced reads
+        const float *row = value + (size_t)y * w;
+        for (int x = threadIdx.x; x < w; x += 256)
+            if (row[x] != 0.0f) {                                          // :161 (a NaN cell counts, as in the reference)
+                xmax = max(xmax, x); xmin = min(xmin, x);
+                ymax = max(ymax, y); ymin = min(ymin, y);
+            }
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        xmax = max(xmax, __shfl_xor(xmax, m)); ymax = max(ymax, __shfl_xor(ymax, m));
+        xmin = min(xmin, __shfl_xor(xmin, m)); ymin = min(ymin, __shfl_xor(ymin, m));
+    }
+    if ((threadIdx.x & 63) == 0 && xmax >= 0) {
+        atomicMax(ext + 0, xmax); atomicMax(ext + 1, ymax);
+        atomicMin(ext + 2, xmin); atomicMin(ext + 3, ymin);
+    }
+}
 __global__ void k5_probability(const float *value, const int32_t *idx, int n, float *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -621,6 +647,27 @@ extern "C" int32_t slamhip_hs_bitmap_download(slamhip_hs *hs, int32_t level, uin
     if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
     (void)hipFree(d);
     SH_HIP(e);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_map_extends(slamhip_hs *hs, int32_t level, int32_t extends[4], int32_t *found)
+{
+    SH_CHECK_ARG(hs && extends && found && level >= 0 && level < hs->n_levels);
+    hs_level &L = hs->lv[level];
+    SH_HIP(hipSetDevice(hs->ctx->device));
+    int32_t *d = nullptr;
+    SH_HIP(hipMalloc(&d, 4 * sizeof(int32_t)));
+    hipLaunchKernelGGL(k5_extends_init, dim3(1), dim3(64), 0, hs->ctx->stream, d);
+    hipLaunchKernelGGL(k5_extends, dim3(L.h < 2048 ? L.h : 2048), dim3(256), 0, hs->ctx->stream, L.d_value, L.w, L.h, d);
+    int32_t e4[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(e4, d, sizeof(e4), hipMemcpyDeviceToHost, hs->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
+    (void)hipFree(d);
+    SH_HIP(e);
+    // :186-205 -- all four must have moved off their start values, otherwise (false, 0, 0, 0, 0)
+    const bool ok = e4[0] != -1 && e4[1] != -1 && e4[2] != 10000 && e4[3] != 10000;
+    for (int i = 0; i < 4; i++) extends[i] = ok ? e4[i] : 0;
+    *found = ok ? 1 : 0;
     return SLAMHIP_OK;
 }
 

@@ -55,6 +55,18 @@ class OccGridMap:
         capi.call("slamhip_hs_bitmap_download", self._rep._h, self.level, out.ctypes.data_as(C.POINTER(C.c_uint8)), n)
         return out
 
+    def GetMapExtends(self):
+        """GridMap.GetMapExtends (GridMap.cs:147-207): (found, xMax, yMax, xMin, yMin), reduced on the device."""
+        e = (C.c_int32 * 4)()
+        f = C.c_int32()
+        capi.call("slamhip_hs_map_extends", self._rep._h, self.level, e, C.byref(f))
+        return (bool(f.value), e[0], e[1], e[2], e[3])
+
+    def GetCell(self, *a):
+        """GridMap.GetCell(x, y) / GetCell(index) (GridMap.cs:70-96): one LogOddsCell read back from the device."""
+        idx = a[1] * self.Dimensions[0] + a[0] if len(a) == 2 else int(a[0])
+        return self.GetCells()[idx]
+
     def GetCachedProbability(self, indices):
         idx = np.ascontiguousarray(np.atleast_1d(indices), np.int32)
         out = np.empty(idx.size, np.float32)

@@ -107,6 +107,24 @@ def trajectory(n, start=(20.0, 20.0, 0.0), step=(0.05, 0.02, math.radians(0.5)))
     return p.astype(np.float32)
 
 
+def lap_trajectory(n=None, step=0.1):
+    """True poses on an ellipse around the inner obstacle (x 11..17 m, y 14..26 m), heading along the tangent; consecutive
+    poses are `step` metres apart; n = None -> one full lap."""
+    cx, cy, ax, ay = 14.0, 20.0, 6.5, 9.0
+    # arc-length parametrisation by fine sampling
+    t = np.linspace(0.0, 2.0 * math.pi, 200001)
+    x, y = cx + ax * np.cos(t), cy + ay * np.sin(t)
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])
+    total = s[-1]
+    if n is None:
+        n = int(total / step)
+    want = (np.arange(n) * step) % total
+    ti = np.interp(want, s, t)
+    px, py = cx + ax * np.cos(ti), cy + ay * np.sin(ti)
+    th = np.arctan2(ay * np.cos(ti), -ax * np.sin(ti))
+    return np.stack([px, py, th], 1).astype(np.float32), total
+
+
 def gaussian_offsets(n, sigma_xy=0.1, sigma_theta=math.radians(10.0), seed=42):
     """(n,3) float32 jitter list: N(0,sigma_xy) for x,y and N(0,sigma_theta) for theta
     (Simulation/MainWindow.xaml.cs:69 values), drawn in the reference's X,Y,theta order

@@ -412,6 +412,36 @@ def test_processor_vs_oracle(cs_mod, ctx, det, sim):
     proc2.Dispose(); proc.Dispose()
 
 
+def test_processor_long_run_vs_oracle(cs_mod, ctx, det, sim):
+    """The simulator's loop (Simulation/MainWindow.xaml.cs:136-210) headless for 160 scans around the inner obstacle: the
+    estimate after every Update and both maps along the way must equal the oracle state machine's bit for bit -- any
+    single differing pixel or a lost tie-break would compound over the following scans."""
+    oc = det
+    segs = sim.default_field()
+    traj, _ = sim.lap_trajectory(150, 0.1)
+    traj = np.concatenate([np.repeat(traj[:1], 10, axis=0), traj[1:]])
+    start = traj[0].copy()
+    proc = cs_mod.CoreSLAMProcessor(40.0, 256, 64, start, 0.1, math.radians(10), 500, 4, ctx=ctx)
+    proc.HoleWidth = 2.0
+    ref = oc.CSProc(40.0, 256, 64, start)
+    ref.set_params(hole_width=2.0)
+    rng = sim.PCG32(5)
+    for i, tp in enumerate(traj):
+        rays, _ = sim.make_scan(segs, tp, 400, rng)
+        est = proc.Pose.copy()
+        offs = sim.gaussian_offsets(2000, seed=1000 + i)
+        proc.SetOffsets(offs)
+        proc.Update([cs_mod.ScanSegment(rays, est)])                   # the simulator poses the segment at the last estimate
+        ref.update(est[None], [0, rays.shape[0]], rays, offs)
+        assert (proc.Pose == ref.pose).all(), i
+        if i % 20 == 19 or i == len(traj) - 1:
+            assert (proc.HoleMap.Pixels == ref.holemap).all(), i
+            assert (proc.ObstacleMap.Pixels == ref.obstaclemap).all(), i
+    err = proc.Pose - traj[-1]
+    assert math.hypot(err[0], err[1]) < 0.3 and abs(err[2]) < math.radians(3)      # and it tracks the true pose
+    proc.Dispose()
+
+
 def test_group_single_gpu(cs_mod, ctx, det, sim):
     """slamhip_group_* (the single-process multi-GPU form: RCCL communicator, sharded search, replicated updates) with a
     one-GPU group: the same answers as the plain operator object and the oracle."""

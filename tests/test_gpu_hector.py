@@ -76,6 +76,7 @@ def test_grid_update_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R):
         got = rep.Maps[l].GetCells()
         assert cells_equal(got, ref[l].cells), l
         assert (rep.Maps[l].GetBitmapData() == ref[l].bitmap()).all()
+        assert rep.Maps[l].GetMapExtends() == ref[l].map_extends()
     # probabilities (expf on the device vs libm expf: <= 1 ulp)
     idx = np.flatnonzero(ref[0].cells["value"] != 0)[:500].astype(np.int32)
     pg = rep.Maps[0].GetCachedProbability(idx)
@@ -95,6 +96,24 @@ def test_grid_update_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R):
     assert (rep.Maps[0].GetCells()["value"] == 0).all() and (rep.Maps[0].GetCells()["update_index"] == -1).all()
     rep.Maps[levels - 1].SetCells(cells)
     assert cells_equal(rep.Maps[levels - 1].GetCells(), cells)
+    rep.close()
+
+
+def test_map_extends_quirks(hs_mod, ctx, det):
+    """GetMapExtends on the device: empty map, NaN cells, and the reference's 10000 start value for the minima."""
+    oc = det
+    rep = hs_mod.MapRepMultiMap(1.0, (10300, 8), 2, ctx=ctx)
+    ref = oc.make_pyramid(1.0, 10300, 8, 2)
+    for l in range(2):
+        assert rep.Maps[l].GetMapExtends() == ref[l].map_extends() == (False, 0, 0, 0, 0)
+    w = 10300
+    for cells_at in ([(10100, 2, 1.0)], [(10000, 1, -2.0)], [(9, 7, np.nan)], [(0, 0, 0.5)]):
+        for x, y, v in cells_at:
+            ref[0].cells["value"][y * w + x] = v
+        rep.Maps[0].SetCells(ref[0].cells)
+        assert rep.Maps[0].GetMapExtends() == ref[0].map_extends()
+    assert rep.Maps[0].GetMapExtends() == (True, 10100, 7, 0, 0)
+    assert rep.Maps[0].GetCell(10100, 2)["value"] == 1.0 and rep.Maps[0].GetCell(7 * w + 9)["value"] != rep.Maps[0].GetCell(7 * w + 9)["value"]
     rep.close()
 
 
@@ -229,3 +248,43 @@ def test_hector_processor_gating(hs_mod, ctx, det, sim):
     proc.Reset()
     assert (proc.MatchPose == start).all() and (proc.MapRep.Maps[0].GetCells()["value"] == 0).all()
     proc.Dispose()
+
+
+def test_hector_processor_long_run(hs_mod, ctx, det, sim):
+    """HectorSLAMProcessor over 120 scans of the lap (simulator settings, :76-86): every match within tolerance of the
+    oracle's match on the oracle's maps; the oracle maps are advanced with the device's pose so that the grids stay
+    comparable bit for bit (a 1e-7 pose difference may legitimately round a beam end into the neighbouring cell)."""
+    oc = det
+    segs = sim.default_field()
+    traj, _ = sim.lap_trajectory(110, 0.1)
+    traj = np.concatenate([np.repeat(traj[:1], 10, axis=0), traj[1:]])
+    start = traj[0].copy()
+    proc = hs_mod.HectorSLAMProcessor(0.1, (400, 400), start, 4, 4, ctx=ctx)
+    proc.MinDistanceDiffForMapUpdate = 0.4
+    proc.MinAngleDiffForMapUpdate = math.radians(8)
+    its = [7, 4, 4, 4]
+    for l in range(4):
+        proc.MapRep.Maps[l].EstimateIterations = its[l]
+    ref = oc.make_pyramid(0.1, 400, 400, 4)
+    rng = sim.PCG32(31)
+    n_updates = 0
+    for loop, tp in enumerate(traj):
+        rays, xy = sim.make_scan(segs, tp, 400, rng)
+        hint = proc.MatchPose.copy()
+        updated = proc.Update(hs_mod.ScanCloud(xy), hint, loop < 10)
+        got = proc.MatchPose
+        want = np.asarray(hint, np.float32) if loop < 10 else oc.match_pyramid(ref, xy, hint, its, 4)
+        assert abs(got[0] - want[0]) < POS_TOL and abs(got[1] - want[1]) < POS_TOL and abs(got[2] - want[2]) < ANG_TOL, loop
+        if updated:
+            n_updates += 1
+            for g in ref:
+                g.update_by_scan(xy, got)
+        if loop % 20 == 19 or loop == len(traj) - 1:
+            for l in range(4):
+                assert cells_equal(proc.MapRep.Maps[l].GetCells(), ref[l].cells), (loop, l)
+                assert proc.MapRep.Maps[l].GetMapExtends() == ref[l].map_extends()
+    assert 10 < n_updates < len(traj)                                  # the distance / angle gate did skip scans
+    err = proc.MatchPose - traj[-1]
+    assert math.hypot(err[0], err[1]) < 0.1 and abs(err[2]) < math.radians(1)
+    proc.Dispose()
+

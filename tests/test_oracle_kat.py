@@ -296,6 +296,25 @@ def test_hector_interp_bounds_and_gradient(oc, npo):
     assert abs(g.interp(cx, cy)[1] - exp_dx) < 1e-7
 
 
+def test_hector_map_extends(oc):
+    """GridMap.GetMapExtends (GridMap.cs:147-207): empty map, a populated rectangle, and the quirk that the minima start
+    at 10000 (:150) so a region entirely beyond column 10000 reads as "nothing found"."""
+    g = oc.Grid(1.0, 40, 24)
+    assert g.map_extends() == (False, 0, 0, 0, 0)
+    c = g.cells
+    c["value"][5 * 40 + 7] = 0.4
+    c["value"][19 * 40 + 31] = -0.4
+    c["value"][11 * 40 + 2] = np.nan                                       # NaN != 0 counts
+    assert g.map_extends() == (True, 31, 19, 2, 5)
+    wide = oc.Grid(1.0, 10300, 4)
+    wide.cells["value"][2 * 10300 + 10100] = 1.0
+    assert wide.map_extends() == (False, 0, 0, 0, 0)                       # xMin never left 10000
+    wide.cells["value"][1 * 10300 + 10000] = 1.0
+    assert wide.map_extends() == (False, 0, 0, 0, 0)                       # x == 10000 is not < 10000 either
+    wide.cells["value"][3 * 10300 + 9] = 1.0
+    assert wide.map_extends() == (True, 10100, 3, 9, 1)
+
+
 def test_hector_pyramid_shape(oc):
     """Quirk 23 (MapRepMultiMap.cs:49-57)."""
     lv = oc.make_pyramid(40.0 / 2048, 2048, 2048, 3)
