@@ -221,7 +221,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
 {
     SH_CHECK_ARG(cs && n >= 0 && (xy || n == 0));
     SH_HIP(hipSetDevice(cs->ctx->device));
-    cs->n_points = n;
+    cs->n_points = 0;                                  // (stays "no scan" if anything below fails)
     cs->n_rb = 0;
     if (n == 0) return SLAMHIP_OK;
     if (n > cs->cap_points) {
@@ -335,6 +335,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     SH_HIP(hipMemcpyAsync(cs->d_scan_blob, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
     SH_HIP(hipEventRecord(cs->ev_scan, cs->ctx->stream));
     cs->scan_in_flight = true;
+    cs->n_points = n;
     return SLAMHIP_OK;
 }
 
@@ -392,10 +393,11 @@ extern "C" int32_t slamhip_cs_distance_poses(slamhip_cs *cs, const float *poses,
 static int32_t ensure_offsets_capacity(slamhip_cs *cs, int n)
 {
     SH_TRY(cs_alloc_candidates(cs, n + 1));
-    // d_offs_flat is sized with the candidate buffers
-    static_assert(sizeof(float) == 4, "float");
-    if (cs->d_offs_flat) { (void)hipFree(cs->d_offs_flat); cs->d_offs_flat = nullptr; }
-    SH_HIP(hipMalloc(&cs->d_offs_flat, sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
+    if (cs->d_offs_flat && n <= cs->cap_offs) return SLAMHIP_OK;
+    if (cs->d_offs_flat) { (void)hipFree(cs->d_offs_flat); cs->d_offs_flat = nullptr; cs->cap_offs = 0; }
+    const int cap = n > 0 ? n + n / 8 : 1;
+    SH_HIP(hipMalloc(&cs->d_offs_flat, sizeof(float) * 3 * (size_t)cap));
+    cs->cap_offs = cap;
     return SLAMHIP_OK;
 }
 
@@ -647,6 +649,24 @@ extern "C" int32_t slamhip_cs_update_obstaclemap(slamhip_cs *cs, const float pos
     const float4 q = pxcs_from_pose(pose, cs->oscale);                      // :545-548
     const float a[4] = { q.x, q.y, q.z, q.w };
     return slamhip_cs_update_obstaclemap_pxcs(cs, a, max_hits);
+}
+
+// both map updates from one pose, enqueued / completed separately so that a multi-GPU caller can overlap its replicas
+int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality, int32_t max_hits)
+{
+    SH_CHECK_ARG(cs && pose && quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    cs->last_hole_pixels = 0;
+    if (cs->n_points <= 0) return SLAMHIP_OK;
+    SH_TRY(cs_launch_holemap_update(cs, nullptr, pxcs_from_pose(pose, cs->hscale), hole_width, quality));   // :499-502
+    SH_TRY(cs_launch_obstacle_update(cs, nullptr, pxcs_from_pose(pose, cs->oscale), max_hits));            // :545-548
+    return SLAMHIP_OK;
+}
+int32_t cs_update_maps_finish(slamhip_cs *cs)
+{
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (cs->n_points <= 0) return SLAMHIP_OK;
+    return finish_holemap(cs);
 }
 
 extern "C" int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out)

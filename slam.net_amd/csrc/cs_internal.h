@@ -37,6 +37,7 @@ struct slamhip_cs {
     std::vector<float> h_offs;    // host copy (n_offs x 3) for shard sorting / pose_from_key
     bool offs_on_device_sorted;   // generated on the device: flat list already theta-sorted
     float *d_offs_flat;           // [n_offs x 3] flat order
+    int cap_offs;                 // jitters d_offs_flat has room for
     int shard_first, shard_count; // evaluation list currently materialised
     float *d_ev_off;              // [cap_cand x 3] offsets in evaluation (theta-sorted) order
     int *d_ev_idx;                // [cap_cand] evaluation position -> flat index
@@ -84,6 +85,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);
 void    cs_holemap_free(slamhip_cs *cs);
+int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality, int32_t max_hits);
+int32_t cs_update_maps_finish(slamhip_cs *cs);
 int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float hole_width, int quality);
 // obstacle.hip
 int32_t cs_obstacle_alloc(slamhip_cs *cs);

@@ -167,9 +167,8 @@ extern "C" int32_t slamhip_group_search(slamhip_group *g, const float pose[3], f
 extern "C" int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float hole_width, int32_t quality, int32_t max_hits)
 {
     SH_CHECK_ARG(g && pose);
-    for (int r = 0; r < g->n; r++) {
-        SH_TRY(slamhip_cs_update_holemap(g->cs[r], pose, hole_width, quality));
-        SH_TRY(slamhip_cs_update_obstaclemap(g->cs[r], pose, max_hits));
-    }
+    // the replicas update concurrently: enqueue on every GPU's stream, then wait for all of them
+    for (int r = 0; r < g->n; r++) SH_TRY(cs_update_maps_enqueue(g->cs[r], pose, hole_width, quality, max_hits));
+    for (int r = 0; r < g->n; r++) SH_TRY(cs_update_maps_finish(g->cs[r]));
     return SLAMHIP_OK;
 }

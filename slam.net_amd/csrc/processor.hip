@@ -105,6 +105,7 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
     SH_CHECK_ARG(p && seg_poses && seg_start && n_seg >= 1 && seg_start[0] == 0);
     const int n = seg_start[n_seg];
     SH_CHECK_ARG(n >= 0 && (rays || n == 0));
+    for (int sgm = 0; sgm < n_seg; sgm++) SH_CHECK_ARG(seg_start[sgm] <= seg_start[sgm + 1]);
     const float odo[3] = { seg_poses[3 * (n_seg - 1)], seg_poses[3 * (n_seg - 1) + 1], seg_poses[3 * (n_seg - 1) + 2] };  // :719
 
     // ScanSegmentsToCloud (:187-207): polar -> cartesian in the robot frame, on the host
