@@ -479,3 +479,36 @@ def test_group_single_gpu(cs_mod, ctx, det, sim):
         assert idx.value == rbi and dist.value == rbd and (out_pose == rpose).all()
     finally:
         capi.call("slamhip_group_destroy", g)
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 flow (shard ranges, per-step key all-reduce on the library's stream, max-over-ranks timing, the
+    per-launch timing pass) with two ranks on this box's single GPU and gloo carrying the key: the JSON line is complete
+    and the winner equals that of one rank searching the whole 2 x 4096 list."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, SLAMHIP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "20", "--warmup", "3", "--size", "1024", "--map-updates", "8", "--no-cpu-baseline"]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--cands", "4096"] + common,
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r2.returncode == 0, r2.stderr.decode(errors="replace")[-3000:]
+    line2 = [l for l in r2.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(line2) == 1                                             # rank 0 prints exactly one JSON line
+    j2 = json.loads(line2[0])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--cands", "8192"] + common,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r1.returncode == 0, r1.stderr.decode(errors="replace")[-3000:]
+    j1 = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["config"]["candidates_total"] == 8192
+    assert j2["config"]["collective"].startswith("gloo")
+    assert (j2["config"]["best_index"], j2["config"]["best_distance"]) == (j1["config"]["best_index"], j1["config"]["best_distance"])
+    assert j2["roofline"]["launches"] == 50 and j2["roofline"]["avg_launch_us"] > 0 and j2["value"] > 0
+    assert j1["roofline"]["launches"] == 20
+
