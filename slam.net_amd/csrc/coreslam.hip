@@ -24,18 +24,36 @@ __global__ void k_pack_holemap(const uint16_t *__restrict__ pix, uint8_t *__rest
 
 // evaluation list: ev_idx[j] (or first + j) is a flat candidate index; flat 0 is the un-jittered pose
 // (theta-sorted flat lists: the un-jittered pose, dtheta = 0, is evaluated at position zero_pos, between the
-// negative and the positive dtheta, so that it does not widen the theta range of the first group)
-__global__ void k_gather_offsets(const float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first,
-                                 int count, int zero_pos, float *__restrict__ ev_off, int *__restrict__ ev_idx_out)
+// negative and the positive dtheta, so that it does not widen the theta range of the first group).
+// One workgroup per candidate group of K1_GROUP: it also leaves the group's jitter bounds {min dx, max dx, min dy,
+// max dy, min dtheta, max dtheta} for K1, which turns them into the bounds of the candidates' (px, py, c, s) for the
+// search pose of the launch without reading the candidates (k1_search_tiled).
+__global__ void __launch_bounds__(K1_GROUP)
+k_gather_offsets(const float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first, int count, int zero_pos,
+                 float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= count) return;
-    int flat = ev_idx_in ? ev_idx_in[j] : first + j;
-    if (!ev_idx_in && zero_pos >= 0) flat = j < zero_pos ? j + 1 : j == zero_pos ? 0 : j;
-    float ox = 0.f, oy = 0.f, ot = 0.f;
-    if (flat > 0) { ox = offs_flat[3 * (flat - 1)]; oy = offs_flat[3 * (flat - 1) + 1]; ot = offs_flat[3 * (flat - 1) + 2]; }
-    ev_off[3 * j] = ox; ev_off[3 * j + 1] = oy; ev_off[3 * j + 2] = ot;
-    if (ev_idx_out) ev_idx_out[j] = flat;
+    __shared__ float red[K1_GROUP / 64][6];
+    const int j = blockIdx.x * K1_GROUP + threadIdx.x;
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    if (j < count) {
+        int flat = ev_idx_in ? ev_idx_in[j] : first + j;
+        if (!ev_idx_in && zero_pos >= 0) flat = j < zero_pos ? j + 1 : j == zero_pos ? 0 : j;
+        float ox = 0.f, oy = 0.f, ot = 0.f;
+        if (flat > 0) { ox = offs_flat[3 * (size_t)(flat - 1)]; oy = offs_flat[3 * (size_t)(flat - 1) + 1]; ot = offs_flat[3 * (size_t)(flat - 1) + 2]; }
+        ev_off[3 * (size_t)j] = ox; ev_off[3 * (size_t)j + 1] = oy; ev_off[3 * (size_t)j + 2] = ot;
+        if (ev_idx_out) ev_idx_out[j] = flat;
+        lo[0] = hi[0] = ox; lo[1] = hi[1] = oy; lo[2] = hi[2] = ot;
+    }
+    for (int m = 1; m < 64; m <<= 1)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], m)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m)); }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; k++) { red[wv][2 * k] = lo[k]; red[wv][2 * k + 1] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < K1_GROUP / 64; w++) v = (threadIdx.x & 1) ? fmaxf(v, red[w][threadIdx.x]) : fminf(v, red[w][threadIdx.x]);
+        grp_bounds[8 * (size_t)blockIdx.x + threadIdx.x] = v;          // (NaN jitters never reach the tiled kernel: sanity flags)
+    }
 }
 
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3")
@@ -494,8 +512,8 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         // flat candidates first .. first+count-1 = the un-jittered pose (flat 0) and jitters in ascending dtheta
         const int n = cs->n_offs;
         const int zero_pos = first == 0 ? (count - 1 < n / 2 ? count - 1 : n / 2) : -1;
-        hipLaunchKernelGGL(k_gather_offsets, dim3(sh_div_up(count, 256)), dim3(256), 0, ctx->stream,
-                           cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx);
+        hipLaunchKernelGGL(k_gather_offsets, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
+                           cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds);
         // the jitters are the strata of N(0, sigma): group ranges from the quantile function (layout balance only)
         for (int g = 0; g < ng; g++) {
             const int k0 = first + g * K1_GROUP, k1 = (first + count < k0 + K1_GROUP ? first + count : k0 + K1_GROUP) - 1;
@@ -526,8 +544,8 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             cs->h_grp_dxy[(size_t)g] = fmaxf(hi[0] - lo[0], hi[1] - lo[1]) * cs->hscale;
         }
         SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_gather_offsets, dim3(sh_div_up(count, 256)), dim3(256), 0, ctx->stream,
-                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr);
+        hipLaunchKernelGGL(k_gather_offsets, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
+                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds);
         SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
     }
     SH_HIP(hipGetLastError());

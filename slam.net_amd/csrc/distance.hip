@@ -217,6 +217,7 @@ struct k1_args {
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
     int n_tab_wgs, uni_g0, uni_ng, uni_nc;
     unsigned short tab_group[K1_TABLE_G];
+    const float *grp_bounds;            // mode 1: per group {min dx, max dx, min dy, max dy, min dtheta, max dtheta, -, -} of the jitters, or null
     unsigned char tab_nbp[K1_TABLE_G];  // band parts: the chunks of a listed group come in sets of nbp that share a ray range and split its bands
     unsigned wg_first[K1_TABLE_G + 1]; // dispatch position p -> first workgroup
     unsigned char wg_pos[K1_TABLE_WGS];// workgroup -> dispatch position
@@ -342,6 +343,12 @@ k1_search_tiled(const k1_args a)
 #ifdef K1_TIMES
     if (t == 0 && blockIdx.x < 4096) { for (int k = 10; k < 16; k++) g_k1_times[blockIdx.x * 16 + k] = 0; g_k1_times[blockIdx.x * 16 + 14] = (unsigned long long)g; g_k1_times[blockIdx.x * 16 + 15] = (unsigned long long)nc; }
     if (lane == 0 && blockIdx.x < 4096) g_k1_wstart[blockIdx.x * 16 + (wv & 15)] = wall_clock64();
+    if (t == 0 && blockIdx.x < 4096) {                                     // which CU runs this workgroup
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_k1_wstart[blockIdx.x * 16 + 15] = ((unsigned long long)(xcc & 15u) << 16) | ((hw >> 8) & 0xffu);   // xcc | se,sh,cu
+    }
 #endif
     // the chunk = rays [rlo, rhi) of the sorted scan, cut into pieces at ray block boundaries (host: <= K1_MAXR
     // rays, <= K1_MAXP pieces)
@@ -374,7 +381,16 @@ k1_search_tiled(const k1_args a)
         else { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
     }
     if (t == 0) { s_nsteps = 0; *(unsigned *)(smem + K1_ZERO_OFS) = 0u; }
-    if (MODE != 0) {
+    // Search mode: the bounds of the group's (px, py, c, s) follow from the group's jitter bounds (left by
+    // k_gather_offsets) and the search pose, so nothing before the first tile depends on the candidates: their
+    // trigonometry runs later, under the tile's global loads.
+    const bool pre = MODE == 1 && a.grp_bounds != nullptr;
+    float gb[6];
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) gb[k] = a.grp_bounds[8 * (size_t)g + k];
+    }
+    if (MODE != 0 && !pre) {
 #pragma unroll
         for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
     }
@@ -388,6 +404,34 @@ k1_search_tiled(const k1_args a)
         }
     }
     K1_STAMP(1)
+    if (pre) {
+        if (wv == 0) {
+            // px = (bx + dx) * scale + 0.5 and theta = btheta + dtheta are monotone in the jitter (every float operation
+            // rounds monotonically), so the extreme jitters give the extreme px, py and theta of the group.  cos and sin
+            // over [theta_lo, theta_hi]: the end points, +-1 where the interval holds a multiple of pi/2 (tested in
+            // double with a margin), and a pad of a few ulps for the last-digit wobble of the trigonometry in between.
+            const float c3lo[3] = { gb[0], gb[2], gb[4] }, c3hi[3] = { gb[1], gb[3], gb[5] };
+            const float4 qlo = k1_candidate<1, true>(c3lo, a.bx, a.by, a.bth, a.scale);
+            const float4 qhi = k1_candidate<1, true>(c3hi, a.bx, a.by, a.bth, a.scale);
+            const double tl = (double)(a.bth + gb[4]) - 1.0e-5, th = (double)(a.bth + gb[5]) + 1.0e-5;
+            const float as = fabsf(a.scale), pad = as * 4.0e-7f;
+            float clo = fminf(qlo.z, qhi.z) - pad, chi = fmaxf(qlo.z, qhi.z) + pad;
+            float slo = fminf(qlo.w, qhi.w) - pad, shi = fmaxf(qlo.w, qhi.w) + pad;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                          // is there an n with k * pi/2 + 2 pi n in [tl, th] ?
+                const double a0 = 1.5707963267948966 * k, n = ceil((tl - a0) * 0.15915494309189535);
+                if (a0 + 6.283185307179586 * n <= th) {
+                    if (k == 0) chi = as + pad; else if (k == 1) shi = as + pad; else if (k == 2) clo = -as - pad; else slo = -as - pad;
+                }
+            }
+            if (lane == 0) {
+                *(float4 *)&bnd[0] = make_float4(qlo.x, qhi.x, qlo.y, qhi.y);
+                *(float4 *)&bnd[4] = make_float4(clo, chi, slo, shi);
+            }
+        }
+        __syncthreads();
+        K1_STAMP(2)
+    } else
     {   // min / max of (px, py, c, s) over the group: the lane's candidates, the wave (DPP), the waves (LDS)
         float lo[4] = { q[0].x, q[0].y, q[0].z, q[0].w }, hi[4] = { q[0].x, q[0].y, q[0].z, q[0].w };
 #pragma unroll
@@ -403,19 +447,19 @@ k1_search_tiled(const k1_args a)
             *(float4 *)&wred[wv][0] = make_float4(m0, m1, m2, m3);
             *(float4 *)&wred[wv][4] = make_float4(m4, m5, m6, m7);
         }
-    }
-    __syncthreads();
-    K1_STAMP(2)
-    if (t < 8) {
-        float v[NW];
+        __syncthreads();
+        K1_STAMP(2)
+        if (t < 8) {
+            float v[NW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) v[w] = wred[w][t];
-        float x = v[0];
+            for (int w = 0; w < NW; w++) v[w] = wred[w][t];
+            float x = v[0];
 #pragma unroll
-        for (int w = 1; w < NW; w++) x = (t & 1) ? fmaxf(x, v[w]) : fminf(x, v[w]);
-        bnd[t] = x;
+            for (int w = 1; w < NW; w++) x = (t & 1) ? fmaxf(x, v[w]) : fminf(x, v[w]);
+            bnd[t] = x;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     K1_STAMP(3)
     for (int p = wv; p < npieces; p += NW) {                       // one wave per piece, one lane per ray
         const int2 pi = pieces[p];
@@ -499,6 +543,10 @@ k1_search_tiled(const k1_args a)
             }                                                                                       \
         }
         K1_PREFETCH(0)
+        if (MODE != 0 && pre) {                                    // (the first tile's loads are in flight)
+#pragma unroll
+            for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
+        }
         for (int s = 0; s < nsteps; s++) {
             __syncthreads();                                       // the previous tile is no longer read
 #pragma unroll
@@ -745,6 +793,10 @@ int32_t cs_alloc_candidates(slamhip_cs *cs, int count)
     SH_HIP(hipMalloc(&cs->d_ev_idx, sizeof(int) * (size_t)cap));
     SH_HIP(hipMalloc(&cs->d_pxcs, sizeof(float4) * (size_t)cap));
     SH_HIP(hipMalloc(&cs->d_dist, sizeof(int32_t) * (size_t)cap));
+    if (cs->d_grp_bounds) (void)hipFree(cs->d_grp_bounds);
+    cs->d_grp_bounds = nullptr; cs->cap_grp = 0;
+    SH_HIP(hipMalloc(&cs->d_grp_bounds, sizeof(float) * 8 * (size_t)(cap / K1_GROUP + 2)));
+    cs->cap_grp = cap / K1_GROUP + 2;
     cs->cap_cand = cap;
     cs->shard_first = -1; cs->shard_count = -1;
     return SLAMHIP_OK;
@@ -807,7 +859,9 @@ static double k1_group_cost(const slamhip_cs *cs, int g, int budget)
         double f = 1.0;
         if (bytes > budget) {
             const double bands = ceil(bytes / budget);
-            f = bands <= K1_MAXBANDS && w <= 504.0 ? 1.9 * bands : 4.5;      // (measured cost per ray relative to a plain tile step)
+            static const double f_band = getenv("SLAMHIP_K1_FBAND") ? atof(getenv("SLAMHIP_K1_FBAND")) : 1.9;
+            static const double f_glob = getenv("SLAMHIP_K1_FGLOBAL") ? atof(getenv("SLAMHIP_K1_FGLOBAL")) : 4.5;
+            f = bands <= K1_MAXBANDS && w <= 504.0 ? f_band * bands : f_glob;      // (measured cost per ray relative to a plain tile step)
         }
         cost += f * (cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b]);
     }
@@ -849,7 +903,8 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
             if (v < 1) v = 1;
             if (v > R / 4) v = R / 4 > 0 ? R / 4 : 1;
             int nbp = 1;                                           // banded tiles (two bands or more on average): chunks in sets
-            if (band_parts > 1 && cost[(size_t)g] >= 2.0 * 1.9 * R && v >= 2 * band_parts) nbp = band_parts;
+            static const double f_band = getenv("SLAMHIP_K1_FBAND") ? atof(getenv("SLAMHIP_K1_FBAND")) : 1.9;
+            if (band_parts > 1 && cost[(size_t)g] >= 2.0 * f_band * R && v >= 2 * band_parts) nbp = band_parts;
             cs->k1_tab_group.push_back(g); cs->k1_tab_nc.push_back(v); cs->k1_tab_nbp.push_back(nbp);
         }
         (void)n_list;
@@ -920,6 +975,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.pxcs = cs->d_pxcs; a.src3 = cs->d_ev_off; a.bx = bx; a.by = by; a.bth = bth; a.scale = cs->hscale;
         a.count = count; a.n_groups = n_groups; a.budget = budget;
         a.ev_idx = cs->d_ev_idx; a.dist_out = dist; a.key_out = key; a.verify = cs->d_verify;
+        static const int no_bounds = env_int("SLAMHIP_K1_NOBOUNDS", 0);
+        a.grp_bounds = (mode == 1 && !no_bounds) ? cs->d_grp_bounds : nullptr;
         a.offs_flat = cs->d_offs_flat; a.best_pose = (mode == 1 && cs->k1_want_pose) ? cs->d_best_pose : nullptr;
         cs->k1_pose_written = a.best_pose != nullptr;
 
@@ -1032,6 +1089,34 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                             h[i * 16 + 9] > h[i * 16 + 8] ? (double)(h[i * 16 + 9] - h[i * 16 + 8]) * 0.01 : 0.0,
                             (double)(endof(i) - t0) * 0.01, (int)h[i * 16 + 14], (int)h[i * 16 + 15], (int)h[i * 16 + 11],
                             (int)h[i * 16 + 12], (int)h[i * 16 + 13]);
+                }
+                {   // per CU: workgroups hosted and the time the last of them ends
+                    std::vector<unsigned long long> ws((size_t)nw * 16);
+                    (void)hipMemcpyFromSymbol(ws.data(), HIP_SYMBOL(g_k1_wstart), sizeof(unsigned long long) * ws.size());
+                    std::vector<int> cnt(16 * 256, 0); std::vector<double> cend(16 * 256, 0.0), csum(16 * 256, 0.0);
+                    for (int i = 0; i < nw; i++) {
+                        const int cu = (int)(((ws[i * 16 + 15] >> 16) & 15) * 256 + (ws[i * 16 + 15] & 255));
+                        cnt[cu]++; cend[cu] = std::max(cend[cu], (double)(endof(i) - t0) * 0.01);
+                        csum[cu] += (double)(h[i * 16 + 7] - h[i * 16 + 6]) * 0.01;
+                    }
+                    int ncu = 0, hist[8] = { 0 }; double emean = 0, emax = 0, emin = 1e9;
+                    for (int c = 0; c < 16 * 256; c++) if (cnt[c]) { ncu++; hist[cnt[c] < 7 ? cnt[c] : 7]++; emean += cend[c]; emax = std::max(emax, cend[c]); emin = std::min(emin, cend[c]); }
+                    fprintf(stderr, "[k1 times] CUs used %d; workgroups per CU: 1:%d 2:%d 3:%d 4+:%d; CU end time mean %.2f min %.2f max %.2f us\n",
+                            ncu, hist[1], hist[2], hist[3], hist[4] + hist[5] + hist[6] + hist[7], emean / std::max(ncu, 1), emin, emax);
+                    // pairs sharing a CU (workgroups i and i + CUs): compute intervals and a solo estimate (half of the overlap each)
+                    int same = 0;
+                    for (int i = 0; i + 256 < nw; i++) if (ws[i * 16 + 15] == ws[(i + 256) * 16 + 15]) same++;
+                    fprintf(stderr, "[k1 times] pairs (i, i+256) on the same CU: %d\n", same);
+                    for (int i = 0; i + 256 < nw; i++) {
+                        const int j = i + 256;
+                        const double sa = (double)(h[i * 16 + 6] - t0) * 0.01, ea = (double)(h[i * 16 + 7] - t0) * 0.01;
+                        const double sb = (double)(h[j * 16 + 6] - t0) * 0.01, eb = (double)(h[j * 16 + 7] - t0) * 0.01;
+                        const double ov = std::max(0.0, std::min(ea, eb) - std::max(sa, sb));
+                        fprintf(stderr, "PAIR %3d g %2d sh %3d gl %3d bd %3d comp %5.2f solo %5.2f | %3d g %2d sh %3d gl %3d bd %3d comp %5.2f solo %5.2f | end %5.2f\n",
+                                i, (int)h[i * 16 + 14], (int)h[i * 16 + 11], (int)h[i * 16 + 12], (int)h[i * 16 + 13], ea - sa, ea - sa - ov / 2,
+                                j, (int)h[j * 16 + 14], (int)h[j * 16 + 11], (int)h[j * 16 + 12], (int)h[j * 16 + 13], eb - sb, eb - sb - ov / 2,
+                                std::max((double)(endof(i) - t0), (double)(endof(j) - t0)) * 0.01);
+                    }
                 }
                 // per group: chunks, ray-steps per kind, mean / max compute time
                 for (int g = 0; g < n_groups; g++) {
