@@ -216,12 +216,19 @@ struct k1_args {
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
     int n_tab_wgs, uni_g0, uni_ng, uni_nc;
-    unsigned short tab_group[K1_TABLE_G];
     const float *grp_bounds;            // mode 1: per group {min dx, max dx, min dy, max dy, min dtheta, max dtheta, -, -} of the jitters, or null
-    unsigned char tab_nbp[K1_TABLE_G];  // band parts: the chunks of a listed group come in sets of nbp that share a ray range and split its bands
-    unsigned wg_first[K1_TABLE_G + 1]; // dispatch position p -> first workgroup
+    // One 8-byte record per dispatch position, every member at a multiple of its size.  (Separate byte / short / word
+    // arrays indexed by the same position let the compiler form the scalar base "kernarg + p" for the byte loads and
+    // reuse it for wider scalar loads, whose base the hardware aligns down to four bytes: seen with 64-bit members.)
+    struct tab_rec {
+        unsigned short group;
+        unsigned short nbp;            // band parts: the chunks of a listed group come in sets of nbp that share a ray range and split its bands
+        unsigned short first, nc;      // first workgroup of the position, workgroups
+    } tab[K1_TABLE_G];
     unsigned char wg_pos[K1_TABLE_WGS];// workgroup -> dispatch position
 };
+static_assert(sizeof(k1_args) <= 4096, "kernel arguments are limited to 4 KB");
+static_assert(sizeof(k1_args::tab_rec) == 8 && offsetof(k1_args, tab) % 8 == 0, "table records are 8-byte aligned");
 
 #ifdef K1_TIMES
 // developer instrumentation (build with SLAMHIP_K1_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
@@ -326,10 +333,11 @@ k1_search_tiled(const k1_args a)
     int g, chunk, nc, nbp = 1;
     if ((int)blockIdx.x < a.n_tab_wgs) {
         const int p = a.wg_pos[blockIdx.x];
-        nc = (int)(a.wg_first[p + 1] - a.wg_first[p]);
-        chunk = blockIdx.x - (int)a.wg_first[p];
-        g = a.tab_group[p];
-        nbp = a.tab_nbp[p];
+        const k1_args::tab_rec rec = a.tab[p];
+        nc = rec.nc;
+        chunk = blockIdx.x - (int)rec.first;
+        g = rec.group;
+        nbp = rec.nbp;
     } else {
         // the uniform part runs chunk-major: the workgroups in flight work on the SAME rays for neighbouring theta groups,
         // whose tiles overlap almost completely (L2 reuse).  (Sending ray chunk c of every group to XCD c % 8 -- one
@@ -1002,14 +1010,14 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         unsigned first = 0;
         const int n_tab = (int)cs->k1_tab_group.size();
         for (int p = 0; p < n_tab; p++) {
-            a.tab_group[p] = (unsigned short)cs->k1_tab_group[(size_t)p];
-            a.tab_nbp[p] = (unsigned char)cs->k1_tab_nbp[(size_t)p];
-            a.wg_first[p] = first;
+            k1_args::tab_rec &rec = a.tab[p];
+            rec.group = (unsigned short)cs->k1_tab_group[(size_t)p];
+            rec.nbp = (unsigned short)cs->k1_tab_nbp[(size_t)p];
+            rec.first = (unsigned short)first; rec.nc = (unsigned short)cs->k1_tab_nc[(size_t)p];
             first += (unsigned)cs->k1_tab_nc[(size_t)p];
         }
         for (int p = 0; p < n_tab; p++)
-            for (unsigned w = a.wg_first[p]; w < a.wg_first[p] + (unsigned)cs->k1_tab_nc[(size_t)p]; w++) a.wg_pos[w] = (unsigned char)p;
-        for (int p = n_tab; p <= K1_TABLE_G; p++) a.wg_first[p] = first;
+            for (unsigned w = a.tab[p].first; w < (unsigned)a.tab[p].first + a.tab[p].nc; w++) a.wg_pos[w] = (unsigned char)p;
         a.n_tab_wgs = (int)first;
         a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
         const int n_wgs = (int)first + cs->k1_uni_nc * cs->k1_uni_ng;
