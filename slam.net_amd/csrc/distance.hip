@@ -416,22 +416,28 @@ k1_search_tiled(const k1_args a)
         if (wv == 0) {
             // px = (bx + dx) * scale + 0.5 and theta = btheta + dtheta are monotone in the jitter (every float operation
             // rounds monotonically), so the extreme jitters give the extreme px, py and theta of the group.  cos and sin
-            // over [theta_lo, theta_hi]: the end points, +-1 where the interval holds a multiple of pi/2 (tested in
-            // double with a margin), and a pad of a few ulps for the last-digit wobble of the trigonometry in between.
-            const float c3lo[3] = { gb[0], gb[2], gb[4] }, c3hi[3] = { gb[1], gb[3], gb[5] };
-            const float4 qlo = k1_candidate<1, true>(c3lo, a.bx, a.by, a.bth, a.scale);
-            const float4 qhi = k1_candidate<1, true>(c3hi, a.bx, a.by, a.bth, a.scale);
-            const double tl = (double)(a.bth + gb[4]) - 1.0e-5, th = (double)(a.bth + gb[5]) + 1.0e-5;
-            const float as = fabsf(a.scale), pad = as * 4.0e-7f;
-            float clo = fminf(qlo.z, qhi.z) - pad, chi = fmaxf(qlo.z, qhi.z) + pad;
-            float slo = fminf(qlo.w, qhi.w) - pad, shi = fmaxf(qlo.w, qhi.w) + pad;
+            // over [theta_lo, theta_hi] only need to be bounded, not reproduced: one reduction by a multiple of 2 pi in
+            // double, the hardware sine / cosine at the end points, +-1 where the interval (with a margin) holds a
+            // multiple of pi/2, and a pad of 1e-4 (a fifth of a pixel at 40 m) that covers the approximation.
+            const float scale = a.scale;
+            const float pxl = (a.bx + gb[0]) * scale + 0.5f, pxh = (a.bx + gb[1]) * scale + 0.5f;
+            const float pyl = (a.by + gb[2]) * scale + 0.5f, pyh = (a.by + gb[3]) * scale + 0.5f;
+            const float tlf = a.bth + gb[4], thf = a.bth + gb[5];
+            const double n2 = rint((double)tlf * 0.15915494309189535) * 6.283185307179586;
+            const float rl = (float)((double)tlf - n2), rh = (float)((double)thf - n2);      // rl in [-pi, pi], rh >= rl
+            const float as = scale, pad = as * 1.0e-4f;                 // (scale = pixels per metre > 0)
+            const float cl = __cosf(rl) * as, ch = __cosf(rh) * as, sl = __sinf(rl) * as, sh = __sinf(rh) * as;
+            float clo = fminf(cl, ch) - pad, chi = fmaxf(cl, ch) + pad, slo = fminf(sl, sh) - pad, shi = fmaxf(sl, sh) + pad;
+            const bool all = !(rh - rl < 6.2f);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {                          // is there an n with k * pi/2 + 2 pi n in [tl, th] ?
-                const double a0 = 1.5707963267948966 * k, n = ceil((tl - a0) * 0.15915494309189535);
-                if (a0 + 6.283185307179586 * n <= th) {
-                    if (k == 0) chi = as + pad; else if (k == 1) shi = as + pad; else if (k == 2) clo = -as - pad; else slo = -as - pad;
+            for (int k = -2; k <= 8; k++) {                        // multiples of pi/2 in [rl, rh] (rh < rl + 2 pi <= 3 pi)
+                const float ang = 1.57079632679f * (float)k;
+                if (all || (ang >= rl - 1.0e-3f && ang <= rh + 1.0e-3f)) {
+                    const int m = k & 3;
+                    if (m == 0) chi = as + pad; else if (m == 1) shi = as + pad; else if (m == 2) clo = -as - pad; else slo = -as - pad;
                 }
             }
+            const float4 qlo = make_float4(pxl, pyl, 0.f, 0.f), qhi = make_float4(pxh, pyh, 0.f, 0.f);
             if (lane == 0) {
                 *(float4 *)&bnd[0] = make_float4(qlo.x, qhi.x, qlo.y, qhi.y);
                 *(float4 *)&bnd[4] = make_float4(clo, chi, slo, shi);
