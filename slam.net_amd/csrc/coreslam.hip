@@ -22,40 +22,6 @@ __global__ void k_pack_holemap(const uint16_t *__restrict__ pix, uint8_t *__rest
     out[i] = (uint8_t)(((pix[i * 2] >> 12) << 4) | (pix[i * 2 + 1] >> 12));      // :51
 }
 
-// evaluation list: ev_idx[j] (or first + j) is a flat candidate index; flat 0 is the un-jittered pose
-// (theta-sorted flat lists: the un-jittered pose, dtheta = 0, is evaluated at position zero_pos, between the
-// negative and the positive dtheta, so that it does not widen the theta range of the first group).
-// One workgroup per candidate group of K1_GROUP: it also leaves the group's jitter bounds {min dx, max dx, min dy,
-// max dy, min dtheta, max dtheta} for K1, which turns them into the bounds of the candidates' (px, py, c, s) for the
-// search pose of the launch without reading the candidates (k1_search_tiled).
-__global__ void __launch_bounds__(K1_GROUP)
-k_gather_offsets(const float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first, int count, int zero_pos,
-                 float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds)
-{
-    __shared__ float red[K1_GROUP / 64][6];
-    const int j = blockIdx.x * K1_GROUP + threadIdx.x;
-    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    if (j < count) {
-        int flat = ev_idx_in ? ev_idx_in[j] : first + j;
-        if (!ev_idx_in && zero_pos >= 0) flat = j < zero_pos ? j + 1 : j == zero_pos ? 0 : j;
-        float ox = 0.f, oy = 0.f, ot = 0.f;
-        if (flat > 0) { ox = offs_flat[3 * (size_t)(flat - 1)]; oy = offs_flat[3 * (size_t)(flat - 1) + 1]; ot = offs_flat[3 * (size_t)(flat - 1) + 2]; }
-        ev_off[3 * (size_t)j] = ox; ev_off[3 * (size_t)j + 1] = oy; ev_off[3 * (size_t)j + 2] = ot;
-        if (ev_idx_out) ev_idx_out[j] = flat;
-        lo[0] = hi[0] = ox; lo[1] = hi[1] = oy; lo[2] = hi[2] = ot;
-    }
-    for (int m = 1; m < 64; m <<= 1)
-        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], m)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m)); }
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; k++) { red[wv][2 * k] = lo[k]; red[wv][2 * k + 1] = hi[k]; }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        float v = red[0][threadIdx.x];
-        for (int w = 1; w < K1_GROUP / 64; w++) v = (threadIdx.x & 1) ? fmaxf(v, red[w][threadIdx.x]) : fminf(v, red[w][threadIdx.x]);
-        grp_bounds[8 * (size_t)blockIdx.x + threadIdx.x] = v;          // (NaN jitters never reach the tiled kernel: sanity flags)
-    }
-}
-
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3")
 __device__ static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
@@ -72,11 +38,8 @@ __device__ static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t
 // (seed, stream, i).  dx,dy ~ N(0, sigma_xy) by Box-Muller; dtheta is STRATIFIED: the i-th of n equal-
 // probability strata of N(0, sigma_theta), so the flat list is already sorted by theta (no sort on the
 // search path) while every dtheta is still N(0, sigma_theta) distributed.
-__global__ void k_generate_offsets(float *__restrict__ offs_flat, int n, float sigma_xy, float sigma_theta,
-                                   uint64_t seed, uint64_t stream)
+__device__ static inline void k_jitter(int i, int n, float sigma_xy, float sigma_theta, uint64_t seed, uint64_t stream, float o[3])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     uint32_t c[4] = { (uint32_t)i, 0u, (uint32_t)stream, (uint32_t)(stream >> 32) };
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -86,9 +49,63 @@ __global__ void k_generate_offsets(float *__restrict__ offs_flat, int n, float s
     float sn, cs;
     sincosf(6.28318530718f * u2, &sn, &cs);
     const float q = ((float)i + u3) / (float)n;
-    offs_flat[3 * i + 0] = sigma_xy * rad * cs;
-    offs_flat[3 * i + 1] = sigma_xy * rad * sn;
-    offs_flat[3 * i + 2] = sigma_theta * normcdfinvf(q);
+    o[0] = sigma_xy * rad * cs;
+    o[1] = sigma_xy * rad * sn;
+    o[2] = sigma_theta * normcdfinvf(q);
+}
+__global__ void k_generate_offsets(float *__restrict__ offs_flat, int n, float sigma_xy, float sigma_theta,
+                                   uint64_t seed, uint64_t stream)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[3];
+    k_jitter(i, n, sigma_xy, sigma_theta, seed, stream, o);
+    offs_flat[3 * i + 0] = o[0]; offs_flat[3 * i + 1] = o[1]; offs_flat[3 * i + 2] = o[2];
+}
+
+// evaluation list: ev_idx[j] (or first + j) is a flat candidate index; flat 0 is the un-jittered pose
+// (theta-sorted flat lists: the un-jittered pose, dtheta = 0, is evaluated at position zero_pos, between the
+// negative and the positive dtheta, so that it does not widen the theta range of the first group).
+// One workgroup per candidate group of K1_GROUP: it also leaves the group's jitter bounds {min dx, max dx, min dy,
+// max dy, min dtheta, max dtheta} for K1, which turns them into the bounds of the candidates' (px, py, c, s) for the
+// search pose of the launch without reading the candidates (k1_search_tiled).
+// GEN: the whole device-generated list is evaluated (first = 0, count = n + 1), so the jitters are produced here, in
+// evaluation order, and stored to the flat list as well: one launch instead of two per scan.
+template <bool GEN>
+__global__ void __launch_bounds__(K1_GROUP)
+k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first, int count, int zero_pos,
+                 float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds,
+                 int gen_n, float gen_sxy, float gen_sth, uint64_t gen_seed, uint64_t gen_stream)
+{
+    __shared__ float red[K1_GROUP / 64][6];
+    const int j = blockIdx.x * K1_GROUP + threadIdx.x;
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    if (j < count) {
+        int flat = ev_idx_in ? ev_idx_in[j] : first + j;
+        if (!ev_idx_in && zero_pos >= 0) flat = j < zero_pos ? j + 1 : j == zero_pos ? 0 : j;
+        float ox = 0.f, oy = 0.f, ot = 0.f;
+        if (flat > 0) {
+            if (GEN) {
+                float o[3];
+                k_jitter(flat - 1, gen_n, gen_sxy, gen_sth, gen_seed, gen_stream, o);
+                ox = o[0]; oy = o[1]; ot = o[2];
+                offs_flat[3 * (size_t)(flat - 1)] = ox; offs_flat[3 * (size_t)(flat - 1) + 1] = oy; offs_flat[3 * (size_t)(flat - 1) + 2] = ot;
+            } else { ox = offs_flat[3 * (size_t)(flat - 1)]; oy = offs_flat[3 * (size_t)(flat - 1) + 1]; ot = offs_flat[3 * (size_t)(flat - 1) + 2]; }
+        }
+        ev_off[3 * (size_t)j] = ox; ev_off[3 * (size_t)j + 1] = oy; ev_off[3 * (size_t)j + 2] = ot;
+        if (ev_idx_out) ev_idx_out[j] = flat;
+        lo[0] = hi[0] = ox; lo[1] = hi[1] = oy; lo[2] = hi[2] = ot;
+    }
+    for (int m = 1; m < 64; m <<= 1)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], m)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m)); }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; k++) { red[wv][2 * k] = lo[k]; red[wv][2 * k + 1] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < K1_GROUP / 64; w++) v = (threadIdx.x & 1) ? fmaxf(v, red[w][threadIdx.x]) : fminf(v, red[w][threadIdx.x]);
+        grp_bounds[8 * (size_t)blockIdx.x + threadIdx.x] = v;          // (NaN jitters never reach the tiled kernel: sanity flags)
+    }
 }
 
 // winner pose from the packed key: search_pose + offs[index-1] (:635-637), theta normalised (:746)
@@ -429,7 +446,7 @@ extern "C" int32_t slamhip_cs_set_offsets(slamhip_cs *cs, const float *offs, int
     cs->h_offs.assign(offs, offs + (size_t)n * 3);
     cs->offs_theta_small = true;
     for (size_t i = 0; i < (size_t)n * 3; i++) if (!(fabsf(offs[i]) < (i % 3 == 2 ? 1.0e4f : 1.0e6f))) { cs->offs_theta_small = false; break; }
-    cs->offs_on_device_sorted = false;
+    cs->offs_on_device_sorted = false; cs->gen_pending = false;
     cs->shard_first = cs->shard_count = -1;
     if (n > 0) SH_HIP(hipMemcpy(cs->d_offs_flat, offs, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     return SLAMHIP_OK;
@@ -450,9 +467,17 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
     cs->gen_sigma_xy = sigma_xy; cs->gen_sigma_theta = sigma_theta;
     cs->offs_on_device_sorted = true;
     cs->shard_first = cs->shard_count = -1;
-    if (n > 0)
-        hipLaunchKernelGGL(k_generate_offsets, dim3(sh_div_up(n, 256)), dim3(256), 0, cs->ctx->stream,
-                           cs->d_offs_flat, n, sigma_xy, sigma_theta, seed, stream);
+    // produced on first use: a full-range search generates the list inside its gather launch (ensure_shard)
+    cs->gen_pending = n > 0; cs->gen_seed = seed; cs->gen_stream = stream;
+    return SLAMHIP_OK;
+}
+
+static int32_t flush_generate(slamhip_cs *cs)
+{
+    if (!cs->gen_pending) return SLAMHIP_OK;
+    cs->gen_pending = false;
+    hipLaunchKernelGGL(k_generate_offsets, dim3(sh_div_up(cs->n_offs, 256)), dim3(256), 0, cs->ctx->stream,
+                       cs->d_offs_flat, cs->n_offs, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream);
     SH_HIP(hipGetLastError());
     return SLAMHIP_OK;
 }
@@ -461,6 +486,7 @@ extern "C" int32_t slamhip_cs_offsets_download(slamhip_cs *cs, float *offs, int3
 {
     SH_CHECK_ARG(cs && offs && n == cs->n_offs);
     SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_TRY(flush_generate(cs));
     if (n > 0) {
         SH_HIP(hipMemcpyAsync(offs, cs->d_offs_flat, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, cs->ctx->stream));
         SH_HIP(hipStreamSynchronize(cs->ctx->stream));
@@ -472,6 +498,7 @@ static int32_t host_offsets(slamhip_cs *cs)
 {
     if (cs->h_offs.size() == (size_t)cs->n_offs * 3) return SLAMHIP_OK;
     cs->h_offs.resize((size_t)cs->n_offs * 3);
+    SH_TRY(flush_generate(cs));
     if (cs->n_offs > 0) {
         SH_HIP(hipMemcpyAsync(cs->h_offs.data(), cs->d_offs_flat, sizeof(float) * 3 * (size_t)cs->n_offs,
                               hipMemcpyDeviceToHost, cs->ctx->stream));
@@ -512,8 +539,17 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         // flat candidates first .. first+count-1 = the un-jittered pose (flat 0) and jitters in ascending dtheta
         const int n = cs->n_offs;
         const int zero_pos = first == 0 ? (count - 1 < n / 2 ? count - 1 : n / 2) : -1;
-        hipLaunchKernelGGL(k_gather_offsets, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
-                           cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds);
+        if (cs->gen_pending && first == 0 && count == n + 1) {
+            cs->gen_pending = false;
+            hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
+                               cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds,
+                               n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream);
+        } else {
+            SH_TRY(flush_generate(cs));
+            hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
+                               cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds,
+                               0, 0.f, 0.f, (uint64_t)0, (uint64_t)0);
+        }
         // the jitters are the strata of N(0, sigma): group ranges from the quantile function (layout balance only)
         for (int g = 0; g < ng; g++) {
             const int k0 = first + g * K1_GROUP, k1 = (first + count < k0 + K1_GROUP ? first + count : k0 + K1_GROUP) - 1;
@@ -544,8 +580,9 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             cs->h_grp_dxy[(size_t)g] = fmaxf(hi[0] - lo[0], hi[1] - lo[1]) * cs->hscale;
         }
         SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_gather_offsets, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
-                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds);
+        hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
+                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds,
+                           0, 0.f, 0.f, (uint64_t)0, (uint64_t)0);
         SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
     }
     SH_HIP(hipGetLastError());

@@ -38,6 +38,7 @@ struct slamhip_cs {
     bool offs_on_device_sorted;   // generated on the device: flat list already theta-sorted
     float *d_offs_flat;           // [n_offs x 3] flat order
     int cap_offs;                 // jitters d_offs_flat has room for
+    bool gen_pending; uint64_t gen_seed, gen_stream;   // device-generated list requested but not produced yet (see ensure_shard)
     int shard_first, shard_count; // evaluation list currently materialised
     float *d_ev_off;              // [cap_cand x 3] offsets in evaluation (theta-sorted) order
     int *d_ev_idx;                // [cap_cand] evaluation position -> flat index

@@ -7,6 +7,26 @@
 #include "cs_internal.h"
 #include "det_trig.h"
 #include <vector>
+#include <chrono>
+#include <stdlib.h>
+
+// developer aid (SLAMHIP_PROC_TIMES=1): average host time of the stages of Update, printed every 64 searching scans
+struct proc_times {
+    bool on; double acc[6]; int n;
+    std::chrono::steady_clock::time_point t;
+    proc_times() : on(getenv("SLAMHIP_PROC_TIMES") != nullptr), n(0) { for (double &a : acc) a = 0; }
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (!on) return; auto u = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::micro>(u - t).count(); t = u; }
+    void done()
+    {
+        if (!on || ++n < 64) return;
+        fprintf(stderr, "[slamhip] Update host stages (us): cloud %.1f | set_scan %.1f | candidates %.1f | search+update (enqueue, wait, read back) %.1f\n",
+                acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
+        for (double &a : acc) a = 0;
+        n = 0;
+    }
+};
+static thread_local proc_times g_pt;
 
 struct slamhip_csproc {
     slamhip_ctx *ctx;
@@ -109,6 +129,7 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
     const float odo[3] = { seg_poses[3 * (n_seg - 1)], seg_poses[3 * (n_seg - 1) + 1], seg_poses[3 * (n_seg - 1) + 2] };  // :719
 
     // ScanSegmentsToCloud (:187-207): polar -> cartesian in the robot frame, on the host
+    g_pt.start();
     p->cloud.resize((size_t)n * 2);
     for (int sgm = 0; sgm < n_seg; sgm++) {                               // :191
         const float px = seg_poses[3 * sgm] - odo[0];                     // :194
@@ -121,7 +142,9 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
             p->cloud[2 * (size_t)r + 1] = py + rays[2 * r + 1] * s;       // :201
         }
     }
+    g_pt.lap(0);
     SH_TRY(slamhip_cs_set_scan(p->cs, p->cloud.data(), n));               // :723
+    g_pt.lap(1);
 
     float new_pose[3];
     if (p->scan_count >= p->search_beginning && n > 0) {                  // :726
@@ -133,9 +156,11 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
         }
         p->scan_no++;
         memcpy(p->last_odo, odo, sizeof(odo));                            // :745
+        g_pt.lap(2);
         // search (:732), NormalizeAngle (:746) and both map updates (:750-751) fused on the device
         SH_TRY(slamhip_cs_search_and_update(p->cs, search, p->hole_width, p->quality, p->max_hits, new_pose, nullptr, nullptr));
         memcpy(p->pose, new_pose, sizeof(new_pose));                      // :747
+        g_pt.lap(3); g_pt.done();
         return SLAMHIP_OK;
     }
     if (p->scan_count < p->search_beginning) p->scan_count++;             // :741

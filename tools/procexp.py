@@ -14,6 +14,6 @@ def seg(i):
     return [cs.ScanSegment(rays, np.zeros(3, np.float32))]
 for i in range(10): proc.Update(seg(i))
 t0 = time.perf_counter()
-for i in range(10, 70): proc.Update(seg(i))
-dt = (time.perf_counter() - t0) / 60
+for i in range(10, 210): proc.Update(seg(10 + i % 60))
+dt = (time.perf_counter() - t0) / 200
 print("CoreSLAMProcessor.Update (%d^2, %d candidates): %.1f us per scan" % (size, K, dt * 1e6))
