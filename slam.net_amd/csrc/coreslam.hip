@@ -667,6 +667,8 @@ static int32_t finish_holemap(slamhip_cs *cs)
     SH_HIP(hipMemcpyAsync(h + 4, cs->d_k2_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, cs->ctx->stream));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     cs->last_hole_pixels = h[4 + 2];
+    static const bool stats = getenv("SLAMHIP_K2_STATS") != nullptr;        // developer aid
+    if (stats) fprintf(stderr, "[slamhip] K2: reach %d px, %d pixels with more than 4 fragments (drawn by the last workgroup), %d blended pixels\n", h[4], h[5], h[6]);
     return SLAMHIP_OK;
 }
 

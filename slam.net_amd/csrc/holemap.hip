@@ -27,6 +27,8 @@
 #include "cs_internal.h"
 #include "det_trig.h"
 #include "raster.h"
+#include <vector>
+#include <algorithm>
 #include <stdlib.h>
 
 #define TS_NO_OBSTACLE 65500
@@ -380,7 +382,16 @@ __device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int si
 // lane per pixel over the bounding square of the scan (persistent grid; a wavefront takes 64 pixels of one row).
 // The bucket table and -- when it fits (LDS_TABLE) -- the candidate table live in LDS: a pixel's lookup is a chain of
 // dependent small reads (bucket bounds -> candidates -> map), which global-memory latency would dominate.
+#ifndef K2_LDS_RAYS
 #define K2_LDS_RAYS 3072
+#endif
+#ifdef K2_TIMES
+// developer instrumentation (build with SLAMHIP_K2_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
+__device__ unsigned long long g_k2_times[512 * 8];
+#define K2_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 512) g_k2_times[blockIdx.x * 8 + (k)] = wall_clock64(); }
+#else
+#define K2_STAMP(k) {}
+#endif
 template <bool LDS_TABLE, typename T>
 __global__ void __launch_bounds__(1024)
 k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g, int n_rays,
@@ -390,32 +401,56 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
     __shared__ int start[4 * K2_NBUCK + 1];
     __shared__ __attribute__((aligned(16))) k2_cand cand_s[LDS_TABLE ? K2_LDS_RAYS : 1];
     __shared__ int sval[16][64];
-    __shared__ int s_last;
+    __shared__ int s_last, s_next_zone, s_next_item;
+    K2_STAMP(0)
     const int R = counters[0], x1 = counters[3], y1 = counters[4];
     if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;       // robot outside the map: nothing is drawn (:509-512)
-    const int X0 = max(x1 - R, 0), X1 = min(x1 + R, size - 1), Y0 = max(y1 - R, 0), Y1 = min(y1 + R, size - 1);
+    int X0 = max(x1 - R, 0), X1 = min(x1 + R, size - 1), Y0 = max(y1 - R, 0), Y1 = min(y1 + R, size - 1);
+#ifdef K2_EXP_CLIP
+    X0 = max(X0, K2_EXP_CLIP); Y0 = max(Y0, K2_EXP_CLIP); X1 = min(X1, size - 1 - K2_EXP_CLIP); Y1 = min(Y1, size - 1 - K2_EXP_CLIP);   // EXPERIMENT (wrong results)
+#endif
+    if (threadIdx.x == 0) { s_next_zone = 0; s_next_item = 0; }
     for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
     if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) cand_s[i] = cand_g[i];     // (entries past the valid rays are never addressed)
     __syncthreads();
+    K2_STAMP(1)
     const k2_cand *cand = LDS_TABLE ? cand_s : cand_g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 16 + wv, nw = gridDim.x * 16;
+    // Work items are dealt to the workgroups round-robin (every workgroup gets pixels from all over the square) and
+    // inside a workgroup to whichever wavefront is free (an LDS counter): the cost of an item depends on how many
+    // rays cross its pixels, and a workgroup is only as fast as its slowest wavefront.
     // (1) the zone around the robot (Chebyshev distance <= Z): one wavefront per pixel
     const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R;
     const int side = 2 * Z + 1, n_zone = side * side;
-    for (int item = gw; item < n_zone; item += nw) {
+    for (;;) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&s_next_zone, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const int item = blockIdx.x + k * gridDim.x;
+        if (item >= n_zone) break;
         const int X = x1 - Z + item % side, Y = y1 - Z + item / side;
         if (X < 0 || X >= size || Y < 0 || Y >= size) continue;              // wave-uniform
+#ifdef K2_EXP_SKIPZ
+        if (max(abs(X - x1), abs(Y - y1)) <= K2_EXP_SKIPZ) continue;         // EXPERIMENT (wrong results)
+#endif
         k2_wave_pixel(X, Y, x1, y1, size, byidx, vprof, n_rays, cand, start, map, alpha, sval[wv]);
     }
+    K2_STAMP(2)
     // (2) the rest of the bounding square: one lane per pixel, a wavefront takes 64 pixels of one row
     const int tiles_x = (X1 - X0 + 64) / 64, items = R > 0 ? tiles_x * (Y1 - Y0 + 1) : 0;
-    for (int item = gw; item < items; item += nw) {
+    for (;;) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&s_next_item, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const int item = blockIdx.x + k * gridDim.x;
+        if (item >= items) break;
         const int row = item / tiles_x, tx = item - row * tiles_x;
         const int X = X0 + tx * 64 + lane, Y = Y0 + row;
         if (X > X1) continue;
         const int dx = X - x1, dy = Y - y1;
         if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K2_ZONE) continue;     // (1)'s pixels
+        const int ptr = Y * size + X;
+        const uint16_t pix_in = map[ptr];                          // requested now, needed after the search (no other lane touches this pixel)
         int cls[2], a[2], b[2];
         const int ncls = rs_classes(dx, dy, cls, a, b);
         int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh = 0;
@@ -440,12 +475,11 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
             }
             if (overflow) break;
         }
-        const int ptr = Y * size + X;
         if (overflow) {
             const int slot = __hip_atomic_fetch_add(&counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (slot < cap_conflict) __hip_atomic_store(&conflict_pix[slot], ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (nh > 0) {
-            uint16_t pix = map[ptr];
+            uint16_t pix = pix_in;
 #pragma unroll
             for (int s = 0; s < K2_MAXHIT; s++) if (s < nh) pix = k2_blend(pix, hval[s], alpha);
             map[ptr] = pix;
@@ -454,14 +488,17 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
     // (3) pixels with more than K2_MAXHIT hits, queued by (2): the last workgroup to finish draws them, one wavefront
     //     per pixel.  Queue entries are published write-through and the count is an agent-scope atomic; every wave
     //     drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
+    K2_STAMP(3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    K2_STAMP(4)
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(&counters[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = old == (int)gridDim.x - 1;
         if (s_last) __hip_atomic_store(&counters[6], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    K2_STAMP(5)
     if (!s_last) return;
     int n_conf = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n_conf > cap_conflict) n_conf = cap_conflict;
@@ -508,12 +545,46 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
     hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
                        hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6);
-#define K2_PIXELS(L, T) hipLaunchKernelGGL((k2_pixels<L, T>), dim3(512), dim3(1024), 0, ctx->stream, (const k2_byidx *)cs->d_rays, \
+    // One round of resident workgroups (a second round would start when the first drains: measured 51 -> 42 us at
+    // 2048^2 together with the per-workgroup work counter): what the occupancy calculator says fits, times the CUs.
+    static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
+#define K2_PIXELS(L, T) {                                                                                                   \
+        static int per_cu = 0;                                                                                              \
+        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2_pixels<L, T>, 1024, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;                                                              \
+        const int grid = grid_env > 0 ? grid_env : (L ? 1 : per_cu < 2 ? per_cu : 2) * cus;   /* (with the LDS table one workgroup per CU measured best) */ \
+        static bool told = false;                                                                                           \
+        if (!told && getenv("SLAMHIP_K2_STATS")) { told = true; fprintf(stderr, "[slamhip] K2 pixel kernel: %d workgroups (%d per CU x %d CUs)\n", grid, per_cu, ctx->num_cus); } \
+        hipLaunchKernelGGL((k2_pixels<L, T>), dim3(grid), dim3(1024), 0, ctx->stream, (const k2_byidx *)cs->d_rays,        \
                            (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
-                           cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict)
-    if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int); else K2_PIXELS(true, long long); }
-    else                  { if (cs->hs <= 16384) K2_PIXELS(false, int); else K2_PIXELS(false, long long); }
+                           cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict); }
+    if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }
+    else                  { if (cs->hs <= 16384) K2_PIXELS(false, int) else K2_PIXELS(false, long long) }
 #undef K2_PIXELS
     SH_HIP(hipGetLastError());
+#ifdef K2_TIMES
+    {
+        static int calls = 0;
+        if (++calls == 12) {
+            (void)hipStreamSynchronize(ctx->stream);
+            std::vector<unsigned long long> h(512 * 8);
+            (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_k2_times), sizeof(unsigned long long) * h.size());
+            // (the symbol is zeroed after the dump: only the workgroups of this launch have stamps)
+            unsigned long long t0 = ~0ull, t1 = 0;
+            int nb = 0;
+            for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8]) { nb++; t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 5]); }
+            static const char *nm[5] = { "tables", "zone", "outer", "drain", "ticket" };
+            double acc[5] = { 0 }, mx[5] = { 0 }, smax = 0;
+            for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8]) {
+                for (int k = 0; k < 5; k++) { const double d = (double)(h[i * 8 + k + 1] - h[i * 8 + k]) * 0.01; acc[k] += d; mx[k] = std::max(mx[k], d); }
+                smax = std::max(smax, (double)(h[i * 8] - t0) * 0.01);
+            }
+            fprintf(stderr, "[k2 times] %d workgroups, span %.2f us; first thread of each workgroup, mean (max):", nb, (double)(t1 - t0) * 0.01);
+            for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f (%.2f) |", nm[k], acc[k] / std::max(nb, 1), mx[k]);
+            fprintf(stderr, " last workgroup starts at %.2f us\n", smax);
+        }
+        if (calls == 11) { std::vector<unsigned long long> z(512 * 8, 0ull); (void)hipStreamSynchronize(ctx->stream); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2_times), z.data(), sizeof(unsigned long long) * z.size()); }
+    }
+#endif
     return SLAMHIP_OK;
 }
