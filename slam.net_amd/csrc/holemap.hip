@@ -302,7 +302,8 @@ __device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int si
     int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
     const int ncls = rs_classes(dx, dy, cls, a, b);
     int nc = 0;
-    for (int k = 0; k < ncls; k++) { rs_range(start, cls[k], a[k], b[k], lo[k], hi[k]); nc += hi[k] - lo[k]; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) if (k < ncls) { rs_range(start, cls[k], a[k], b[k], 0.0f, lo[k], hi[k]); nc += hi[k] - lo[k]; }
     uint16_t pix = map[ptr];
     bool stable = false;
     int last_v = 0;
@@ -457,7 +458,7 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
         bool overflow = false;
         for (int k = 0; k < ncls; k++) {
             int lo, hi;
-            rs_range(start, cls[k], a[k], b[k], lo, hi);
+            rs_range(start, cls[k], a[k], b[k], 0.0f, lo, hi);
             for (int ci = lo; ci < hi; ci++) {
                 const k2_cand c = cand[ci];
                 if (!k2_hit<T>(c, a[k], b[k])) continue;

@@ -3,7 +3,7 @@
 // A Bresenham-type walk from a common start cell takes, at its i-th step, i cells along its major axis and
 // m(i) cells along the minor one with |m(i) - slope * i| <= 1/2 (slope = minor length / major length): a cell at
 // major offset a and signed minor offset b can only be drawn by lines of its direction class (major axis and its
-// sign) whose signed slope lies in [(b - 1) / a, (b + 1) / a].  Lines are counting-sorted by (class, slope bucket),
+// sign) whose signed slope lies in [(b - 1/2) / a, (b + 1/2) / a].  Lines are counting-sorted by (class, slope bucket),
 // so the candidates of a cell are one contiguous range of that table; the exact closed-form test follows.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,13 +18,15 @@ __device__ static inline int rs_bucket(float t)
 // direction class of a line: 0 E, 1 W (x major), 2 S, 3 N (y major)
 __device__ static inline int rs_class(bool major_x, int smaj) { return major_x ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3); }
 
-// candidate range of cell (a, b) in one class (+- one bucket for the float arithmetic of the bucket function)
-__device__ static inline void rs_range(const int *start, int cls, int a, int b, int &lo, int &hi)
+// candidate range of cell (a, b) in one class.  The walks take their m-th minor step where slope * i passes m - 1/2
+// (K2: m(i) = ceil(slope * i - 1/2), CoreSLAMProcessor.cs:394-441; K5: m(i) = floor((da / 2 + i * db) / da),
+// OccGridMap.cs:220-239, whose integer da / 2 adds up to 1 / (2 da) <= 1 / (2 a) to slope * i -- `extra`, in slope units), so a
+// line that draws (a, b) has its signed slope in [(b - 1/2) / a - extra, (b + 1/2) / a + extra].  The margin covers the
+// float roundings of this range and of the slopes the lines were bucketed with (each below 2e-7; a bucket is 2e-3 wide).
+__device__ static inline void rs_range(const int *start, int cls, int a, int b, float extra, int &lo, int &hi)
 {
-    const float ra = 1.0f / (float)a;
-    int blo = rs_bucket((float)(b - 1) * ra) - 1, bhi = rs_bucket((float)(b + 1) * ra) + 1;
-    if (blo < 0) blo = 0;
-    if (bhi > RS_NBUCK - 1) bhi = RS_NBUCK - 1;
+    const float ra = 1.0f / (float)a, m = extra + 4.0e-6f;
+    const int blo = rs_bucket(((float)b - 0.5f) * ra - m), bhi = rs_bucket(((float)b + 0.5f) * ra + m);
     lo = start[cls * RS_NBUCK + blo];
     hi = start[cls * RS_NBUCK + bhi + 1];
 }
