@@ -820,8 +820,9 @@ extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3]
             for (int l = 0; l < hs->n_levels; l++) tot += (double)hs->lv[l].w * hs->lv[l].h;
             int first = 0;
             for (int l = 0; l < hs->n_levels; l++) {
-                int k = (int)(512.0 * ((double)hs->lv[l].w * hs->lv[l].h) / tot);
-                if (k < 64) k = 64;
+                static const int wgs_env = getenv("SLAMHIP_K5_WGS") ? atoi(getenv("SLAMHIP_K5_WGS")) : 512;
+                int k = (int)((double)wgs_env * ((double)hs->lv[l].w * hs->lv[l].h) / tot);
+                if (k < wgs_env / 8) k = wgs_env / 8;
                 A.lv[l].wg0 = first; A.lv[l].wgn = k;
                 first += k;
             }
