@@ -1,6 +1,7 @@
 // coreslam.hip -- CoreSLAM operator-level entry points of include/slamhip.h (gfx950 only).
 #include "cs_internal.h"
 #include "det_trig.h"
+#include "obstacle_dev.h"
 #include <algorithm>
 #include <numeric>
 #include <math.h>
@@ -762,8 +763,17 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     if (!cs->k1_pose_written)                                    // (fallback search kernels: decode the key in a launch of its own)
         hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
                            cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);
-    SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality));   // :750
-    SH_TRY(cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits));             // :751
+    // :750-751 -- the two maps are independent: the ObstacleMap update's ray walks and cell pass ride on the HoleMap
+    // update's two launches as extra workgroups (two dependent launches less per scan); with per-kernel timing on, each
+    // update keeps its own launches so that the timers mean what they say
+    if (ctx->timing == 0) {
+        k3_ride ride;
+        cs_obstacle_ride(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits, &ride);
+        SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality, &ride));
+    } else {
+        SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality));
+        SH_TRY(cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits));
+    }
     float *hp = (float *)(cs->h_key + 1);
     SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, 32, hipMemcpyDeviceToHost, ctx->stream));
     SH_HIP(hipStreamSynchronize(ctx->stream));

@@ -88,7 +88,9 @@ int32_t cs_holemap_alloc(slamhip_cs *cs);
 void    cs_holemap_free(slamhip_cs *cs);
 int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality, int32_t max_hits);
 int32_t cs_update_maps_finish(slamhip_cs *cs);
-int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float hole_width, int quality);
+struct k3_ride;
+int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float hole_width, int quality, const k3_ride *ride = nullptr);
+void cs_obstacle_ride(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, int max_hits, k3_ride *out);
 // obstacle.hip
 int32_t cs_obstacle_alloc(slamhip_cs *cs);
 void    cs_obstacle_free(slamhip_cs *cs);

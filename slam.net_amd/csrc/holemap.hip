@@ -27,6 +27,7 @@
 #include "cs_internal.h"
 #include "det_trig.h"
 #include "raster.h"
+#include "obstacle_dev.h"
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
@@ -220,8 +221,13 @@ __device__ static inline bool k2_hit(const k2_cand c, int a, int b)
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
            k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, int *__restrict__ start,
-           int *__restrict__ counters, int *__restrict__ total_out)
+           int *__restrict__ counters, int *__restrict__ total_out, const k3_ride ride)
 {
+    if (blockIdx.x > 0) {                                          // riding along: the ray walks of the ObstacleMap update
+        k3_rays_unit((blockIdx.x - 1) * 16 + (threadIdx.x >> 6), threadIdx.x & 63, ride.pts, ride.n_points, ride.size, ride.scale,
+                     ride.d_pose, ride.h_pxcs, ride.hits, ride.nohit, ride.chunks_per_ray);
+        return;
+    }
     __shared__ int hist[4 * K2_NBUCK];
     __shared__ int wsum[16];
     __shared__ int s_R, s_total;
@@ -397,8 +403,12 @@ template <bool LDS_TABLE, typename T>
 __global__ void __launch_bounds__(1024)
 k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g, int n_rays,
           const int *__restrict__ start_g, int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
-          int *__restrict__ conflict_pix, int cap_conflict)
+          int *__restrict__ conflict_pix, int cap_conflict, int n_pix_wgs, const k3_ride ride)
 {
+    if ((int)blockIdx.x >= n_pix_wgs) {                            // riding along: the cell pass of the ObstacleMap update
+        k3_apply_cell(((int)blockIdx.x - n_pix_wgs) * 1024 + threadIdx.x, ride.map, ride.n_cells, ride.hits, ride.nohit, ride.max_hits);
+        return;
+    }
     __shared__ int start[4 * K2_NBUCK + 1];
     __shared__ __attribute__((aligned(16))) k2_cand cand_s[LDS_TABLE ? K2_LDS_RAYS : 1];
     __shared__ int sval[16][64];
@@ -427,7 +437,7 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
         int k = 0;
         if (lane == 0) k = atomicAdd(&s_next_zone, 1);
         k = __builtin_amdgcn_readfirstlane(k);
-        const int item = blockIdx.x + k * gridDim.x;
+        const int item = blockIdx.x + k * n_pix_wgs;
         if (item >= n_zone) break;
         const int X = x1 - Z + item % side, Y = y1 - Z + item / side;
         if (X < 0 || X >= size || Y < 0 || Y >= size) continue;              // wave-uniform
@@ -443,7 +453,7 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
         int k = 0;
         if (lane == 0) k = atomicAdd(&s_next_item, 1);
         k = __builtin_amdgcn_readfirstlane(k);
-        const int item = blockIdx.x + k * gridDim.x;
+        const int item = blockIdx.x + k * n_pix_wgs;
         if (item >= items) break;
         const int row = item / tiles_x, tx = item - row * tiles_x;
         const int X = X0 + tx * 64 + lane, Y = Y0 + row;
@@ -495,7 +505,7 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
     K2_STAMP(4)
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(&counters[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == (int)gridDim.x - 1;
+        s_last = old == n_pix_wgs - 1;
         if (s_last) __hip_atomic_store(&counters[6], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -527,8 +537,13 @@ void cs_holemap_free(slamhip_cs *cs)
     (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_conflict_pix);
 }
 
-int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, float hole_width, int quality)
+// ride != nullptr: the ObstacleMap update (prepared by cs_obstacle_ride) travels in the same two launches
+int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, float hole_width, int quality, const k3_ride *ride_in)
 {
+    k3_ride ride;
+    if (ride_in) ride = *ride_in; else memset(&ride, 0, sizeof(ride));
+    const int ride_rays = ride.n_blocks ? sh_div_up(ride.n_points * ride.chunks_per_ray, 16) : 0;
+    const int ride_cells = ride.n_blocks ? sh_div_up(ride.n_cells, 1024) : 0;
     slamhip_ctx *ctx = cs->ctx;
     const int n = cs->n_points;
     if (n <= 0) return SLAMHIP_OK;
@@ -544,8 +559,8 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         cs->cap_rays = cap;
     }
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
-    hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6);
+    hipLaunchKernelGGL(k2_prepare, dim3(1 + ride_rays), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
+                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, ride);
     // One round of resident workgroups (a second round would start when the first drains: measured 51 -> 42 us at
     // 2048^2 together with the per-workgroup work counter): what the occupancy calculator says fits, times the CUs.
     static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
@@ -556,9 +571,9 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         const int grid = grid_env > 0 ? grid_env : (L ? 1 : per_cu < 2 ? per_cu : 2) * cus;   /* (with the LDS table one workgroup per CU measured best) */ \
         static bool told = false;                                                                                           \
         if (!told && getenv("SLAMHIP_K2_STATS")) { told = true; fprintf(stderr, "[slamhip] K2 pixel kernel: %d workgroups (%d per CU x %d CUs)\n", grid, per_cu, ctx->num_cus); } \
-        hipLaunchKernelGGL((k2_pixels<L, T>), dim3(grid), dim3(1024), 0, ctx->stream, (const k2_byidx *)cs->d_rays,        \
+        hipLaunchKernelGGL((k2_pixels<L, T>), dim3(grid + ride_cells), dim3(1024), 0, ctx->stream, (const k2_byidx *)cs->d_rays, \
                            (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
-                           cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict); }
+                           cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }
     if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }
     else                  { if (cs->hs <= 16384) K2_PIXELS(false, int) else K2_PIXELS(false, long long) }
 #undef K2_PIXELS

@@ -13,72 +13,30 @@
 // then applies hits + decay and clears the per-scan scratch.
 #include "cs_internal.h"
 #include "det_trig.h"
+#include "obstacle_dev.h"
 
 __global__ void __launch_bounds__(256)
 k3_rays(const float2 *__restrict__ pts, int n_points, int size, float scale, const float *d_pose, float4 h_pxcs,
         uint32_t *__restrict__ hits, uint8_t *__restrict__ nohit, int chunks_per_ray)
 {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);             // (ray, chunk), wave-uniform
-    const int ray = w / chunks_per_ray, chunk = w - ray * chunks_per_ray;
-    if (ray >= n_points) return;
-    float4 q = h_pxcs;
-    if (d_pose) {
-        float s, c;
-        sh_det_sincosf(d_pose[2], &s, &c);
-        q.x = d_pose[0] * scale + 0.5f;                                    // :545
-        q.y = d_pose[1] * scale + 0.5f;                                    // :546
-        q.z = c * scale;                                                   // :547
-        q.w = s * scale;                                                   // :548
-    }
-    const int x1 = sh_f2i(q.x), y1 = sh_f2i(q.y);                          // :553-554
-    if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;              // :557-560
-    const float2 p = pts[ray];
-    float fx = q.x + q.z * p.x;  fx = fx - q.w * p.y;                      // :566
-    float fy = q.y + q.w * p.x;  fy = fy + q.z * p.y;                      // :567
-    const int x2 = sh_f2i(fx), y2 = sh_f2i(fy);
-    const int ddx = sh_wsub(x2, x1), ddy = sh_wsub(y2, y1);
-    if (ddx == INT32_MIN || ddy == INT32_MIN) return;                      // Math.Abs overflow (throws in C#)
-    const int dx = sh_abs(ddx), sx = sh_sign(ddx);                         // :458
-    const int dy = sh_abs(ddy), sy = sh_sign(ddy);                         // :459
-    const long long n = dx > dy ? dx : dy;                                 // iterations to the end point
-    const long long i = (long long)chunk * 64 + (threadIdx.x & 63);
-    // the part of the walk that can lie in the map is shorter than 2 * size iterations (host: chunks_per_ray)
-    if (i > n) return;
-    long long ax, ay;                                                      // steps taken along x / y before iteration i
-    if (dx > dy) {
-        const long long num = i * dy - dx / 2;                             // err0 = dx / 2 (:460)
-        ax = i; ay = num <= 0 ? 0 : (num + dx - 1) / dx;
-    } else {
-        const long long num = i * dx - dy / 2;                             // err0 = -dy / 2 = -(dy / 2) in C#
-        ay = i; ax = (num <= 0 || dy == 0) ? 0 : (num + dy - 1) / dy;
-    }
-    const long long X = x1 + sx * ax, Y = y1 + sy * ay;
-    if (X < 0 || X >= size || Y < 0 || Y >= size) return;                  // :465-469 (everything after it is outside too)
-    const int idx = (int)Y * size + (int)X;
-    if (i == n) atomicAdd(&hits[idx], 1u);                                 // :471-477 (applied in k3_apply)
-    else nohit[idx] = 1;                                                   // :483
+    k3_rays_unit(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, pts, n_points, size, scale, d_pose, h_pxcs, hits, nohit, chunks_per_ray);
 }
 
 __global__ void __launch_bounds__(256)
 k3_apply(int8_t *__restrict__ map, int n_cells, uint32_t *__restrict__ hits, uint8_t *__restrict__ nohit, int max_hits)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cells) return;
-    const uint32_t h = hits[i];
-    const uint8_t nh = nohit[i];
-    if (h == 0 && nh == 0) return;
-    int v = map[i];
-    if (h) {
-        const int m = (int)(int8_t)max_hits;                               // sbyte MaxObstacleHits (:101)
-        if (v < m) { const int room = m - v; v += (h < (uint32_t)room) ? (int)h : room; }   // :474-477, k times
-        hits[i] = 0;
-    }
-    if (nh) {
-        if (v < 0) v++;                                                    // :582-585
-        else if (v > 0) v--;                                               // :586-589
-        nohit[i] = 0;                                                      // next scan's ArrayEx.Fill(noHitMap,false) :542
-    }
-    map[i] = (int8_t)v;
+    k3_apply_cell(blockIdx.x * blockDim.x + threadIdx.x, map, n_cells, hits, nohit, max_hits);
+}
+
+// the same update as extra workgroups of the two HoleMap launches (holemap.hip)
+void cs_obstacle_ride(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, int max_hits, k3_ride *r)
+{
+    memset(r, 0, sizeof(*r));
+    if (cs->n_points <= 0) return;
+    r->pts = cs->d_pts; r->n_points = cs->n_points; r->size = cs->os; r->scale = cs->oscale; r->d_pose = d_pose; r->h_pxcs = h_pxcs;
+    r->hits = cs->d_o_hits; r->nohit = cs->d_o_nohit; r->chunks_per_ray = sh_div_up(cs->os + 1, 64);
+    r->map = cs->d_obst; r->n_cells = cs->os * cs->os; r->max_hits = max_hits;
+    r->n_blocks = 1;                                               // (the launches size their extra workgroups from the fields above)
 }
 
 int32_t cs_obstacle_alloc(slamhip_cs *cs)
