@@ -47,6 +47,7 @@ struct slamhip_hs {
     float odds_free, odds_occ, lo_free, lo_occ;          // OccGridMap.cs:24-27
     int n_points, cap_points;
     float2 *d_pts; float origin[2];
+    float *h_pts; hipEvent_t ev_pts; bool pts_in_flight;   // pinned staging of the scan: one async copy, no wait in set_scan
     float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
     // K5 line tables, per level: lines by index, lines sorted by (direction class, slope bucket), bucket starts, header
     void *d_k5_byidx, *d_k5_cand; int *d_k5_start, *d_k5_hdr; int cap_lines;
@@ -511,6 +512,8 @@ extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
         (void)hipFree(hs->lv[l].d_value); (void)hipFree(hs->lv[l].d_upd);
     }
     (void)hipFree(hs->d_pts); (void)hipFree(hs->d_io);
+    if (hs->h_pts) (void)hipHostFree(hs->h_pts);
+    if (hs->ev_pts) (void)hipEventDestroy(hs->ev_pts);
     (void)hipFree(hs->d_k5_byidx); (void)hipFree(hs->d_k5_cand); (void)hipFree(hs->d_k5_start); (void)hipFree(hs->d_k5_hdr);
     if (hs->h_io) (void)hipHostFree(hs->h_io);
     free(hs);
@@ -695,17 +698,27 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
 {
     SH_CHECK_ARG(hs && n >= 0 && (xy || n == 0));
     SH_HIP(hipSetDevice(hs->ctx->device));
-    hs->n_points = n;
     hs->origin[0] = origin ? origin[0] : 0.0f;
     hs->origin[1] = origin ? origin[1] : 0.0f;
+    hs->n_points = 0;                                  // (stays "no scan" if anything below fails)
     if (n == 0) return SLAMHIP_OK;
     if (n > hs->cap_points) {
+        SH_HIP(hipStreamSynchronize(hs->ctx->stream));
         (void)hipFree(hs->d_pts); hs->d_pts = nullptr; hs->cap_points = 0;
-        SH_HIP(hipMalloc(&hs->d_pts, sizeof(float2) * (size_t)(n + n / 4 + 64)));
-        hs->cap_points = n + n / 4 + 64;
+        if (hs->h_pts) { (void)hipHostFree(hs->h_pts); hs->h_pts = nullptr; }
+        const int cap = n + n / 4 + 64;
+        SH_HIP(hipMalloc(&hs->d_pts, sizeof(float2) * (size_t)cap));
+        SH_HIP(hipHostMalloc(&hs->h_pts, sizeof(float2) * (size_t)cap));
+        if (!hs->ev_pts) SH_HIP(hipEventCreateWithFlags(&hs->ev_pts, hipEventDisableTiming));
+        hs->cap_points = cap;
+        hs->pts_in_flight = false;
     }
-    SH_HIP(hipMemcpyAsync(hs->d_pts, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, hs->ctx->stream));
-    SH_HIP(hipStreamSynchronize(hs->ctx->stream));
+    if (hs->pts_in_flight) { SH_HIP(hipEventSynchronize(hs->ev_pts)); hs->pts_in_flight = false; }   // the previous copy has left the staging block
+    memcpy(hs->h_pts, xy, sizeof(float) * 2 * (size_t)n);
+    SH_HIP(hipMemcpyAsync(hs->d_pts, hs->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, hs->ctx->stream));
+    SH_HIP(hipEventRecord(hs->ev_pts, hs->ctx->stream));
+    hs->pts_in_flight = true;
+    hs->n_points = n;
     return SLAMHIP_OK;
 }
 
