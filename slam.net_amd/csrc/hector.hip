@@ -106,8 +106,12 @@ __device__ static inline double hs_wave_sum(double v)
 
 // GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) broadcast in sums[].
 // order: dTr.x, dTr.y, dTr.z, H11, H22, H33, H12, H13, H23
+// PRE: the thread's (at most HS_PRE) points are already in registers (pre[]): the scan does not change between the
+// iterations of a match, and the point load heads a chain of two dependent memory round trips (point -> four taps).
+#define HS_PRE 2
+template <bool PRE>
 __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__restrict__ pts, int n, const float pose[3],
-                                        double *red /* [16*9 + 9] LDS */, float sums[9])
+                                        double *red /* [16*9 + 9] LDS */, float sums[9], const float2 *pre = nullptr)
 {
     const sh_m3x2 t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]),
                                               sh_m3x2_translation(pose[0] * L.cell, pose[1] * L.cell)),
@@ -116,8 +120,10 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
     sh_det_sincosf(pose[2], &s, &c);
     const float sinRot = s * L.stm, cosRot = c * L.stm;                    // :145-146
     float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float2 p = pts[i];
+#pragma unroll
+    for (int u = 0; u < (PRE ? HS_PRE : 1); u++)
+    for (int i = threadIdx.x + (PRE ? u * (int)blockDim.x : 0); i < n; i += PRE ? n : (int)blockDim.x) {
+        const float2 p = PRE ? pre[u] : pts[i];
         float mx, my, P, gx, gy;
         sh_v2_transform(p.x, p.y, t, &mx, &my);                            // :161
         hs_interp(L, mx, my, P, gx, gy);                                   // :162
@@ -175,6 +181,13 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
     const int b = blockIdx.x;
     float est_w[3] = { hint1.x, hint1.y, hint1.z };                         // :43 (a single hint travels in the launch arguments)
     if (hints) { est_w[0] = hints[3 * b]; est_w[1] = hints[3 * b + 1]; est_w[2] = hints[3 * b + 2]; }
+    const bool pre_ok = n <= HS_PRE * (int)blockDim.x;
+    float2 pre[HS_PRE];
+#pragma unroll
+    for (int u = 0; u < HS_PRE; u++) {
+        const int i = threadIdx.x + u * (int)blockDim.x;
+        pre[u] = (pre_ok && i < n) ? pts[i] : make_float2(0.f, 0.f);
+    }
     if (n > 0) {                                                           // :66 (else: hint returned, :83)
         const int l_hi = only_level >= 0 ? only_level : A.n - 1;
         const int l_lo = only_level >= 0 ? only_level : 0;
@@ -186,7 +199,8 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
             const int iters = only_level >= 0 ? iters_override : L.iterations;
             for (int it = 0; it < iters; it++) {                           // :70-73
                 float sums[9];
-                hs_hessian_block(L, pts, n, est, red, sums);
+                if (pre_ok) hs_hessian_block<true>(L, pts, n, est, red, sums, pre);
+                else hs_hessian_block<false>(L, pts, n, est, red, sums);
                 hs_step(sums, est);
             }
             est[2] = sh_normalize_angle(est[2]);                           // :76
@@ -204,7 +218,7 @@ k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, co
     __shared__ double red[16 * 9 + 9];
     float pose[3] = { pose_in[0], pose_in[1], pose_in[2] };
     float sums[9];
-    hs_hessian_block(A.lv[level], pts, n, pose, red, sums);
+    hs_hessian_block<false>(A.lv[level], pts, n, pose, red, sums);
     if (threadIdx.x == 0) {
         out12[0] = sums[3]; out12[1] = sums[6]; out12[2] = sums[7];
         out12[3] = sums[6]; out12[4] = sums[4]; out12[5] = sums[8];
