@@ -49,7 +49,8 @@ __device__ static inline void k_jitter(int i, int n, float sigma_xy, float sigma
     const float rad = sqrtf(-2.0f * logf(u1));
     float sn, cs;
     sincosf(6.28318530718f * u2, &sn, &cs);
-    const float q = ((float)i + u3) / (float)n;
+    // (the top stratum's quantile can round to 1.0f, whose normal quantile is +inf: keep it below)
+    const float q = fminf(((float)i + u3) / (float)n, 0.99999994f);
     o[0] = sigma_xy * rad * cs;
     o[1] = sigma_xy * rad * sn;
     o[2] = sigma_theta * normcdfinvf(q);

@@ -172,6 +172,14 @@ def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
         keys = [dev.search_shard(base, K * r // n, K * (r + 1) // n - K * r // n) for r in range(n)]
         p2, d2, i2 = dev.pose_from_key(base, min(keys))
         assert i2 == rbi and d2 == rbd and (p2 == rpose).all()
+    # a list that is searched before anyone reads it is produced inside the search's gather launch: same list, same answer
+    dev.generate_offsets(K - 1, 0.07, math.radians(6.0), seed=11, stream=5)
+    pose, dist, idx = dev.search(base)
+    goffs2 = dev.offsets_download()
+    dev.generate_offsets(K - 1, 0.07, math.radians(6.0), seed=11, stream=5)
+    assert (dev.offsets_download() == goffs2).all() and not (goffs2 == goffs).all()
+    rbi, rpose, rbd, _ = oc.search(pix, size, scale, xy, base, goffs2)
+    assert idx == rbi and dist == rbd and (pose == rpose).all()
     assert dev.selfcheck_failures == 0
     dev.close()
 

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU + CPU oracle): random map sizes, poses (also at and beyond the map edge), ray counts, hole
+widths, candidate lists and Hector pyramids; every integer output must equal the oracle's bit for bit, Hector match poses
+within 1e-4.  Prints one line per case and a summary; exit code 1 on the first mismatch.
+
+    python tools/fuzz_parity.py [--seconds 120 --seed 1]
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))          # test infrastructure: the checker
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dump", default="", help="npz file for the inputs and device outputs of a failing map case")
+    a = ap.parse_args()
+    import oracle_c as oc
+    import slam.net_amd.coreslam as cs
+    import slam.net_amd.hector as hs
+    import slam.net_amd.sim as sim
+    oc.set_trig_mode(oc.TRIG_DET)
+    rng = np.random.default_rng(a.seed)
+    segs = sim.default_field()
+    ctx = cs.Context(0)
+    t_end = time.time() + a.seconds
+    n_cases = 0
+    while time.time() < t_end:
+        n_cases += 1
+        kind = n_cases % 3
+        if kind in (0, 1):
+            size = int(rng.choice([64, 120, 256, 400, 513, 1024, 1536, 2048]))
+            osize = int(rng.choice([16, 64, 100, 256]))
+            R = int(rng.choice([1, 7, 90, 360, 1080, 2500]))
+            hw = float(rng.choice([0.1, 0.6, 2.0, 5.0]))
+            q = int(rng.choice([1, 50, 128, 255]))
+            dev = cs.CoreSlamDevice(ctx, 40.0, size, osize)
+            ref = np.full(size * size, 32750, np.uint16)
+            oref = np.full(osize * osize, -5, np.int8)
+            prng = sim.PCG32(int(rng.integers(1, 1 << 30)))
+            pose = np.array([rng.uniform(4, 36), rng.uniform(4, 36), rng.uniform(-7, 7)], np.float32)
+            if rng.random() < 0.15:
+                pose[0] = rng.choice([-0.3, 0.0, 39.99, 40.2])         # robot at / beyond the map edge
+            ok = True
+            why = []
+            trace = []
+            for it in range(int(rng.integers(1, 5))):
+                p = (pose + np.array([0.1 * it, -0.05 * it, 0.02 * it], np.float32)).astype(np.float32)
+                inside = 5.5 < p[0] < 34.5 and 5.5 < p[1] < 34.5
+                if inside:
+                    rays, xy = sim.make_scan(segs, p, R, prng)
+                else:
+                    ang = rng.uniform(-np.pi, np.pi, R); rad = rng.uniform(0.01, 30.0, R)
+                    xy = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1).astype(np.float32)
+                if rng.random() < 0.3:
+                    xy = xy[rng.permutation(xy.shape[0])]                # ray order matters for the blend
+                if xy.shape[0] == 0:
+                    continue
+                trace.append((xy.copy(), p.copy()))
+                dev.set_scan(xy)
+                dev.update_holemap(p, hw, q)
+                dev.update_obstaclemap(p, 10)
+                n = oc.update_holemap(ref, size, dev.hole_scale, xy, p, hw, q)
+                oc.update_obstaclemap(oref, osize, dev.obst_scale, xy, p, 10)
+                if dev.last_holemap_pixels != n:
+                    ok = False; why.append("pixel count %d vs %d at update %d" % (dev.last_holemap_pixels, n, it))
+            got = dev.holemap_download()
+            gob = dev.obstaclemap_download().ravel()
+            if not (got == ref).all():
+                bad = np.flatnonzero(got != ref)
+                ok = False; why.append("holemap: %d pixels differ, first %s got %s want %s" % (bad.size, [(int(b) % size, int(b) // size) for b in bad[:4]], got[bad[:4]], ref[bad[:4]]))
+            if not (gob == oref).all():
+                bad = np.flatnonzero(gob != oref)
+                ok = False; why.append("obstaclemap: %d cells differ, first %s got %s want %s" % (bad.size, [(int(b) % osize, int(b) // osize) for b in bad[:4]], gob[bad[:4]], oref[bad[:4]]))
+            desc = "maps size %d/%d rays %d hw %.1f q %d pose %s" % (size, osize, R, hw, q, np.round(pose, 2))
+            if ok and kind == 1 and xy.shape[0] > 0:
+                K = int(rng.choice([2, 300, 1025, 4096, 20000, 70000]))
+                sxy, sth = float(rng.choice([0.02, 0.1, 0.5])), float(rng.choice([0.01, 0.17, 0.8, 3.0]))
+                base = (pose + np.array([0.03, -0.02, 0.017], np.float32)).astype(np.float32)
+                if rng.random() < 0.5:
+                    offs = sim.gaussian_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)))
+                    dev.set_offsets(offs)
+                    gp, gd, gi = dev.search(base)
+                else:
+                    dev.generate_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)), stream=n_cases)
+                    gp, gd, gi = dev.search_and_update(base, hw, q, 10)[:3] if rng.random() < 0.5 else dev.search(base)
+                    offs = dev.offsets_download()
+                rbi, rpose, rbd, _ = oc.search(got, size, dev.hole_scale, xy, base, offs)
+                ok = gi == rbi and gd == rbd and bool((np.asarray(gp)[:2] == rpose[:2]).all())
+                if not ok: why.append("search: got idx %d dist %d pose %s, oracle idx %d dist %d pose %s" % (gi, gd, gp, rbi, rbd, rpose))
+                ok = ok and dev.selfcheck_failures == 0
+                desc += " | search K %d sigma %.2f/%.2f -> idx %d dist %d" % (K, sxy, sth, gi, gd)
+            if why: desc += " || " + "; ".join(why)
+            if not ok and a.dump:
+                np.savez(a.dump, size=size, osize=osize, hw=hw, q=q, got=got, gob=gob, n_updates=len(trace),
+                         **{"xy%d" % i: t[0] for i, t in enumerate(trace)}, **{"p%d" % i: t[1] for i, t in enumerate(trace)})
+            dev.close()
+        else:
+            side = int(rng.choice([64, 200, 401, 1024]))
+            levels = int(rng.choice([1, 2, 3]))
+            cell = 40.0 / side
+            R = int(rng.choice([8, 180, 1080, 3000]))
+            rep = hs.MapRepMultiMap(cell, (side, side), levels, ctx=ctx)
+            ref = oc.make_pyramid(cell, side, side, levels)
+            prng = sim.PCG32(int(rng.integers(1, 1 << 30)))
+            pose = np.array([rng.uniform(8, 32), rng.uniform(8, 32), rng.uniform(-3, 3)], np.float32)
+            ok = True
+            for it in range(int(rng.integers(2, 6))):
+                p = (pose + np.array([0.06 * it, 0.03 * it, 0.01 * it], np.float32)).astype(np.float32)
+                rays, xy = sim.make_scan(segs, p, R, prng)
+                if xy.shape[0] == 0:
+                    continue
+                rep.UpdateByScan(hs.ScanCloud(xy), p)
+                for g in ref:
+                    g.update_by_scan(xy, p)
+            for l in range(levels):
+                c = rep.Maps[l].GetCells()
+                ok = ok and bool((c["update_index"] == ref[l].cells["update_index"]).all() and (c["value"] == ref[l].cells["value"]).all())
+                ok = ok and rep.Maps[l].GetMapExtends() == ref[l].map_extends()
+            hint = (p + np.array([0.05, -0.04, 0.02], np.float32)).astype(np.float32)
+            m = hs.ScanMatcher(4).MatchData(rep, hs.ScanCloud(xy), hint)
+            w = oc.match_pyramid(ref, xy, hint, [3] * levels, 4)
+            cells_ok = ok
+            # (a handful of rays gives a near-singular Hessian: the 1e-7 differences between summation orders -- the
+            # reference's own result depends on its thread count there -- are amplified without bound, so the match is
+            # only compared for scans that constrain the pose)
+            # The reference sums its fp32 terms thread chunk by thread chunk, so its own result moves with the thread
+            # count; that spread (oracle at 1 and 4 threads) is the floor of any comparison and is added to the tolerance.
+            # A match that runs away from its hint (coarse grids, few iterations) amplifies those differences from
+            # iteration to iteration and is not compared either.
+            if R >= 180 and math.hypot(w[0] - hint[0], w[1] - hint[1]) < 0.5 and abs(w[2] - hint[2]) < 0.1:
+                w1 = oc.match_pyramid(ref, xy, hint, [3] * levels, 1)
+                tol = 1e-4 + 10.0 * np.abs(w1 - w)
+                ok = ok and bool(np.all(np.abs(np.asarray(m) - w) < tol))
+            desc = "hector side %d levels %d rays %d pose %s" % (side, levels, R, np.round(pose, 2))
+            if not ok:
+                desc += " | cells equal: %s, match %s vs oracle %s (hint %s)" % (cells_ok, np.asarray(m), w, hint)
+            rep.close()
+        print(("ok   " if ok else "FAIL ") + desc, flush=True)
+        if not ok:
+            print("MISMATCH after %d cases (seed %d)" % (n_cases, a.seed))
+            sys.exit(1)
+    print("fuzz: %d cases, all equal to the oracle (seed %d)" % (n_cases, a.seed))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
