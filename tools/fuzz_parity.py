@@ -90,13 +90,38 @@ def main():
                     offs = sim.gaussian_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)))
                     dev.set_offsets(offs)
                     gp, gd, gi = dev.search(base)
+                    fused = False
                 else:
                     dev.generate_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)), stream=n_cases)
-                    gp, gd, gi = dev.search_and_update(base, hw, q, 10)[:3] if rng.random() < 0.5 else dev.search(base)
+                    fused = rng.random() < 0.5
+                    gp, gd, gi = dev.search_and_update(base, hw, q, 10)[:3] if fused else dev.search(base)
                     offs = dev.offsets_download()
-                rbi, rpose, rbd, _ = oc.search(got, size, dev.hole_scale, xy, base, offs)
+                rbi, rpose, rbd, rall = oc.search(got, size, dev.hole_scale, xy, base, offs)
                 ok = gi == rbi and gd == rbd and bool((np.asarray(gp)[:2] == rpose[:2]).all())
                 if not ok: why.append("search: got idx %d dist %d pose %s, oracle idx %d dist %d pose %s" % (gi, gd, gp, rbi, rbd, rpose))
+                if ok and fused:
+                    # the fused call also drew both maps from the winner's pose, theta normalised (:746-751)
+                    wp = np.array([rpose[0], rpose[1], oc.normalize_angle(float(rpose[2]))], np.float32)
+                    ok = bool((np.asarray(gp) == wp).all())
+                    n = oc.update_holemap(ref, size, dev.hole_scale, xy, wp, hw, q)
+                    oc.update_obstaclemap(oref, osize, dev.obst_scale, xy, wp, 10)
+                    ok = ok and dev.last_holemap_pixels == n and bool((dev.holemap_download() == ref).all()) \
+                        and bool((dev.obstaclemap_download().ravel() == oref).all())
+                    if not ok: why.append("fused update: maps or pose differ (pose %s vs %s)" % (gp, wp))
+                elif ok and K <= 4096:
+                    # every candidate's distance through the explicit-pose entry points, with a few hostile poses mixed in
+                    poses = np.vstack([base[None], base[None] + offs]).astype(np.float32)
+                    dd, bi, bd = dev.distance_poses(poses)
+                    ok = bool((dd == rall).all()) and bi == rbi and bd == rbd
+                    bad_poses = poses.copy()
+                    bad_poses[1 % K] = [np.nan, 1.0, 0.0]; bad_poses[K // 2] = [1e30, -1e30, 3.0]; bad_poses[K - 1] = [20.0, 20.0, np.inf]
+                    dd2 = dev.distance_poses(bad_poses)[0]
+                    keep = np.ones(K, bool); keep[[1 % K, K // 2, K - 1]] = False
+                    ok = ok and bool((dd2[keep] == rall[keep]).all())
+                    pxcs = np.stack([oc.pose_to_pxcs(pp, dev.hole_scale) for pp in poses[:256]])
+                    dd3 = dev.distance_pxcs(pxcs)[0]
+                    ok = ok and bool((dd3 == rall[:len(pxcs)]).all())
+                    if not ok: why.append("distance_poses / distance_pxcs differ")
                 ok = ok and dev.selfcheck_failures == 0
                 desc += " | search K %d sigma %.2f/%.2f -> idx %d dist %d" % (K, sxy, sth, gi, gd)
             if why: desc += " || " + "; ".join(why)
