@@ -106,7 +106,7 @@ __device__ static inline cs_ray k2_make_ray(const float2 p, int size, const floa
     const int xp = sh_f2i(px + x2p);                                       // :521
     const int yp = sh_f2i(py + y2p);                                       // :522
     // MathF.Sqrt is the IEEE square root.  (Not __fsqrt_rn: on this toolchain it lowers to the bare v_sqrt_f32, 1 ulp off
-    // for some inputs -- found by tools/fuzz_parity.py as a ray end one pixel out.  The binary64 square root of a binary32
+    // for some inputs -- found by tests/fuzz_parity.py as a ray end one pixel out.  The binary64 square root of a binary32
     // value, rounded once more to binary32, is the correctly rounded binary32 root: 53 >= 2 * 24 + 2.)
     const float dist = (float)sqrt((double)(x2p * x2p + y2p * y2p));       // :524
     const float add = __fdiv_rn(__fdiv_rn(hole_width * scale, 2.0f), dist); // :525

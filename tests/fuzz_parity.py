@@ -3,7 +3,7 @@
 widths, candidate lists and Hector pyramids; every integer output must equal the oracle's bit for bit, Hector match poses
 within 1e-4.  Prints one line per case and a summary; exit code 1 on the first mismatch.
 
-    python tools/fuzz_parity.py [--seconds 120 --seed 1]
+    python tests/fuzz_parity.py [--seconds 120 --seed 1]
 """
 import argparse
 import math

@@ -523,12 +523,12 @@ def test_bench_two_ranks_share_one_gpu():
 
 
 def test_fuzz_parity_short():
-    """Twenty seconds of tools/fuzz_parity.py (random sizes, poses at and beyond the map edge, 1 .. 2500 rays in random
+    """Twenty seconds of tests/fuzz_parity.py (random sizes, poses at and beyond the map edge, 1 .. 2500 rays in random
     order, hole widths, candidate lists with tiny to huge sigmas, Hector pyramids): everything equal to the oracle."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seconds", "20", "--seed", "12345"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "--seconds", "20", "--seed", "12345"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "all equal to the oracle" in out, out[-3000:]
