@@ -95,12 +95,18 @@ def main():
 
     key = torch.full((1,), -1, dtype=torch.int64, device="cuda")
     ext = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", local))
+    if world > 1:
+        torch.cuda.set_stream(ext)          # the collectives are enqueued on the library's stream, behind the search
+    # the per-step host path, bound once: one C call (the search launch) and, with N > 1, one collective
+    import ctypes as C
+    search_fn = capi.lib().slamhip_cs_search_shard_async
+    search_args = (dev._h, capi.fptr(base), int(first), int(count), C.c_void_p(key.data_ptr()))
+    assert key.dtype == torch.int64 and key.numel() == 1           # packed (distance << 32 | index): MIN on int64 is exact
 
     def step():
-        dev.search_shard_async(base, first, count, key.data_ptr())
+        capi.check(search_fn(*search_args))
         if world > 1:
-            with torch.cuda.stream(ext):
-                D.allreduce_min_key(key)                           # one 8-byte RCCL min all-reduce per step
+            dist.all_reduce(key, op=dist.ReduceOp.MIN)             # one 8-byte RCCL min all-reduce per step
 
     def sync_all():
         ctx.synchronize()
