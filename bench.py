@@ -165,7 +165,7 @@ def main():
             avg_s = (k1_ms / k1_n) * 1e-3
             achieved = a.cands * bytes_per_eval / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a),
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a), "peak_measured": measured_peak(),
                     "kernel": "k1_search_tiled", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
                     "bytes_per_launch": a.cands * bytes_per_eval}
         out = {
@@ -204,6 +204,16 @@ def pmc_traffic(a):
     except Exception:
         pass
     return None
+
+
+def measured_peak():
+    """Read bandwidth of a stream over 4 GiB on this box (tools/hbm_probe.py, committed as profiles/r01_hbm_probe.json):
+    the ceiling the hardware delivers, next to the 8 TB/s specification `peak` is quoted from.  GB/s or null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_probe.json")) as f:
+            return float(json.load(f)["4_GiB"]["sum_GBps_read"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(a, dev, xy, base, offs, gpu_key):

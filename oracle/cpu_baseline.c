@@ -63,6 +63,16 @@ double oracle_cpu_baseline_search(const uint16_t *pixels, int size, float scale,
                                   int n_threads, int iters, int n_scans,
                                   int64_t *out_evals, int32_t *out_best_index, int32_t *out_best_dist)
 {
+    return oracle_cpu_baseline_search_timed(pixels, size, scale, xy, n_points, search_pose, offs, n_threads, iters, n_scans,
+                                            out_evals, out_best_index, out_best_dist, NULL);
+}
+
+/* the same, with the wall time of every scan in scan_secs[n_scans] (median / p95 of the baseline) */
+double oracle_cpu_baseline_search_timed(const uint16_t *pixels, int size, float scale, const float *xy, int n_points,
+                                        const float search_pose[3], const float *offs,
+                                        int n_threads, int iters, int n_scans,
+                                        int64_t *out_evals, int32_t *out_best_index, int32_t *out_best_dist, double *scan_secs)
+{
     worker_t *ws = (worker_t *)calloc((size_t)n_threads, sizeof(worker_t));
     int32_t *dist = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_threads);
     int32_t *bl = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_threads);
@@ -78,6 +88,8 @@ double oracle_cpu_baseline_search(const uint16_t *pixels, int size, float scale,
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int sc = 0; sc < n_scans; sc++) {
+        struct timespec s0, s1;
+        if (scan_secs) clock_gettime(CLOCK_MONOTONIC, &s0);
         for (int i = 0; i < n_threads; i++) {                 /* Work(): enqueue + signal :102-111 */
             pthread_mutex_lock(&ws[i].mu);
             ws[i].has_work = 1; ws[i].done = 0;
@@ -96,6 +108,10 @@ double oracle_cpu_baseline_search(const uint16_t *pixels, int size, float scale,
                 /* flat index: 0 = base pose, 1 + thread*iters + (local-1) otherwise */
                 best_i = bl[i] == 0 ? 0 : 1 + i * iters + (bl[i] - 1);
             }
+        if (scan_secs) {
+            clock_gettime(CLOCK_MONOTONIC, &s1);
+            scan_secs[sc] = (double)(s1.tv_sec - s0.tv_sec) + 1e-9 * (double)(s1.tv_nsec - s0.tv_nsec);
+        }
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     for (int i = 0; i < n_threads; i++) {

@@ -162,6 +162,10 @@ double oracle_cpu_baseline_search(const uint16_t *pixels, int size, float scale,
                                   const float search_pose[3], const float *offs /* T*iters x 3 */,
                                   int n_threads, int iters_per_thread, int n_scans,
                                   int64_t *out_evals, int32_t *out_best_index, int32_t *out_best_dist);
+double oracle_cpu_baseline_search_timed(const uint16_t *pixels, int size, float scale, const float *xy, int n_points,
+                                  const float search_pose[3], const float *offs /* T*iters x 3 */,
+                                  int n_threads, int iters_per_thread, int n_scans,
+                                  int64_t *out_evals, int32_t *out_best_index, int32_t *out_best_dist, double *scan_secs);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,9 @@ def _declare(L):
     L.oracle_cpu_baseline_search.argtypes = [u16p, C.c_int, f, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(i64), ip, ip]
     L.oracle_cpu_baseline_search.restype = C.c_double
+    L.oracle_cpu_baseline_search_timed.argtypes = [u16p, C.c_int, f, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int,
+                                                   C.POINTER(i64), ip, ip, C.POINTER(C.c_double)]
+    L.oracle_cpu_baseline_search_timed.restype = C.c_double
 
 
 CELL_DTYPE = np.dtype([("update_index", np.int32), ("value", np.float32)])
@@ -403,3 +406,16 @@ def cpu_baseline_search(pixels, size, scale, xy, search_pose, offs, n_threads, i
                                             xy.shape[0], _p(sp, C.c_float), _p(offs, C.c_float),
                                             n_threads, iters, n_scans, C.byref(ev), C.byref(bi), C.byref(bd))
     return secs, ev.value, bi.value, bd.value
+
+
+def cpu_baseline_search_timed(pixels, size, scale, xy, search_pose, offs, n_threads, iters, n_scans):
+    """As cpu_baseline_search, plus the wall time of every scan (float64[n_scans])."""
+    xy = _f32(xy); sp = _f32(search_pose); offs = _f32(offs).reshape(-1, 3)
+    assert offs.shape[0] >= n_threads * iters
+    ev, bi, bd = C.c_int64(), C.c_int32(), C.c_int32()
+    per = np.zeros(n_scans, np.float64)
+    secs = lib().oracle_cpu_baseline_search_timed(_p(pixels, C.c_uint16), size, C.c_float(scale), _p(xy, C.c_float),
+                                                  xy.shape[0], _p(sp, C.c_float), _p(offs, C.c_float),
+                                                  n_threads, iters, n_scans, C.byref(ev), C.byref(bi), C.byref(bd),
+                                                  per.ctypes.data_as(C.POINTER(C.c_double)))
+    return secs, ev.value, bi.value, bd.value, per

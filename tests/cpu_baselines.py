@@ -24,9 +24,12 @@ for name, size, R, iters in (("C1_400_360", 400, 360, 1000), ("headline_2048_108
     res = {}
     for T in sorted(set([1, 4, min(os.cpu_count() or 1, 64)])):
         offs = sim.gaussian_offsets(T * iters, 0.1, math.radians(10.0), seed=42)
-        secs, evals, _, _ = oc.cpu_baseline_search(pix, size, scale, xy, base, offs, T, iters, 2)      # warm-up
-        scans = max(int(4.0 * evals / secs / evals), 3)
-        secs, evals, bi, bd = oc.cpu_baseline_search(pix, size, scale, xy, base, offs, T, iters, scans)
-        res["T%d" % T] = {"evals_per_s": evals / secs, "scans": scans, "iterations_per_thread": iters, "seconds": secs}
+        secs, evals, _, _ = oc.cpu_baseline_search(pix, size, scale, xy, base, offs, T, iters, 5)      # warm-up: 5 scans
+        scans = max(int(4.0 / (secs / 5)), 100)                                                          # >= 100 scans, ~4 s
+        secs, evals, bi, bd, per = oc.cpu_baseline_search_timed(pix, size, scale, xy, base, offs, T, iters, scans)
+        per_scan_evals = evals / scans
+        res["T%d" % T] = {"evals_per_s": evals / secs, "evals_per_s_median": per_scan_evals / float(np.median(per)),
+                          "evals_per_s_p95_scan": per_scan_evals / float(np.percentile(per, 95)),
+                          "scans": scans, "iterations_per_thread": iters, "seconds": secs}
     out[name] = res
 print(json.dumps(out, indent=1))
