@@ -230,13 +230,14 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key):
     secs, evals, bi, bd = oc.cpu_baseline_search(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, 1)
     rate = evals / secs
     scans = max(int(a.cpu_seconds * rate / evals) - 1, 1)
-    secs2, evals2, bi, bd = oc.cpu_baseline_search(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, scans)
+    secs2, evals2, bi, bd, per = oc.cpu_baseline_search_timed(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, scans)
     # parity spot-check on the full candidate list of the GPU step (single oracle pass, ~0.1 s)
     rbi, _, rbd, _ = oc.search(pix, dev.hole_size, dev.hole_scale, xy, base, offs)
     same = bool(((rbd << 32) | rbi) == gpu_key)
     return {"value": evals2 / secs2, "unit": "evals/s", "cores": T, "kind": "port",
             "sample": "%d scans x %d threads x (%d jitters + base) on the same map/scan/candidates, %.1f s"
                       % (scans, T, iters, secs2),
+            "median_scan": (evals2 / scans) / float(np.median(per)), "p95_scan": (evals2 / scans) / float(np.percentile(per, 95)),
             "argmin_matches_gpu": same}
 
 
