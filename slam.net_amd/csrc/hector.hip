@@ -63,6 +63,12 @@ __device__ static inline float hs_prob(const float *__restrict__ value, int idx)
     return odds / (odds + 1.0f);                                           // :102
 }
 
+__device__ static inline float hs_prob_v(float v)
+{
+    const float odds = expf(v);                                            // :101
+    return odds / (odds + 1.0f);                                           // :102
+}
+
 // InterpMapValueWithDerivatives (ScanMatcher.cs:211-249)
 __device__ static inline void hs_interp(const hs_level_dev &L, float cx, float cy, float &P, float &gx, float &gy)
 {
@@ -74,8 +80,16 @@ __device__ static inline void hs_interp(const hs_level_dev &L, float cx, float c
     const int ix = (int)floorf(cx), iy = (int)floorf(cy);                  // :222
     const float fx = cx - (float)ix, fy = cy - (float)iy;                  // :225
     const int idx = iy * L.w + ix;                                         // :227
-    const float i0 = hs_prob(L.value, idx), i1 = hs_prob(L.value, idx + 1);            // :230-231
-    const float i2 = hs_prob(L.value, idx + L.w), i3 = hs_prob(L.value, idx + L.w + 1);// :232-233
+    // the two taps of a row are adjacent: one 8-byte load each (4-byte aligned is enough for global dwordx2)
+    float2 r0, r1;
+#if defined(K4_EXP) && K4_EXP == 1
+    r0 = make_float2(cx * 0.001f, 0.1f); r1 = make_float2(0.2f, cy * 0.001f);      // EXPERIMENT (wrong results): no tap loads
+#else
+    __builtin_memcpy(&r0, L.value + idx, sizeof(float2));
+    __builtin_memcpy(&r1, L.value + idx + L.w, sizeof(float2));
+#endif
+    const float i0 = hs_prob_v(r0.x), i1 = hs_prob_v(r0.y);                // :230-231
+    const float i2 = hs_prob_v(r1.x), i3 = hs_prob_v(r1.y);                // :232-233
     const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;            // :235-239
     const float xi = 1.0f - fx, yi = 1.0f - fy;                            // :241-242
     P = ((i0 * xi + i1 * fx) * yi) + ((i2 * xi + i3 * fx) * fy);           // :245-246
@@ -104,12 +118,31 @@ __device__ static inline double hs_wave_sum(double v)
     return v;
 }
 
+// the same tree in binary32: one DPP-modified add per step.  (The nine binary64 wave sums of an iteration -- two DPP moves
+// and a double add per step, in dependent chains -- were half of the matcher's run time; the reference itself sums these
+// terms in binary32, sequentially per thread chunk, ScanMatcher.cs:166-180, so a binary32 tree over 64 lanes is at least
+// as accurate as what it is compared with.  The 16 wave partials are still added in binary64.)
+template <int CTRL, int ROWS> __device__ static inline float hs_dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+__device__ static inline float hs_wave_sum_f32(float v)
+{
+    v += hs_dpp_f32<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
+    v += hs_dpp_f32<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
+    v += hs_dpp_f32<0x124, 0xf>(v);         // row_ror:4
+    v += hs_dpp_f32<0x128, 0xf>(v);         // row_ror:8
+    v += hs_dpp_f32<0x142, 0xa>(v);         // row_bcast:15 -> rows 1, 3
+    v += hs_dpp_f32<0x143, 0xc>(v);         // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) broadcast in sums[].
 // order: dTr.x, dTr.y, dTr.z, H11, H22, H33, H12, H13, H23
 // PRE: the thread's (at most HS_PRE) points are already in registers (pre[]): the scan does not change between the
 // iterations of a match, and the point load heads a chain of two dependent memory round trips (point -> four taps).
 #define HS_PRE 2
-template <bool PRE>
+template <bool PRE, int BDIM>
 __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__restrict__ pts, int n, const float pose[3],
                                         double *red /* [16*9 + 9] LDS */, float sums[9], const float2 *pre = nullptr)
 {
@@ -117,12 +150,16 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
                                               sh_m3x2_translation(pose[0] * L.cell, pose[1] * L.cell)),
                                   sh_m3x2_scale(L.stm));                   // :139-142
     float s, c;
+#if defined(K4_EXP) && K4_EXP == 3
+    s = pose[2] * 0.9f; c = 1.0f - pose[2] * pose[2] * 0.5f;               // EXPERIMENT (wrong results): no trigonometry
+#else
     sh_det_sincosf(pose[2], &s, &c);
+#endif
     const float sinRot = s * L.stm, cosRot = c * L.stm;                    // :145-146
     float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
     for (int u = 0; u < (PRE ? HS_PRE : 1); u++)
-    for (int i = threadIdx.x + (PRE ? u * (int)blockDim.x : 0); i < n; i += PRE ? n : (int)blockDim.x) {
+    for (int i = threadIdx.x + (PRE ? u * BDIM : 0); i < n; i += PRE ? n : BDIM) {
         const float2 p = PRE ? pre[u] : pts[i];
         float mx, my, P, gx, gy;
         sh_v2_transform(p.x, p.y, t, &mx, &my);                            // :161
@@ -133,9 +170,14 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
         acc[3] += gx * gx;   acc[4] += gy * gy;   acc[5] += rot * rot;     // :174-176
         acc[6] += gx * gy;   acc[7] += gx * rot;  acc[8] += gy * rot;      // :178-180
     }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int nw = BDIM >> 6;           // (the block size is a template parameter: read from the dispatch packet it was re-loaded from memory in every iteration)
     for (int k = 0; k < 9; k++) {
-        const double v = hs_wave_sum((double)acc[k]);
+#if defined(K4_EXP) && K4_EXP == 2
+        const double v = (double)acc[k];                                   // EXPERIMENT (wrong results): no wave sums
+#else
+        const double v = (double)hs_wave_sum_f32(acc[k]);
+#endif
         if (lane == 63) red[k * 16 + wid] = v;
     }
     __syncthreads();
@@ -173,7 +215,8 @@ __device__ static inline void hs_step(const float sums[9], float est[3])
 
 // MatchData(MapRepMultiMap) (:41-54): one workgroup per hint; levels coarse -> fine.
 // only_level >= 0 restricts to one level with `iters_override` iterations (MatchData(OccGridMap), :64-84).
-__global__ void __launch_bounds__(1024)
+template <int BDIM>
+__global__ void __launch_bounds__(BDIM)
 k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float3 hint1,
          float *__restrict__ out, int only_level, int iters_override)
 {
@@ -181,11 +224,11 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
     const int b = blockIdx.x;
     float est_w[3] = { hint1.x, hint1.y, hint1.z };                         // :43 (a single hint travels in the launch arguments)
     if (hints) { est_w[0] = hints[3 * b]; est_w[1] = hints[3 * b + 1]; est_w[2] = hints[3 * b + 2]; }
-    const bool pre_ok = n <= HS_PRE * (int)blockDim.x;
+    const bool pre_ok = n <= HS_PRE * BDIM;
     float2 pre[HS_PRE];
 #pragma unroll
     for (int u = 0; u < HS_PRE; u++) {
-        const int i = threadIdx.x + u * (int)blockDim.x;
+        const int i = threadIdx.x + u * BDIM;
         pre[u] = (pre_ok && i < n) ? pts[i] : make_float2(0.f, 0.f);
     }
     if (n > 0) {                                                           // :66 (else: hint returned, :83)
@@ -199,8 +242,8 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
             const int iters = only_level >= 0 ? iters_override : L.iterations;
             for (int it = 0; it < iters; it++) {                           // :70-73
                 float sums[9];
-                if (pre_ok) hs_hessian_block<true>(L, pts, n, est, red, sums, pre);
-                else hs_hessian_block<false>(L, pts, n, est, red, sums);
+                if (pre_ok) hs_hessian_block<true, BDIM>(L, pts, n, est, red, sums, pre);
+                else hs_hessian_block<false, BDIM>(L, pts, n, est, red, sums);
                 hs_step(sums, est);
             }
             est[2] = sh_normalize_angle(est[2]);                           // :76
@@ -218,7 +261,7 @@ k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, co
     __shared__ double red[16 * 9 + 9];
     float pose[3] = { pose_in[0], pose_in[1], pose_in[2] };
     float sums[9];
-    hs_hessian_block<false>(A.lv[level], pts, n, pose, red, sums);
+    hs_hessian_block<false, 256>(A.lv[level], pts, n, pose, red, sums);
     if (threadIdx.x == 0) {
         out12[0] = sums[3]; out12[1] = sums[6]; out12[2] = sums[7];
         out12[3] = sums[6]; out12[4] = sums[4]; out12[5] = sums[8];
@@ -761,9 +804,12 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
         sh_timer t(ctx, SLAMHIP_K_HS_MATCH);
         // a single match is a latency chain (levels x iterations): 1024 lanes leave one or two scan points per lane;
         // batches keep 256 lanes per hint (throughput: many workgroups per CU)
-        const int lanes = B <= 64 ? 1024 : 256;
-        hipLaunchKernelGGL(k4_match, dim3(B), dim3(lanes), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
-                           B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters);
+        if (B <= 64)
+            hipLaunchKernelGGL(k4_match<1024>, dim3(B), dim3(1024), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
+                               B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters);
+        else
+            hipLaunchKernelGGL(k4_match<256>, dim3(B), dim3(256), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
+                               (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters);
     }
     SH_HIP(hipGetLastError());
     SH_HIP(hipMemcpyAsync(hs->h_io + 3 * (size_t)B, d_out, sizeof(float) * 3 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
