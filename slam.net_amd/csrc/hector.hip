@@ -29,6 +29,7 @@ struct hs_level {
     int w, h; float cell, stm;             // MapProperties: Dimensions, CellLength, ScaleToMap (MapProperties.cs:22-32)
     sh_m3x2 map_t_world, world_t_map;      // GridMap.cs:46-47
     float *d_value; int32_t *d_upd;        // LogOddsCell SoA (GridMap.cs:13)
+    float *d_prob;                         // GetCachedProbability of every cell (OccGridMap.cs:97-107), kept current by every writer of d_value
     int curr_update_index;                 // OccGridMap.cs:20
     int iterations;                        // EstimateIterations (OccGridMap.cs:53)
 };
@@ -37,6 +38,7 @@ struct hs_level_dev {                      // what the kernels need, by value
     int w, h; float cell, stm;
     sh_m3x2 map_t_world, world_t_map;
     const float *value;
+    const float *prob;                     // what the matcher's taps read: exp and divide happen when a cell changes, not per tap
     int iterations;
 };
 
@@ -65,6 +67,9 @@ __device__ static inline float hs_prob(const float *__restrict__ value, int idx)
 
 __device__ static inline float hs_prob_v(float v)
 {
+#if defined(K4_EXP) && K4_EXP == 4
+    return 0.5f + 0.1f * v;                                                // EXPERIMENT (wrong results): no exp, no divide
+#endif
     const float odds = expf(v);                                            // :101
     return odds / (odds + 1.0f);                                           // :102
 }
@@ -80,16 +85,17 @@ __device__ static inline void hs_interp(const hs_level_dev &L, float cx, float c
     const int ix = (int)floorf(cx), iy = (int)floorf(cy);                  // :222
     const float fx = cx - (float)ix, fy = cy - (float)iy;                  // :225
     const int idx = iy * L.w + ix;                                         // :227
-    // the two taps of a row are adjacent: one 8-byte load each (4-byte aligned is enough for global dwordx2)
+    // the two taps of a row are adjacent: one 8-byte load each (4-byte aligned is enough for global dwordx2), from the
+    // grid of cached probabilities (:97-107 -- the reference caches them per cell and map-update epoch as well)
     float2 r0, r1;
 #if defined(K4_EXP) && K4_EXP == 1
     r0 = make_float2(cx * 0.001f, 0.1f); r1 = make_float2(0.2f, cy * 0.001f);      // EXPERIMENT (wrong results): no tap loads
 #else
-    __builtin_memcpy(&r0, L.value + idx, sizeof(float2));
-    __builtin_memcpy(&r1, L.value + idx + L.w, sizeof(float2));
+    __builtin_memcpy(&r0, L.prob + idx, sizeof(float2));
+    __builtin_memcpy(&r1, L.prob + idx + L.w, sizeof(float2));
 #endif
-    const float i0 = hs_prob_v(r0.x), i1 = hs_prob_v(r0.y);                // :230-231
-    const float i2 = hs_prob_v(r1.x), i3 = hs_prob_v(r1.y);                // :232-233
+    const float i0 = r0.x, i1 = r0.y;                                      // :230-231
+    const float i2 = r1.x, i3 = r1.y;                                      // :232-233
     const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;            // :235-239
     const float xi = 1.0f - fx, yi = 1.0f - fy;                            // :241-242
     P = ((i0 * xi + i1 * fx) * yi) + ((i2 * xi + i3 * fx) * fy);           // :245-246
@@ -278,7 +284,7 @@ k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, co
 // processed in index order by the reference, and a cell changes at most twice per update (BresenhamCellFree marks it,
 // BresenhamCellOcc overrides the mark), so all a cell needs is the smallest index of a line that crosses it as "free",
 // the smallest index of a line that ends in it, and their order -- no atomics, no per-cell scratch, coalesced rows.
-struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; int mark_free, mark_occ; int wg0, wgn; };
+struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; float *prob; int mark_free, mark_occ; int wg0, wgn; };
 struct k5_arg { k5_level lv[HS_MAX_LEVELS]; int n; };
 struct k5_line { int da, sdb, ray, flags; };      // major length, signed minor length, line index, valid | major_x << 1 | (smaj + 1) << 2
 #define K5_ZONE 16                     // Chebyshev radius around the begin cell handled one wavefront per cell
@@ -390,6 +396,7 @@ __device__ static inline void k5_apply(const k5_level &L, int cell, int first_fr
     k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
     L.value[cell] = v;
     L.upd[cell] = u;
+    L.prob[cell] = hs_prob_v(v);
 }
 
 // wave-wide minimum by DPP (butterfly in rows of 16, row_bcast:15 / :31): valid in lane 63
@@ -457,6 +464,7 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
             k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
             L.value[cell] = v;
             L.upd[cell] = u;
+            L.prob[cell] = hs_prob_v(v);
         }
     }
     // (2) the rest of the bounding square: one lane per cell, a wavefront takes 64 cells of one row
@@ -485,11 +493,12 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
     }
 }
 
-__global__ void k5_fill_cells(float *value, int32_t *upd, size_t n)
+__global__ void k5_fill_cells(float *value, int32_t *upd, float *prob, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) { value[i] = 0.0f; upd[i] = -1; }   // LogOddsCell.Reset :38-42
+    const float p0 = hs_prob_v(0.0f);
+    for (; i < n; i += stride) { value[i] = 0.0f; upd[i] = -1; prob[i] = p0; }   // LogOddsCell.Reset :38-42
 }
 
 __global__ void k5_pack_cells(const float *value, const int32_t *upd, slamhip_cell *out, size_t n)
@@ -497,10 +506,10 @@ __global__ void k5_pack_cells(const float *value, const int32_t *upd, slamhip_ce
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { out[i].update_index = upd[i]; out[i].value = value[i]; }
 }
-__global__ void k5_unpack_cells(const slamhip_cell *in, float *value, int32_t *upd, size_t n)
+__global__ void k5_unpack_cells(const slamhip_cell *in, float *value, int32_t *upd, float *prob, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { upd[i] = in[i].update_index; value[i] = in[i].value; }
+    if (i < n) { upd[i] = in[i].update_index; value[i] = in[i].value; prob[i] = hs_prob_v(in[i].value); }
 }
 // GridMap.GetBitmapData (GridMap.cs:104-115)
 __global__ void k5_bitmap(const float *value, uint8_t *out, size_t n)
@@ -555,7 +564,7 @@ static hs_levels_arg levels_arg(slamhip_hs *hs)
         const hs_level &L = hs->lv[l];
         A.lv[l].w = L.w; A.lv[l].h = L.h; A.lv[l].cell = L.cell; A.lv[l].stm = L.stm;
         A.lv[l].map_t_world = L.map_t_world; A.lv[l].world_t_map = L.world_t_map;
-        A.lv[l].value = L.d_value; A.lv[l].iterations = L.iterations;
+        A.lv[l].value = L.d_value; A.lv[l].prob = L.d_prob; A.lv[l].iterations = L.iterations;
     }
     return A;
 }
@@ -566,7 +575,7 @@ extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
     (void)hipSetDevice(hs->ctx->device);
     (void)hipStreamSynchronize(hs->ctx->stream);
     for (int l = 0; l < hs->n_levels; l++) {
-        (void)hipFree(hs->lv[l].d_value); (void)hipFree(hs->lv[l].d_upd);
+        (void)hipFree(hs->lv[l].d_value); (void)hipFree(hs->lv[l].d_upd); (void)hipFree(hs->lv[l].d_prob);
     }
     (void)hipFree(hs->d_pts); (void)hipFree(hs->d_io);
     if (hs->h_pts) (void)hipHostFree(hs->h_pts);
@@ -583,7 +592,7 @@ extern "C" int32_t slamhip_hs_reset(slamhip_hs *hs)
     SH_HIP(hipSetDevice(hs->ctx->device));
     for (int l = 0; l < hs->n_levels; l++) {
         hs_level &L = hs->lv[l];
-        hipLaunchKernelGGL(k5_fill_cells, dim3(1024), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, (size_t)L.w * L.h);                             // GridMap.Reset :56-62
+        hipLaunchKernelGGL(k5_fill_cells, dim3(1024), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, L.d_prob, (size_t)L.w * L.h);                   // GridMap.Reset :56-62
         L.curr_update_index = 0;                                           // OccGridMap.Reset :244-252
     }
     SH_HIP(hipStreamSynchronize(hs->ctx->stream));
@@ -611,7 +620,8 @@ extern "C" int32_t slamhip_hs_create(slamhip_ctx *ctx, float cell_length, int32_
         L.map_t_world = sh_m3x2_mul(sh_m3x2_scale(L.stm), sh_m3x2_translation(0.0f, 0.0f));   // GridMap.cs:46 (offset = 0)
         if (!sh_m3x2_invert(L.map_t_world, &L.world_t_map)) { slamhip_set_error("Map to world matrix is not invertible"); rc = SLAMHIP_ERR_INVALID; break; }  // :47-50
         const size_t n = (size_t)w * h;
-        if (hipMalloc(&L.d_value, sizeof(float) * n) != hipSuccess || hipMalloc(&L.d_upd, sizeof(int32_t) * n) != hipSuccess) {
+        if (hipMalloc(&L.d_value, sizeof(float) * n) != hipSuccess || hipMalloc(&L.d_upd, sizeof(int32_t) * n) != hipSuccess ||
+            hipMalloc(&L.d_prob, sizeof(float) * n) != hipSuccess) {
             slamhip_set_error("device allocation failed (level %d)", l); rc = SLAMHIP_ERR_NOMEM; break;
         }
         w /= 2; h /= 2;                                                   // :55
@@ -663,7 +673,7 @@ extern "C" int32_t slamhip_hs_cells_upload(slamhip_hs *hs, int32_t level, const 
     SH_HIP(hipMalloc(&d, sizeof(slamhip_cell) * n));
     hipError_t e = hipMemcpyAsync(d, cells, sizeof(slamhip_cell) * n, hipMemcpyHostToDevice, hs->ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k5_unpack_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, d, L.d_value, L.d_upd, n);
+        hipLaunchKernelGGL(k5_unpack_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, d, L.d_value, L.d_upd, L.d_prob, n);
         e = hipStreamSynchronize(hs->ctx->stream);
     }
     (void)hipFree(d);
@@ -868,7 +878,7 @@ extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3]
         A.lv[l].w = L.w; A.lv[l].h = L.h;
         A.lv[l].t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]), sh_m3x2_translation(pose[0], pose[1])),
                                 sh_m3x2_scale(L.stm));                    // OccGridMap.cs:120-123
-        A.lv[l].value = L.d_value; A.lv[l].upd = L.d_upd;
+        A.lv[l].value = L.d_value; A.lv[l].upd = L.d_upd; A.lv[l].prob = L.d_prob;
         A.lv[l].mark_free = L.curr_update_index + 1;                      // :116
         A.lv[l].mark_occ = L.curr_update_index + 2;                       // :117
     }
