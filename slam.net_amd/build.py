@@ -29,6 +29,8 @@ def extra_defs():
         d.append("-DK1_TIMES=1")
     if os.environ.get("SLAMHIP_K1_FAKETRIG"):   # developer experiment only (wrong results): cost of the trigonometry
         d.append("-DK1_FAKETRIG=1")
+    if os.environ.get("SLAMHIP_K4_TIMES"):      # developer build: phase stamps in the Hector matcher
+        d.append("-DK4_TIMES=1")
     if os.environ.get("SLAMHIP_K4_EXP"):        # developer experiments only (wrong results)
         d.append("-DK4_EXP=%s" % os.environ["SLAMHIP_K4_EXP"])
     if os.environ.get("SLAMHIP_K2_TIMES"):      # developer build: per-workgroup phase stamps in the K2 pixel kernel

@@ -143,6 +143,17 @@ __device__ static inline float hs_wave_sum_f32(float v)
     return v;
 }
 
+#ifdef K4_TIMES
+// developer instrumentation (build with SLAMHIP_K4_TIMES=1): wall-clock ticks (100 MHz) per phase of an iteration,
+// accumulated by thread 0 of workgroup 0
+__device__ unsigned long long g_k4_times[16];
+#define K4_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = wall_clock64(); g_k4_times[k] += t_ - k4_last; k4_last = t_; } }
+#define K4_STAMP_BEGIN unsigned long long k4_last = wall_clock64();
+#else
+#define K4_STAMP(k) {}
+#define K4_STAMP_BEGIN
+#endif
+
 // GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) broadcast in sums[].
 // order: dTr.x, dTr.y, dTr.z, H11, H22, H33, H12, H13, H23
 // PRE: the thread's (at most HS_PRE) points are already in registers (pre[]): the scan does not change between the
@@ -155,6 +166,7 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
     const sh_m3x2 t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]),
                                               sh_m3x2_translation(pose[0] * L.cell, pose[1] * L.cell)),
                                   sh_m3x2_scale(L.stm));                   // :139-142
+    K4_STAMP_BEGIN
     float s, c;
 #if defined(K4_EXP) && K4_EXP == 3
     s = pose[2] * 0.9f; c = 1.0f - pose[2] * pose[2] * 0.5f;               // EXPERIMENT (wrong results): no trigonometry
@@ -162,6 +174,7 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
     sh_det_sincosf(pose[2], &s, &c);
 #endif
     const float sinRot = s * L.stm, cosRot = c * L.stm;                    // :145-146
+    K4_STAMP(0)                                                            // transform + trigonometry
     float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
     for (int u = 0; u < (PRE ? HS_PRE : 1); u++)
@@ -178,15 +191,27 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int nw = BDIM >> 6;           // (the block size is a template parameter: read from the dispatch packet it was re-loaded from memory in every iteration)
-    for (int k = 0; k < 9; k++) {
-#if defined(K4_EXP) && K4_EXP == 2
-        const double v = (double)acc[k];                                   // EXPERIMENT (wrong results): no wave sums
-#else
-        const double v = (double)hs_wave_sum_f32(acc[k]);
-#endif
-        if (lane == 63) red[k * 16 + wid] = v;
+    K4_STAMP(1)                                                            // points: taps, interpolation, products
+    // the nine trees step by step side by side (independent adds between the steps of one tree), then one store block
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += hs_dpp_f32<0xB1, 0xf>(acc[k]);          // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += hs_dpp_f32<0x4E, 0xf>(acc[k]);          // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += hs_dpp_f32<0x124, 0xf>(acc[k]);         // row_ror:4
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += hs_dpp_f32<0x128, 0xf>(acc[k]);         // row_ror:8
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += hs_dpp_f32<0x142, 0xa>(acc[k]);         // row_bcast:15 -> rows 1, 3
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += hs_dpp_f32<0x143, 0xc>(acc[k]);         // row_bcast:31 -> rows 2, 3
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) red[k * 16 + wid] = (double)acc[k];
     }
+    K4_STAMP(2)                                                            // wave sums + store
     __syncthreads();
+    K4_STAMP(3)                                                            // barrier 1
     // nine sums over (up to) 16 wave partials: lane k*16 + w holds partial w of sum k, so each sum is one DPP row
     if (threadIdx.x < 9 * 16) {
         const int w = threadIdx.x & 15;
@@ -197,9 +222,12 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
         v += hs_dpp_f64<0x128, 0xf>(v);
         if (w == 0) red[9 * 16 + (threadIdx.x >> 4)] = v;
     }
+    K4_STAMP(4)                                                            // partial sums
     __syncthreads();
+    K4_STAMP(5)                                                            // barrier 2
     for (int k = 0; k < 9; k++) sums[k] = (float)red[9 * 16 + k];
     __syncthreads();
+    K4_STAMP(6)                                                            // read totals + barrier 3
 }
 
 // EstimateTransformationLogLh (:93-125) applied by every thread identically (uniform registers)
@@ -822,6 +850,22 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
                                (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters);
     }
     SH_HIP(hipGetLastError());
+#ifdef K4_TIMES
+    {
+        static int calls = 0;
+        if (B == 1 && ++calls == 20) {
+            (void)hipStreamSynchronize(ctx->stream);
+            unsigned long long h[16];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k4_times), sizeof(h));
+            static const char *nm[7] = { "transform+trig", "points", "wave sums", "barrier 1", "partials", "barrier 2", "totals+barrier 3" };
+            double tot = 0;
+            for (int k = 0; k < 7; k++) tot += (double)h[k];
+            fprintf(stderr, "[k4 times] %d matches, thread 0 of the workgroup, us per match:", calls);
+            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.2f |", nm[k], (double)h[k] * 0.01 / calls);
+            fprintf(stderr, " sum %.2f\n", tot * 0.01 / calls);
+        }
+    }
+#endif
     SH_HIP(hipMemcpyAsync(hs->h_io + 3 * (size_t)B, d_out, sizeof(float) * 3 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     SH_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(out, hs->h_io + 3 * (size_t)B, sizeof(float) * 3 * (size_t)B);
