@@ -39,7 +39,7 @@ def main():
         n_cases += 1
         kind = n_cases % 3
         if kind in (0, 1):
-            size = int(rng.choice([64, 120, 256, 400, 513, 1024, 1536, 2048]))
+            size = int(rng.choice([64, 120, 256, 400, 513, 1024, 1536, 2048, 2048, 4096]))
             osize = int(rng.choice([16, 64, 100, 256]))
             R = int(rng.choice([1, 7, 90, 360, 1080, 2500]))
             hw = float(rng.choice([0.1, 0.6, 2.0, 5.0]))
@@ -131,7 +131,7 @@ def main():
                          **{"xy%d" % i: t[0] for i, t in enumerate(trace)}, **{"p%d" % i: t[1] for i, t in enumerate(trace)})
             dev.close()
         else:
-            side = int(rng.choice([64, 200, 401, 1024]))
+            side = int(rng.choice([64, 200, 401, 1024, 2048]))
             levels = int(rng.choice([1, 2, 3]))
             cell = 40.0 / side
             R = int(rng.choice([8, 180, 1080, 3000]))
@@ -176,8 +176,9 @@ def main():
                     # answer by millimetres.  The device result must then be what the reference arithmetic gives for a hint
                     # a digit or two away.
                     prng2 = np.random.default_rng(n_cases)
-                    outs = np.array([oc.match_pyramid(ref, xy, (hint * (1.0 + prng2.uniform(-3e-7, 3e-7, 3))).astype(np.float32), [3] * levels, 4)
-                                     for _ in range(96)])
+                    # (on coarse grids the intermediate estimates differ by up to ~1e-5: three scales of perturbation)
+                    outs = np.array([oc.match_pyramid(ref, xy, (hint * (1.0 + prng2.uniform(-3e-7, 3e-7, 3)) + prng2.uniform(-sc, sc, 3)).astype(np.float32), [3] * levels, 4)
+                                     for sc in (1e-6, 1e-5, 3e-5) for _ in range(40)])
                     close = bool(np.any(np.all(np.abs(outs - np.asarray(m)[None]) < tol, axis=1)))
                     if not close:
                         # many different answers in that neighbourhood (a chaotic case): inside their envelope is all one can ask
