@@ -59,7 +59,17 @@ __device__ static inline void k1_gather_global(const uint16_t *__restrict__ map,
 __device__ static inline unsigned long long k1_finish(uint64_t sum, uint32_t cnt, int n_points, int flat,
                                                       int32_t *__restrict__ dist_out)
 {
-    const int32_t d = cnt > 0 ? (int32_t)((sum * 1024ull) / (uint64_t)n_points) : INT32_MAX;
+    // (sum * 1024) / R in 64 bits (:253).  The 64-bit integer division is a long software routine on this hardware and sits
+    // on the critical path of the last arriver: take the quotient from one binary64 division (sum * 1024 < 2^50 is exact in
+    // binary64, so the estimate is within one of the truth) and settle it with the exact remainder.
+    uint64_t q = 0;
+    if (cnt > 0) {
+        const uint64_t num = sum * 1024ull, den = (uint64_t)n_points;
+        q = (uint64_t)((double)num / (double)den);
+        const int64_t rem = (int64_t)num - (int64_t)(q * den);
+        if (rem < 0) q--; else if (rem >= (int64_t)den) q++;
+    }
+    const int32_t d = cnt > 0 ? (int32_t)q : INT32_MAX;
     if (dist_out) dist_out[flat] = d;
     return ((unsigned long long)(uint32_t)d << 32) | (uint32_t)flat;
 }
@@ -833,25 +843,30 @@ static int env_int(const char *name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
-// Smallest chunk count >= nc whose chunks (equal ray ranges) hold at most K1_MAXR rays and K1_MAXP block pieces.
-static int k1_legal_chunks(const slamhip_cs *cs, int nc)
+// Do nc equal ray ranges hold at most K1_MAXR rays and K1_MAXP block pieces each?  (Not monotone in nc: the cuts move.)
+static bool k1_chunks_legal(const slamhip_cs *cs, int nc)
 {
     const int R = cs->n_points, n_rb = cs->n_rb;
     const int *rb = cs->h_rb_start.data();
+    if (nc < 1 || nc > R) return false;
+    int b = 0;
+    for (int c = 0; c < nc; c++) {
+        const int rlo = (int)(((long long)c * R) / nc), rhi = (int)(((long long)(c + 1) * R) / nc);
+        while (b + 1 < n_rb && rb[b + 1] <= rlo) b++;                  // block of ray rlo
+        int e = b;
+        while (e + 1 < n_rb && rb[e + 1] < rhi) e++;                   // block of ray rhi - 1
+        if (e - b + 1 > K1_MAXP || rhi - rlo > K1_MAXR) return false;
+    }
+    return true;
+}
+
+// Smallest legal chunk count >= nc (one ray per chunk is always legal).
+static int k1_legal_chunks(const slamhip_cs *cs, int nc)
+{
+    const int R = cs->n_points;
     if (nc < sh_div_up(R, K1_MAXR)) nc = sh_div_up(R, K1_MAXR);
     if (nc > R) nc = R;
-    for (; nc < R; nc++) {
-        bool ok = true;
-        int b = 0;
-        for (int c = 0; c < nc && ok; c++) {
-            const int rlo = (int)(((long long)c * R) / nc), rhi = (int)(((long long)(c + 1) * R) / nc);
-            while (b + 1 < n_rb && rb[b + 1] <= rlo) b++;              // block of ray rlo
-            int e = b;
-            while (e + 1 < n_rb && rb[e + 1] < rhi) e++;               // block of ray rhi - 1
-            if (e - b + 1 > K1_MAXP || rhi - rlo > K1_MAXR) ok = false;
-        }
-        if (ok) break;
-    }
+    while (nc < R && !k1_chunks_legal(cs, nc)) nc++;
     return nc;
 }
 
@@ -938,13 +953,17 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
     long long tot = (long long)cs->k1_uni_ng * cs->k1_uni_nc;
     for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) tot += cs->k1_tab_nc[i];
     if (n_groups <= K1_TABLE_G) {
-        const int lower = k1_legal_chunks(cs, 1);
         for (int guard = 0; tot > target_wgs && guard < 4096 && !cs->k1_tab_nc.empty(); guard++) {
             size_t im = 0;
             for (size_t i = 1; i < cs->k1_tab_nc.size(); i++) if (cs->k1_tab_nc[i] > cs->k1_tab_nc[im]) im = i;
-            const int step = cs->k1_tab_nbp[im];
-            if (cs->k1_tab_nc[im] - step < lower * step) break;
-            cs->k1_tab_nc[im] -= step; tot -= step;
+            // the next smaller count of ray ranges that is legal itself (a count below a legal one need not be: tests/
+            // fuzz_parity.py found a 2500-ray scan of one-ray blocks whose trimmed count put 18 pieces into a chunk)
+            const int nbp = cs->k1_tab_nbp[im];
+            int nrc = cs->k1_tab_nc[im] / nbp - 1;
+            while (nrc >= 1 && !k1_chunks_legal(cs, nrc)) nrc--;
+            if (nrc < 1) break;
+            tot -= cs->k1_tab_nc[im] - nrc * nbp;
+            cs->k1_tab_nc[im] = nrc * nbp;
         }
     }
     long long tab = 0;

@@ -99,7 +99,12 @@ def main():
                     offs = dev.offsets_download()
                 rbi, rpose, rbd, rall = oc.search(got, size, dev.hole_scale, xy, base, offs)
                 ok = gi == rbi and gd == rbd and bool((np.asarray(gp)[:2] == rpose[:2]).all())
-                if not ok: why.append("search: got idx %d dist %d pose %s, oracle idx %d dist %d pose %s" % (gi, gd, gp, rbi, rbd, rpose))
+                if not ok:
+                    why.append("search: got idx %d dist %d pose %s, oracle idx %d dist %d pose %s" % (gi, gd, gp, rbi, rbd, rpose))
+                    if a.dump:
+                        poses_ = np.vstack([base[None], base[None] + offs]).astype(np.float32)
+                        dd_ = dev.distance_poses(poses_)[0] if K <= 200000 else np.zeros(0, np.int32)
+                        np.savez(a.dump + ".search.npz", size=size, xy=xy, base=base, offs=offs, got=got, rall=rall, dd=dd_, gi=gi, gd=gd, fused=fused)
                 if ok and fused:
                     # the fused call also drew both maps from the winner's pose, theta normalised (:746-751)
                     wp = np.array([rpose[0], rpose[1], oc.normalize_angle(float(rpose[2]))], np.float32)
