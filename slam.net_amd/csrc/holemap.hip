@@ -212,6 +212,10 @@ __device__ static inline bool k2_hit(const k2_cand c, int a, int b)
 {
     if (a > c.dxc) return false;
     const int B = b < 0 ? -b : b, dyc = c.sdyc < 0 ? -c.sdyc : c.sdyc;
+    // the walk takes at most one minor step per major step (m(x) <= x).  With dyc <= dxc the tests below imply it; a ray
+    // whose ClipRay arithmetic wrapped (:329,:340 -- an end point a million pixels out) can come back with dyc > dxc, and
+    // the zone's all-rays scan, which asks every ray about every pixel, needs the cap spelled out (found by the soak)
+    if (B > a) return false;
     if (B > 0 && (c.sdyc == 0 || (b > 0) != (c.sdyc > 0))) return false;
     const T N = (T)2 * dyc * a - c.dxc, D = (T)2 * c.dxc;
     if (B == 0) return N <= 0;

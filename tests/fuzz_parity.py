@@ -41,14 +41,14 @@ def main():
         if kind in (0, 1):
             size = int(rng.choice([64, 120, 256, 400, 513, 1024, 1536, 2048, 2048, 4096]))
             osize = int(rng.choice([16, 64, 100, 256]))
-            R = int(rng.choice([1, 7, 90, 360, 1080, 2500]))
+            R = int(rng.choice([1, 7, 90, 360, 1080, 1080, 2500, 4097]))
             hw = float(rng.choice([0.1, 0.6, 2.0, 5.0]))
             q = int(rng.choice([1, 50, 128, 255]))
             dev = cs.CoreSlamDevice(ctx, 40.0, size, osize)
             ref = np.full(size * size, 32750, np.uint16)
             oref = np.full(osize * osize, -5, np.int8)
             prng = sim.PCG32(int(rng.integers(1, 1 << 30)))
-            pose = np.array([rng.uniform(4, 36), rng.uniform(4, 36), rng.uniform(-7, 7)], np.float32)
+            pose = np.array([rng.uniform(4, 36), rng.uniform(4, 36), rng.uniform(-7, 7) * (30.0 if rng.random() < 0.1 else 1.0)], np.float32)
             if rng.random() < 0.15:
                 pose[0] = rng.choice([-0.3, 0.0, 39.99, 40.2])         # robot at / beyond the map edge
             ok = True
@@ -64,6 +64,10 @@ def main():
                     xy = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1).astype(np.float32)
                 if rng.random() < 0.3:
                     xy = xy[rng.permutation(xy.shape[0])]                # ray order matters for the blend
+                if rng.random() < 0.1 and xy.shape[0] > 4:               # hostile points: far away, duplicates, at the robot
+                    xy = xy.copy()
+                    xy[0] = [3.0e4, -2.0e4]; xy[1] = xy[2]; xy[3] = [0.0, 0.0]
+                    if rng.random() < 0.3: xy[4 % xy.shape[0]] = [np.nan, 1.0]
                 if xy.shape[0] == 0:
                     continue
                 trace.append((xy.copy(), p.copy()))
@@ -84,8 +88,8 @@ def main():
                 ok = False; why.append("obstaclemap: %d cells differ, first %s got %s want %s" % (bad.size, [(int(b) % osize, int(b) // osize) for b in bad[:4]], gob[bad[:4]], oref[bad[:4]]))
             desc = "maps size %d/%d rays %d hw %.1f q %d pose %s" % (size, osize, R, hw, q, np.round(pose, 2))
             if ok and kind == 1 and xy.shape[0] > 0:
-                K = int(rng.choice([2, 300, 1025, 4096, 20000, 70000]))
-                sxy, sth = float(rng.choice([0.02, 0.1, 0.5])), float(rng.choice([0.01, 0.17, 0.8, 3.0]))
+                K = int(rng.choice([1, 2, 300, 1023, 1024, 1025, 2049, 4096, 20000, 70000]))
+                sxy, sth = float(rng.choice([0.0, 0.02, 0.1, 0.5])), float(rng.choice([0.0, 0.01, 0.17, 0.8, 3.0]))
                 base = (pose + np.array([0.03, -0.02, 0.017], np.float32)).astype(np.float32)
                 if rng.random() < 0.5:
                     offs = sim.gaussian_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)))
