@@ -44,6 +44,7 @@ def main():
             R = int(rng.choice([1, 7, 90, 360, 1080, 1080, 2500, 4097]))
             hw = float(rng.choice([0.1, 0.6, 2.0, 5.0]))
             q = int(rng.choice([1, 50, 128, 255]))
+            mh = int(rng.choice([10, 1, 127, -3]))
             dev = cs.CoreSlamDevice(ctx, 40.0, size, osize)
             ref = np.full(size * size, 32750, np.uint16)
             oref = np.full(osize * osize, -5, np.int8)
@@ -73,9 +74,9 @@ def main():
                 trace.append((xy.copy(), p.copy()))
                 dev.set_scan(xy)
                 dev.update_holemap(p, hw, q)
-                dev.update_obstaclemap(p, 10)
+                dev.update_obstaclemap(p, mh)
                 n = oc.update_holemap(ref, size, dev.hole_scale, xy, p, hw, q)
-                oc.update_obstaclemap(oref, osize, dev.obst_scale, xy, p, 10)
+                oc.update_obstaclemap(oref, osize, dev.obst_scale, xy, p, mh)
                 if dev.last_holemap_pixels != n:
                     ok = False; why.append("pixel count %d vs %d at update %d" % (dev.last_holemap_pixels, n, it))
             got = dev.holemap_download()
@@ -99,7 +100,7 @@ def main():
                 else:
                     dev.generate_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)), stream=n_cases)
                     fused = rng.random() < 0.5
-                    gp, gd, gi = dev.search_and_update(base, hw, q, 10)[:3] if fused else dev.search(base)
+                    gp, gd, gi = dev.search_and_update(base, hw, q, mh)[:3] if fused else dev.search(base)
                     offs = dev.offsets_download()
                 rbi, rpose, rbd, rall = oc.search(got, size, dev.hole_scale, xy, base, offs)
                 ok = gi == rbi and gd == rbd and bool((np.asarray(gp)[:2] == rpose[:2]).all())
@@ -114,7 +115,7 @@ def main():
                     wp = np.array([rpose[0], rpose[1], oc.normalize_angle(float(rpose[2]))], np.float32)
                     ok = bool((np.asarray(gp) == wp).all())
                     n = oc.update_holemap(ref, size, dev.hole_scale, xy, wp, hw, q)
-                    oc.update_obstaclemap(oref, osize, dev.obst_scale, xy, wp, 10)
+                    oc.update_obstaclemap(oref, osize, dev.obst_scale, xy, wp, mh)
                     ok = ok and dev.last_holemap_pixels == n and bool((dev.holemap_download() == ref).all()) \
                         and bool((dev.obstaclemap_download().ravel() == oref).all())
                     if not ok: why.append("fused update: maps or pose differ (pose %s vs %s)" % (gp, wp))
@@ -146,6 +147,11 @@ def main():
             R = int(rng.choice([8, 180, 1080, 3000]))
             rep = hs.MapRepMultiMap(cell, (side, side), levels, ctx=ctx)
             ref = oc.make_pyramid(cell, side, side, levels)
+            if rng.random() < 0.2:
+                ff, fo = float(rng.choice([0.3, 0.45])), float(rng.choice([0.6, 0.8, 0.95]))
+                rep.SetUpdateFactorFree(ff); rep.SetUpdateFactorOccupied(fo)
+                for g in ref:
+                    g.set_factors(ff, fo)
             prng = sim.PCG32(int(rng.integers(1, 1 << 30)))
             pose = np.array([rng.uniform(8, 32), rng.uniform(8, 32), rng.uniform(-3, 3)], np.float32)
             ok = True
@@ -155,10 +161,14 @@ def main():
                 rays, xy = sim.make_scan(segs, p, R, prng)
                 if xy.shape[0] == 0:
                     continue
+                if rng.random() < 0.1 and xy.shape[0] > 5:             # hostile points: far away, duplicates, at the origin, NaN
+                    xy = xy.copy()
+                    xy[0] = [3.0e4, -2.0e4]; xy[1] = xy[2]; xy[3] = [0.0, 0.0]; xy[4] = [np.nan, 1.0]
+                org = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))) if rng.random() < 0.2 else (0.0, 0.0)
                 htrace.append((xy.copy(), p.copy()))
-                rep.UpdateByScan(hs.ScanCloud(xy), p)
+                rep.UpdateByScan(hs.ScanCloud(xy, (org[0], org[1], 0.0)), p)
                 for g in ref:
-                    g.update_by_scan(xy, p)
+                    g.update_by_scan(xy, p, origin=org)
             for l in range(levels):
                 c = rep.Maps[l].GetCells()
                 ok = ok and bool((c["update_index"] == ref[l].cells["update_index"]).all() and (c["value"] == ref[l].cells["value"]).all())
