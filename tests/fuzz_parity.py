@@ -37,8 +37,41 @@ def main():
     n_near = 0
     while time.time() < t_end:
         n_cases += 1
-        kind = n_cases % 3
-        if kind in (0, 1):
+        kind = n_cases % 3 if n_cases % 16 else 3
+        if kind == 3:
+            # CoreSLAMProcessor.Update sequences: the state machine above the kernels (scan counter, odometry bookkeeping,
+            # multi-segment clouds, empty scans, Reset) against the oracle's, estimate and maps after every scan
+            size = int(rng.choice([64, 256, 400, 1024])); osize = int(rng.choice([16, 64, 100]))
+            start = np.array([rng.uniform(12, 28), rng.uniform(12, 28), rng.uniform(-3, 3)], np.float32)
+            K = int(rng.choice([1, 200, 1500])); thr = int(rng.choice([1, 4]))
+            proc = cs.CoreSLAMProcessor(40.0, size, osize, start, 0.1, 0.17, K, thr, ctx=ctx)
+            ref = oc.CSProc(40.0, size, osize, start)
+            hw = float(rng.choice([0.6, 2.0])); q = int(rng.choice([50, 200])); sb = int(rng.choice([0, 2, 5])); mh = int(rng.choice([10, 3]))
+            proc.HoleWidth = hw; proc.Quality = q; proc.PositionSearchBeginning = sb; proc.MaxObstacleHits = mh
+            ref.set_params(quality=q, hole_width=hw, search_beginning=sb, max_hits=mh)
+            prng = sim.PCG32(int(rng.integers(1, 1 << 30)))
+            ok = True; desc = "processor size %d/%d K %dx%d hw %.1f q %d begin %d" % (size, osize, K, thr, hw, q, sb)
+            true = start.astype(np.float64).copy()
+            for it in range(int(rng.integers(4, 14))):
+                true += [rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(-0.03, 0.03)]
+                R = int(rng.choice([0, 1, 90, 400])) if rng.random() < 0.3 else 360
+                rays = sim.make_scan(segs, true.astype(np.float32), R, prng)[0] if R else np.zeros((0, 2), np.float32)
+                est = proc.Pose.copy()
+                nseg = int(rng.integers(1, 4)) if rays.shape[0] >= 3 else 1
+                cuts = np.sort(rng.choice(np.arange(1, max(rays.shape[0], 2)), nseg - 1, replace=False)) if nseg > 1 else np.zeros(0, int)
+                seg_start = np.concatenate([[0], cuts, [rays.shape[0]]]).astype(np.int32)
+                odo = (est + np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), rng.uniform(-0.02, 0.02)], np.float32)).astype(np.float32)
+                seg_poses = np.stack([(odo + np.array([0.01 * (k - nseg + 1), 0.0, 0.002 * (k - nseg + 1)], np.float32)).astype(np.float32) for k in range(nseg)])
+                offs = sim.gaussian_offsets(K * thr, 0.1, 0.17, seed=int(rng.integers(1, 1 << 30)))
+                proc.SetOffsets(offs)
+                proc.Update([cs.ScanSegment(rays[seg_start[k]:seg_start[k + 1]], seg_poses[k], k == nseg - 1) for k in range(nseg)])
+                ref.update(seg_poses, seg_start, rays, offs)
+                if not ((proc.Pose == ref.pose).all() and (proc.HoleMap.Pixels == ref.holemap).all() and (proc.ObstacleMap.Pixels.ravel() == ref.obstaclemap.ravel()).all()):
+                    ok = False; desc += " || differs at scan %d: pose %s vs %s" % (it, proc.Pose, ref.pose); break
+                if rng.random() < 0.08:
+                    proc.Reset(); ref.reset()
+            proc.Dispose(); ref.close()
+        elif kind in (0, 1):
             size = int(rng.choice([64, 120, 256, 400, 513, 1024, 1536, 2048, 2048, 4096]))
             osize = int(rng.choice([16, 64, 100, 256]))
             R = int(rng.choice([1, 7, 90, 360, 1080, 1080, 2500, 4097]))
