@@ -78,7 +78,8 @@ def main():
             hw = float(rng.choice([0.1, 0.6, 2.0, 5.0]))
             q = int(rng.choice([1, 50, 128, 255]))
             mh = int(rng.choice([10, 1, 127, -3]))
-            dev = cs.CoreSlamDevice(ctx, 40.0, size, osize)
+            phys = float(rng.choice([40.0, 40.0, 25.0, 100.0]))                 # pixels per metre = size / phys
+            dev = cs.CoreSlamDevice(ctx, phys, size, osize)
             ref = np.full(size * size, 32750, np.uint16)
             oref = np.full(osize * osize, -5, np.int8)
             prng = sim.PCG32(int(rng.integers(1, 1 << 30)))
@@ -175,11 +176,13 @@ def main():
             dev.close()
         else:
             side = int(rng.choice([64, 200, 401, 1024, 2048]))
-            levels = int(rng.choice([1, 2, 3]))
+            levels = int(rng.choice([1, 2, 3, 4]))
             cell = 40.0 / side
             R = int(rng.choice([8, 180, 1080, 3000]))
-            rep = hs.MapRepMultiMap(cell, (side, side), levels, ctx=ctx)
-            ref = oc.make_pyramid(cell, side, side, levels)
+            side_h = side if rng.random() < 0.7 else int(rng.choice([side // 2 + 3, side + 37]))      # rectangular maps too
+            rep = hs.MapRepMultiMap(cell, (side, side_h), levels, ctx=ctx)
+            ref = oc.make_pyramid(cell, side, side_h, levels)
+            ff, fo = 0.4, 0.9
             if rng.random() < 0.2:
                 ff, fo = float(rng.choice([0.3, 0.45])), float(rng.choice([0.6, 0.8, 0.95]))
                 rep.SetUpdateFactorFree(ff); rep.SetUpdateFactorOccupied(fo)
@@ -198,7 +201,7 @@ def main():
                     xy = xy.copy()
                     xy[0] = [3.0e4, -2.0e4]; xy[1] = xy[2]; xy[3] = [0.0, 0.0]; xy[4] = [np.nan, 1.0]
                 org = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))) if rng.random() < 0.2 else (0.0, 0.0)
-                htrace.append((xy.copy(), p.copy()))
+                htrace.append((xy.copy(), np.concatenate([p, np.array(org, np.float32)])))
                 rep.UpdateByScan(hs.ScanCloud(xy, (org[0], org[1], 0.0)), p)
                 for g in ref:
                     g.update_by_scan(xy, p, origin=org)
@@ -227,22 +230,29 @@ def main():
                     # last-digit difference in an intermediate estimate can move a point into the neighbouring cell and the
                     # answer by millimetres.  The device result must then be what the reference arithmetic gives for a hint
                     # a digit or two away.
+                    # the reference's own thread counts first: another chunking of the fp32 sums is enough to flip it
+                    alt = np.array([oc.match_pyramid(ref, xy, hint, [3] * levels, T) for T in (2, 3, 5, 8, 16)])
+                    close = bool(np.any(np.all(np.abs(alt - np.asarray(m)[None]) < tol, axis=1)))
                     prng2 = np.random.default_rng(n_cases)
                     # (on coarse grids the intermediate estimates differ by up to ~1e-5: three scales of perturbation)
                     outs = np.array([oc.match_pyramid(ref, xy, (hint * (1.0 + prng2.uniform(-3e-7, 3e-7, 3)) + prng2.uniform(-sc, sc, 3)).astype(np.float32), [3] * levels, 4)
                                      for sc in (1e-6, 1e-5, 3e-5) for _ in range(40)])
-                    close = bool(np.any(np.all(np.abs(outs - np.asarray(m)[None]) < tol, axis=1)))
+                    close = close or bool(np.any(np.all(np.abs(outs - np.asarray(m)[None]) < tol, axis=1)))
                     if not close:
                         # many different answers in that neighbourhood (a chaotic case): inside their envelope is all one can ask
+                        # (or the reference's own answers over that cloud spread by more than the tolerance)
                         distinct = len({tuple(np.round(o, 5)) for o in outs})
-                        close = distinct >= 8 and bool(np.all(np.asarray(m) > outs.min(0) - tol) and np.all(np.asarray(m) < outs.max(0) + tol))
+                        spread = outs.max(0) - outs.min(0)
+                        pad = tol + (spread if bool(np.any(spread > 1e-4)) else 0.0)
+                        close = (distinct >= 8 or bool(np.any(spread > 1e-4))) and \
+                            bool(np.all(np.asarray(m) > outs.min(0) - pad) and np.all(np.asarray(m) < outs.max(0) + pad))
                     n_near += 1
                 ok = ok and close
             desc = "hector side %d levels %d rays %d pose %s" % (side, levels, R, np.round(pose, 2))
             if not ok:
                 desc += " | cells equal: %s, match %s vs oracle %s (hint %s)" % (cells_ok, np.asarray(m), w, hint)
                 if a.dump:
-                    np.savez(a.dump, side=side, levels=levels, cell=cell, hint=hint, m=np.asarray(m), w=w, n_updates=len(htrace),
+                    np.savez(a.dump, side=side, side_h=side_h, ff=ff, fo=fo, levels=levels, cell=cell, hint=hint, m=np.asarray(m), w=w, n_updates=len(htrace),
                              **{"xy%d" % i: t[0] for i, t in enumerate(htrace)}, **{"p%d" % i: t[1] for i, t in enumerate(htrace)})
             rep.close()
         print(("ok   " if ok else "FAIL ") + desc, flush=True)
