@@ -168,6 +168,31 @@ def test_holemap_update_c_vs_numpy(oc, npo, sim):
             assert (a == b).all()
 
 
+def test_holemap_hostile_points_c_vs_numpy(oc, npo, sim):
+    """The inputs the randomised soak leans on: an end point tens of kilometres out (ClipRay's int32 products wrap,
+    CoreSLAMProcessor.cs:329,:340 -- the clipped ray can come back with dyc > dxc), duplicates, a point at the robot,
+    NaN, weights 1 and 255.  The two independently written restatements must agree pixel for pixel."""
+    segs = sim.default_field()
+    for size, q, hw, pose in [(64, 1, 2.0, (25.2, 16.0, -2.55)), (128, 255, 0.1, (20.0, 20.0, 0.4)), (96, 128, 5.0, (30.1, 9.7, 3.3))]:
+        rays, xy = sim.make_scan(segs, pose, 60, sim.PCG32(11))
+        xy = xy.copy()
+        xy[0] = [3.0e4, -2.0e4]; xy[1] = xy[2]; xy[3] = [0.0, 0.0]; xy[4] = [np.nan, 1.0]; xy[5] = [-7.0e5, 9.0e5]
+        scale = oc.map_scale(size, 40.0)
+        a = uniform_map(size); b = a.copy()
+        for it in range(2):
+            p = (pose[0] + 0.1 * it, pose[1] - 0.05 * it, pose[2] + 0.02 * it)
+            pxcs = oc.pose_to_pxcs(p, scale)
+            n1 = oc.update_holemap_pxcs(a, size, scale, xy, pxcs, hw, q)
+            n2 = npo.update_holemap_pxcs(b, size, scale, xy, pxcs, hw, q)
+            assert n1 == n2 and n1 > 0
+            assert (a == b).all()
+        oa = np.full(32 * 32, -5, np.int8); ob = np.full((32, 32), -5, np.int8)
+        pxo = oc.pose_to_pxcs(pose, oc.map_scale(32, 40.0))
+        oc.update_obstaclemap_pxcs(oa, 32, xy, pxo, 10)
+        npo.update_obstaclemap_pxcs(ob, 32, xy, pxo, 10)
+        assert (oa.reshape(32, 32) == ob).all()
+
+
 def test_holemap_robot_outside_map(oc):
     """Quirk 11 (:509-512)."""
     pix = uniform_map(64)
