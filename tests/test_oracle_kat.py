@@ -391,3 +391,26 @@ def test_hector_grid_update_c_vs_numpy(oc, npo, sim):
             assert (g.cells["value"] == ng.value).all()
     finally:
         oc.set_trig_mode(oc.TRIG_LIBM)
+
+
+def test_hector_grid_hostile_points_c_vs_numpy(oc, npo, sim):
+    """Far, duplicate, NaN and at-the-origin points, a scan origin off the robot, a rectangular grid: the two
+    restatements of OccGridMap.UpdateByScan agree cell for cell."""
+    segs = sim.default_field()
+    oc.set_trig_mode(oc.TRIG_DET)
+    try:
+        g = oc.Grid(0.25, 120, 77)
+        ng = npo.NpGrid(0.25, 120, 77)
+        for it in range(3):
+            pose = (14 + 0.3 * it, 9 - 0.1 * it, 0.2 * it)
+            rays, xy = sim.make_scan(segs, pose, 90, sim.PCG32(it))
+            xy = xy.copy()
+            xy[0] = [3.0e4, -2.0e4]; xy[1] = xy[2]; xy[3] = [0.0, 0.0]; xy[4] = [np.nan, 1.0]
+            g.update_by_scan(xy, pose, origin=(0.3, -0.2))
+            ng.update_by_scan(xy, pose, origin=(0.3, -0.2))
+            assert (g.cells["update_index"] == ng.upd).all()
+            assert (g.cells["value"] == ng.value).all()
+        assert (g.cells["value"] != 0).sum() > 50
+    finally:
+        oc.set_trig_mode(oc.TRIG_LIBM)
+
