@@ -20,7 +20,7 @@
 //            rank-sorted by ray index and blended in that order; the few pixels with more than 64 candidates scan
 //            all rays in index order
 // All integer arithmetic wraps like C# unchecked int; float->int follows cvttss2si (sh_f2i).
-// Deviations from the reference (all in exception / platform-dependent territory; the oracle does the same):
+// Deviations from the reference (all in exception / platform-dependent territory; the CPU checker used by the tests does the same):
 //   D1 non-representable pixel coordinates (NaN/inf, e.g. zero-range point) skip the ray;
 //   D2 Math.Abs(int.MinValue) / int.MinValue / -1 skip the ray;
 //   D4 a clipped endpoint outside the map (reachable only through int32 overflow in :329/:340) skips the ray.
