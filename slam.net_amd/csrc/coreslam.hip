@@ -161,7 +161,7 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
             hipMalloc(&cs->d_key, 64) != hipSuccess ||          // result block: key (8 B) | winner pose (16 B) | blended pixels (4 B)
 
             hipMalloc(&cs->d_verify, sizeof(unsigned int) * 8) != hipSuccess ||
-            hipHostMalloc(&cs->h_key, 128) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
+            hipHostMalloc(&cs->h_key, 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
         cs->d_best_pose = (float *)cs->d_key + 2;
         if (hipMemset(cs->d_verify, 0, sizeof(unsigned int) * 8) != hipSuccess) { slamhip_set_error("hipMemset failed"); rc = SLAMHIP_ERR_HIP; break; }
         if ((rc = cs_holemap_alloc(cs)) != SLAMHIP_OK) break;
@@ -610,9 +610,38 @@ extern "C" int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float pos
     return search_enqueue(cs, pose, first, count, d_out_key);     // prep arms the key, K1/K1r min into it
 }
 
+// Wait for a completion word in pinned host memory that the stream's last kernel writes after its results (which it
+// stored to the same pinned block): no device-to-host copy, no stream synchronisation.  A kernel that never gets there
+// (fault) is reported by the stream itself after the time-out.
+static int32_t host_wait(slamhip_cs *cs, volatile unsigned *flag, unsigned val)
+{
+    for (long spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return SLAMHIP_OK;
+        if ((spins & 0xfffff) == 0xfffff) {                        // every ~million polls: is the stream in trouble, or done without the word?
+            const hipError_t e = hipStreamQuery(cs->ctx->stream);
+            if (e == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == val ? SLAMHIP_OK : (slamhip_set_error("completion word missing"), SLAMHIP_ERR_HIP);
+            if (e != hipErrorNotReady) SH_HIP(e);
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 extern "C" int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count, uint64_t *out_key)
 {
     SH_CHECK_ARG(cs && out_key);
+    static const bool spin = !(getenv("SLAMHIP_NO_HOSTWAIT") && atoi(getenv("SLAMHIP_NO_HOSTWAIT")));
+    if (spin) {
+        // the launch stores the key straight into the pinned block and ends with the completion word
+        volatile unsigned *flag = (volatile unsigned *)(cs->h_key + 15);
+        cs->k1_done_flag = (unsigned *)flag; cs->k1_done_val = ++cs->host_seq;
+        const int32_t rc = search_enqueue(cs, pose, first, count, cs->h_key);
+        cs->k1_done_flag = nullptr;
+        SH_TRY(rc);
+        if (cs->k1_done_armed) SH_TRY(host_wait(cs, flag, cs->host_seq));
+        else SH_HIP(hipStreamSynchronize(cs->ctx->stream));        // (fallback kernels: the key is in the pinned block when the stream is idle)
+        *out_key = *(volatile uint64_t *)cs->h_key;
+        return SLAMHIP_OK;
+    }
     SH_TRY(search_enqueue(cs, pose, first, count, cs->d_key));
     SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, cs->ctx->stream));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));

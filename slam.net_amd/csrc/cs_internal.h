@@ -64,6 +64,9 @@ struct slamhip_cs {
     float *d_best_pose;           // winner's pose (theta normalised), device-resident for the fused path (inside d_key's block)
     bool k1_want_pose;            // the next search launch also writes d_best_pose (fused search + update)
     bool k1_pose_written;         // ... and it did (tiled kernel); the fallback kernels do not
+    unsigned *k1_done_flag; unsigned k1_done_val;   // the next search launch ends with k1_done_val -> *k1_done_flag (pinned host word), if set
+    bool k1_done_armed;           // ... and it will (tiled kernel)
+    unsigned host_seq;            // blocking calls: sequence number of the completion word in h_key[15]
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------
     void *d_rays; int cap_rays;                 // rays by index (k2_byidx): clipped lengths, flags

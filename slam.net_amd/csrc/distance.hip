@@ -222,6 +222,7 @@ struct k1_args {
     unsigned long long *key_out;
     unsigned *verify;
     const float *offs_flat; float *best_pose;   // fused search + update: the winner's pose (theta normalised) for the map updates
+    unsigned *done_flag; unsigned done_val;     // blocking search: the launch's last act is done_val -> *done_flag (host memory the caller spins on), or null
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
@@ -256,6 +257,15 @@ __device__ static inline unsigned k1_tile_addr(int ix, int iy, int pitch2, int k
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(t) : "v"(ix), "s"(kofs));
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a) : "v"(iy), "s"(pitch2), "v"(t));
     return a;
+}
+// The same address from the float coordinates (tile steps whose end points all lie in the tile): truncation, the row-major
+// element index iy * pitch + ix as one FMA and the byte address 2 * (index - first element) + tile base read off the
+// mantissa of (index + mc) with mc = 2^22 - first element + base / 2 -- every value is an integer below 2^24, so the
+// float arithmetic is exact; five full-rate operations instead of two conversions and two integer multiply-adds at half rate
+__device__ static inline unsigned k1_tile_addr_f(float fx, float fy, float pitch, float mc)
+{
+    const float g = fmaf(truncf(fy), pitch, truncf(fx)) + mc;
+    return __float_as_uint(g) & 0x7fffffu;
 }
 // 16-bit LDS load at an absolute LDS byte address (saves the per-access `tile + offset` add)
 typedef __attribute__((address_space(3))) const uint16_t k1_lds_u16;
@@ -373,7 +383,10 @@ k1_search_tiled(const k1_args a)
     // (theta-tail groups: nbp workgroups share a ray range and take every nbp-th band of its banded tiles -- their
     // run time is the number of tile steps, which more ray ranges would not reduce)
     const int rc = chunk / nbp, bp = chunk - rc * nbp, nrc = nc / nbp;
-    const int rlo = (int)(((long long)rc * a.n_rays) / nrc), rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc);
+    int rlo, rhi;
+    if (a.n_rays <= 46340) {                                       // (rc < nrc <= n_rays: the products fit 32 bits; the 64-bit division is a hundred scalar instructions)
+        rlo = (int)(((unsigned)rc * (unsigned)a.n_rays) / (unsigned)nrc); rhi = (int)(((unsigned)(rc + 1) * (unsigned)a.n_rays) / (unsigned)nrc);
+    } else { rlo = (int)(((long long)rc * a.n_rays) / nrc); rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc); }
     const int nrays = rhi - rlo;
     const int blk_first = a.ray_blk[rlo].z;
     const int npieces = a.ray_blk[rhi - 1].z - blk_first + 1;
@@ -593,6 +606,15 @@ k1_search_tiled(const k1_args a)
             const int pitch2 = w8 << 1;
             const int kofs = (int)smem_lds + K1_TILE_OFS - ((y0 * w8 + x0a) << 1);
             const unsigned zaddr = smem_lds + K1_ZERO_OFS + (unsigned)zv;
+            // (float form of the tile address, k1_tile_addr_f: element indices of the map stay below 2^24 up to 16384 rows of at most
+            // 512 pixels; pitch and offset live in VGPRs -- an SGPR operand costs a VALU operation 1.6x the issue time)
+            const bool faddr = S <= 16384;
+            float pf_v, mc_v;
+            {
+                const float pf_s = (float)w8, mc_s = 4194304.0f - (float)(y0 * w8 + x0a) + (float)((smem_lds + K1_TILE_OFS) >> 1);
+                asm volatile("v_mov_b32 %0, %1" : "=v"(pf_v) : "s"(pf_s));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(mc_v) : "s"(mc_s));
+            }
             if (kind != K1_KIND_GLOBAL) {
                 // SHARED: every end point of every candidate lies in the tile (the box is rigorous).  BAND: the band
                 // holds rows [y0, y0+h) x columns [x0a, x0a+w8) of the map; an end point outside it (another band's,
@@ -608,7 +630,36 @@ k1_search_tiled(const k1_args a)
 #pragma unroll
                 for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(zaddr); vb[k] = k1_lds_load(zaddr); }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!checked) {
+                if (!checked && faddr) {
+                    for (; r + 1 < nr; r += 2) {
+                        const float2 pa = pa_n, pb = pb_n;
+                        pa_n = k1_point_lds(pbase + r * 8 + 16); pb_n = k1_point_lds(pbase + r * 8 + 24);
+                        unsigned ada[CPL], adb[CPL];
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) {
+                            float fxa, fya, fxb, fyb;
+                            k1_coords(q[k], pa, fxa, fya);
+                            k1_coords(q[k], pb, fxb, fyb);
+                            const int ixa = (int)fxa, iya = (int)fya, ixb = (int)fxb, iyb = (int)fyb;
+                            ada[k] = k1_tile_addr_f(fxa, fya, pf_v, mc_v);
+                            adb[k] = k1_tile_addr_f(fxb, fyb, pf_v, mc_v);
+                            if (VERIFY) {
+                                if (ixa < x0a || ixa >= x0a + w8 || iya < y0 || iya >= y0 + h ||
+                                    ixb < x0a || ixb >= x0a + w8 || iyb < y0 || iyb >= y0 + h) atomicAdd(a.verify, 1u);
+                                else if (map[(size_t)iya * S + ixa] != *(const uint16_t *)(smem + (ada[k] - smem_lds)) ||
+                                         map[(size_t)iyb * S + ixb] != *(const uint16_t *)(smem + (adb[k] - smem_lds)))
+                                    atomicAdd(a.verify, 1u);               // the staged tile must equal the map
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) sum[k] += va[k] + vb[k];
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(ada[k]); vb[k] = k1_lds_load(adb[k]); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    cnt_all += (uint32_t)nr;
+                } else if (!checked) {
                     for (; r + 1 < nr; r += 2) {
                         const float2 pa = pa_n, pb = pb_n;
                         pa_n = k1_point_lds(pbase + r * 8 + 16); pb_n = k1_point_lds(pbase + r * 8 + 24);
@@ -798,6 +849,9 @@ k1_search_tiled(const k1_args a)
             if (flat > 0) { x = a.bx + a.offs_flat[3 * (flat - 1)]; y = a.by + a.offs_flat[3 * (flat - 1) + 1]; th = a.bth + a.offs_flat[3 * (flat - 1) + 2]; }
             a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
             a.best_pose[3] = th;                                   // un-normalised, as MonteCarloSearch returns it
+        }
+        if (a.done_flag) {                                         // (release at system scope: the key above is in host memory before the flag)
+            __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     K1_STAMP(9)
@@ -1012,6 +1066,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.grp_bounds = (mode == 1 && !no_bounds) ? cs->d_grp_bounds : nullptr;
         a.offs_flat = cs->d_offs_flat; a.best_pose = (mode == 1 && cs->k1_want_pose) ? cs->d_best_pose : nullptr;
         cs->k1_pose_written = a.best_pose != nullptr;
+        a.done_flag = cs->k1_done_flag; a.done_val = cs->k1_done_val;
+        cs->k1_done_armed = a.done_flag != nullptr;
 
         // launch layout
         const bool have_spread = mode == 1 && !no_table && (int)cs->h_grp_dth.size() == n_groups;
@@ -1174,7 +1230,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     }
 
     // ---- fallback: candidate transform, bounds-checked global gathers, reduction -----------------------------------
-    cs->k1_pose_written = false;
+    cs->k1_pose_written = false; cs->k1_done_armed = false;
     {
         sh_timer t(ctx, SLAMHIP_K_CS_PREP);
         const dim3 grid(sh_div_up(count, K1_THREADS));

@@ -1,0 +1,27 @@
+"""Blocking-call latencies of the operator entry points (one MI355X): what a per-scan caller waits for."""
+import sys, os, math, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import slam.net_amd.coreslam as cs, slam.net_amd.sim as sim
+
+def med(f, n=300, warm=30):
+    for _ in range(warm): f()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"median_us": ts[len(ts) // 2] * 1e6, "p10_us": ts[len(ts) // 10] * 1e6, "p90_us": ts[len(ts) * 9 // 10] * 1e6}
+
+K, size, R = 16384, 2048, 1080
+ctx = cs.Context(0); dev = cs.CoreSlamDevice(ctx, 40.0, size, size // 4)
+segs = sim.default_field(); rng = sim.PCG32(1234); traj = sim.trajectory(31)
+for p in traj[:-1]:
+    _, xy = sim.make_scan(segs, p, R, rng); dev.set_scan(xy); dev.update_holemap(p)
+_, xy = sim.make_scan(segs, traj[-1], R, rng)
+base = (traj[-1] + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
+dev.set_scan(xy); dev.set_offsets(sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0)))
+out = {"search_shard_blocking": med(lambda: dev.search_shard(base, 0, K)),
+       "search_and_update_blocking": med(lambda: dev.search_and_update(base)),
+       "update_holemap_blocking": med(lambda: dev.update_holemap(base)),
+       "update_obstaclemap_blocking": med(lambda: dev.update_obstaclemap(base))}
+print(json.dumps(out, indent=1))
