@@ -43,7 +43,10 @@ extern "C" int32_t slamhip_ctx_create(int32_t device, slamhip_ctx **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) { free(c); SH_FAIL(SLAMHIP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    memset(c->mailbox, 0, 64);
+    c->mail_off = getenv("SLAMHIP_NO_HOSTWAIT") && atoi(getenv("SLAMHIP_NO_HOSTWAIT"));
     *out = c;
     return SLAMHIP_OK;
 }
@@ -60,6 +63,7 @@ extern "C" int32_t slamhip_ctx_destroy(slamhip_ctx *c)
     (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
     (void)hipStreamDestroy(c->aux_stream);
     (void)hipStreamDestroy(c->stream);
+    if (c->mailbox) (void)hipHostFree(c->mailbox);
     free(c);
     return SLAMHIP_OK;
 }
@@ -79,6 +83,46 @@ extern "C" int32_t slamhip_ctx_device(slamhip_ctx *c, int32_t *out)
 }
 
 extern "C" void *slamhip_ctx_stream(slamhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---- mailbox: results and completion of a blocking call in pinned host memory ---------------------------------
+__global__ void k_publish(const uint32_t *__restrict__ src, int n_words, uint32_t *__restrict__ mailbox, uint32_t seq)
+{
+    if ((int)threadIdx.x < n_words) mailbox[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();                                               // (one wavefront: orders the lanes' stores before lane 0's release)
+    if (threadIdx.x == 0) __hip_atomic_store(mailbox + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words)
+{
+    SH_CHECK_ARG(n_words >= 0 && n_words <= 15 && (d_src || n_words == 0));
+    const uint32_t seq = sh_mail_seq_next(ctx);
+    if (ctx->mail_off) {                                           // (SLAMHIP_NO_HOSTWAIT=1: the copy + synchronise form)
+        if (n_words > 0) SH_HIP(hipMemcpyAsync(ctx->mailbox, d_src, sizeof(uint32_t) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
+        return SLAMHIP_OK;
+    }
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t *)d_src, n_words, ctx->mailbox, seq);
+    SH_HIP(hipGetLastError());
+    return SLAMHIP_OK;
+}
+
+int32_t sh_host_wait(slamhip_ctx *ctx)
+{
+    if (ctx->mail_off) { SH_HIP(hipStreamSynchronize(ctx->stream)); return SLAMHIP_OK; }
+    volatile uint32_t *flag = ctx->mailbox + 15;
+    const uint32_t val = ctx->mail_seq;
+    for (long spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return SLAMHIP_OK;
+        if ((spins & 0xfffff) == 0xfffff) {                        // every ~million polls: is the stream in trouble, or idle without the word?
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return SLAMHIP_OK;
+                SH_FAIL(SLAMHIP_ERR_HIP, "the stream is idle but the completion word never arrived");
+            }
+            if (e != hipErrorNotReady) SH_HIP(e);
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 // ---- timing ------------------------------------------------------------------------------------
 static hipEvent_t ev_get(slamhip_ctx *c)

@@ -161,7 +161,7 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
             hipMalloc(&cs->d_key, 64) != hipSuccess ||          // result block: key (8 B) | winner pose (16 B) | blended pixels (4 B)
 
             hipMalloc(&cs->d_verify, sizeof(unsigned int) * 8) != hipSuccess ||
-            hipHostMalloc(&cs->h_key, 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
+            hipHostMalloc(&cs->h_key, 128) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
         cs->d_best_pose = (float *)cs->d_key + 2;
         if (hipMemset(cs->d_verify, 0, sizeof(unsigned int) * 8) != hipSuccess) { slamhip_set_error("hipMemset failed"); rc = SLAMHIP_ERR_HIP; break; }
         if ((rc = cs_holemap_alloc(cs)) != SLAMHIP_OK) break;
@@ -380,10 +380,17 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
 static int32_t finish_distance(slamhip_cs *cs, int K, int32_t *out_dist, int32_t *out_best_index, int32_t *out_best_dist)
 {
     slamhip_ctx *ctx = cs->ctx;
-    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (out_dist) SH_HIP(hipMemcpyAsync(out_dist, cs->d_dist, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
-    SH_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t key = *cs->h_key;
+    uint64_t key;
+    if (out_dist) {
+        SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SH_HIP(hipMemcpyAsync(out_dist, cs->d_dist, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+        SH_HIP(hipStreamSynchronize(ctx->stream));
+        key = *cs->h_key;
+    } else {
+        SH_TRY(sh_publish(ctx, cs->d_key, 2));
+        SH_TRY(sh_host_wait(ctx));
+        key = *(volatile uint64_t *)ctx->mailbox;
+    }
     if (out_best_index) *out_best_index = (int32_t)(uint32_t)key;
     if (out_best_dist) *out_best_dist = (int32_t)(uint32_t)(key >> 32);
     return SLAMHIP_OK;
@@ -610,41 +617,26 @@ extern "C" int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float pos
     return search_enqueue(cs, pose, first, count, d_out_key);     // prep arms the key, K1/K1r min into it
 }
 
-// Wait for a completion word in pinned host memory that the stream's last kernel writes after its results (which it
-// stored to the same pinned block): no device-to-host copy, no stream synchronisation.  A kernel that never gets there
-// (fault) is reported by the stream itself after the time-out.
-static int32_t host_wait(slamhip_cs *cs, volatile unsigned *flag, unsigned val)
-{
-    for (long spins = 0;; spins++) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return SLAMHIP_OK;
-        if ((spins & 0xfffff) == 0xfffff) {                        // every ~million polls: is the stream in trouble, or done without the word?
-            const hipError_t e = hipStreamQuery(cs->ctx->stream);
-            if (e == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == val ? SLAMHIP_OK : (slamhip_set_error("completion word missing"), SLAMHIP_ERR_HIP);
-            if (e != hipErrorNotReady) SH_HIP(e);
-        }
-        __builtin_ia32_pause();
-    }
-}
-
 extern "C" int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count, uint64_t *out_key)
 {
     SH_CHECK_ARG(cs && out_key);
-    static const bool spin = !(getenv("SLAMHIP_NO_HOSTWAIT") && atoi(getenv("SLAMHIP_NO_HOSTWAIT")));
-    if (spin) {
-        // the launch stores the key straight into the pinned block and ends with the completion word
-        volatile unsigned *flag = (volatile unsigned *)(cs->h_key + 15);
-        cs->k1_done_flag = (unsigned *)flag; cs->k1_done_val = ++cs->host_seq;
-        const int32_t rc = search_enqueue(cs, pose, first, count, cs->h_key);
+    slamhip_ctx *ctx = cs->ctx;
+    if (!ctx->mail_off) {
+        // the launch ends with the key and the completion word into the mailbox (tiled kernel), or a publish launch
+        // follows the fallback kernels
+        cs->k1_done_flag = ctx->mailbox + 15; cs->k1_done_val = ctx->mail_seq + 1;
+        const int32_t rc = search_enqueue(cs, pose, first, count, cs->d_key);
         cs->k1_done_flag = nullptr;
         SH_TRY(rc);
-        if (cs->k1_done_armed) SH_TRY(host_wait(cs, flag, cs->host_seq));
-        else SH_HIP(hipStreamSynchronize(cs->ctx->stream));        // (fallback kernels: the key is in the pinned block when the stream is idle)
-        *out_key = *(volatile uint64_t *)cs->h_key;
+        if (cs->k1_done_armed) (void)sh_mail_seq_next(ctx);
+        else SH_TRY(sh_publish(ctx, cs->d_key, 2));
+        SH_TRY(sh_host_wait(ctx));
+        *out_key = *(volatile uint64_t *)ctx->mailbox;
         return SLAMHIP_OK;
     }
     SH_TRY(search_enqueue(cs, pose, first, count, cs->d_key));
-    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, cs->ctx->stream));
-    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SH_HIP(hipStreamSynchronize(ctx->stream));
     *out_key = *cs->h_key;
     return SLAMHIP_OK;
 }
@@ -694,12 +686,12 @@ static float4 pxcs_from_pose(const float pose[3], float scale)
 
 static int32_t finish_holemap(slamhip_cs *cs)
 {
-    int *h = (int *)cs->h_key;
-    SH_HIP(hipMemcpyAsync(h + 4, cs->d_k2_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, cs->ctx->stream));
-    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
-    cs->last_hole_pixels = h[4 + 2];
+    SH_TRY(sh_publish(cs->ctx, cs->d_k2_counters, 4));
+    SH_TRY(sh_host_wait(cs->ctx));
+    const int *m = (const int *)cs->ctx->mailbox;                           // [0] longest ray, [1] conflict pixels, [2] blended pixels
+    cs->last_hole_pixels = m[2];
     static const bool stats = getenv("SLAMHIP_K2_STATS") != nullptr;        // developer aid
-    if (stats) fprintf(stderr, "[slamhip] K2: reach %d px, %d pixels with more than 4 fragments (drawn by the last workgroup), %d blended pixels\n", h[4], h[5], h[6]);
+    if (stats) fprintf(stderr, "[slamhip] K2: reach %d px, %d pixels with more than 4 fragments (drawn by the last workgroup), %d blended pixels\n", m[0], m[1], m[2]);
     return SLAMHIP_OK;
 }
 
@@ -727,8 +719,8 @@ extern "C" int32_t slamhip_cs_update_obstaclemap_pxcs(slamhip_cs *cs, const floa
     SH_HIP(hipSetDevice(cs->ctx->device));
     if (cs->n_points <= 0) return SLAMHIP_OK;
     SH_TRY(cs_launch_obstacle_update(cs, nullptr, make_float4(pxcs[0], pxcs[1], pxcs[2], pxcs[3]), max_hits));
-    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
-    return SLAMHIP_OK;
+    SH_TRY(sh_publish(cs->ctx, nullptr, 0));
+    return sh_host_wait(cs->ctx);
 }
 
 extern "C" int32_t slamhip_cs_update_obstaclemap(slamhip_cs *cs, const float pose[3], int32_t max_hits)
@@ -804,11 +796,12 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
         SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality));
         SH_TRY(cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits));
     }
-    float *hp = (float *)(cs->h_key + 1);
-    SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, 32, hipMemcpyDeviceToHost, ctx->stream));
-    SH_HIP(hipStreamSynchronize(ctx->stream));
-    cs->last_hole_pixels = ((int *)cs->h_key)[6];
-    const uint64_t key = *cs->h_key;
+    SH_TRY(sh_publish(ctx, cs->d_key, 8));
+    SH_TRY(sh_host_wait(ctx));
+    const volatile uint64_t *hk = (const volatile uint64_t *)ctx->mailbox;
+    const float *hp = (const float *)(ctx->mailbox + 2);
+    cs->last_hole_pixels = ((const int *)ctx->mailbox)[6];
+    const uint64_t key = hk[0];
     if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
     if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);
     if (out_index) *out_index = (int32_t)(uint32_t)key;

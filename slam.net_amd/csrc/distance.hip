@@ -222,7 +222,8 @@ struct k1_args {
     unsigned long long *key_out;
     unsigned *verify;
     const float *offs_flat; float *best_pose;   // fused search + update: the winner's pose (theta normalised) for the map updates
-    unsigned *done_flag; unsigned done_val;     // blocking search: the launch's last act is done_val -> *done_flag (host memory the caller spins on), or null
+    unsigned *done_flag; unsigned done_val;     // blocking search: word 15 of the context's mailbox (pinned host memory, common.h) -- the launch's last act is the key into
+                                                // words 0-1 and done_val into word 15 -- or null
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
@@ -850,7 +851,8 @@ k1_search_tiled(const k1_args a)
             a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
             a.best_pose[3] = th;                                   // un-normalised, as MonteCarloSearch returns it
         }
-        if (a.done_flag) {                                         // (release at system scope: the key above is in host memory before the flag)
+        if (a.done_flag) {                                         // blocking search: the key into the mailbox, then its completion word
+            *(unsigned long long *)(a.done_flag - 15) = best;
             __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

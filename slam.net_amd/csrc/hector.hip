@@ -252,7 +252,7 @@ __device__ static inline void hs_step(const float sums[9], float est[3])
 template <int BDIM>
 __global__ void __launch_bounds__(BDIM)
 k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float3 hint1,
-         float *__restrict__ out, int only_level, int iters_override)
+         float *__restrict__ out, int only_level, int iters_override, uint32_t *mail, uint32_t mail_seq)
 {
     __shared__ double red[16 * 9 + 9];
     const int b = blockIdx.x;
@@ -285,7 +285,13 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
             est_w[2] = est[2];
         }
     }
-    if (threadIdx.x == 0) { out[3 * b] = est_w[0]; out[3 * b + 1] = est_w[1]; out[3 * b + 2] = est_w[2]; }
+    if (threadIdx.x == 0) {
+        out[3 * b] = est_w[0]; out[3 * b + 1] = est_w[1]; out[3 * b + 2] = est_w[2];
+        if (mail) {                                                        // a single blocking match: the pose and the completion word into the context's mailbox (common.h)
+            ((float *)mail)[0] = est_w[0]; ((float *)mail)[1] = est_w[1]; ((float *)mail)[2] = est_w[2];
+            __hip_atomic_store(mail + 15, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -834,6 +840,7 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     slamhip_ctx *ctx = hs->ctx;
     SH_TRY(ensure_io(hs, 6 * B));
     float *d_in = hs->d_io, *d_out = hs->d_io + 3 * (size_t)B;
+    const bool mail1 = B == 1 && !ctx->mail_off;                          // one match: the kernel itself delivers the pose to the host
     if (B > 1) {
         memcpy(hs->h_io, hints, sizeof(float) * 3 * (size_t)B);
         SH_HIP(hipMemcpyAsync(d_in, hs->h_io, sizeof(float) * 3 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
@@ -844,10 +851,11 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
         // batches keep 256 lanes per hint (throughput: many workgroups per CU)
         if (B <= 64)
             hipLaunchKernelGGL(k4_match<1024>, dim3(B), dim3(1024), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
-                               B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters);
+                               B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters,
+                               mail1 ? ctx->mailbox : (uint32_t *)nullptr, mail1 ? sh_mail_seq_next(ctx) : 0u);
         else
             hipLaunchKernelGGL(k4_match<256>, dim3(B), dim3(256), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
-                               (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters);
+                               (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters, (uint32_t *)nullptr, 0u);
     }
     SH_HIP(hipGetLastError());
 #ifdef K4_TIMES
@@ -866,6 +874,12 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
         }
     }
 #endif
+    if (mail1) {
+        SH_TRY(sh_host_wait(ctx));
+        const volatile float *m = (const volatile float *)ctx->mailbox;
+        out[0] = m[0]; out[1] = m[1]; out[2] = m[2];
+        return SLAMHIP_OK;
+    }
     SH_HIP(hipMemcpyAsync(hs->h_io + 3 * (size_t)B, d_out, sizeof(float) * 3 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     SH_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(out, hs->h_io + 3 * (size_t)B, sizeof(float) * 3 * (size_t)B);
@@ -965,8 +979,8 @@ extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3]
     }
     SH_HIP(hipGetLastError());
     for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144
-    SH_HIP(hipStreamSynchronize(ctx->stream));
-    return SLAMHIP_OK;
+    SH_TRY(sh_publish(ctx, nullptr, 0));
+    return sh_host_wait(ctx);
 }
 
 // ---- HectorSLAMProcessor (Main/HectorSLAMProcessor.cs) ---------------------------------------------------------------

@@ -25,3 +25,18 @@ out = {"search_shard_blocking": med(lambda: dev.search_shard(base, 0, K)),
        "update_holemap_blocking": med(lambda: dev.update_holemap(base)),
        "update_obstaclemap_blocking": med(lambda: dev.update_obstaclemap(base))}
 print(json.dumps(out, indent=1))
+
+# Hector: 3-level 2048^2 pyramid, 1080 rays
+import slam.net_amd.hector as hs
+rep = hs.MapRepMultiMap(40.0 / 2048, (2048, 2048), 3, ctx=ctx)
+rng = sim.PCG32(3)
+scans = []
+for it in range(12):
+    p = np.array([20 + 0.05 * it, 20 + 0.02 * it, 0.01 * it], np.float32)
+    scans.append((sim.make_scan(segs, p, 1080, rng)[1], p))
+for xy2, p in scans[:10]: rep.UpdateByScan(hs.ScanCloud(xy2), p)
+m = hs.ScanMatcher(4)
+xy2, p = scans[-1]; scan = hs.ScanCloud(xy2); hint = p + np.array([0.1, -0.08, 0.03], np.float32)
+out2 = {"hector_match_blocking": med(lambda: m.MatchData(rep, scan, hint)),
+        "hector_update_blocking": med(lambda: rep.UpdateByScan(scan, p), n=100, warm=10)}
+print(json.dumps(out2, indent=1))
