@@ -103,13 +103,50 @@ def main():
     search_args = (dev._h, capi.fptr(base), int(first), int(count), C.c_void_p(key.data_ptr()))
     assert key.dtype == torch.int64 and key.numel() == 1           # packed (distance << 32 | index): MIN on int64 is exact
 
-    def step():
+    def step_torch():
         capi.check(search_fn(*search_args))
         if world > 1:
             dist.all_reduce(key, op=dist.ReduceOp.MIN)             # one 8-byte RCCL min all-reduce per step
 
+    # N > 1: the library's own communicator (slamhip_comm_*, RCCL resolved from the copy torch loaded): a step is ONE C
+    # call -- K1 on the operator's stream, the 8-byte min all-reduce behind an event on the communicator's stream, so
+    # the next search overlaps the collective and no interpreter / c10d work sits between them.  It is checked against
+    # the torch.distributed path on this very workload first; any failure or disagreement on any rank falls back to
+    # that path (SLAMHIP_BENCH_COLLECTIVE=torch forces it; "lib1" exercises the library path on a single rank).
+    coll = os.environ.get("SLAMHIP_BENCH_COLLECTIVE", "lib")
+    comm = None
+    collective = "none"
+    if (world > 1 and backend == "nccl" and coll == "lib") or (world == 1 and coll == "lib1"):
+        ok = 1
+        try:
+            comm = D.LibComm(ctx, rank, world)
+            lib_step = comm.bind_step(dev, base, first, count)
+            lib_step()
+            k_lib = comm.wait()
+            step_torch()
+            ctx.synchronize(); torch.cuda.synchronize()
+            ok = int(k_lib == int(key.item()))
+        except Exception as e:                                     # noqa: BLE001 -- any failure means "use the torch path"
+            print("bench.py: library communicator unavailable on rank %d (%s); using torch.distributed" % (rank, e), file=sys.stderr)
+            ok = 0
+        if world > 1:
+            okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = int(okt.item())
+        if not ok and comm is not None:
+            comm.close(); comm = None
+    if comm is not None:
+        step = lib_step
+        collective = "rccl ncclAllReduce(min, uint64 x 1)/step issued by libslamhip on its own stream (overlaps the next search)"
+    else:
+        step = step_torch
+        if world > 1:
+            collective = "%s all_reduce(min, 8 B)/step via torch.distributed" % ("rccl" if backend == "nccl" else backend)
+
     def sync_all():
         ctx.synchronize()
+        if comm is not None:
+            comm.synchronize()
         torch.cuda.synchronize()
 
     for _ in range(max(a.warmup, 1)):
@@ -154,7 +191,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_key = int(key.item())
+    final_key = comm.wait() if comm is not None else int(key.item())
 
     if rank == 0:
         evals = float(K_total) * a.steps
@@ -176,7 +213,7 @@ def main():
             "config": {"workload": "CoreSLAM Monte-Carlo distance search, %dx%d HoleMap, %d rays, %d candidates/GPU/step"
                                    % (a.size, a.size, a.rays, a.cands),
                        "map": a.size, "rays": a.rays, "candidates_per_gpu": a.cands, "candidates_total": K_total,
-                       "collective": ("%s all_reduce(min, 8 B)/step" % ("rccl" if backend == "nccl" else backend)) if world > 1 else "none",
+                       "collective": collective,
                        "best_index": final_key & 0xFFFFFFFF, "best_distance": final_key >> 32},
             "roofline": roof,
         }
@@ -184,6 +221,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs, final_key)
         print(json.dumps(out))
         sys.stdout.flush()
+    if comm is not None:
+        comm.close()
     dev.close()
     ctx.close()
     if world > 1:

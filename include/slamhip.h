@@ -46,6 +46,7 @@ typedef struct slamhip_csproc slamhip_csproc;  /* CoreSLAMProcessor state machin
 typedef struct slamhip_hs     slamhip_hs;      /* HectorSLAM MapRepMultiMap pyramid + ScanMatcher */
 typedef struct slamhip_hsproc slamhip_hsproc;  /* HectorSLAMProcessor state machine on top of slamhip_hs */
 typedef struct slamhip_group  slamhip_group;   /* N GPUs in one process + RCCL communicator */
+typedef struct slamhip_comm   slamhip_comm;    /* one rank (one process per GPU) of an RCCL communicator */
 
 /* {int UpdateIndex; float Value} -- HectorSLAM/Map/LogOddsCell.cs:16-21 */
 typedef struct { int32_t update_index; float value; } slamhip_cell;
@@ -287,6 +288,22 @@ int32_t slamhip_group_search(slamhip_group *g, const float search_pose[3], float
 /* replicas apply the identical deterministic update (integer-exact kernels keep them bit-identical) */
 int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float hole_width, int32_t quality,
                                   int32_t max_obstacle_hits);
+
+
+/* One process per GPU (torch.distributed.run, MPI, ...): this rank's end of an RCCL communicator.  The host framework
+ * only carries the 128-byte id from rank 0 to the other ranks; the per-scan exchange -- the cross-thread arg-min of
+ * CoreSLAMProcessor.cs:695-705 as ncclAllReduce(min, uint64, count 1) over xGMI -- is issued by the library on the
+ * communicator's own stream, behind an event, so that the next search does not wait for the last collective. */
+int32_t slamhip_comm_unique_id(uint8_t out_id[128]);                                  /* rank 0 */
+int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t id[128], int32_t rank, int32_t n_ranks, slamhip_comm **out);
+int32_t slamhip_comm_destroy(slamhip_comm *comm);
+int32_t slamhip_comm_info(slamhip_comm *comm, int32_t *out_rank, int32_t *out_n_ranks);
+/* One sharded search step (asynchronous): flat candidates [first, first+count) on this rank, then the all-reduce.
+ * *d_out_key (optional) = device address where this step's reduced key will be (valid for 64 further steps). */
+int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_comm *comm, const float search_pose[3], int32_t first,
+                                          int32_t count, uint64_t **d_out_key);
+/* Wait for every step issued so far; *out_key (optional) = the reduced key of the last one. */
+int32_t slamhip_comm_wait(slamhip_comm *comm, uint64_t *out_key);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,7 @@ struct slamhip_cs {
     bool k1_pose_written;         // ... and it did (tiled kernel); the fallback kernels do not
     unsigned *k1_done_flag; unsigned k1_done_val;   // the next search launch ends with k1_done_val -> *k1_done_flag (pinned host word), if set
     bool k1_done_armed;           // ... and it will (tiled kernel)
+    unsigned long long *k1_sig; unsigned long long k1_sig_val; bool k1_sig_armed;   // the same for an HSA signal (slamhip_comm: the collectives' stream waits for it)
     unsigned host_seq;            // blocking calls: sequence number of the completion word in h_key[15]
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------

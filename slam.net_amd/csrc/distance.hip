@@ -222,6 +222,7 @@ struct k1_args {
     unsigned long long *key_out;
     unsigned *verify;
     const float *offs_flat; float *best_pose;   // fused search + update: the winner's pose (theta normalised) for the map updates
+    unsigned long long *sig; unsigned long long sig_val;   // sharded search: sig_val -> *sig (an HSA signal another stream waits for) once the key is out, or null
     unsigned *done_flag; unsigned done_val;     // blocking search: word 15 of the context's mailbox (pinned host memory, common.h) -- the launch's last act is the key into
                                                 // words 0-1 and done_val into word 15 -- or null
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
@@ -851,6 +852,7 @@ k1_search_tiled(const k1_args a)
             a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
             a.best_pose[3] = th;                                   // un-normalised, as MonteCarloSearch returns it
         }
+        if (a.sig) __hip_atomic_store(a.sig, a.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (a.done_flag) {                                         // blocking search: the key into the mailbox, then its completion word
             *(unsigned long long *)(a.done_flag - 15) = best;
             __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1070,6 +1072,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         cs->k1_pose_written = a.best_pose != nullptr;
         a.done_flag = cs->k1_done_flag; a.done_val = cs->k1_done_val;
         cs->k1_done_armed = a.done_flag != nullptr;
+        a.sig = cs->k1_sig; a.sig_val = cs->k1_sig_val;
+        cs->k1_sig_armed = a.sig != nullptr;
 
         // launch layout
         const bool have_spread = mode == 1 && !no_table && (int)cs->h_grp_dth.size() == n_groups;
@@ -1232,7 +1236,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     }
 
     // ---- fallback: candidate transform, bounds-checked global gathers, reduction -----------------------------------
-    cs->k1_pose_written = false; cs->k1_done_armed = false;
+    cs->k1_pose_written = false; cs->k1_done_armed = false; cs->k1_sig_armed = false;
     {
         sh_timer t(ctx, SLAMHIP_K_CS_PREP);
         const dim3 grid(sh_div_up(count, K1_THREADS));

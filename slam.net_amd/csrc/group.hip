@@ -15,6 +15,8 @@
 
 struct rccl_api {
     void *lib;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
@@ -31,6 +33,8 @@ static int32_t load_rccl(rccl_api *api)
     if (!api->lib) SH_FAIL(SLAMHIP_ERR_RCCL, "cannot load librccl: %s", dlerror());
 #define SH_SYM(field, name) do { *(void **)(&api->field) = dlsym(api->lib, name); \
         if (!api->field) SH_FAIL(SLAMHIP_ERR_RCCL, "librccl lacks %s", name); } while (0)
+    SH_SYM(GetUniqueId, "ncclGetUniqueId");
+    SH_SYM(CommInitRank, "ncclCommInitRank");
     SH_SYM(CommInitAll, "ncclCommInitAll");
     SH_SYM(CommDestroy, "ncclCommDestroy");
     SH_SYM(AllReduce, "ncclAllReduce");
@@ -170,5 +174,158 @@ extern "C" int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[
     // the replicas update concurrently: enqueue on every GPU's stream, then wait for all of them
     for (int r = 0; r < g->n; r++) SH_TRY(cs_update_maps_enqueue(g->cs[r], pose, hole_width, quality, max_hits));
     for (int r = 0; r < g->n; r++) SH_TRY(cs_update_maps_finish(g->cs[r]));
+    return SLAMHIP_OK;
+}
+
+// ---- one process per GPU: this rank's end of an RCCL communicator -------------------------------------------------
+// The host framework (torch.distributed.run, MPI, ...) only carries the 128-byte RCCL id from rank 0 to the others;
+// the per-scan exchange is issued by the library itself: K1 over this rank's block of the flat candidate list on the
+// context's stream, then ncclAllReduce(min, uint64, 1) of the packed key on the communicator's OWN stream behind an
+// event -- so the next search does not wait for the collective of the last one (a ring of key slots keeps them apart),
+// and no interpreter or framework call sits between the kernel and the collective.
+#define SH_COMM_SLOTS 64
+struct slamhip_comm {
+    slamhip_ctx *ctx;
+    rccl_api api;
+    ncclComm_t comm;
+    int rank, n_ranks;
+    hipStream_t stream;                            // the collectives' stream
+    uint64_t *d_keys;                              // [SH_COMM_SLOTS] key slots (device)
+    hipEvent_t ev_k1[SH_COMM_SLOTS], ev_ar[SH_COMM_SLOTS];
+    bool ar_pending[SH_COMM_SLOTS];
+    uint64_t step;
+    unsigned long long *d_sig;                     // HSA signal memory: the search kernel stores the step number, the collectives' stream waits for it
+    bool by_value;
+    uint64_t *h_key;                               // pinned
+};
+
+static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+
+extern "C" int32_t slamhip_comm_unique_id(uint8_t out[128])
+{
+    SH_CHECK_ARG(out);
+    rccl_api api;
+    SH_TRY(load_rccl(&api));
+    ncclUniqueId id;
+    const ncclResult_t r = api.GetUniqueId(&id);
+    if (r != ncclSuccess) { slamhip_set_error("ncclGetUniqueId failed: %s", api.GetErrorString(r)); dlclose(api.lib); return SLAMHIP_ERR_RCCL; }
+    memcpy(out, &id, 128);
+    dlclose(api.lib);                              // (reference counted: the communicator keeps its own handle)
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_comm_destroy(slamhip_comm *c)
+{
+    if (!c) return SLAMHIP_OK;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) c->api.CommDestroy(c->comm);
+    for (int i = 0; i < SH_COMM_SLOTS; i++) { if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]); if (c->ev_ar[i]) (void)hipEventDestroy(c->ev_ar[i]); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    (void)hipFree(c->d_keys);
+    if (c->d_sig) (void)hipFree(c->d_sig);
+    if (c->h_key) (void)hipHostFree(c->h_key);
+    if (c->api.lib) dlclose(c->api.lib);
+    delete c;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t unique_id[128], int32_t rank, int32_t n_ranks, slamhip_comm **out)
+{
+    SH_CHECK_ARG(ctx && unique_id && out && n_ranks >= 1 && rank >= 0 && rank < n_ranks);
+    SH_HIP(hipSetDevice(ctx->device));
+    slamhip_comm *c = new slamhip_comm();
+    c->ctx = ctx; c->rank = rank; c->n_ranks = n_ranks;
+    int32_t rc = load_rccl(&c->api);
+    if (rc == SLAMHIP_OK) {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&c->d_keys, sizeof(uint64_t) * SH_COMM_SLOTS);
+        if (e == hipSuccess) e = hipMemset(c->d_keys, 0xFF, sizeof(uint64_t) * SH_COMM_SLOTS);
+        if (e == hipSuccess) e = hipHostMalloc(&c->h_key, 64);
+        for (int i = 0; i < SH_COMM_SLOTS && e == hipSuccess; i++) {
+            e = hipEventCreateWithFlags(&c->ev_k1[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ar[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) { slamhip_set_error("communicator resources: %s", hipGetErrorString(e)); rc = SLAMHIP_ERR_HIP; }
+        // K1 -> collective dependency: an event pair costs the search stream ~9 us per step on this stack (measured); where
+        // the device supports stream memory operations the kernel's last act is the step number into an HSA signal that the
+        // collectives' stream waits for -- nothing is inserted into the search stream (SLAMHIP_COMM_DEP=event keeps events)
+        const char *dep = getenv("SLAMHIP_COMM_DEP");
+        int can = 0;
+        if (rc == SLAMHIP_OK && !(dep && strcmp(dep, "event") == 0) &&
+            hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can &&
+            hipExtMallocWithFlags((void **)&c->d_sig, 8, hipMallocSignalMemory) == hipSuccess) {
+            *c->d_sig = 0ull;                                     // (signal memory is host-visible)
+            c->by_value = true;
+        } else (void)hipGetLastError();
+    }
+    if (rc == SLAMHIP_OK) {
+        ncclUniqueId id;
+        memcpy(&id, unique_id, 128);
+        const ncclResult_t r = c->api.CommInitRank(&c->comm, n_ranks, id, rank);
+        if (r != ncclSuccess) { slamhip_set_error("ncclCommInitRank failed: %s", c->api.GetErrorString(r)); c->comm = nullptr; rc = SLAMHIP_ERR_RCCL; }
+    }
+    if (rc != SLAMHIP_OK) { slamhip_comm_destroy(c); return rc; }
+    *out = c;
+    return SLAMHIP_OK;
+}
+
+// One sharded search step: returns at once; the reduced key of this step will be in *d_out_key (device memory owned by
+// the communicator, valid until SH_COMM_SLOTS (64) further steps have been issued).
+extern "C" int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_comm *c, const float pose[3], int32_t first, int32_t count,
+                                                     uint64_t **d_out_key)
+{
+    SH_CHECK_ARG(cs && c && pose && cs->ctx == c->ctx);
+    SH_HIP(hipSetDevice(c->ctx->device));
+    const int slot = (int)(c->step % SH_COMM_SLOTS);
+    uint64_t *key = c->d_keys + slot;
+    hipStream_t main = c->ctx->stream;
+    // the slot's last collective (SH_COMM_SLOTS steps ago) must have read it: a host-side wait that is normally a no-op
+    if (c->ar_pending[slot]) { SH_HIP(hipEventSynchronize(c->ev_ar[slot])); c->ar_pending[slot] = false; }
+    bool signalled = false;
+    if (count > 0) {
+        if (c->by_value) { cs->k1_sig = c->d_sig; cs->k1_sig_val = c->step + 1; }
+        const int32_t rc = slamhip_cs_search_shard_async(cs, pose, first, count, key);
+        cs->k1_sig = nullptr;
+        SH_TRY(rc);
+        signalled = c->by_value && cs->k1_sig_armed;
+    } else SH_HIP(hipMemsetAsync(key, 0xFF, sizeof(uint64_t), main));                                   // (a rank without candidates: the neutral key)
+    if (c->by_value) {
+        if (!signalled) SH_HIP(hipStreamWriteValue64(main, c->d_sig, c->step + 1, 0));                   // (fallback kernels, empty shard)
+        SH_HIP(hipStreamWaitValue64(c->stream, c->d_sig, c->step + 1, hipStreamWaitValueGte, ~0ull));
+    } else {
+        SH_HIP(hipEventRecord(c->ev_k1[slot], main));
+        SH_HIP(hipStreamWaitEvent(c->stream, c->ev_k1[slot], 0));
+    }
+    SH_NCCL(c, c->api.AllReduce(key, key, 1, ncclUint64, ncclMin, c->comm, c->stream));
+    SH_HIP(hipEventRecord(c->ev_ar[slot], c->stream));
+    c->ar_pending[slot] = true;
+    c->step++;
+    if (d_out_key) *d_out_key = key;
+    return SLAMHIP_OK;
+}
+
+// Wait for every step issued so far; *out_key = the reduced key of the last one.
+extern "C" int32_t slamhip_comm_wait(slamhip_comm *c, uint64_t *out_key)
+{
+    SH_CHECK_ARG(c);
+    SH_HIP(hipSetDevice(c->ctx->device));
+    if (out_key) {
+        if (c->step == 0) SH_FAIL(SLAMHIP_ERR_STATE, "no search step has been issued on this communicator");
+        const int slot = (int)((c->step - 1) % SH_COMM_SLOTS);
+        SH_HIP(hipMemcpyAsync(c->h_key, c->d_keys + slot, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    SH_HIP(hipStreamSynchronize(c->stream));
+    SH_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (out_key) *out_key = *c->h_key;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_comm_info(slamhip_comm *c, int32_t *rank, int32_t *n_ranks)
+{
+    SH_CHECK_ARG(c);
+    if (rank) *rank = c->rank;
+    if (n_ranks) *n_ranks = c->n_ranks;
     return SLAMHIP_OK;
 }

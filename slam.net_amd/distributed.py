@@ -7,8 +7,13 @@ candidate list and contributes ONE packed 64-bit key (distance << 32 | flat inde
 reproduces the reference winner and its tie-break (lowest flat index = earliest thread / earliest draw).
 Distances are non-negative int32, so the key fits a signed int64 and MIN on int64 tensors is exact.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import capi
 
 INT32_MAX = 2 ** 31 - 1
 
@@ -34,3 +39,45 @@ def allreduce_min_key(key_tensor):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(key_tensor, op=dist.ReduceOp.MIN)
     return key_tensor
+
+
+class LibComm:
+    """This rank's end of the library's own RCCL communicator (slamhip_comm_*): torch.distributed only carries the
+    128-byte RCCL id from rank 0 to the others; every search step is then ONE C call that enqueues K1 on the operator's
+    stream and the 8-byte min all-reduce on the communicator's stream (the next search does not wait for it)."""
+
+    def __init__(self, ctx, rank, world):
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            capi.call("slamhip_comm_unique_id", uid.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if world > 1:
+            t = torch.from_numpy(uid).cuda() if dist.get_backend() == "nccl" else torch.from_numpy(uid)
+            dist.broadcast(t, 0)
+            uid = np.ascontiguousarray(t.cpu().numpy())
+        self._h = C.c_void_p()
+        capi.call("slamhip_comm_create", ctx._h, uid.ctypes.data_as(C.POINTER(C.c_uint8)), int(rank), int(world), C.byref(self._h))
+        self._step = capi.lib().slamhip_cs_search_allreduce_async
+
+    def bind_step(self, dev, pose, first, count):
+        """The per-step call with its arguments bound once: returns a zero-argument function."""
+        self._pose = np.ascontiguousarray(pose, np.float32)        # (the bound pointer refers to this array)
+        args = (dev._h, self._h, capi.fptr(self._pose), int(first), int(count), None)
+        fn = self._step
+
+        def step():
+            capi.check(fn(*args))
+        return step
+
+    def wait(self):
+        """Waits for every step issued so far; returns the reduced key of the last one."""
+        k = C.c_uint64()
+        capi.call("slamhip_comm_wait", self._h, C.byref(k))
+        return int(k.value)
+
+    def synchronize(self):
+        capi.call("slamhip_comm_wait", self._h, None)
+
+    def close(self):
+        if self._h:
+            capi.lib().slamhip_comm_destroy(self._h)
+            self._h = C.c_void_p()

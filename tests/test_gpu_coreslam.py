@@ -533,3 +533,30 @@ def test_fuzz_parity_short():
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "all equal to the oracle" in out, out[-3000:]
 
+
+
+def test_lib_comm_single_rank(cs_mod, ctx, sim):
+    """slamhip_comm_* (one process per GPU; here one rank): a search step = K1 + the 8-byte RCCL min all-reduce issued by the
+    library on its own stream.  More steps than key slots, shards of every kind, the same keys as the blocking search."""
+    import slam.net_amd.distributed as D
+    size, R, K = 512, 360, 5000
+    dev = make_dev(cs_mod, ctx, size, 64)
+    segs = sim.default_field()
+    rng = sim.PCG32(5)
+    for p in sim.trajectory(6):
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy)
+        dev.update_holemap(p)
+    base = sim.trajectory(7)[-1]
+    dev.set_offsets(sim.gaussian_offsets(K - 1))
+    comm = D.LibComm(ctx, 0, 1)
+    try:
+        for first, count in ((0, K), (0, K // 3), (K // 3, K - K // 3), (K - 1, 1)):
+            want = dev.search_shard(base, first, count)
+            step = comm.bind_step(dev, base, first, count)
+            for _ in range(19):                                    # (the ring of key slots wraps twice)
+                step()
+            assert comm.wait() == want
+    finally:
+        comm.close()
+        dev.close()
