@@ -1,0 +1,99 @@
+// HectorSLAM.Main.MapRepMultiMap on the GPU (reference: HectorSLAM/Main/MapRepMultiMap.cs:19-97): level i has
+// size / 2^i cells of resolution * 2^i metres; the levels are independent maps drawn from the same scan.  All levels live
+// in ONE native pyramid and are updated by one pair of launches (the reference runs a Parallel.ForEach over them, :76).
+using System;
+using System.Drawing;
+using System.Numerics;
+using System.Runtime.InteropServices;
+using BaseSLAM;
+using HectorSLAM.Map;
+using SlamHip;
+
+namespace HectorSLAM.Main
+{
+    public class MapRepMultiMap : IDisposable
+    {
+        internal readonly Device Device;
+        private readonly bool ownsDevice;
+        internal readonly Handle Pyramid;
+
+        public int NumLevels => Maps.Length;
+
+        public OccGridMap[] Maps { get; }
+
+        /// <param name="startCoords">must be Vector2.Zero (the only value the reference passes, HectorSLAMProcessor.cs:71)</param>
+        public MapRepMultiMap(float mapResolution, Point mapSize, int numDepth, Vector2 startCoords, Device device = null)
+        {
+            if (startCoords != Vector2.Zero)
+                throw new NotSupportedException("the device maps have no offset");
+            Device = device ?? new Device(0);
+            ownsDevice = device == null;
+            Native.Check(Native.slamhip_hs_create(Device.Ctx.Ptr, mapResolution, mapSize.X, mapSize.Y, numDepth, out IntPtr h));
+            Pyramid = new Handle(h, Native.slamhip_hs_destroy);
+            Maps = new OccGridMap[numDepth];
+            for (int i = 0; i < numDepth; i++)
+            {
+                Maps[i] = new OccGridMap(Device, Pyramid, i);
+                Maps[i].IterationsChanged = PushIterations;
+                Maps[i].FactorsChanged = () => { };                     // per-level factor setters exist for source compatibility; the pyramid's factors are set below
+            }
+            PushIterations();
+        }
+
+        private unsafe void PushIterations()
+        {
+            int* it = stackalloc int[Maps.Length];
+            for (int i = 0; i < Maps.Length; i++) it[i] = Maps[i] != null ? Maps[i].EstimateIterations : 3;
+            Native.Check(Native.slamhip_hs_set_iterations(Pyramid.Ptr, it));
+        }
+
+        public void Reset()                                              // MapRepMultiMap.cs:63-66
+        {
+            Native.Check(Native.slamhip_hs_reset(Pyramid.Ptr));
+            foreach (OccGridMap m in Maps) m.mirrorStale = true;
+        }
+
+        /// <summary>Every level from the same scan (MapRepMultiMap.cs:73-77).</summary>
+        public unsafe void UpdateByScan(ScanCloud scan, Vector3 pose)
+        {
+            SetScan(scan);
+            Native.Check(Native.slamhip_hs_update_by_scan(Pyramid.Ptr, pose));
+            foreach (OccGridMap m in Maps) m.mirrorStale = true;
+        }
+
+        // the scan most recently handed to the device: matching and updating with the same ScanCloud uploads it once
+        private ScanCloud deviceScan;
+        private int deviceScanCount = -1;
+
+        internal unsafe void SetScan(ScanCloud scan)
+        {
+            if (ReferenceEquals(scan, deviceScan) && scan.Points.Count == deviceScanCount) return;
+            fixed (Vector2* p = CollectionsMarshal.AsSpan(scan.Points))
+                Native.Check(Native.slamhip_hs_set_scan(Pyramid.Ptr, p, scan.Points.Count, new Vector2(scan.Pose.X, scan.Pose.Y)));
+            deviceScan = scan;
+            deviceScanCount = scan.Points.Count;
+        }
+
+        /// <summary>Forget the cached scan (call after mutating a ScanCloud's Points in place).</summary>
+        public void InvalidateScan() => deviceScan = null;
+
+        public void SetUpdateFactorFree(float factor)                    // MapRepMultiMap.cs:83-89
+        {
+            foreach (OccGridMap m in Maps) m.SetFactorsSilently(factor, m.UpdateOccupiedFactor);
+            Native.Check(Native.slamhip_hs_set_factors(Pyramid.Ptr, factor, Maps[0].UpdateOccupiedFactor));
+        }
+
+        public void SetUpdateFactorOccupied(float factor)                // MapRepMultiMap.cs:92-95
+        {
+            foreach (OccGridMap m in Maps) m.SetFactorsSilently(m.UpdateFreeFactor, factor);
+            Native.Check(Native.slamhip_hs_set_factors(Pyramid.Ptr, Maps[0].UpdateFreeFactor, factor));
+        }
+
+        public void Dispose()
+        {
+            Pyramid.Dispose();
+            if (ownsDevice) Device.Dispose();
+            GC.SuppressFinalize(this);
+        }
+    }
+}
