@@ -552,8 +552,12 @@ k1_search_tiled(const k1_args a)
 
     // ---- steps ---------------------------------------------------------------------------------------------------
     // Tile staging through registers: the global loads of the NEXT step's tile are issued before the current
-    // step is consumed and stay in flight meanwhile.  Exactly PF loads are always issued (lanes without work
-    // re-read row 0) so that the compiler can count them.
+    // step is consumed and stay in flight meanwhile.  The lanes that have no tile vector are masked off: a masked lane
+    // costs the address unit nothing, where a dummy load -- even of one address for the whole wave -- does (measured
+    // 31.2 -> 29.3 us at 16 384 candidates, 164 -> 157 us at 262 144).  The code generation of this macro is fragile: with
+    // loads under an exec mask the compiler's vmcnt waits become vmcnt(0), and variants whose address temporaries share
+    // registers with pending loads (32-bit offsets, addresses formed up front) got one between every two loads of the
+    // prefetch inside the step loop and were slower than no masking at all (33.5 us).
     uint32_t sum[CPL], cnt[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) { sum[k] = 0; cnt[k] = 0; }
@@ -577,7 +581,7 @@ k1_search_tiled(const k1_args a)
                 const int row = (wv + k_ * NW) * rpi + srow;                                        \
                 const bool live = colok & (row < h_);                                               \
                 const int rr = live ? row : 0;                                                      \
-                R[k_] = *(const k1_u32x4 *)(gbase + (size_t)rr * S);                                \
+                if (live) R[k_] = *(const k1_u32x4 *)(gbase + (size_t)rr * S);   /* (see above) */  \
                 dst[k_] = live ? ldsb + rr * pitchb : -1;                                           \
             }                                                                                       \
         }
