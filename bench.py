@@ -230,18 +230,20 @@ def main():
 
 
 def pmc_traffic(a):
-    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs of this very command, gfx950 read-side correction applied; profiles/r01_k1_traffic.json).
-    PMC counters cannot be read from inside the timed run, so the figure is only reported when the committed
-    profile was taken on the same workload; otherwise null."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_k1_traffic.json")) as f:
-            t = json.load(f)
-        w = t["workload"]
-        if (w["map"], w["rays"], w["candidates_per_gpu"]) == (a.size, a.rays, a.cands):
-            return int(t["hbm_bytes_per_launch_gfx950_corrected"])
-    except Exception:
-        pass
+    """HBM-side bytes per K1 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of this very command by tools/prof_bench.sh, gfx950 read-side correction applied;
+    profiles/rNN_k1_traffic.json, newest round first).  PMC counters cannot be read from inside the timed run, so the
+    figure is only reported when the committed profile was taken on the same workload; otherwise null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k1_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            w = t["workload"]
+            if (w["map"], w["rays"], w["candidates_per_gpu"]) == (a.size, a.rays, a.cands):
+                return int(t["hbm_bytes_per_launch_gfx950_corrected"])
+        except Exception:
+            pass
     return None
 
 

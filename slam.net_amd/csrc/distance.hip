@@ -401,8 +401,8 @@ k1_search_tiled(const k1_args a)
     for (int u = 0; u < RU; u++) {
         const int i = u * LANES + t;
         const int r = rlo + (i < nrays ? i : 0);
-        rinfo[u] = a.ray_blk[r];
-        rpt[u] = a.pts[r];
+        rinfo[u] = make_int4(0, 0, 0, 0); rpt[u] = make_float2(0.f, 0.f);
+        if (i < nrays) { rinfo[u] = a.ray_blk[r]; rpt[u] = a.pts[r]; }   // (lanes beyond the chunk issue nothing)
     }
     float4 q[CPL];
     float c3[CPL][3];
