@@ -36,6 +36,12 @@ struct slamhip_ctx {
     uint32_t *mailbox; uint32_t mail_seq; bool mail_off;
 };
 int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words);   // enqueue; returns after the launch
+// Per-scan upload as a launch: one workgroup pulls `bytes` (a multiple of 16) from a pinned staging block over PCIe and then
+// stores `seq` into the pinned word `h_flag`; sh_flag_wait(h_flag, seq) tells the host that the staging block may be refilled.
+// (A hipMemcpyAsync right after a mailbox wait takes the runtime's slow path -- it has not seen the stream finish yet -- and the
+// cross-engine dependency delays the first kernel: measured 8 us per scan; with this the per-scan path is launches only.)
+int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flag, uint32_t seq);
+int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *h_flag, uint32_t seq);
 int32_t sh_host_wait(slamhip_ctx *ctx);                                  // until the last sh_publish of this context has landed
 // (a kernel that is the last of its call may write the mailbox itself: words first, then sh_mail_seq_next() into word 15, released at system scope)
 static inline uint32_t sh_mail_seq_next(slamhip_ctx *ctx) { return ++ctx->mail_seq; }

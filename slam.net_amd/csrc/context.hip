@@ -105,11 +105,24 @@ int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words)
     return SLAMHIP_OK;
 }
 
-int32_t sh_host_wait(slamhip_ctx *ctx)
+__global__ void __launch_bounds__(1024)
+k_upload16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16, uint32_t *__restrict__ flag, uint32_t seq)
 {
-    if (ctx->mail_off) { SH_HIP(hipStreamSynchronize(ctx->stream)); return SLAMHIP_OK; }
-    volatile uint32_t *flag = ctx->mailbox + 15;
-    const uint32_t val = ctx->mail_seq;
+    for (int i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    __syncthreads();                                               // every lane's loads have returned (its stores depend on them)
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flag, uint32_t seq)
+{
+    SH_CHECK_ARG(h_src && d_dst && h_flag && bytes % 16 == 0 && bytes / 16 < (size_t)INT32_MAX);
+    hipLaunchKernelGGL(k_upload16, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)h_src, (uint4 *)d_dst, (int)(bytes / 16), h_flag, seq);
+    SH_HIP(hipGetLastError());
+    return SLAMHIP_OK;
+}
+
+int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val)
+{
     for (long spins = 0;; spins++) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return SLAMHIP_OK;
         if ((spins & 0xfffff) == 0xfffff) {                        // every ~million polls: is the stream in trouble, or idle without the word?
@@ -122,6 +135,12 @@ int32_t sh_host_wait(slamhip_ctx *ctx)
         }
         __builtin_ia32_pause();
     }
+}
+
+int32_t sh_host_wait(slamhip_ctx *ctx)
+{
+    if (ctx->mail_off) { SH_HIP(hipStreamSynchronize(ctx->stream)); return SLAMHIP_OK; }
+    return sh_flag_wait(ctx, ctx->mailbox + 15, ctx->mail_seq);
 }
 
 // ---- timing ------------------------------------------------------------------------------------

@@ -161,8 +161,9 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
             hipMalloc(&cs->d_key, 64) != hipSuccess ||          // result block: key (8 B) | winner pose (16 B) | blended pixels (4 B)
 
             hipMalloc(&cs->d_verify, sizeof(unsigned int) * 8) != hipSuccess ||
-            hipHostMalloc(&cs->h_key, 128) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
+            hipHostMalloc(&cs->h_key, 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { slamhip_set_error("device allocation failed"); rc = SLAMHIP_ERR_NOMEM; break; }
         cs->d_best_pose = (float *)cs->d_key + 2;
+        memset(cs->h_key, 0, 128);
         if (hipMemset(cs->d_verify, 0, sizeof(unsigned int) * 8) != hipSuccess) { slamhip_set_error("hipMemset failed"); rc = SLAMHIP_ERR_HIP; break; }
         if ((rc = cs_holemap_alloc(cs)) != SLAMHIP_OK) break;
         if ((rc = cs_obstacle_alloc(cs)) != SLAMHIP_OK) break;
@@ -268,7 +269,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         (void)hipFree(cs->d_scan_blob); if (cs->h_scan_blob) (void)hipHostFree(cs->h_scan_blob);
         cs->d_scan_blob = nullptr; cs->h_scan_blob = nullptr; cs->cap_points = 0;
         const int cap = n + n / 4 + 64;
-        const size_t bytes = (size_t)cap * (16 + 8 + 8) + sizeof(int) * (size_t)(cap + 2);
+        const size_t bytes = (((size_t)cap * (16 + 8 + 8) + sizeof(int) * (size_t)(cap + 2)) + 15) & ~(size_t)15;      // (the upload moves 16-byte units)
         SH_HIP(hipMalloc(&cs->d_scan_blob, bytes));
         SH_HIP(hipHostMalloc(&cs->h_scan_blob, bytes));
         if (!cs->ev_scan) SH_HIP(hipEventCreateWithFlags(&cs->ev_scan, hipEventDisableTiming));
@@ -280,7 +281,11 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->cap_points = cap;
         cs->scan_in_flight = false;
     }
-    if (cs->scan_in_flight) { SH_HIP(hipEventSynchronize(cs->ev_scan)); cs->scan_in_flight = false; }   // the previous copy has left the staging block
+    if (cs->scan_in_flight) {                           // the previous copy has left the staging block
+        if (!cs->ctx->mail_off) SH_TRY(sh_flag_wait(cs->ctx, (volatile uint32_t *)cs->h_key + 30, cs->upload_seq));
+        else SH_HIP(hipEventSynchronize(cs->ev_scan));
+        cs->scan_in_flight = false;
+    }
     const int cap_ = cs->cap_points;
     int *h_rayblk = (int *)cs->h_scan_blob;
     float *h_pts = (float *)((char *)cs->h_scan_blob + (size_t)cap_ * 16);
@@ -369,8 +374,16 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     cs->k1_layout_dirty = true;
     memcpy(h_rb, rb.data(), sizeof(int) * rb.size());
     const size_t used = (size_t)cap_ * 32 + sizeof(int) * rb.size();
-    SH_HIP(hipMemcpyAsync(cs->d_scan_blob, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
-    SH_HIP(hipEventRecord(cs->ev_scan, cs->ctx->stream));
+    // (a blocking call that returned through the mailbox leaves a stream the runtime has not yet seen finish; the copy takes
+    // its immediate path only on a stream the runtime knows to be idle: one query lets it find out)
+    if (!cs->ctx->mail_off) {
+        // the upload is a launch that pulls the staging block and then tells the host (h_key word 30) that it may be refilled
+        cs->upload_seq++;
+        SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, (used + 15) & ~(size_t)15, (uint32_t *)cs->h_key + 30, cs->upload_seq));
+    } else {
+        SH_HIP(hipMemcpyAsync(cs->d_scan_blob, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
+        SH_HIP(hipEventRecord(cs->ev_scan, cs->ctx->stream));
+    }
     cs->scan_in_flight = true;
     cs->n_points = n;
     return SLAMHIP_OK;

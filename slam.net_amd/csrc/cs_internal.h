@@ -67,7 +67,7 @@ struct slamhip_cs {
     unsigned *k1_done_flag; unsigned k1_done_val;   // the next search launch ends with k1_done_val -> *k1_done_flag (pinned host word), if set
     bool k1_done_armed;           // ... and it will (tiled kernel)
     unsigned long long *k1_sig; unsigned long long k1_sig_val; bool k1_sig_armed;   // the same for an HSA signal (slamhip_comm: the collectives' stream waits for it)
-    unsigned host_seq;            // blocking calls: sequence number of the completion word in h_key[15]
+    uint32_t upload_seq;          // set_scan uploads issued (the launch stores it into word 30 of h_key when it has read the staging block)
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------
     void *d_rays; int cap_rays;                 // rays by index (k2_byidx): clipped lengths, flags

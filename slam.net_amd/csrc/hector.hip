@@ -49,7 +49,8 @@ struct slamhip_hs {
     float odds_free, odds_occ, lo_free, lo_occ;          // OccGridMap.cs:24-27
     int n_points, cap_points;
     float2 *d_pts; float origin[2];
-    float *h_pts; hipEvent_t ev_pts; bool pts_in_flight;   // pinned staging of the scan: one async copy, no wait in set_scan
+    float *h_pts; hipEvent_t ev_pts; bool pts_in_flight;   // pinned staging of the scan: one async copy (or upload launch), no wait in set_scan
+    uint32_t upload_seq;                                   // upload launches issued; the launch stores it behind the staged points (h_pts + 2 * cap) when it has read them
     float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
     // K5 line tables, per level: lines by index, lines sorted by (direction class, slope bucket), bucket starts, header
     void *d_k5_byidx, *d_k5_cand; int *d_k5_start, *d_k5_hdr; int cap_lines;
@@ -807,17 +808,29 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
         SH_HIP(hipStreamSynchronize(hs->ctx->stream));
         (void)hipFree(hs->d_pts); hs->d_pts = nullptr; hs->cap_points = 0;
         if (hs->h_pts) { (void)hipHostFree(hs->h_pts); hs->h_pts = nullptr; }
-        const int cap = n + n / 4 + 64;
+        const int cap = (n + n / 4 + 64 + 1) & ~1;                         // (even: the upload launch moves 16-byte units)
         SH_HIP(hipMalloc(&hs->d_pts, sizeof(float2) * (size_t)cap));
-        SH_HIP(hipHostMalloc(&hs->h_pts, sizeof(float2) * (size_t)cap));
+        SH_HIP(hipHostMalloc(&hs->h_pts, sizeof(float2) * (size_t)cap + 64, hipHostMallocMapped | hipHostMallocCoherent));   // (+ the upload's completion word)
+        memset(hs->h_pts + 2 * (size_t)cap, 0, 64);
+        hs->upload_seq = 0;
         if (!hs->ev_pts) SH_HIP(hipEventCreateWithFlags(&hs->ev_pts, hipEventDisableTiming));
         hs->cap_points = cap;
         hs->pts_in_flight = false;
     }
-    if (hs->pts_in_flight) { SH_HIP(hipEventSynchronize(hs->ev_pts)); hs->pts_in_flight = false; }   // the previous copy has left the staging block
+    uint32_t *up_flag = (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points);
+    if (hs->pts_in_flight) {                            // the previous copy has left the staging block
+        if (!hs->ctx->mail_off) SH_TRY(sh_flag_wait(hs->ctx, up_flag, hs->upload_seq));
+        else SH_HIP(hipEventSynchronize(hs->ev_pts));
+        hs->pts_in_flight = false;
+    }
     memcpy(hs->h_pts, xy, sizeof(float) * 2 * (size_t)n);
-    SH_HIP(hipMemcpyAsync(hs->d_pts, hs->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, hs->ctx->stream));
-    SH_HIP(hipEventRecord(hs->ev_pts, hs->ctx->stream));
+    if (!hs->ctx->mail_off) {                           // (see slamhip_cs_set_scan: the per-scan path is launches only)
+        hs->upload_seq++;
+        SH_TRY(sh_upload(hs->ctx, hs->h_pts, hs->d_pts, (sizeof(float) * 2 * (size_t)n + 15) & ~(size_t)15, up_flag, hs->upload_seq));
+    } else {
+        SH_HIP(hipMemcpyAsync(hs->d_pts, hs->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, hs->ctx->stream));
+        SH_HIP(hipEventRecord(hs->ev_pts, hs->ctx->stream));
+    }
     hs->pts_in_flight = true;
     hs->n_points = n;
     return SLAMHIP_OK;
