@@ -238,7 +238,7 @@ struct k1_args {
         unsigned short nbp;            // band parts: the chunks of a listed group come in sets of nbp that share a ray range and split its bands
         unsigned short first, nc;      // first workgroup of the position, workgroups
     } tab[K1_TABLE_G];
-    unsigned char wg_pos[K1_TABLE_WGS];// workgroup -> dispatch position
+    alignas(4) unsigned char wg_pos[K1_TABLE_WGS];   // workgroup -> dispatch position (read a word at a time)
 };
 static_assert(sizeof(k1_args) <= 4096, "kernel arguments are limited to 4 KB");
 static_assert(sizeof(k1_args::tab_rec) == 8 && offsetof(k1_args, tab) % 8 == 0, "table records are 8-byte aligned");
@@ -354,7 +354,10 @@ k1_search_tiled(const k1_args a)
     const int ng = a.n_groups;
     int g, chunk, nc, nbp = 1;
     if ((int)blockIdx.x < a.n_tab_wgs) {
-        const int p = a.wg_pos[blockIdx.x];
+        // (a byte load from the kernel arguments is a VECTOR load on this target -- a full memory round trip at the head of the
+        // workgroup; the containing word is a scalar load)
+        const unsigned pw = ((const unsigned *)a.wg_pos)[blockIdx.x >> 2];
+        const int p = (int)((pw >> ((blockIdx.x & 3u) * 8u)) & 0xffu);
         const k1_args::tab_rec rec = a.tab[p];
         nc = rec.nc;
         chunk = blockIdx.x - (int)rec.first;
@@ -390,19 +393,23 @@ k1_search_tiled(const k1_args a)
         rlo = (int)(((unsigned)rc * (unsigned)a.n_rays) / (unsigned)nrc); rhi = (int)(((unsigned)(rc + 1) * (unsigned)a.n_rays) / (unsigned)nrc);
     } else { rlo = (int)(((long long)rc * a.n_rays) / nrc); rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc); }
     const int nrays = rhi - rlo;
-    const int blk_first = a.ray_blk[rlo].z;
-    const int npieces = a.ray_blk[rhi - 1].z - blk_first + 1;
+    // (the two block numbers are uniform, and the compiler would wait for them -- to move them into SGPRs -- before it issues
+    // the loads below: a memory round trip at the head of every workgroup.  Loaded through an address that looks
+    // lane-dependent they stay in VGPRs and are waited for where they are used)
+    const int blk_first = a.ray_blk[rlo + zv].z;
+    const int blk_last_v = a.ray_blk[rhi - 1 + zv].z;
 
     // ---- prologue: rays, candidates, bounds, boxes, steps ----------------------------------------------------------
-    // every global load first, then the arithmetic
-    int4 rinfo[RU];
-    float2 rpt[RU];
+    // every global load first, then the arithmetic -- and the unconditional loads before the masked ones: the merge after a
+    // masked load makes the compiler wait for it, which would hold back whatever is issued after it
+    // Search mode: the bounds of the group's (px, py, c, s) follow from the group's jitter bounds (left by
+    // k_gather_offsets) and the search pose, so nothing before the first tile depends on the candidates: their
+    // trigonometry runs later, under the tile's global loads.
+    const bool pre = MODE == 1 && a.grp_bounds != nullptr;
+    float gb[6];
+    if (pre) {
 #pragma unroll
-    for (int u = 0; u < RU; u++) {
-        const int i = u * LANES + t;
-        const int r = rlo + (i < nrays ? i : 0);
-        rinfo[u] = make_int4(0, 0, 0, 0); rpt[u] = make_float2(0.f, 0.f);
-        if (i < nrays) { rinfo[u] = a.ray_blk[r]; rpt[u] = a.pts[r]; }   // (lanes beyond the chunk issue nothing)
+        for (int k = 0; k < 6; k++) gb[k] = a.grp_bounds[8 * (size_t)g + k];
     }
     float4 q[CPL];
     float c3[CPL][3];
@@ -413,16 +420,16 @@ k1_search_tiled(const k1_args a)
         if (MODE == 0) q[k] = a.pxcs[jc];
         else { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
     }
-    if (t == 0) { s_nsteps = 0; *(unsigned *)(smem + K1_ZERO_OFS) = 0u; }
-    // Search mode: the bounds of the group's (px, py, c, s) follow from the group's jitter bounds (left by
-    // k_gather_offsets) and the search pose, so nothing before the first tile depends on the candidates: their
-    // trigonometry runs later, under the tile's global loads.
-    const bool pre = MODE == 1 && a.grp_bounds != nullptr;
-    float gb[6];
-    if (pre) {
+    int4 rinfo[RU];
+    float2 rpt[RU];
 #pragma unroll
-        for (int k = 0; k < 6; k++) gb[k] = a.grp_bounds[8 * (size_t)g + k];
+    for (int u = 0; u < RU; u++) {
+        const int i = u * LANES + t;
+        const int r = rlo + (i < nrays ? i : 0);
+        rinfo[u] = make_int4(0, 0, 0, 0); rpt[u] = make_float2(0.f, 0.f);
+        if (i < nrays) { rinfo[u] = a.ray_blk[r]; rpt[u] = a.pts[r]; }   // (lanes beyond the chunk issue nothing)
     }
+    if (t == 0) { s_nsteps = 0; *(unsigned *)(smem + K1_ZERO_OFS) = 0u; }
     if (MODE != 0 && !pre) {
 #pragma unroll
         for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
@@ -500,6 +507,7 @@ k1_search_tiled(const k1_args a)
         __syncthreads();
     }
     K1_STAMP(3)
+    const int npieces = __builtin_amdgcn_readfirstlane(blk_last_v - blk_first + 1);
     for (int p = wv; p < npieces; p += NW) {                       // one wave per piece, one lane per ray
         const int2 pi = pieces[p];
         const float2 pt = cpts[pi.x + (lane < pi.y ? lane : pi.y - 1)];
@@ -554,10 +562,11 @@ k1_search_tiled(const k1_args a)
     // Tile staging through registers: the global loads of the NEXT step's tile are issued before the current
     // step is consumed and stay in flight meanwhile.  The lanes that have no tile vector are masked off: a masked lane
     // costs the address unit nothing, where a dummy load -- even of one address for the whole wave -- does (measured
-    // 31.2 -> 29.3 us at 16 384 candidates, 164 -> 157 us at 262 144).  The code generation of this macro is fragile: with
-    // loads under an exec mask the compiler's vmcnt waits become vmcnt(0), and variants whose address temporaries share
-    // registers with pending loads (32-bit offsets, addresses formed up front) got one between every two loads of the
-    // prefetch inside the step loop and were slower than no masking at all (33.5 us).
+    // 31.2 -> 29.3 us at 16 384 candidates, 164 -> 157 us at 262 144).  With loads under an exec mask the compiler's vmcnt
+    // waits become vmcnt(0), and whenever an address temporary of the prefetch inside the step loop shared a register with a
+    // load it could not prove complete, it put one between every two loads -- slower than no masking at all (33.5 us); which
+    // registers are shared changes with unrelated edits.  The staging registers are therefore claimed once per step, outside
+    // any branch, before the tile is written to LDS (see there).
     uint32_t sum[CPL], cnt[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) { sum[k] = 0; cnt[k] = 0; }
@@ -592,6 +601,11 @@ k1_search_tiled(const k1_args a)
         }
         for (int s = 0; s < nsteps; s++) {
             __syncthreads();                                       // the previous tile is no longer read
+            // (every staging register is claimed here, outside any branch: the loads that filled them sit under exec masks,
+            // where the compiler cannot count them, and without this it guards the NEXT prefetch's address temporaries --
+            // which share these registers -- with a vmcnt(0) between every two loads: the prefetch serialises, +4 us per launch)
+#pragma unroll
+            for (int k = 0; k < PF; k++) asm volatile("" : "+v"(R[k]));
 #pragma unroll
             for (int k = 0; k < PF; k++) if (dst[k] >= 0) *(k1_u32x4 *)(smem + dst[k]) = R[k];
             __syncthreads();
