@@ -214,6 +214,7 @@ struct k1_args {
     float bx, by, bth, scale;
     int count, n_groups;
     int budget;                        // tile bytes
+    float band_stage;                  // cost of staging one band of a banded tile, in ray units (a large value: always band when it fits)
     unsigned long long *acc;           // [n_groups][K1_GROUP] per-candidate accumulators; zero between launches
     unsigned *tickets;                 // [n_groups] chunk arrivals + [1] group arrivals; zero between launches
     unsigned long long *gkey;          // [n_groups] group minima
@@ -537,7 +538,12 @@ k1_search_tiled(const k1_args a)
             const int sh = vpr <= 1 ? 0 : 32 - __clz(vpr - 1);
             const int hmax = min(a.budget / (ww * 2), PF * NW * (64 >> (sh & 31)));
             const int H = cy1 - cy0 + 1;
-            if (vpr <= 64 && hmax >= 1 && (H + hmax - 1) / hmax <= K1_MAXBANDS) {
+            // bands pay for themselves only when the rays of the piece amortise the staging of every band: a band costs about
+            // as much as K1_BAND_STAGE rays of gathers to stage, a range-tested gather 1.9 and a global gather 4.5 ray units
+            const int nb_ = hmax >= 1 ? (H + hmax - 1) / hmax : K1_MAXBANDS + 1;
+            const int nr_ = pieces[pc].y;
+            const bool bands_pay = nb_ == 1 || (float)nb_ * (a.band_stage + 1.9f * (float)nr_) < 4.5f * (float)nr_;      // (the host's cost estimate mirrors this: k1_group_cost)
+            if (vpr <= 64 && hmax >= 1 && nb_ <= K1_MAXBANDS && bands_pay) {
                 nsteps = (H + hmax - 1) / hmax;
                 const int hb = (H + nsteps - 1) / nsteps;
                 const bool whole = nsteps == 1 && cx0 == bx.x && cy0 == bx.y && cx1 == bx.z && cy1 == bx.w;
@@ -946,6 +952,14 @@ static int k1_legal_chunks(const slamhip_cs *cs, int nc)
     return nc;
 }
 
+// Cost of staging one band of a banded tile, in ray units (measured best on MI355X: 5; a huge value: multi-band tiles
+// never, global gathers instead; a hugely negative one: bands whenever they fit)
+static float k1_band_stage()
+{
+    static const float v = getenv("SLAMHIP_K1_BAND_STAGE") ? (float)atof(getenv("SLAMHIP_K1_BAND_STAGE")) : 5.0f;
+    return v;
+}
+
 // Estimated cost of a group in ray units (tile steps cost 1 per ray): from the theta range and the translation spread
 // of the group (ensure_shard), the bounding box of each ray block (set_scan) and the search pose's heading.  A box
 // beyond the tile budget is staged in bands with range-tested gathers.  Only the balance of the launch depends on
@@ -966,7 +980,10 @@ static double k1_group_cost(const slamhip_cs *cs, int g, int budget)
             const double bands = ceil(bytes / budget);
             static const double f_band = getenv("SLAMHIP_K1_FBAND") ? atof(getenv("SLAMHIP_K1_FBAND")) : 1.9;
             static const double f_glob = getenv("SLAMHIP_K1_FGLOBAL") ? atof(getenv("SLAMHIP_K1_FGLOBAL")) : 4.5;
-            f = bands <= K1_MAXBANDS && w <= 504.0 ? f_band * bands : f_glob;      // (measured cost per ray relative to a plain tile step)
+            // (measured cost per ray relative to a plain tile step; the kernel takes bands only where they pay: k1_search_tiled)
+            const double nr = cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b];
+            const bool pay = bands <= 1.0 || bands * ((double)k1_band_stage() + f_band * nr) < f_glob * nr;
+            f = bands <= K1_MAXBANDS && w <= 504.0 && pay ? f_band * bands + (bands > 1.0 ? bands * fmax((double)k1_band_stage(), 0.0) / fmax(nr, 1.0) : 0.0) : f_glob;
         }
         cost += f * (cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b]);
     }
@@ -1083,6 +1100,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.map = cs->d_hole; a.S = cs->hs; a.pts = cs->d_pts_sorted; a.ray_blk = cs->d_ray_blk; a.n_rays = cs->n_points;
         a.pxcs = cs->d_pxcs; a.src3 = cs->d_ev_off; a.bx = bx; a.by = by; a.bth = bth; a.scale = cs->hscale;
         a.count = count; a.n_groups = n_groups; a.budget = budget;
+        a.band_stage = k1_band_stage();
         a.ev_idx = cs->d_ev_idx; a.dist_out = dist; a.key_out = key; a.verify = cs->d_verify;
         static const int no_bounds = env_int("SLAMHIP_K1_NOBOUNDS", 0);
         a.grp_bounds = (mode == 1 && !no_bounds) ? cs->d_grp_bounds : nullptr;
