@@ -195,6 +195,7 @@ k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_poin
 #define K1_MAXR 512                    // rays per chunk
 #define K1_MAXBANDS 4
 #define K1_MAXSTEPS (K1_MAXP * K1_MAXBANDS)
+static_assert(K1_MAXBANDS == 4, "the step threads split t into (piece, band) with shifts");
 #define K1_TABLE_G 64                  // groups with their own chunk count (the rest: one uniform count)
 #define K1_TABLE_WGS 2048
 #define K1_ZERO_OFS 0                  // dynamic LDS: a zero word (16 bytes), then the tile
@@ -295,6 +296,16 @@ __device__ static inline void k1_ray_box(const float *b, const float2 p, int &x0
     float ylo = b[2] + fminf(sx0, sx1);  ylo = ylo + fminf(cy0, cy1);
     float yhi = b[3] + fmaxf(sx0, sx1);  yhi = yhi + fmaxf(cy0, cy1);
     x0 = (int)xlo; x1 = (int)xhi; y0 = (int)ylo; y1 = (int)yhi;
+}
+
+// a / b for 0 <= a < 2^24, 1 <= b < 2^24: one v_rcp_f32 and an exact remainder fix-up instead of the ~35-instruction
+// integer division sequence (the step records are made by a few lanes on the critical path of every workgroup)
+__device__ static inline int k1_div(int a, int b)
+{
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    const int r = a - q * b;
+    if (r < 0) q--; else if (r >= b) q++;
+    return q;
 }
 
 // wave-wide reduction (min / max) in six DPP steps, no LDS traffic: butterfly inside each row of 16 lanes, then
@@ -525,7 +536,7 @@ k1_search_tiled(const k1_args a)
     if (t < npieces * K1_MAXBANDS) {
         // one thread per (piece, band); the threads of a piece take the same decision.  Steps are appended in
         // arrival order: any order gives the same integer sums.
-        const int pc = t / K1_MAXBANDS, band = t - pc * K1_MAXBANDS;
+        const int pc = t >> 2, band = t & 3;                       // (K1_MAXBANDS == 4)
         const int4 bx = *(const int4 *)&boxes[pc][0];
         const int prec = pieces[pc].x | (pieces[pc].y << 16);
         // the box clipped to the map, cut into row bands that fit the tile budget (one band, not clipped: SHARED)
@@ -536,16 +547,16 @@ k1_search_tiled(const k1_args a)
         else {
             const int xa = cx0 & ~7, ww = ((cx1 - xa + 1) + 7) & ~7, vpr = ww >> 3;
             const int sh = vpr <= 1 ? 0 : 32 - __clz(vpr - 1);
-            const int hmax = min(a.budget / (ww * 2), PF * NW * (64 >> (sh & 31)));
+            const int hmax = min(k1_div(a.budget, ww * 2), PF * NW * (64 >> (sh & 31)));
             const int H = cy1 - cy0 + 1;
             // bands pay for themselves only when the rays of the piece amortise the staging of every band: a band costs about
             // as much as K1_BAND_STAGE rays of gathers to stage, a range-tested gather 1.9 and a global gather 4.5 ray units
-            const int nb_ = hmax >= 1 ? (H + hmax - 1) / hmax : K1_MAXBANDS + 1;
+            const int nb_ = hmax >= 1 ? k1_div(H + hmax - 1, hmax) : K1_MAXBANDS + 1;
             const int nr_ = pieces[pc].y;
             const bool bands_pay = nb_ == 1 || (float)nb_ * (a.band_stage + 1.9f * (float)nr_) < 4.5f * (float)nr_;      // (the host's cost estimate mirrors this: k1_group_cost)
             if (vpr <= 64 && hmax >= 1 && nb_ <= K1_MAXBANDS && bands_pay) {
-                nsteps = (H + hmax - 1) / hmax;
-                const int hb = (H + nsteps - 1) / nsteps;
+                nsteps = nb_;
+                const int hb = k1_div(H + nsteps - 1, nsteps);
                 const bool whole = nsteps == 1 && cx0 == bx.x && cy0 == bx.y && cx1 == bx.z && cy1 == bx.w;
                 kind = whole ? K1_KIND_SHARED : K1_KIND_BAND;
                 x0a = xa; w8 = ww; shift = sh;
@@ -554,7 +565,7 @@ k1_search_tiled(const k1_args a)
                 if (h <= 0) nsteps = 0;                            // (rounding can leave the last band empty)
             }
         }
-        if (band < nsteps && (kind == K1_KIND_BAND ? band % nbp == bp : bp == 0)) {
+        if (band < nsteps && (kind == K1_KIND_BAND ? (nbp == 2 ? (band & 1) == bp : band % nbp == bp) : bp == 0)) {
             int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
             dst[0] = make_int4(x0a, y0, w8, h);
             dst[1] = make_int4(shift, kind, prec, 0);
