@@ -53,3 +53,35 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"oracle_c|np_oracle|liboracle|oracle/", txt), os.path.join(dp, f)
+
+
+def test_csharp_shim_binds_declared_symbols(capi):
+    """bindings/csharp/SlamHip (source only: no .NET in this image) must only P/Invoke entry points that include/slamhip.h
+    declares and the library exports, with the argument count of the C prototype; the shim classes must call only
+    P/Invoke stubs that exist."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = os.path.join(root, "bindings", "csharp", "SlamHip")
+    native = open(os.path.join(shim, "SlamHip.Native.cs")).read()
+    header = open(os.path.join(root, "include", "slamhip.h")).read()
+    declared = set(capi.declared_symbols())
+    stubs = {}
+    for m in re.finditer(r"static extern \w+ (slamhip_\w+)\(([^;]*?)\);", native, re.S):
+        name, args = m.group(1), m.group(2).strip()
+        stubs[name] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    assert len(stubs) >= 50
+    unknown = sorted(n for n in stubs if n not in declared)
+    assert not unknown, unknown
+    for name, n_args in stubs.items():
+        proto = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % re.escape(name), header, re.S)
+        assert proto, name
+        c_args = proto.group(1).strip()
+        n_c = 0 if c_args in ("", "void") else len([a for a in c_args.split(",") if a.strip()])
+        assert n_c == n_args, (name, n_c, n_args)
+    used = set()
+    for dp, _, fs in os.walk(shim):
+        for f in fs:
+            if f.endswith(".cs") and f != "SlamHip.Native.cs":
+                used |= set(re.findall(r"Native\.(slamhip_\w+)", open(os.path.join(dp, f)).read()))
+    assert used and not sorted(used - set(stubs)), sorted(used - set(stubs))
