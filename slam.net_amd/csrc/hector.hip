@@ -484,7 +484,7 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
             const int ncls = rs_classes(dx, dy, cls, a, b);
             for (int k = 0; k < ncls; k++) {
                 int lo, hi;
-                rs_range(start, cls[k], a[k], b[k], 0.5f / ((float)a[k] * (float)a[k]), lo, hi);
+                rs_range(start, cls[k], a[k], b[k], 0.5f, lo, hi);
                 for (int ci = lo + lane; ci < hi; ci += 64) {
                     const k5_line c = cand[ci];
                     const int h = k5_hit(c, a[k], b[k]);
@@ -516,7 +516,7 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
         int first_free = 0x7fffffff, first_occ = 0x7fffffff;
         for (int k = 0; k < ncls; k++) {
             int lo, hi;
-            rs_range(start, cls[k], a[k], b[k], 0.5f / ((float)a[k] * (float)a[k]), lo, hi);
+            rs_range(start, cls[k], a[k], b[k], 0.5f, lo, hi);
             for (int ci = lo; ci < hi; ci++) {
                 const k5_line c = cand[ci];
                 const int h = k5_hit(c, a[k], b[k]);

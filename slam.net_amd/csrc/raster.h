@@ -23,9 +23,11 @@ __device__ static inline int rs_class(bool major_x, int smaj) { return major_x ?
 // OccGridMap.cs:220-239, whose integer da / 2 adds up to 1 / (2 da) <= 1 / (2 a) to slope * i -- `extra`, in slope units), so a
 // line that draws (a, b) has its signed slope in [(b - 1/2) / a - extra, (b + 1/2) / a + extra].  The margin covers the
 // float roundings of this range and of the slopes the lines were bucketed with (each below 2e-7; a bucket is 2e-3 wide).
-__device__ static inline void rs_range(const int *start, int cls, int a, int b, float extra, int &lo, int &hi)
+// (1 / a is the hardware reciprocal, within 1 ulp: a slope error below 1e-7, inside the margin; `extra_a2` is the extra term
+// times a^2 -- 0 for K2, 1/2 for K5 -- so that the callers need no division of their own)
+__device__ static inline void rs_range(const int *start, int cls, int a, int b, float extra_a2, int &lo, int &hi)
 {
-    const float ra = 1.0f / (float)a, m = extra + 4.0e-6f;
+    const float ra = __builtin_amdgcn_rcpf((float)a), m = extra_a2 * ra * ra + 4.0e-6f;
     const int blo = rs_bucket(((float)b - 0.5f) * ra - m), bhi = rs_bucket(((float)b + 0.5f) * ra + m);
     lo = start[cls * RS_NBUCK + blo];
     hi = start[cls * RS_NBUCK + bhi + 1];
