@@ -356,7 +356,9 @@ k5_prepare(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, 
     sh_v2_transform(ox, oy, L.t, &bxf, &byf);                              // :126
     const int bx = sh_f2i(rintf(bxf)), by = sh_f2i(rintf(byf));            // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
     int my_R = 0, my_nv = 0, my_first = 0x7fffffff;
-    for (int i = t; i < n; i += 1024) {
+    k5_line keep[2];                                                       // a thread's first two lines stay in registers for the second pass
+    keep[0].flags = 0; keep[1].flags = 0;
+    for (int i = t, it = 0; i < n; i += 1024, it++) {
         float exf, eyf;
         sh_v2_transform(pts[i].x, pts[i].y, L.t, &exf, &eyf);              // :133
         const int ex = sh_f2i(rintf(exf)), ey = sh_f2i(rintf(eyf));        // :134
@@ -377,6 +379,7 @@ k5_prepare(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, 
             my_first = min(my_first, i);
         }
         byidx[i] = e;
+        if (it == 0) keep[0] = e; else if (it == 1) keep[1] = e;
     }
     for (int off = 32; off > 0; off >>= 1) {
         my_R = max(my_R, __shfl_down(my_R, off, 64)); my_nv += __shfl_down(my_nv, off, 64); my_first = min(my_first, __shfl_down(my_first, off, 64));
@@ -401,8 +404,8 @@ k5_prepare(k5_arg A, const float2 *__restrict__ pts, int n, float ox, float oy, 
         if (t == 1023) start[4 * RS_NBUCK] = base;
     }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) {
-        const k5_line e = byidx[i];
+    for (int i = t, it = 0; i < n; i += 1024, it++) {
+        const k5_line e = it == 0 ? keep[0] : it == 1 ? keep[1] : byidx[i];      // (its own store: no other thread wrote byidx[i])
         if (e.flags & 1) {
             const int smaj = ((e.flags >> 2) & 3) - 1;
             const int pos = atomicAdd(&hist[rs_class((e.flags & 2) != 0, smaj) * RS_NBUCK + rs_bucket((float)e.sdb / (float)e.da)], 1);

@@ -244,11 +244,14 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     __syncthreads();
     const float4 q = k2_pxcs(d_pose, h_pxcs, scale);
     int my_R = 0, my_total = 0;
-    for (int i = t; i < n; i += 1024) {
+    k2_byidx keep[2];                                              // a thread's first two rays stay in registers for the second pass (scans of up to 2048 rays)
+    keep[0].flags = 0; keep[1].flags = 0;
+    for (int i = t, it = 0; i < n; i += 1024, it++) {
         const cs_ray r = k2_make_ray(pts[i], size, q, scale, hole_width);
         k2_byidx e; e.dxc = r.dxc; e.sdyc = r.smin * r.dyc; e.lim2 = r.lim2;
         e.flags = (r.valid ? 1 : 0) | (r.major_x ? 2 : 0) | ((r.smaj + 1) << 2);
         byidx[i] = e;
+        if (it == 0) keep[0] = e; else if (it == 1) keep[1] = e;
         if (r.valid) {
             k2_vprof vp; vp.derrorv = r.derrorv; vp.incv = r.incv; vp.lim2 = r.lim2; vp.lim1 = r.lim1;
             vprof[i] = vp;
@@ -283,8 +286,8 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
         if (t == 1023) start[4 * K2_NBUCK] = base;
     }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) {
-        const k2_byidx e = byidx[i];
+    for (int i = t, it = 0; i < n; i += 1024, it++) {
+        const k2_byidx e = it == 0 ? keep[0] : it == 1 ? keep[1] : byidx[i];      // (its own store: no other thread wrote byidx[i])
         if (e.flags & 1) {
             const int smaj = ((e.flags >> 2) & 3) - 1;
             const int cls = (e.flags & 2) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3);
