@@ -294,6 +294,7 @@ int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float h
  * only carries the 128-byte id from rank 0 to the other ranks; the per-scan exchange -- the cross-thread arg-min of
  * CoreSLAMProcessor.cs:695-705 as ncclAllReduce(min, uint64, count 1) over xGMI -- is issued by the library on the
  * communicator's own stream, behind an event, so that the next search does not wait for the last collective. */
+int32_t slamhip_comm_probe(void);                       /* every rank, before anything collective: can librccl be resolved here? */
 int32_t slamhip_comm_unique_id(uint8_t out_id[128]);                                  /* rank 0 */
 int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t id[128], int32_t rank, int32_t n_ranks, slamhip_comm **out);
 int32_t slamhip_comm_destroy(slamhip_comm *comm);

@@ -201,6 +201,16 @@ struct slamhip_comm {
 
 static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
 
+// Can this process create a communicator at all (librccl resolvable, with the entry points used here)?  A collective
+// ncclCommInitRank that only SOME ranks reach blocks the others for good, so hosts check this on every rank first.
+extern "C" int32_t slamhip_comm_probe(void)
+{
+    rccl_api api;
+    SH_TRY(load_rccl(&api));
+    dlclose(api.lib);
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_comm_unique_id(uint8_t out[128])
 {
     SH_CHECK_ARG(out);

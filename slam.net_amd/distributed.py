@@ -47,9 +47,24 @@ class LibComm:
     stream and the 8-byte min all-reduce on the communicator's stream (the next search does not wait for it)."""
 
     def __init__(self, ctx, rank, world):
+        # ncclCommInitRank is collective: a rank that cannot get there (no librccl, no id) would leave the others blocked in
+        # it for good, so every rank reports first whether it can, and nobody goes on unless all can
         uid = np.zeros(128, np.uint8)
-        if rank == 0:
-            capi.call("slamhip_comm_unique_id", uid.ctypes.data_as(C.POINTER(C.c_uint8)))
+        ok = 1
+        try:
+            capi.call("slamhip_comm_probe")
+            if rank == 0:
+                capi.call("slamhip_comm_unique_id", uid.ctypes.data_as(C.POINTER(C.c_uint8)))
+        except Exception:                                          # noqa: BLE001
+            ok = 0
+        if world > 1:
+            okt = torch.tensor([ok], dtype=torch.int32)
+            if dist.get_backend() == "nccl":
+                okt = okt.cuda()
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = int(okt.item())
+        if not ok:
+            raise RuntimeError("librccl cannot be resolved on every rank")
         if world > 1:
             t = torch.from_numpy(uid).cuda() if dist.get_backend() == "nccl" else torch.from_numpy(uid)
             dist.broadcast(t, 0)
