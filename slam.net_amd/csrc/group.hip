@@ -184,6 +184,7 @@ extern "C" int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[
 // event -- so the next search does not wait for the collective of the last one (a ring of key slots keeps them apart),
 // and no interpreter or framework call sits between the kernel and the collective.
 #define SH_COMM_SLOTS 64
+#define SH_COMM_BLOCK 16                 // steps per completion event of the collectives' stream
 struct slamhip_comm {
     slamhip_ctx *ctx;
     rccl_api api;
@@ -291,8 +292,11 @@ extern "C" int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_com
     const int slot = (int)(c->step % SH_COMM_SLOTS);
     uint64_t *key = c->d_keys + slot;
     hipStream_t main = c->ctx->stream;
-    // the slot's last collective (SH_COMM_SLOTS steps ago) must have read it: a host-side wait that is normally a no-op
-    if (c->ar_pending[slot]) { SH_HIP(hipEventSynchronize(c->ev_ar[slot])); c->ar_pending[slot] = false; }
+    // the slot's last collective (SH_COMM_SLOTS steps ago) must have read it: the collectives' stream records an event per
+    // block of SH_COMM_BLOCK steps, and a block starts after a host-side wait -- normally a no-op -- for the event of the
+    // block that used its slots last
+    const int blk = (slot / SH_COMM_BLOCK);
+    if (slot % SH_COMM_BLOCK == 0 && c->ar_pending[blk]) { SH_HIP(hipEventSynchronize(c->ev_ar[blk])); c->ar_pending[blk] = false; }
     bool signalled = false;
     if (count > 0) {
         if (c->by_value) { cs->k1_sig = c->d_sig; cs->k1_sig_val = c->step + 1; }
@@ -309,8 +313,7 @@ extern "C" int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_com
         SH_HIP(hipStreamWaitEvent(c->stream, c->ev_k1[slot], 0));
     }
     SH_NCCL(c, c->api.AllReduce(key, key, 1, ncclUint64, ncclMin, c->comm, c->stream));
-    SH_HIP(hipEventRecord(c->ev_ar[slot], c->stream));
-    c->ar_pending[slot] = true;
+    if (slot % SH_COMM_BLOCK == SH_COMM_BLOCK - 1) { SH_HIP(hipEventRecord(c->ev_ar[blk], c->stream)); c->ar_pending[blk] = true; }
     c->step++;
     if (d_out_key) *d_out_key = key;
     return SLAMHIP_OK;
