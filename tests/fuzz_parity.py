@@ -231,7 +231,7 @@ def main():
                     # answer by millimetres.  The device result must then be what the reference arithmetic gives for a hint
                     # a digit or two away.
                     # the reference's own thread counts first: another chunking of the fp32 sums is enough to flip it
-                    alt = np.array([oc.match_pyramid(ref, xy, hint, [3] * levels, T) for T in (2, 3, 5, 8, 16)])
+                    alt = np.array([oc.match_pyramid(ref, xy, hint, [3] * levels, T) for T in (2, 3, 5, 8, 16, 32, 64)])      # (up to the 64 threads WaitHandle.WaitAll allows the reference; seed 13 of round 2: the device's answer digit for digit at 32 and 64)
                     close = bool(np.any(np.all(np.abs(alt - np.asarray(m)[None]) < tol, axis=1)))
                     prng2 = np.random.default_rng(n_cases)
                     # (on coarse grids the intermediate estimates differ by up to ~1e-5: three scales of perturbation)
