@@ -249,6 +249,8 @@ static_assert(sizeof(k1_args::tab_rec) == 8 && offsetof(k1_args, tab) % 8 == 0, 
 // developer instrumentation (build with SLAMHIP_K1_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
 __device__ unsigned long long g_k1_times[4096 * 16];
 __device__ unsigned long long g_k1_wstart[4096 * 16];
+__device__ unsigned long long g_k1_sub[4096 * 8];      // per workgroup: [0] staging (barrier, tile write, barrier) [1] prefetch issue [2] gather loops [3] steps [4] shader clocks of the compute phase
+#define K1_SUB(k, v) { if (threadIdx.x == 0 && blockIdx.x < 4096) g_k1_sub[blockIdx.x * 8 + (k)] += (v); }
 #define K1_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 4096) g_k1_times[blockIdx.x * 16 + (k)] = wall_clock64(); }
 #else
 #define K1_STAMP(k) {}
@@ -386,6 +388,7 @@ k1_search_tiled(const k1_args a)
     }
     K1_STAMP(0)
 #ifdef K1_TIMES
+    if (t == 0 && blockIdx.x < 4096) { for (int k = 0; k < 8; k++) g_k1_sub[blockIdx.x * 8 + k] = 0; }
     if (t == 0 && blockIdx.x < 4096) { for (int k = 10; k < 16; k++) g_k1_times[blockIdx.x * 16 + k] = 0; g_k1_times[blockIdx.x * 16 + 14] = (unsigned long long)g; g_k1_times[blockIdx.x * 16 + 15] = (unsigned long long)nc; }
     if (lane == 0 && blockIdx.x < 4096) g_k1_wstart[blockIdx.x * 16 + (wv & 15)] = wall_clock64();
     if (t == 0 && blockIdx.x < 4096) {                                     // which CU runs this workgroup
@@ -591,32 +594,45 @@ k1_search_tiled(const k1_args a)
     if (nsteps > 0) {
         k1_u32x4 R[PF];
         int dst[PF];
-#define K1_PREFETCH(step)                                                                           \
+#define K1_PREFETCH(step, enable)                                                                   \
         {                                                                                           \
+            /* 32-bit byte offsets from the map base (a map holds less than 2^32 bytes): a load's address is the scalar   */ \
+            /* base plus one VGPR offset, and from one load to the next the offsets advance by uniform strides (64-bit      */ \
+            /* per-lane products were two quarter-rate multiplies per load).                                                */ \
             const int4 pa_ = *(const int4 *)&stepbuf[(step) * 8];                                   \
             const int shift_ = __builtin_amdgcn_readfirstlane(stepbuf[(step) * 8 + 4]);             \
-            const int w8_ = __builtin_amdgcn_readfirstlane(pa_.z), h_ = __builtin_amdgcn_readfirstlane(pa_.w); \
+            const int w8_ = __builtin_amdgcn_readfirstlane(pa_.z), h_ = (enable) ? __builtin_amdgcn_readfirstlane(pa_.w) : 0; \
             const int rpi = 64 >> shift_;                       /* tile rows per wave-wide load */   \
             const int srow = lane >> shift_, scol = lane & ((1 << shift_) - 1);                     \
             const bool colok = scol < (w8_ >> 3);                                                   \
             const int cc = colok ? scol : 0;                                                        \
-            const uint16_t *__restrict__ gbase = map + (size_t)__builtin_amdgcn_readfirstlane(pa_.y) * S + __builtin_amdgcn_readfirstlane(pa_.x) + (cc << 3); \
+            const unsigned S2_ = (unsigned)S * 2u;                                                  \
+            const unsigned gofs = ((unsigned)__builtin_amdgcn_readfirstlane(pa_.y) * (unsigned)S + (unsigned)__builtin_amdgcn_readfirstlane(pa_.x)) * 2u; \
             const int pitchb = w8_ << 1;                                                            \
-            const int ldsb = K1_TILE_OFS + (cc << 4);                                               \
+            const int row0 = wv * rpi + srow, rstep = NW * rpi;                                     \
+            unsigned vofs = gofs + (unsigned)row0 * S2_ + ((unsigned)cc << 4);                      \
+            int ldsd = K1_TILE_OFS + (cc << 4) + row0 * pitchb;                                     \
+            const unsigned vstep = (unsigned)rstep * S2_;                                           \
+            const int lstep = rstep * pitchb;                                                       \
             _Pragma("unroll") for (int k_ = 0; k_ < PF; k_++) {                                     \
-                const int row = (wv + k_ * NW) * rpi + srow;                                        \
-                const bool live = colok & (row < h_);                                               \
-                const int rr = live ? row : 0;                                                      \
-                if (live) R[k_] = *(const k1_u32x4 *)(gbase + (size_t)rr * S);   /* (see above) */  \
-                dst[k_] = live ? ldsb + rr * pitchb : -1;                                           \
+                const bool live = colok & (row0 + k_ * rstep < h_);                                 \
+                if (live) R[k_] = *(const k1_u32x4 *)((const char *)map + vofs);   /* (see above) */ \
+                dst[k_] = live ? ldsd : -1;                                                         \
+                vofs += vstep; ldsd += lstep;                                                       \
             }                                                                                       \
         }
-        K1_PREFETCH(0)
+        K1_PREFETCH(0, true)
         if (MODE != 0 && pre) {                                    // (the first tile's loads are in flight)
 #pragma unroll
             for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
         }
+#ifdef K1_TIMES
+        const unsigned long long sclk0 = clock64();
+#endif
         for (int s = 0; s < nsteps; s++) {
+#ifdef K1_TIMES
+            const unsigned long long ts0 = wall_clock64();
+#endif
             __syncthreads();                                       // the previous tile is no longer read
             // (every staging register is claimed here, outside any branch: the loads that filled them sit under exec masks,
             // where the compiler cannot count them, and without this it guards the NEXT prefetch's address temporaries --
@@ -627,11 +643,20 @@ k1_search_tiled(const k1_args a)
             for (int k = 0; k < PF; k++) if (dst[k] >= 0) *(k1_u32x4 *)(smem + dst[k]) = R[k];
             __syncthreads();
             if (s == 0) K1_STAMP(6)
+#ifdef K1_TIMES
+            const unsigned long long ts1 = wall_clock64();
+            if (s > 0) K1_SUB(0, ts1 - ts0)
+#endif
             const int4 ca = *(const int4 *)&stepbuf[s * 8], cb = *(const int4 *)&stepbuf[s * 8 + 4];
-            {   // issue the next step's loads now; nothing in the compute loops below waits on vector memory
+            {   // issue the next step's loads now; nothing in the compute loops below waits on vector memory.  (After the last step
+                // there is no next tile: every lane is idle and every load is skipped -- the last tile used to be fetched again.)
                 const int sn = s + 1 < nsteps ? s + 1 : s;
-                K1_PREFETCH(sn)
+                K1_PREFETCH(sn, s + 1 < nsteps)
             }
+#ifdef K1_TIMES
+            const unsigned long long ts2 = wall_clock64();
+            K1_SUB(1, ts2 - ts1) K1_SUB(3, 1ull)
+#endif
             const int kind = __builtin_amdgcn_readfirstlane(cb.y);             // (the record is uniform: keep it in SGPRs)
             const int nr = __builtin_amdgcn_readfirstlane(cb.z) >> 16;         // <= CS_RB_MAX = 64
 #ifdef K1_TIMES
@@ -805,7 +830,13 @@ k1_search_tiled(const k1_args a)
                 }
                 if (VERIFY && t == 0) atomicAdd(a.verify + 3, (unsigned)(nr * 4));
             }
+#ifdef K1_TIMES
+            K1_SUB(2, wall_clock64() - ts2)
+#endif
         }
+#ifdef K1_TIMES
+        K1_SUB(4, clock64() - sclk0)
+#endif
 #undef K1_PREFETCH
     }
     K1_STAMP(7)
@@ -1263,6 +1294,23 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                                 i, (int)h[i * 16 + 14], (int)h[i * 16 + 11], (int)h[i * 16 + 12], (int)h[i * 16 + 13], ea - sa, ea - sa - ov / 2,
                                 j, (int)h[j * 16 + 14], (int)h[j * 16 + 11], (int)h[j * 16 + 12], (int)h[j * 16 + 13], eb - sb, eb - sb - ov / 2,
                                 std::max((double)(endof(i) - t0), (double)(endof(j) - t0)) * 0.01);
+                    }
+                }
+                {   // inside the compute phase (wave 0 of every workgroup): staging of the steps after the first, prefetch issue, gather loops
+                    std::vector<unsigned long long> sb((size_t)nw * 8);
+                    (void)hipMemcpyFromSymbol(sb.data(), HIP_SYMBOL(g_k1_sub), sizeof(unsigned long long) * sb.size());
+                    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, mhz = 0; int nm_ = 0;
+                    for (int i = 0; i < nw; i++) {
+                        a0 += (double)sb[i * 8] * 0.01; a1 += (double)sb[i * 8 + 1] * 0.01; a2 += (double)sb[i * 8 + 2] * 0.01; a3 += (double)sb[i * 8 + 3];
+                        const double comp = (double)(h[i * 16 + 7] - h[i * 16 + 6]) * 0.01;
+                        if (comp > 1.0) { mhz += (double)sb[i * 8 + 4] / (comp + (double)(h[i * 16 + 6] - h[i * 16 + 5]) * 0.01); nm_++; }
+                    }
+                    fprintf(stderr, "[k1 times] compute phase, mean per WG: steps %.2f | restaging %.2f us | prefetch issue %.2f us | gather loops %.2f us | shader clock ~%.0f MHz (steps incl. first staging)\n",
+                            a3 / nw, a0 / nw, a1 / nw, a2 / nw, nm_ ? mhz / nm_ : 0.0);
+                    for (int oi = 0; oi < nw; oi += nw / 24 > 0 ? nw / 24 : 1) {
+                        const int i = order[(size_t)oi];
+                        fprintf(stderr, "  wg %4d g %2d: steps %d restaging %5.2f prefetch %5.2f loops %5.2f | rays shared %d global %d band %d\n", i, (int)h[i * 16 + 14], (int)sb[i * 8 + 3],
+                                (double)sb[i * 8] * 0.01, (double)sb[i * 8 + 1] * 0.01, (double)sb[i * 8 + 2] * 0.01, (int)h[i * 16 + 11], (int)h[i * 16 + 12], (int)h[i * 16 + 13]);
                     }
                 }
                 // per group: chunks, ray-steps per kind, mean / max compute time
