@@ -215,6 +215,7 @@ struct k1_args {
     float bx, by, bth, scale;
     int count, n_groups;
     int budget;                        // tile bytes
+    int noden;                         // developer / test switch: tile addresses from the integer pixel coordinates (k1_tile_addr) everywhere
     float band_stage;                  // cost of staging one band of a banded tile, in ray units (a large value: always band when it fits)
     unsigned long long *acc;           // [n_groups][K1_GROUP] per-candidate accumulators; zero between launches
     unsigned *tickets;                 // [n_groups] chunk arrivals + [1] group arrivals; zero between launches
@@ -264,14 +265,18 @@ __device__ static inline unsigned k1_tile_addr(int ix, int iy, int pitch2, int k
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a) : "v"(iy), "s"(pitch2), "v"(t));
     return a;
 }
-// The same address from the float coordinates (tile steps whose end points all lie in the tile): truncation, the row-major
-// element index iy * pitch + ix as one FMA and the byte address 2 * (index - first element) + tile base read off the
-// mantissa of (index + mc) with mc = 2^22 - first element + base / 2 -- every value is an integer below 2^24, so the
-// float arithmetic is exact; five full-rate operations instead of two conversions and two integer multiply-adds at half rate
-__device__ static inline unsigned k1_tile_addr_f(float fx, float fy, float pitch, float mc)
+// The address of a tile step whose end points all lie in the tile, from the float coordinates: binary32 denormals are the integers 0 .. 2^23 - 1 in units of 2^-149 and
+// their bit pattern IS that integer, the FMA unit handles them at full rate (the kernel runs with denormals on), and every term
+// here -- 2 * ix, iy * pitch2, the offset c = tile base - 2 * first element, each partial sum -- is an integer of magnitude below
+// 2^23, so the arithmetic is exact: truncation x 2 and two FMAs, no add, no mask.  two_d, pitch2_d, c_d are the integers 2,
+// pitch2 and c as denormals (k1_den).  Valid while S * pitch2 + 2 * S + 2^18 < 2^23 (the caller checks; beyond, k1_tile_addr).
+// (Six full-rate operations less per ray pair and candidate than truncation, FMA, the add of 2^22 + offset and the mantissa mask
+// of the round-1 form; that one replaced two conversions and two integer multiply-adds at half rate.)
+__device__ static inline float k1_den(int v) { return __uint_as_float(v < 0 ? (0x80000000u | (unsigned)(-v)) : (unsigned)v); }
+__device__ static inline unsigned k1_tile_addr_d(float fx, float fy, float two_d, float pitch2_d, float c_d)
 {
-    const float g = fmaf(truncf(fy), pitch, truncf(fx)) + mc;
-    return __float_as_uint(g) & 0x7fffffu;
+    const float g = fmaf(truncf(fy), pitch2_d, fmaf(truncf(fx), two_d, c_d));
+    return __float_as_uint(g);
 }
 // 16-bit LDS load at an absolute LDS byte address (saves the per-access `tile + offset` add)
 typedef __attribute__((address_space(3))) const uint16_t k1_lds_u16;
@@ -284,6 +289,14 @@ __device__ static inline float2 k1_point_lds(unsigned lds_addr)
 {
     k1_lds_f *p = (k1_lds_f *)(size_t)lds_addr;
     return make_float2(p[0], p[1]);
+}
+
+// two consecutive ray points with one LDS read (the list is 8-byte aligned: ds_read2_b64)
+typedef float k1_f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ static inline float4 k1_points2_lds(unsigned lds_addr)
+{
+    const k1_f32x4a8 v = *(__attribute__((address_space(3))) const k1_f32x4a8 *)(size_t)lds_addr;
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // end-point pixel box of one ray over a candidate set, by interval arithmetic on the reference's own
@@ -668,14 +681,15 @@ k1_search_tiled(const k1_args a)
             const int pitch2 = w8 << 1;
             const int kofs = (int)smem_lds + K1_TILE_OFS - ((y0 * w8 + x0a) << 1);
             const unsigned zaddr = smem_lds + K1_ZERO_OFS + (unsigned)zv;
-            // (float form of the tile address, k1_tile_addr_f: element indices of the map stay below 2^24 up to 16384 rows of at most
-            // 512 pixels; pitch and offset live in VGPRs -- an SGPR operand costs a VALU operation 1.6x the issue time)
-            const bool faddr = S <= 16384;
-            float pf_v, mc_v;
+            // (float form of the tile address, k1_tile_addr_d; its constants live in VGPRs -- an SGPR operand costs a VALU operation
+            // 1.6x the issue time)
+            const bool daddr = !a.noden && (unsigned)S * (unsigned)pitch2 + 2u * (unsigned)S + (1u << 18) < (1u << 23);   // k1_tile_addr_d is exact
+            float two_v, p2d_v, cd_v;
             {
-                const float pf_s = (float)w8, mc_s = 4194304.0f - (float)(y0 * w8 + x0a) + (float)((smem_lds + K1_TILE_OFS) >> 1);
-                asm volatile("v_mov_b32 %0, %1" : "=v"(pf_v) : "s"(pf_s));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(mc_v) : "s"(mc_s));
+                const float two_s = k1_den(2), p2d_s = k1_den(pitch2), cd_s = k1_den(kofs);
+                asm volatile("v_mov_b32 %0, %1" : "=v"(two_v) : "s"(two_s));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(p2d_v) : "s"(p2d_s));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(cd_v) : "s"(cd_s));
             }
             if (kind != K1_KIND_GLOBAL) {
                 // SHARED: every end point of every candidate lies in the tile (the box is rigorous).  BAND: the band
@@ -688,38 +702,52 @@ k1_search_tiled(const k1_args a)
                 const bool checked = kind == K1_KIND_BAND;
                 uint32_t va[CPL], vb[CPL];
                 int r = 0;
-                float2 pa_n = k1_point_lds(pbase), pb_n = k1_point_lds(pbase + 8);      // (cpts has room for the over-read)
+                float4 pn = k1_points2_lds(pbase);                                      // (cpts has room for the over-read)
+                float2 pa_n = make_float2(pn.x, pn.y), pb_n = make_float2(pn.z, pn.w);
 #pragma unroll
                 for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(zaddr); vb[k] = k1_lds_load(zaddr); }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!checked && faddr) {
-                    for (; r + 1 < nr; r += 2) {
-                        const float2 pa = pa_n, pb = pb_n;
-                        pa_n = k1_point_lds(pbase + r * 8 + 16); pb_n = k1_point_lds(pbase + r * 8 + 24);
-                        unsigned ada[CPL], adb[CPL];
-#pragma unroll
-                        for (int k = 0; k < CPL; k++) {
-                            float fxa, fya, fxb, fyb;
-                            k1_coords(q[k], pa, fxa, fya);
-                            k1_coords(q[k], pb, fxb, fyb);
-                            const int ixa = (int)fxa, iya = (int)fya, ixb = (int)fxb, iyb = (int)fyb;
-                            ada[k] = k1_tile_addr_f(fxa, fya, pf_v, mc_v);
-                            adb[k] = k1_tile_addr_f(fxb, fyb, pf_v, mc_v);
-                            if (VERIFY) {
-                                if (ixa < x0a || ixa >= x0a + w8 || iya < y0 || iya >= y0 + h ||
-                                    ixb < x0a || ixb >= x0a + w8 || iyb < y0 || iyb >= y0 + h) atomicAdd(a.verify, 1u);
-                                else if (map[(size_t)iya * S + ixa] != *(const uint16_t *)(smem + (ada[k] - smem_lds)) ||
-                                         map[(size_t)iyb * S + ixb] != *(const uint16_t *)(smem + (adb[k] - smem_lds)))
-                                    atomicAdd(a.verify, 1u);               // the staged tile must equal the map
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int k = 0; k < CPL; k++) sum[k] += va[k] + vb[k];
-#pragma unroll
-                        for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(ada[k]); vb[k] = k1_lds_load(adb[k]); }
-                        __builtin_amdgcn_sched_barrier(0);
+                if (!checked && daddr) {
+                    // two ray pairs per iteration, the point registers of the pairs taking turns (a rotation of one set costs four
+                    // moves per pair); the points of two rays come with one 16-byte LDS read
+#define K1_DPAIR(P, NEXTREAD)                                                                       \
+                    {                                                                               \
+                        unsigned ada[CPL], adb[CPL];                                                \
+                        _Pragma("unroll") for (int k = 0; k < CPL; k++) {                           \
+                            float fxa, fya, fxb, fyb;                                               \
+                            k1_coords(q[k], make_float2((P).x, (P).y), fxa, fya);                   \
+                            k1_coords(q[k], make_float2((P).z, (P).w), fxb, fyb);                   \
+                            ada[k] = k1_tile_addr_d(fxa, fya, two_v, p2d_v, cd_v);                  \
+                            adb[k] = k1_tile_addr_d(fxb, fyb, two_v, p2d_v, cd_v);                  \
+                            if (VERIFY) {                                                           \
+                                const int ixa = (int)fxa, iya = (int)fya, ixb = (int)fxb, iyb = (int)fyb; \
+                                if (ixa < x0a || ixa >= x0a + w8 || iya < y0 || iya >= y0 + h ||    \
+                                    ixb < x0a || ixb >= x0a + w8 || iyb < y0 || iyb >= y0 + h) atomicAdd(a.verify, 1u); \
+                                else if (ada[k] != k1_tile_addr(ixa, iya, pitch2, kofs) || adb[k] != k1_tile_addr(ixb, iyb, pitch2, kofs) || \
+                                         map[(size_t)iya * S + ixa] != *(const uint16_t *)(smem + (ada[k] - smem_lds)) || \
+                                         map[(size_t)iyb * S + ixb] != *(const uint16_t *)(smem + (adb[k] - smem_lds))) \
+                                    atomicAdd(a.verify, 1u);               /* the staged tile must equal the map */ \
+                            }                                                                       \
+                        }                                                                           \
+                        __builtin_amdgcn_sched_barrier(0);                                          \
+                        NEXTREAD;     /* (after the arithmetic: issued at the top, the wait for P would also wait for the gathers before it) */ \
+                        _Pragma("unroll") for (int k = 0; k < CPL; k++) sum[k] += va[k] + vb[k];    \
+                        _Pragma("unroll") for (int k = 0; k < CPL; k++) { va[k] = k1_lds_load(ada[k]); vb[k] = k1_lds_load(adb[k]); } \
+                        __builtin_amdgcn_sched_barrier(0);                                          \
                     }
+                    for (; r + 3 < nr; r += 4) {
+                        const float4 p0 = pn;
+                        float4 p1;
+                        K1_DPAIR(p0, p1 = k1_points2_lds(pbase + r * 8 + 16))
+                        K1_DPAIR(p1, pn = k1_points2_lds(pbase + r * 8 + 32))
+                    }
+                    if (r + 1 < nr) {
+                        const float4 p0 = pn;
+                        K1_DPAIR(p0, pn = k1_points2_lds(pbase + r * 8 + 16))
+                        r += 2;
+                    }
+#undef K1_DPAIR
+                    pa_n = make_float2(pn.x, pn.y);
                     cnt_all += (uint32_t)nr;
                 } else if (!checked) {
                     for (; r + 1 < nr; r += 2) {
@@ -1143,6 +1171,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.pxcs = cs->d_pxcs; a.src3 = cs->d_ev_off; a.bx = bx; a.by = by; a.bth = bth; a.scale = cs->hscale;
         a.count = count; a.n_groups = n_groups; a.budget = budget;
         a.band_stage = k1_band_stage();
+        static const int noden = env_int("SLAMHIP_K1_NODEN", 0);
+        a.noden = noden;
         a.ev_idx = cs->d_ev_idx; a.dist_out = dist; a.key_out = key; a.verify = cs->d_verify;
         static const int no_bounds = env_int("SLAMHIP_K1_NOBOUNDS", 0);
         a.grp_bounds = (mode == 1 && !no_bounds) ? cs->d_grp_bounds : nullptr;
