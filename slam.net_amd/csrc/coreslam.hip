@@ -133,7 +133,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
     (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_verify);
-    (void)hipFree(cs->d_k1_tickets); (void)hipFree(cs->d_k1_gkey); (void)hipFree(cs->d_k1_acc);
+    (void)hipFree(cs->d_k1_gmin); (void)hipFree(cs->d_k1_acc);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
     cs_holemap_free(cs);
     cs_obstacle_free(cs);
@@ -153,7 +153,7 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
     cs->hs = hole_size; cs->hscale = (float)hole_size / physical;          // HoleMap.cs:19-20
     cs->os = obst_size; cs->oscale = (float)obst_size / physical;          // ObstacleMap.cs:19-20
     cs->shard_first = cs->shard_count = -1;
-    cs->offs_theta_small = true; cs->k1_layout_dirty = true; cs->k1_tickets_groups = -1;
+    cs->offs_theta_small = true; cs->k1_layout_dirty = true;
     int32_t rc = SLAMHIP_OK;
     do {
         if (hipMalloc(&cs->d_hole, sizeof(uint16_t) * (size_t)hole_size * hole_size) != hipSuccess ||

@@ -45,10 +45,9 @@ struct slamhip_cs {
     int cap_cand;
     float4 *d_pxcs;               // [cap_cand] (px,py,c,s) in evaluation order
     void *d_partial; size_t cap_partial;       // K1 partial rows (bytes)
-    unsigned int *d_k1_tickets;   // K1: [groups] chunk arrivals + [1] group arrivals (zero between launches)
-    unsigned long long *d_k1_gkey;              // K1: per-group arg-min keys
+    unsigned long long *d_k1_gmin;              // K1: [0] running minimum of the finished candidates' keys (all ones between launches), [1] their count (zero)
     unsigned long long *d_k1_acc;               // K1: per-candidate accumulators [groups][K1_GROUP] (zero between launches)
-    int k1_cap_groups, k1_tickets_groups;
+    int k1_cap_groups;
     // K1 launch layout: per group of 1024 evaluation-order candidates the theta range (rad) and translation spread
     // (pixels) -- from the offsets (ensure_shard) -- and the chunks per group derived from them and the scan
     std::vector<float> h_grp_dth, h_grp_dxy;

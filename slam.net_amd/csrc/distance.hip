@@ -198,6 +198,8 @@ k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_poin
 static_assert(K1_MAXBANDS == 4, "the step threads split t into (piece, band) with shifts");
 #define K1_TABLE_G 64                  // groups with their own chunk count (the rest: one uniform count)
 #define K1_TABLE_WGS 2048
+#define K1_ACC_INMAP 36                // accumulator fields: pixel sum below (R < 2^20 rays x 65535), workgroups with an in-map end point,
+#define K1_ACC_ARRIVED 50              // workgroups arrived (chunks per group < 2^14)
 #define K1_ZERO_OFS 0                  // dynamic LDS: a zero word (16 bytes), then the tile
 #define K1_TILE_OFS 16
 // step record: [0] x0a  [1] y0  [2] w8 (pitch, px)  [3] h  [4] shift = log2(lanes per row)  [5] kind
@@ -217,9 +219,9 @@ struct k1_args {
     int budget;                        // tile bytes
     int noden;                         // developer / test switch: tile addresses from the integer pixel coordinates (k1_tile_addr) everywhere
     float band_stage;                  // cost of staging one band of a banded tile, in ray units (a large value: always band when it fits)
-    unsigned long long *acc;           // [n_groups][K1_GROUP] per-candidate accumulators; zero between launches
-    unsigned *tickets;                 // [n_groups] chunk arrivals + [1] group arrivals; zero between launches
-    unsigned long long *gkey;          // [n_groups] group minima
+    unsigned long long *acc;           // [n_groups][K1_GROUP] per-candidate accumulators (sum | in-map | arrived); zero between launches
+    unsigned long long *gmin;          // running minimum of the finished candidates' keys; all ones between launches
+    unsigned *done;                    // finished candidates; zero between launches
     const int *ev_idx;
     int32_t *dist_out;
     unsigned long long *key_out;
@@ -369,7 +371,8 @@ k1_search_tiled(const k1_args a)
     __shared__ __attribute__((aligned(16))) float bnd[8];
     __shared__ __attribute__((aligned(16))) int boxes[K1_MAXP][4];
     __shared__ unsigned long long wkey[NW];
-    __shared__ int s_nsteps, s_last;
+    __shared__ unsigned wfin[NW];
+    __shared__ int s_nsteps;
     const unsigned cpts_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cpts;
 
     const uint16_t *__restrict__ map = a.map;
@@ -664,7 +667,11 @@ k1_search_tiled(const k1_args a)
             {   // issue the next step's loads now; nothing in the compute loops below waits on vector memory.  (After the last step
                 // there is no next tile: every lane is idle and every load is skipped -- the last tile used to be fetched again.)
                 const int sn = s + 1 < nsteps ? s + 1 : s;
+#ifdef K1_EXPNOPF
+                K1_PREFETCH(sn, false)                             // developer experiment (wrong results): what the later tiles' loads cost
+#else
                 K1_PREFETCH(sn, s + 1 < nsteps)
+#endif
             }
 #ifdef K1_TIMES
             const unsigned long long ts2 = wall_clock64();
@@ -870,87 +877,71 @@ k1_search_tiled(const k1_args a)
     K1_STAMP(7)
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
-    // Every candidate has one 64-bit accumulator (pixel sum | steps with an in-map end point << 40): the workgroup adds
-    // its partial sums with agent-scope atomics (performed at the memory side: correct for any placement of the group's
-    // workgroups over CUs and XCDs), drains every wave, then ONE lane takes the group's arrival ticket.  The workgroup
-    // that draws the last ticket of the group swaps the accumulators back to zero (read + reset for the next launch in
-    // one round trip, whatever the number of chunks), finishes the distances and takes the group arg-min; the last
-    // group takes the overall arg-min.  No fences, no spinning; tickets and accumulators are zero between launches.
+    // Every candidate has one 64-bit accumulator: pixel sum (36 bits) | workgroups that saw an end point of it in the map (14) |
+    // workgroups that have arrived (14).  A workgroup adds its share with one agent-scope atomic per candidate (performed at the
+    // memory side: correct for any placement of the group's workgroups over CUs and XCDs) and gets the old value back: the lane
+    // whose add completes the arrival count holds the candidate's total -- no drain, no ticket, no second read -- zeroes the
+    // accumulator for the next launch and finishes the distance.  Workgroups that finished candidates min-reduce their keys into
+    // one device word and add their number to a counter; the workgroup that completes the count reads the minimum back, resets both
+    // words and delivers the result.  (Round 1 drained the adds, drew a ticket per group, had the last arriver swap the
+    // accumulators back and the last group walk the group minima: five dependent round trips after the slowest workgroup's last
+    // gather; now three.)  No fences, no spinning; accumulators, minimum (all ones) and counter (zero) are at rest between launches.
     typedef unsigned long long u64;
     u64 *acc = a.acc + (size_t)g * K1_GROUP + (size_t)t * CPL;                 // (the candidates of a lane are adjacent)
+    u64 tot[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
-        const u64 add = (u64)sum[k] | ((u64)((cnt[k] | cnt_all) ? 1u : 0u) << 40);
-        if (add) __hip_atomic_fetch_add(acc + k, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 add = (u64)sum[k] | ((u64)((cnt[k] | cnt_all) ? 1u : 0u) << K1_ACC_INMAP) | (1ull << K1_ACC_ARRIVED);
+        tot[k] = __hip_atomic_fetch_add(acc + k, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == (unsigned)nc - 1u;
-        if (s_last) __hip_atomic_store(a.tickets + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    K1_STAMP(8)
-    if (!s_last) return;
     u64 key = ~0ull;
-    {
-        u64 tot[CPL];
+    unsigned nfin = 0;
 #pragma unroll
-        for (int k = 0; k < CPL; k++) tot[k] = __hip_atomic_exchange(acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < CPL; k++) {
+    for (int k = 0; k < CPL; k++) {
+        if ((unsigned)(tot[k] >> K1_ACC_ARRIVED) == (unsigned)nc) {
+            __hip_atomic_store(acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int j = g * K1_GROUP + k * LANES + t;
             if (j < count) {
-                const u64 kk = k1_finish(tot[k] & ((1ull << 40) - 1), (uint32_t)(tot[k] >> 40), a.n_rays, a.ev_idx ? a.ev_idx[j] : j, a.dist_out);
+                const u64 kk = k1_finish(tot[k] & ((1ull << K1_ACC_INMAP) - 1), (uint32_t)(tot[k] >> K1_ACC_INMAP) & ((1u << (K1_ACC_ARRIVED - K1_ACC_INMAP)) - 1u),
+                                         a.n_rays, a.ev_idx ? a.ev_idx[j] : j, a.dist_out);
                 key = kk < key ? kk : key;
+                nfin++;
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const u64 o = __shfl_down(key, off, 64);
-        key = o < key ? o : key;
-    }
-    if (lane == 0) wkey[wv] = key;
-    __syncthreads();
-    if (t == 0) {
-        for (int w = 1; w < NW; w++) key = wkey[w] < key ? wkey[w] : key;
-        __hip_atomic_store(a.gkey + g, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned old = __hip_atomic_fetch_add(a.tickets + ng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == (unsigned)ng - 1u;
-        if (s_last) __hip_atomic_store(a.tickets + ng, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // the last group: minimum over the groups, by the whole workgroup (a single lane would walk hundreds of dependent
-    // loads at large candidate counts)
-    u64 best = ~0ull;
-    for (int i = t; i < ng; i += LANES) {
-        const u64 k = __hip_atomic_load(a.gkey + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        best = k < best ? k : best;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const u64 o = __shfl_down(best, off, 64);
-        best = o < best ? o : best;
-    }
-    if (lane == 0) wkey[wv] = best;
-    __syncthreads();
-    if (t == 0) {
-        for (int w = 1; w < NW; w++) best = wkey[w] < best ? wkey[w] : best;
-        *a.key_out = best;
-        if (a.best_pose) {                                         // search_pose + offs[index - 1] (:635-637), theta normalised (:746)
-            const uint32_t flat = (uint32_t)best;
-            float x = a.bx, y = a.by, th = a.bth;
-            if (flat > 0) { x = a.bx + a.offs_flat[3 * (flat - 1)]; y = a.by + a.offs_flat[3 * (flat - 1) + 1]; th = a.bth + a.offs_flat[3 * (flat - 1) + 2]; }
-            a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
-            a.best_pose[3] = th;                                   // un-normalised, as MonteCarloSearch returns it
+    K1_STAMP(8)
+    if (__builtin_amdgcn_ballot_w64(nfin != 0) != 0) {             // (most workgroups complete nothing: no shuffles)
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 o = __shfl_down(key, off, 64);
+            key = o < key ? o : key;
+            nfin += (unsigned)__shfl_down((int)nfin, off, 64);
         }
-        if (a.sig) __hip_atomic_store(a.sig, a.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (a.done_flag) {                                         // blocking search: the key into the mailbox, then its completion word
-            *(unsigned long long *)(a.done_flag - 15) = best;
-            __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    }
+    if (lane == 0) { wkey[wv] = key; wfin[wv] = nfin; }
+    __syncthreads();
+    if (t != 0) return;
+    for (int w = 1; w < NW; w++) { key = wkey[w] < key ? wkey[w] : key; nfin += wfin[w]; }
+    if (nfin == 0) return;
+    (void)__hip_atomic_fetch_min(a.gmin, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (with return: performed before the count below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned before = __hip_atomic_fetch_add(a.done, nfin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + nfin != (unsigned)count) return;
+    // the last finisher
+    const u64 best = __hip_atomic_load(a.gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.gmin, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *a.key_out = best;
+    if (a.best_pose) {                                             // search_pose + offs[index - 1] (:635-637), theta normalised (:746)
+        const uint32_t flat = (uint32_t)best;
+        float x = a.bx, y = a.by, th = a.bth;
+        if (flat > 0) { x = a.bx + a.offs_flat[3 * (flat - 1)]; y = a.by + a.offs_flat[3 * (flat - 1) + 1]; th = a.bth + a.offs_flat[3 * (flat - 1) + 2]; }
+        a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
+        a.best_pose[3] = th;                                       // un-normalised, as MonteCarloSearch returns it
+    }
+    if (a.sig) __hip_atomic_store(a.sig, a.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.done_flag) {                                             // blocking search: the key into the mailbox, then its completion word
+        *(unsigned long long *)(a.done_flag - 15) = best;
+        __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     K1_STAMP(9)
 }
@@ -1196,6 +1187,11 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             k1_make_layout(cs, n_groups, target, budget, have_spread, band_parts);
             cs->k1_layout_dirty = false; cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread;
         }
+        {   // the accumulators count up to 2^14 - 1 arrivals per candidate and sum up to 2^20 rays (pathological scans: fallback kernels)
+            int nc_max = cs->k1_uni_nc;
+            for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) nc_max = std::max(nc_max, cs->k1_tab_nc[i]);
+            if (nc_max >= (1 << (K1_ACC_ARRIVED - K1_ACC_INMAP)) || cs->n_points >= (1 << 20)) goto fallback;
+        }
         static const int dump = env_int("SLAMHIP_K1_DUMP", 0);
         if (dump) {                                                // debugging aid: the launch layout and its cost estimates
             fprintf(stderr, "[slamhip] K1 layout: %d groups, %zu listed, uniform [%d, %d) x %d chunks\n", n_groups, cs->k1_tab_group.size(),
@@ -1225,26 +1221,21 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         // 1 (16 waves: slow start) and 4 (4 waves: the VALU starves at 2 waves / SIMD) stay selectable for experiments
         const int cpl = cpl_env == 1 || cpl_env == 4 ? cpl_env : 2;
         if (n_groups > cs->k1_cap_groups) {
-            if (cs->d_k1_tickets) (void)hipFree(cs->d_k1_tickets);
-            if (cs->d_k1_gkey) (void)hipFree(cs->d_k1_gkey);
-            cs->d_k1_tickets = nullptr; cs->d_k1_gkey = nullptr; cs->k1_cap_groups = 0;
-            const int cap = n_groups + n_groups / 4 + 16;
-            SH_HIP(hipMalloc(&cs->d_k1_tickets, sizeof(unsigned) * (size_t)(cap + 1)));
-            SH_HIP(hipMalloc(&cs->d_k1_gkey, sizeof(unsigned long long) * (size_t)cap));
             if (cs->d_k1_acc) (void)hipFree(cs->d_k1_acc);
-            cs->d_k1_acc = nullptr;
+            cs->d_k1_acc = nullptr; cs->k1_cap_groups = 0;
+            const int cap = n_groups + n_groups / 4 + 16;
             SH_HIP(hipMalloc(&cs->d_k1_acc, sizeof(unsigned long long) * (size_t)cap * K1_GROUP));
             SH_HIP(hipMemsetAsync(cs->d_k1_acc, 0, sizeof(unsigned long long) * (size_t)cap * K1_GROUP, ctx->stream));
             cs->k1_cap_groups = cap;
-            cs->k1_tickets_groups = -1;
         }
-        if (cs->k1_tickets_groups != n_groups) {
-            // tickets are zero between launches (the last arriver resets them); the group ticket lives at index
-            // n_groups, so a change of the group count (or a fresh buffer) zeroes the lot
-            SH_HIP(hipMemsetAsync(cs->d_k1_tickets, 0, sizeof(unsigned) * (size_t)(cs->k1_cap_groups + 1), ctx->stream));
-            cs->k1_tickets_groups = n_groups;
+        if (!cs->d_k1_gmin) {
+            // the running minimum (all ones at rest) and the count of finished candidates (zero at rest): the launch's last
+            // finisher leaves them so
+            SH_HIP(hipMalloc(&cs->d_k1_gmin, 16));
+            SH_HIP(hipMemsetAsync(cs->d_k1_gmin, 0xff, 8, ctx->stream));
+            SH_HIP(hipMemsetAsync((char *)cs->d_k1_gmin + 8, 0, 8, ctx->stream));
         }
-        a.tickets = cs->d_k1_tickets; a.gkey = cs->d_k1_gkey; a.acc = cs->d_k1_acc;
+        a.gmin = cs->d_k1_gmin; a.done = (unsigned *)((char *)cs->d_k1_gmin + 8); a.acc = cs->d_k1_acc;
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
 #define K1_LAUNCH(M, V, C) hipLaunchKernelGGL((k1_search_tiled<M, V, C>), dim3(n_wgs), dim3(K1_GROUP / C), lds, ctx->stream, a)
@@ -1360,6 +1351,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         return SLAMHIP_OK;
     }
 
+fallback:
     // ---- fallback: candidate transform, bounds-checked global gathers, reduction -----------------------------------
     cs->k1_pose_written = false; cs->k1_done_armed = false; cs->k1_sig_armed = false;
     {
