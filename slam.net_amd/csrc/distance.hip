@@ -1040,8 +1040,13 @@ static double k1_group_cost(const slamhip_cs *cs, int g, int budget)
         if (bytes > budget) {
             const double bands = ceil(bytes / budget);
             static const double f_band = getenv("SLAMHIP_K1_FBAND") ? atof(getenv("SLAMHIP_K1_FBAND")) : 1.9;
-            static const double f_glob = getenv("SLAMHIP_K1_FGLOBAL") ? atof(getenv("SLAMHIP_K1_FGLOBAL")) : 4.5;
-            // (measured cost per ray relative to a plain tile step; the kernel takes bands only where they pay: k1_search_tiled)
+            static const double f_glob = getenv("SLAMHIP_K1_FGLOBAL") ? atof(getenv("SLAMHIP_K1_FGLOBAL")) : 3.0;
+            // (cost per ray relative to a plain tile step.  The kernel takes bands where they pay against 4.5 for a global gather
+            // (k1_search_tiled) -- what a gather costs the workgroup that issues it.  In the balance of the launch a global-gather
+            // step weighs less: it leaves the VALU and the LDS to the workgroup it shares the compute unit with.  Measured, three
+            // runs each, 4.5 -> 3.0: 16 384 candidates 27.1 -> 26.1 us per launch with events, sigma_theta 20 degrees 36.0 -> 31.9,
+            // 4096^2 map with 32 768 candidates 68.2 -> 51.5, 4096 candidates 23.8 -> 22.5, the other sizes unchanged; 3.5 and 2.5
+            // each have sizes that lose 4-12 us to a second round of workgroups.)
             const double nr = cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b];
             const bool pay = bands <= 1.0 || bands * ((double)k1_band_stage() + f_band * nr) < f_glob * nr;
             f = bands <= K1_MAXBANDS && w <= 504.0 && pay ? f_band * bands + (bands > 1.0 ? bands * fmax((double)k1_band_stage(), 0.0) / fmax(nr, 1.0) : 0.0) : f_glob;
