@@ -1003,6 +1003,28 @@ static bool k1_chunks_legal(const slamhip_cs *cs, int nc)
     return true;
 }
 
+// The slowest of nc equal ray ranges in ray units, a tile step (a ray block fragment) counted as `step` rays: a step costs a
+// workgroup about a microsecond of staging whatever its size (barrier, tile write, barrier, the next tile's loads), eight rays'
+// worth of gathers, and where the cuts fall on the block boundaries a range is one step -- one ray range more or less per group
+// moved a launch by 4 us (1024^2 map, 26 against 27 ranges per group).  < 0: not a legal count.
+static double k1_chunks_score(const slamhip_cs *cs, int nc, double step)
+{
+    const int R = cs->n_points, n_rb = cs->n_rb;
+    const int *rb = cs->h_rb_start.data();
+    if (nc < 1 || nc > R) return -1.0;
+    int b = 0;
+    double worst = 0.0;
+    for (int c = 0; c < nc; c++) {
+        const int rlo = (int)(((long long)c * R) / nc), rhi = (int)(((long long)(c + 1) * R) / nc);
+        while (b + 1 < n_rb && rb[b + 1] <= rlo) b++;                  // block of ray rlo
+        int e = b;
+        while (e + 1 < n_rb && rb[e + 1] < rhi) e++;                   // block of ray rhi - 1
+        if (e - b + 1 > K1_MAXP || rhi - rlo > K1_MAXR) return -1.0;
+        worst = std::max(worst, (double)(rhi - rlo) + step * (double)(e - b + 1));
+    }
+    return worst;
+}
+
 // Smallest legal chunk count >= nc (one ray per chunk is always legal).
 static int k1_legal_chunks(const slamhip_cs *cs, int nc)
 {
@@ -1081,8 +1103,52 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
         double total = (double)(hi - lo) * ref;
         for (int g = 0; g < lo; g++) total += cost[(size_t)g];
         for (int g = hi; g < n_groups; g++) total += cost[(size_t)g];
-        const double per_cost = (double)target_wgs / total;
+        double per_cost = (double)target_wgs / total;
         uni_want = (int)floor(ref * per_cost + 0.5);
+        static const double step_cost = getenv("SLAMHIP_K1_STEPCOST") ? atof(getenv("SLAMHIP_K1_STEPCOST")) : 8.0;
+        if (n_groups <= K1_TABLE_G && step_cost > 0.0 && uni_want >= 1) {
+            // One round of workgroups: the uniform part's count of ray ranges is the one, near the proportional share, whose slowest
+            // range -- steps included -- balances best against the slowest listed group with what is left (weighted 1.5: its
+            // gathers miss the L2 on large maps).  Measured against the proportional shares, two runs each, us per launch with
+            // events: 16 384 candidates 26.8 -> 25.7, 8192: 25.1 -> 23.3, sigma_theta 20 degrees 31.9 -> 30.4, 4096^2 map with
+            // 16 384 / 32 768 candidates 46.6 -> 40.5 / 51.6 -> 50.8, 1024^2 23.9 -> 23.7; 360-ray scans lose 0.9 and 32 768
+            // candidates 0.7.  The landscape is rough (one ray range more or less moves a launch by up to 4 us), the rule is a
+            // compromise over these sizes.
+            const double list_total = total - (double)(hi - lo) * ref;
+            const int nl = lo + (n_groups - hi), min_legal = k1_legal_chunks(cs, 1);   // (a listed group gets a legal count too)
+            int best_nc = -1; double best_t = 0.0;
+            for (int nc = std::max(1, (int)(0.6 * uni_want)); nc <= (int)(1.6 * uni_want) + 1; nc++) {
+                const long long left = (long long)target_wgs - (long long)(hi - lo) * nc;
+                if (nl > 0 ? left < (long long)nl * std::max(2, min_legal) : left < 0) break;
+                const double tu = k1_chunks_score(cs, nc, step_cost) * (ref / (double)R);
+                if (tu < 0.0) continue;
+                double tt = 0.0;
+                if (nl > 0) {
+                    // what the listed groups get out of `left` workgroups: their proportional shares, none below the smallest legal
+                    // count, the largest trimmed until the sum fits -- and the slowest of them
+                    std::vector<int> share; std::vector<double> lc;
+                    long long sum = 0;
+                    for (int g = 0; g < n_groups; g++) if (g < lo || g >= hi) {
+                        const int v = std::max(min_legal, (int)floor(cost[(size_t)g] * (double)left / list_total + 0.5));
+                        share.push_back(v); lc.push_back(cost[(size_t)g]); sum += v;
+                    }
+                    for (int guard = 0; sum > left && guard < 4096; guard++) {
+                        size_t im = 0;
+                        for (size_t i = 1; i < share.size(); i++) if (share[i] > share[im]) im = i;
+                        if (share[im] <= min_legal) break;
+                        share[im]--; sum--;
+                    }
+                    static const double tail_w = getenv("SLAMHIP_K1_TAILW") ? atof(getenv("SLAMHIP_K1_TAILW")) : 1.5;
+                    for (size_t i = 0; i < share.size(); i++) tt = std::max(tt, tail_w * lc[i] / (double)share[i] + step_cost);
+                }
+                const double tm = std::max(tu, tt);
+                if (best_nc < 0 || tm < best_t) { best_nc = nc; best_t = tm; }
+            }
+            if (best_nc > 0) {
+                uni_want = best_nc;
+                if (list_total > 0.0) per_cost = (double)(target_wgs - (long long)(hi - lo) * best_nc) / list_total;
+            }
+        }
         const int n_list = lo + (n_groups - hi);
         for (int p = 0; p < 2 * std::max(lo, n_groups - hi); p++) {    // dispatch order: theta extremes first
             const int k = p >> 1, g = (p & 1) ? n_groups - 1 - k : k;
@@ -1123,6 +1189,17 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
             if (nrc < 1) break;
             tot -= cs->k1_tab_nc[im] - nrc * nbp;
             cs->k1_tab_nc[im] = nrc * nbp;
+        }
+    }
+    if (n_groups <= K1_TABLE_G) {
+        // still more than one round (the listed groups' legal counts are sparse: trimming them stopped short): the uniform part
+        // gives way, one legal count at a time
+        for (int guard = 0; tot > target_wgs && cs->k1_uni_nc > 1 && guard < 4096; guard++) {
+            int nc = cs->k1_uni_nc - 1;
+            while (nc >= 1 && !k1_chunks_legal(cs, nc)) nc--;
+            if (nc < 1) break;
+            tot -= (long long)cs->k1_uni_ng * (cs->k1_uni_nc - nc);
+            cs->k1_uni_nc = nc;
         }
     }
     long long tab = 0;
@@ -1199,8 +1276,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         }
         static const int dump = env_int("SLAMHIP_K1_DUMP", 0);
         if (dump) {                                                // debugging aid: the launch layout and its cost estimates
-            fprintf(stderr, "[slamhip] K1 layout: %d groups, %zu listed, uniform [%d, %d) x %d chunks\n", n_groups, cs->k1_tab_group.size(),
-                    cs->k1_uni_g0, cs->k1_uni_g0 + cs->k1_uni_ng, cs->k1_uni_nc);
+            fprintf(stderr, "[slamhip] K1 layout: %d groups, %zu listed, uniform [%d, %d) x %d chunks (slowest range %.0f ray units with 8 per step; %d ray blocks)\n", n_groups, cs->k1_tab_group.size(),
+                    cs->k1_uni_g0, cs->k1_uni_g0 + cs->k1_uni_ng, cs->k1_uni_nc, k1_chunks_score(cs, cs->k1_uni_nc, 8.0), cs->n_rb);
             for (size_t i = 0; i < cs->k1_tab_group.size(); i++) {
                 const int g = cs->k1_tab_group[i];
                 fprintf(stderr, "   group %3d: chunks %3d, dtheta %.4f rad, spread %.1f px, cost %.0f ray units\n", g, cs->k1_tab_nc[i],
