@@ -369,7 +369,6 @@ k1_search_tiled(const k1_args a)
     __shared__ int2 pieces[K1_MAXP];                     // (first ray, rays), chunk-relative
     __shared__ __attribute__((aligned(16))) float wred[NW][8];
     __shared__ __attribute__((aligned(16))) float bnd[8];
-    __shared__ __attribute__((aligned(16))) int boxes[K1_MAXP][4];
     __shared__ unsigned long long wkey[NW];
     __shared__ unsigned wfin[NW];
     __shared__ int s_nsteps;
@@ -492,13 +491,13 @@ k1_search_tiled(const k1_args a)
             const float cl = __cosf(rl) * as, ch = __cosf(rh) * as, sl = __sinf(rl) * as, sh = __sinf(rh) * as;
             float clo = fminf(cl, ch) - pad, chi = fmaxf(cl, ch) + pad, slo = fminf(sl, sh) - pad, shi = fmaxf(sl, sh) + pad;
             const bool all = !(rh - rl < 6.2f);
-#pragma unroll
-            for (int k = -2; k <= 8; k++) {                        // multiples of pi/2 in [rl, rh] (rh < rl + 2 pi <= 3 pi)
-                const float ang = 1.57079632679f * (float)k;
-                if (all || (ang >= rl - 1.0e-3f && ang <= rh + 1.0e-3f)) {
-                    const int m = k & 3;
-                    if (m == 0) chi = as + pad; else if (m == 1) shi = as + pad; else if (m == 2) clo = -as - pad; else slo = -as - pad;
-                }
+            {   // multiples k of pi/2 in [rl - 1e-3, rh + 1e-3]: k_lo .. k_hi; residue m is among them iff (m - k_lo) mod 4 <= k_hi - k_lo
+                // (this wave's arithmetic is on the critical path of the workgroup: a loop over the eleven possible k was 0.3 us)
+                const int k_lo = (int)ceilf((rl - 1.0e-3f) * 0.636619772f), span = (int)floorf((rh + 1.0e-3f) * 0.636619772f) - k_lo;
+                if (all || ((0 - k_lo) & 3) <= span) chi = as + pad;
+                if (all || ((1 - k_lo) & 3) <= span) shi = as + pad;
+                if (all || ((2 - k_lo) & 3) <= span) clo = -as - pad;
+                if (all || ((3 - k_lo) & 3) <= span) slo = -as - pad;
             }
             const float4 qlo = make_float4(pxl, pyl, 0.f, 0.f), qhi = make_float4(pxh, pyh, 0.f, 0.f);
             if (lane == 0) {
@@ -544,19 +543,17 @@ k1_search_tiled(const k1_args a)
         const float2 pt = cpts[pi.x + (lane < pi.y ? lane : pi.y - 1)];
         const float4 b0 = *(const float4 *)&bnd[0], b1 = *(const float4 *)&bnd[4];
         const float bb8[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
-        int x0, y0, x1, y1;
-        k1_ray_box(bb8, pt, x0, y0, x1, y1);
-        x0 = k1_wave_red<false>(x0); y0 = k1_wave_red<false>(y0);
-        x1 = k1_wave_red<true>(x1);  y1 = k1_wave_red<true>(y1);
-        if (lane == 63) *(int4 *)&boxes[p][0] = make_int4(x0, y0, x1, y1);
-    }
-    __syncthreads();
-    K1_STAMP(4)
-    if (t < npieces * K1_MAXBANDS) {
-        // one thread per (piece, band); the threads of a piece take the same decision.  Steps are appended in
-        // arrival order: any order gives the same integer sums.
-        const int pc = t >> 2, band = t & 3;                       // (K1_MAXBANDS == 4)
-        const int4 bx = *(const int4 *)&boxes[pc][0];
+        int bx0, by0, bx1, by1;
+        k1_ray_box(bb8, pt, bx0, by0, bx1, by1);
+        bx0 = k1_wave_red<false>(bx0); by0 = k1_wave_red<false>(by0);
+        bx1 = k1_wave_red<true>(bx1);  by1 = k1_wave_red<true>(by1);
+        K1_STAMP(4)
+        if (lane < 64 - K1_MAXBANDS) continue;
+        // The last K1_MAXBANDS lanes of the wave (row 3 holds the reduced box) make the piece's steps, one lane per band; the lanes of
+        // a piece take the same decision.  Steps are appended in arrival order: any order gives the same integer sums.  (The boxes
+        // used to go through the LDS and a barrier to one thread per (piece, band).)
+        const int pc = p, band = lane - (64 - K1_MAXBANDS);
+        const int4 bx = make_int4(bx0, by0, bx1, by1);
         const int prec = pieces[pc].x | (pieces[pc].y << 16);
         // the box clipped to the map, cut into row bands that fit the tile budget (one band, not clipped: SHARED)
         const int cx0 = max(bx.x, 0), cy0 = max(bx.y, 0), cx1 = min(bx.z, S - 1), cy1 = min(bx.w, S - 1);
