@@ -74,29 +74,32 @@ __global__ void k_generate_offsets(float *__restrict__ offs_flat, int n, float s
 // GEN: the whole device-generated list is evaluated (first = 0, count = n + 1), so the jitters are produced here, in
 // evaluation order, and stored to the flat list as well: one launch instead of two per scan.
 template <bool GEN>
-__global__ void __launch_bounds__(K1_GROUP)
+__global__ void __launch_bounds__(1024)
 k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first, int count, int zero_pos,
-                 float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds,
+                 float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds, int grp,
                  int gen_n, float gen_sxy, float gen_sth, uint64_t gen_seed, uint64_t gen_stream)
 {
-    __shared__ float red[K1_GROUP / 64][6];
-    const int j = blockIdx.x * K1_GROUP + threadIdx.x;
+    __shared__ float red[16][6];
     float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    if (j < count) {
-        int flat = ev_idx_in ? ev_idx_in[j] : first + j;
-        if (!ev_idx_in && zero_pos >= 0) flat = j < zero_pos ? j + 1 : j == zero_pos ? 0 : j;
-        float ox = 0.f, oy = 0.f, ot = 0.f;
-        if (flat > 0) {
-            if (GEN) {
-                float o[3];
-                k_jitter(flat - 1, gen_n, gen_sxy, gen_sth, gen_seed, gen_stream, o);
-                ox = o[0]; oy = o[1]; ot = o[2];
-                offs_flat[3 * (size_t)(flat - 1)] = ox; offs_flat[3 * (size_t)(flat - 1) + 1] = oy; offs_flat[3 * (size_t)(flat - 1) + 2] = ot;
-            } else { ox = offs_flat[3 * (size_t)(flat - 1)]; oy = offs_flat[3 * (size_t)(flat - 1) + 1]; ot = offs_flat[3 * (size_t)(flat - 1) + 2]; }
+    for (int jj = threadIdx.x; jj < grp; jj += 1024) {            // (grp = 1024 or 2048 candidates per group)
+        const int j = blockIdx.x * grp + jj;
+        if (j < count) {
+            int flat = ev_idx_in ? ev_idx_in[j] : first + j;
+            if (!ev_idx_in && zero_pos >= 0) flat = j < zero_pos ? j + 1 : j == zero_pos ? 0 : j;
+            float ox = 0.f, oy = 0.f, ot = 0.f;
+            if (flat > 0) {
+                if (GEN) {
+                    float o[3];
+                    k_jitter(flat - 1, gen_n, gen_sxy, gen_sth, gen_seed, gen_stream, o);
+                    ox = o[0]; oy = o[1]; ot = o[2];
+                    offs_flat[3 * (size_t)(flat - 1)] = ox; offs_flat[3 * (size_t)(flat - 1) + 1] = oy; offs_flat[3 * (size_t)(flat - 1) + 2] = ot;
+                } else { ox = offs_flat[3 * (size_t)(flat - 1)]; oy = offs_flat[3 * (size_t)(flat - 1) + 1]; ot = offs_flat[3 * (size_t)(flat - 1) + 2]; }
+            }
+            ev_off[3 * (size_t)j] = ox; ev_off[3 * (size_t)j + 1] = oy; ev_off[3 * (size_t)j + 2] = ot;
+            if (ev_idx_out) ev_idx_out[j] = flat;
+            lo[0] = fminf(lo[0], ox); hi[0] = fmaxf(hi[0], ox); lo[1] = fminf(lo[1], oy); hi[1] = fmaxf(hi[1], oy);
+            lo[2] = fminf(lo[2], ot); hi[2] = fmaxf(hi[2], ot);
         }
-        ev_off[3 * (size_t)j] = ox; ev_off[3 * (size_t)j + 1] = oy; ev_off[3 * (size_t)j + 2] = ot;
-        if (ev_idx_out) ev_idx_out[j] = flat;
-        lo[0] = hi[0] = ox; lo[1] = hi[1] = oy; lo[2] = hi[2] = ot;
     }
     for (int m = 1; m < 64; m <<= 1)
         for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], m)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m)); }
@@ -105,7 +108,7 @@ k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_i
     __syncthreads();
     if (threadIdx.x < 6) {
         float v = red[0][threadIdx.x];
-        for (int w = 1; w < K1_GROUP / 64; w++) v = (threadIdx.x & 1) ? fmaxf(v, red[w][threadIdx.x]) : fminf(v, red[w][threadIdx.x]);
+        for (int w = 1; w < 16; w++) v = (threadIdx.x & 1) ? fmaxf(v, red[w][threadIdx.x]) : fminf(v, red[w][threadIdx.x]);
         grp_bounds[8 * (size_t)blockIdx.x + threadIdx.x] = v;          // (NaN jitters never reach the tiled kernel: sanity flags)
     }
 }
@@ -554,7 +557,14 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
 {
     if (cs->shard_first == first && cs->shard_count == count) return SLAMHIP_OK;
     slamhip_ctx *ctx = cs->ctx;
-    const int ng = sh_div_up(count, K1_GROUP);
+    // Candidates per group: 1024 (512 lanes x 2); from 98 304 candidates on 2048 (512 lanes x 4) -- a tile then serves twice
+    // the candidates, and the theta tails, whose groups widen, are a negligible part of the launch (measured, 1024 -> 2048, us per
+    // launch: 1 M candidates 489 -> 395, 524 288: 267 -> 233, 262 144: 152 -> 138, 131 072: 89 -> 75, 98 304: 73 -> 67, but
+    // 65 536: 50 -> 54 and 16 384: 25 -> 48).
+    static const int grp_env = getenv("SLAMHIP_K1_GROUP") ? atoi(getenv("SLAMHIP_K1_GROUP")) : 0;
+    const int grp = grp_env == K1_GROUP || grp_env == K1_GROUP_BIG ? grp_env : count >= 98304 ? K1_GROUP_BIG : K1_GROUP;
+    cs->k1_group = grp;
+    const int ng = sh_div_up(count, grp);
     cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);
     cs->k1_layout_dirty = true;
     if (cs->offs_on_device_sorted) {
@@ -563,18 +573,18 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         const int zero_pos = first == 0 ? (count - 1 < n / 2 ? count - 1 : n / 2) : -1;
         if (cs->gen_pending && first == 0 && count == n + 1) {
             cs->gen_pending = false;
-            hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
-                               cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds,
+            hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng), dim3(1024), 0, ctx->stream,
+                               cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
                                n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream);
         } else {
             SH_TRY(flush_generate(cs));
-            hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
-                               cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds,
+            hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(1024), 0, ctx->stream,
+                               cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
                                0, 0.f, 0.f, (uint64_t)0, (uint64_t)0);
         }
         // the jitters are the strata of N(0, sigma): group ranges from the quantile function (layout balance only)
         for (int g = 0; g < ng; g++) {
-            const int k0 = first + g * K1_GROUP, k1 = (first + count < k0 + K1_GROUP ? first + count : k0 + K1_GROUP) - 1;
+            const int k0 = first + g * grp, k1 = (first + count < k0 + grp ? first + count : k0 + grp) - 1;
             const double q0 = fmin(fmax((k0 - 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
             const double q1 = fmin(fmax((k1 + 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
             cs->h_grp_dth[(size_t)g] = (float)(fabs(cs->gen_sigma_theta) * (host_normcdfinv(q1) - host_normcdfinv(q0)));
@@ -591,7 +601,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         });
         for (int g = 0; g < ng; g++) {
             float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
-            for (int j = g * K1_GROUP; j < count && j < (g + 1) * K1_GROUP; j++) {
+            for (int j = g * grp; j < count && j < (g + 1) * grp; j++) {
                 const int flat = perm[(size_t)j];
                 for (int k = 0; k < 3; k++) {
                     const float v = flat > 0 ? o[3 * (size_t)(flat - 1) + k] : 0.0f;
@@ -602,8 +612,8 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             cs->h_grp_dxy[(size_t)g] = fmaxf(hi[0] - lo[0], hi[1] - lo[1]) * cs->hscale;
         }
         SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(K1_GROUP), 0, ctx->stream,
-                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds,
+        hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(1024), 0, ctx->stream,
+                           cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds, grp,
                            0, 0.f, 0.f, (uint64_t)0, (uint64_t)0);
         SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
     }

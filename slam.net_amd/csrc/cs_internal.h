@@ -8,7 +8,8 @@
 // (1024 candidates) x (a chunk of ray blocks) and stages one HoleMap tile in LDS per ray block.
 #define CS_RB_MAX 64
 #define CS_RB_EXTENT_PX 128.0f         // upper limit; set_scan lowers it at fine map scales (coreslam.hip)
-#define K1_GROUP 1024                  // theta-consecutive candidates per K1 workgroup ("group"): 256 lanes x 4
+#define K1_GROUP 1024                  // theta-consecutive candidates per K1 workgroup ("group"): 512 lanes x 2 ...
+#define K1_GROUP_BIG 2048              // ... or 512 lanes x 4 for large searches (slamhip_cs::k1_group, ensure_shard)
 
 
 struct slamhip_cs {
@@ -47,7 +48,8 @@ struct slamhip_cs {
     void *d_partial; size_t cap_partial;       // K1 partial rows (bytes)
     unsigned long long *d_k1_gmin;              // K1: [0] running minimum of the finished candidates' keys (all ones between launches), [1] their count (zero)
     unsigned long long *d_k1_acc;               // K1: per-candidate accumulators [groups][K1_GROUP] (zero between launches)
-    int k1_cap_groups;
+    int k1_cap_groups;                          // (in units of K1_GROUP candidates)
+    int k1_group;                               // candidates per group of the materialised evaluation list (its jitter bounds are per group)
     // K1 launch layout: per group of 1024 evaluation-order candidates the theta range (rad) and translation spread
     // (pixels) -- from the offsets (ensure_shard) -- and the chunks per group derived from them and the scan
     std::vector<float> h_grp_dth, h_grp_dxy;

@@ -356,11 +356,11 @@ template <bool MAX> __device__ static inline float k1_wave_redf(float x)      //
 
 typedef unsigned int k1_u32x4 __attribute__((ext_vector_type(4)));   // a staging register quad (native vector: stays in VGPRs)
 
-template <int MODE, bool VERIFY, int CPL>
-__global__ void __launch_bounds__(K1_GROUP / CPL, K1_GROUP / CPL / 64 / 2)      // two workgroups per CU
+template <int MODE, bool VERIFY, int CPL, int GROUP>
+__global__ void __launch_bounds__(GROUP / CPL, GROUP / CPL / 64 / 2)          // two workgroups per CU
 k1_search_tiled(const k1_args a)
 {
-    constexpr int LANES = K1_GROUP / CPL, NW = LANES / 64, PF = 4 * CPL;      // PF staging vectors per lane: 64 KB per pass
+    constexpr int LANES = GROUP / CPL, NW = LANES / 64, PF = 65536 / (LANES * 16);      // PF staging vectors per lane: 64 KB per pass
     constexpr int RU = (K1_MAXR + LANES - 1) / LANES;                          // ray slots per lane in the prologue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte address
@@ -445,7 +445,7 @@ k1_search_tiled(const k1_args a)
     float c3[CPL][3];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
-        const int j = g * K1_GROUP + k * LANES + t;
+        const int j = g * GROUP + k * LANES + t;
         const int jc = j < count ? j : count - 1;
         if (MODE == 0) q[k] = a.pxcs[jc];
         else { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
@@ -884,7 +884,7 @@ k1_search_tiled(const k1_args a)
     // accumulators back and the last group walk the group minima: five dependent round trips after the slowest workgroup's last
     // gather; now three.)  No fences, no spinning; accumulators, minimum (all ones) and counter (zero) are at rest between launches.
     typedef unsigned long long u64;
-    u64 *acc = a.acc + (size_t)g * K1_GROUP + (size_t)t * CPL;                 // (the candidates of a lane are adjacent)
+    u64 *acc = a.acc + (size_t)g * GROUP + (size_t)t * CPL;                 // (the candidates of a lane are adjacent)
     u64 tot[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
@@ -897,7 +897,7 @@ k1_search_tiled(const k1_args a)
     for (int k = 0; k < CPL; k++) {
         if ((unsigned)(tot[k] >> K1_ACC_ARRIVED) == (unsigned)nc) {
             __hip_atomic_store(acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int j = g * K1_GROUP + k * LANES + t;
+            const int j = g * GROUP + k * LANES + t;
             if (j < count) {
                 const u64 kk = k1_finish(tot[k] & ((1ull << K1_ACC_INMAP) - 1), (uint32_t)(tot[k] >> K1_ACC_INMAP) & ((1u << (K1_ACC_ARRIVED - K1_ACC_INMAP)) - 1u),
                                          a.n_rays, a.ev_idx ? a.ev_idx[j] : j, a.dist_out);
@@ -1231,7 +1231,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     const float bx = pose ? pose[0] : 0.f, by = pose ? pose[1] : 0.f, bth = pose ? pose[2] : 0.f;
 
     if (tiled) {
-        const int n_groups = sh_div_up(count, K1_GROUP);
+        const int group = mode == 1 && cs->k1_group == K1_GROUP_BIG ? K1_GROUP_BIG : K1_GROUP;   // (explicit lists: always 1024)
+        const int n_groups = sh_div_up(count, group);
         int budget = tile_kb * 1024;
         if (budget > 64 * 1024) budget = 64 * 1024;                // what the staging registers hold per pass
         const size_t lds = (size_t)K1_TILE_OFS + (size_t)budget;
@@ -1299,10 +1300,10 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         // candidates per lane: 2 (512 lanes, 8 waves) measured best or equal from 16k to 256k candidates on MI355X;
         // 1 (16 waves: slow start) and 4 (4 waves: the VALU starves at 2 waves / SIMD) stay selectable for experiments
         const int cpl = cpl_env == 1 || cpl_env == 4 ? cpl_env : 2;
-        if (n_groups > cs->k1_cap_groups) {
+        if (sh_div_up(count, K1_GROUP) + 2 > cs->k1_cap_groups) {
             if (cs->d_k1_acc) (void)hipFree(cs->d_k1_acc);
             cs->d_k1_acc = nullptr; cs->k1_cap_groups = 0;
-            const int cap = n_groups + n_groups / 4 + 16;
+            const int cap = sh_div_up(count, K1_GROUP) + sh_div_up(count, K1_GROUP) / 4 + 16;
             SH_HIP(hipMalloc(&cs->d_k1_acc, sizeof(unsigned long long) * (size_t)cap * K1_GROUP));
             SH_HIP(hipMemsetAsync(cs->d_k1_acc, 0, sizeof(unsigned long long) * (size_t)cap * K1_GROUP, ctx->stream));
             cs->k1_cap_groups = cap;
@@ -1317,8 +1318,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.gmin = cs->d_k1_gmin; a.done = (unsigned *)((char *)cs->d_k1_gmin + 8); a.acc = cs->d_k1_acc;
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
-#define K1_LAUNCH(M, V, C) hipLaunchKernelGGL((k1_search_tiled<M, V, C>), dim3(n_wgs), dim3(K1_GROUP / C), lds, ctx->stream, a)
-#define K1_LAUNCH_C(M, V) { if (cpl == 4) K1_LAUNCH(M, V, 4); else if (cpl == 2) K1_LAUNCH(M, V, 2); else K1_LAUNCH(M, V, 1); }
+#define K1_LAUNCH(M, V, C, G) hipLaunchKernelGGL((k1_search_tiled<M, V, C, G>), dim3(n_wgs), dim3(G / C), lds, ctx->stream, a)
+#define K1_LAUNCH_C(M, V) { if (group == K1_GROUP_BIG) K1_LAUNCH(M, V, 4, K1_GROUP_BIG); else if (cpl == 4) K1_LAUNCH(M, V, 4, K1_GROUP); else if (cpl == 2) K1_LAUNCH(M, V, 2, K1_GROUP); else K1_LAUNCH(M, V, 1, K1_GROUP); }
             if (verify) { if (mode == 0) K1_LAUNCH_C(0, true) else if (mode == 1) K1_LAUNCH_C(1, true) else K1_LAUNCH_C(2, true) }
             else        { if (mode == 0) K1_LAUNCH_C(0, false) else if (mode == 1) K1_LAUNCH_C(1, false) else K1_LAUNCH_C(2, false) }
 #undef K1_LAUNCH_C
@@ -1351,7 +1352,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                     double skew = 0, mx = 0;
                     for (int i = 0; i < nw; i++) {
                         unsigned long long lo = ~0ull, hi = 0;
-                        for (int w = 0; w < K1_GROUP / cpl / 64; w++) { lo = std::min(lo, ws[i * 16 + w]); hi = std::max(hi, ws[i * 16 + w]); }
+                        for (int w = 0; w < (group == K1_GROUP_BIG ? 8 : K1_GROUP / cpl / 64); w++) { lo = std::min(lo, ws[i * 16 + w]); hi = std::max(hi, ws[i * 16 + w]); }
                         skew += (double)(hi - lo) * 0.01; mx = std::max(mx, (double)(hi - lo) * 0.01);
                     }
                     fprintf(stderr, "[k1 times] wave start skew inside a workgroup: mean %.2f us, max %.2f us\n", skew / nw, mx);
