@@ -250,7 +250,7 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
 
     def time_search(d, pose, count, steps):
         key = torch.full((1,), -1, dtype=torch.int64, device="cuda")
-        for _ in range(3):
+        for _ in range(6):
             d.search_shard_async(pose, 0, count, key.data_ptr())
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -263,7 +263,7 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
 
     out = {}
     sweep = {}
-    for K, steps in ((65536, 100), (262144, 40), (1048576, 12)):
+    for K, steps in ((65536, 100), (262144, 50), (1048576, 25)):
         dev.set_offsets(sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=42))
         sweep[str(K)] = time_search(dev, base, K, steps)
     out["search_candidates_per_step_sweep_%d_map" % a.size] = sweep

@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python3 $root/bench.py --steps 100 --warmup 20 --no-cpu-baseline"
+cmd="python3 $root/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- $cmd > $out/stats_bench.json 2> $out/stats.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $cmd > $out/fetch_bench.json 2> $out/fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- $cmd > $out/write_bench.json 2> $out/write.log
