@@ -299,7 +299,8 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     // 64-pixel granularity so that a ray block's end points stay close together in the map (the rigid
     // candidate transform preserves distances), then cut the sorted list into blocks of <= CS_RB_MAX.
     bool sane = true;
-    std::vector<uint64_t> keys((size_t)n);
+    std::vector<uint64_t> &keys = cs->h_sort_keys;                 // (kept between scans: no allocation per scan)
+    keys.resize((size_t)n);
     const float cell = 64.0f / cs->hscale;          // metres per 64 px
     for (int i = 0; i < n; i++) {
         const float X = xy[2 * i], Y = xy[2 * i + 1];
@@ -311,13 +312,15 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     }
     {   // LSD radix sort on the 32-bit Morton code (3 stable passes of 11 bits; ties keep ray order): std::sort was
         // most of this function's time at ~1000 rays
-        std::vector<uint64_t> tmp((size_t)n);
+        std::vector<uint64_t> &tmp = cs->h_sort_tmp;
+        tmp.resize((size_t)n);
         uint64_t *src = keys.data(), *dst = tmp.data();
         for (int pass = 0; pass < 3; pass++) {
             const int shift = 32 + 11 * pass;
             unsigned cnt[2048];
             memset(cnt, 0, sizeof(cnt));
             for (int i = 0; i < n; i++) cnt[(src[i] >> shift) & 2047u]++;
+            if (cnt[(src[0] >> shift) & 2047u] == (unsigned)n) continue;      // every key in one bin (a scan spans few 64-pixel cells: the high digits are equal)
             unsigned sum = 0;
             for (int k = 0; k < 2048; k++) { const unsigned c = cnt[k]; cnt[k] = sum; sum += c; }
             for (int i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
