@@ -15,6 +15,7 @@ Launch:  python bench.py [--gpus N --steps K --warmup W]
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -162,6 +163,10 @@ def main():
     if world > 1:
         dist.barrier()
     sync_all()
+    # (the interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a full collection is a
+    # pause of tens of milliseconds -- it once landed in a loop of 100 blocking calls and read as 440 us per call instead of 70)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     if world == 1 and not a.no_kernel_timing:
         with torch.cuda.stream(ext):
@@ -176,6 +181,7 @@ def main():
         dist.barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     k1_ms, k1_n = (0.0, 0)
     if not a.no_kernel_timing:
         if world == 1:
@@ -225,6 +231,7 @@ def main():
                 out["other_workloads"] = other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval)
             except Exception as e:                                 # noqa: BLE001 -- extras must never cost the headline line
                 out["other_workloads"] = {"error": repr(e)}
+            gc.enable()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs, final_key)
         print(json.dumps(out))
@@ -263,6 +270,8 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
 
     out = {}
     sweep = {}
+    gc.collect()
+    gc.disable()                   # (re-enabled before returning; see main)
     for K, steps in ((65536, 100), (262144, 50), (1048576, 25)):
         dev.set_offsets(sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=42))
         sweep[str(K)] = time_search(dev, base, K, steps)
@@ -330,6 +339,7 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
                                                     "batched_matches_per_s_incl_transfers": B / dtb}
     # the headline list is restored for the CPU baseline's parity spot-check
     dev.set_offsets(sim.gaussian_offsets(a.cands - 1, 0.1, math.radians(10.0), seed=42))
+    gc.enable()
     return out
 
 
