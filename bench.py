@@ -154,10 +154,12 @@ def main():
     for _ in range(max(a.warmup, 1)):
         step()
     sync_all()
-    # K1's average launch duration for the roofline figure.  A step is exactly one K1 launch, so at N = 1 two HIP
-    # events on the operator's stream around the timed region give it without touching the region (per-launch event
-    # pairs cost ~8 us per step on this stack and would depress `value`).  At N > 1 the stream also carries the
-    # all-reduce, so K1 is timed per launch in a short pass AFTER the timed region instead.
+    # K1's average launch duration for the roofline figure.  A step is exactly one K1 launch, so two HIP events on the
+    # operator's stream around the timed region give it without touching the region (per-launch event pairs cost ~8 us per
+    # step on this stack and would depress `value`) -- at N = 1, and at N > 1 when the library issues the collective on its
+    # own stream (the operator's stream then carries K1 launches only).  With the torch.distributed path the stream also
+    # carries the all-reduce, so K1 is timed per launch in a short pass AFTER the timed region instead.
+    two_events = (world == 1 or comm is not None) and not a.no_kernel_timing
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     if world > 1:
@@ -168,12 +170,12 @@ def main():
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
-    if world == 1 and not a.no_kernel_timing:
+    if two_events:
         with torch.cuda.stream(ext):
             ev0.record()
     for _ in range(a.steps):
         step()
-    if world == 1 and not a.no_kernel_timing:
+    if two_events:
         with torch.cuda.stream(ext):
             ev1.record()
     sync_all()
@@ -184,7 +186,7 @@ def main():
     gc.enable()
     k1_ms, k1_n = (0.0, 0)
     if not a.no_kernel_timing:
-        if world == 1:
+        if two_events:
             k1_ms, k1_n = ev0.elapsed_time(ev1), a.steps
         else:
             ctx.timing_reset()

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <vector>
+#include <string>
 
 struct rccl_api {
     void *lib;
@@ -27,9 +28,28 @@ struct rccl_api {
 
 static int32_t load_rccl(rccl_api *api)
 {
-    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    // The librccl that belongs to the HIP runtime this library is bound to -- the one in the same directory -- first.  A process
+    // may hold two installations (PyTorch wheels bring their own libamdhip64 / libhsa-runtime64 / librccl, and whichever of
+    // libslamhip and torch is loaded first decides which HIP runtime both run on): a librccl from the other installation opens
+    // its own, uninitialised HSA runtime and fails in ncclCommInitRank ("no ROCm-capable device is detected"; seen when a test
+    // loaded libslamhip before it imported torch).
     api->lib = nullptr;
-    for (const char *nm : names) { api->lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (api->lib) break; }
+    {
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char *nm : { "librccl.so.1", "librccl.so" }) {
+                    api->lib = dlopen((dir + nm).c_str(), RTLD_NOW | RTLD_LOCAL);
+                    if (api->lib) break;
+                }
+            }
+        }
+    }
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char *nm : names) { if (api->lib) break; api->lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); }
     if (!api->lib) SH_FAIL(SLAMHIP_ERR_RCCL, "cannot load librccl: %s", dlerror());
 #define SH_SYM(field, name) do { *(void **)(&api->field) = dlsym(api->lib, name); \
         if (!api->field) SH_FAIL(SLAMHIP_ERR_RCCL, "librccl lacks %s", name); } while (0)
