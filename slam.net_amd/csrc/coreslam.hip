@@ -560,12 +560,15 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
 {
     if (cs->shard_first == first && cs->shard_count == count) return SLAMHIP_OK;
     slamhip_ctx *ctx = cs->ctx;
-    // Candidates per group: 1024 (512 lanes x 2); from 98 304 candidates on 2048 (512 lanes x 4) -- a tile then serves twice
-    // the candidates, and the theta tails, whose groups widen, are a negligible part of the launch (measured, 1024 -> 2048, us per
-    // launch: 1 M candidates 489 -> 395, 524 288: 267 -> 233, 262 144: 152 -> 138, 131 072: 89 -> 75, 98 304: 73 -> 67, but
-    // 65 536: 50 -> 54 and 16 384: 25 -> 48).
+    // Candidates per group -- the candidates that share a tile: 1024 (512 lanes x 2); 2048 (512 lanes x 4) from 98 304 candidates
+    // on -- a tile then serves twice the candidates, and the theta tails, whose groups widen, are a negligible part of the launch
+    // (measured, 1024 -> 2048, us per launch: 1 M candidates 489 -> 395, 524 288: 267 -> 233, 262 144: 152 -> 138, 131 072: 89 ->
+    // 75, 98 304: 73 -> 67, but 65 536: 50 -> 54 and 16 384: 25 -> 48); 512 (512 lanes x 1) up to 8192 candidates -- the groups'
+    // theta ranges halve, which is worth more there than the tiles' reuse (1024 -> 512: 4096 candidates 22.7 -> 18.8, the
+    // simulator's 4000 candidates on a 256^2 map with 400 rays 14.6 -> 13.3, 8192: 23.1 -> 22.5, but 16 384: 25.4 -> 26.1).
     static const int grp_env = getenv("SLAMHIP_K1_GROUP") ? atoi(getenv("SLAMHIP_K1_GROUP")) : 0;
-    const int grp = grp_env == K1_GROUP || grp_env == K1_GROUP_BIG ? grp_env : count >= 98304 ? K1_GROUP_BIG : K1_GROUP;
+    const int grp = grp_env == K1_GROUP || grp_env == K1_GROUP_BIG || grp_env == K1_GROUP_SMALL ? grp_env
+                    : count >= 98304 ? K1_GROUP_BIG : count <= 8192 ? K1_GROUP_SMALL : K1_GROUP;
     cs->k1_group = grp;
     const int ng = sh_div_up(count, grp);
     cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);

@@ -9,7 +9,8 @@
 #define CS_RB_MAX 64
 #define CS_RB_EXTENT_PX 128.0f         // upper limit; set_scan lowers it at fine map scales (coreslam.hip)
 #define K1_GROUP 1024                  // theta-consecutive candidates per K1 workgroup ("group"): 512 lanes x 2 ...
-#define K1_GROUP_BIG 2048              // ... or 512 lanes x 4 for large searches (slamhip_cs::k1_group, ensure_shard)
+#define K1_GROUP_BIG 2048              // ... or 512 lanes x 4 for large searches,
+#define K1_GROUP_SMALL 512             // 512 lanes x 1 for small ones (slamhip_cs::k1_group, ensure_shard)
 
 
 struct slamhip_cs {

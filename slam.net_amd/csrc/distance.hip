@@ -959,8 +959,8 @@ int32_t cs_alloc_candidates(slamhip_cs *cs, int count)
     SH_HIP(hipMalloc(&cs->d_dist, sizeof(int32_t) * (size_t)cap));
     if (cs->d_grp_bounds) (void)hipFree(cs->d_grp_bounds);
     cs->d_grp_bounds = nullptr; cs->cap_grp = 0;
-    SH_HIP(hipMalloc(&cs->d_grp_bounds, sizeof(float) * 8 * (size_t)(cap / K1_GROUP + 2)));
-    cs->cap_grp = cap / K1_GROUP + 2;
+    SH_HIP(hipMalloc(&cs->d_grp_bounds, sizeof(float) * 8 * (size_t)(cap / K1_GROUP_SMALL + 2)));      // (the smallest groups: the most)
+    cs->cap_grp = cap / K1_GROUP_SMALL + 2;
     cs->cap_cand = cap;
     cs->shard_first = -1; cs->shard_count = -1;
     return SLAMHIP_OK;
@@ -1231,7 +1231,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     const float bx = pose ? pose[0] : 0.f, by = pose ? pose[1] : 0.f, bth = pose ? pose[2] : 0.f;
 
     if (tiled) {
-        const int group = mode == 1 && cs->k1_group == K1_GROUP_BIG ? K1_GROUP_BIG : K1_GROUP;   // (explicit lists: always 1024)
+        const int group = mode == 1 && (cs->k1_group == K1_GROUP_BIG || cs->k1_group == K1_GROUP_SMALL) ? cs->k1_group : K1_GROUP;   // (explicit lists: always 1024)
         const int n_groups = sh_div_up(count, group);
         int budget = tile_kb * 1024;
         if (budget > 64 * 1024) budget = 64 * 1024;                // what the staging registers hold per pass
@@ -1319,7 +1319,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
 #define K1_LAUNCH(M, V, C, G) hipLaunchKernelGGL((k1_search_tiled<M, V, C, G>), dim3(n_wgs), dim3(G / C), lds, ctx->stream, a)
-#define K1_LAUNCH_C(M, V) { if (group == K1_GROUP_BIG) K1_LAUNCH(M, V, 4, K1_GROUP_BIG); else if (cpl == 4) K1_LAUNCH(M, V, 4, K1_GROUP); else if (cpl == 2) K1_LAUNCH(M, V, 2, K1_GROUP); else K1_LAUNCH(M, V, 1, K1_GROUP); }
+#define K1_LAUNCH_C(M, V) { if (group == K1_GROUP_BIG) K1_LAUNCH(M, V, 4, K1_GROUP_BIG); else if (group == K1_GROUP_SMALL) K1_LAUNCH(M, V, 1, K1_GROUP_SMALL); else if (cpl == 4) K1_LAUNCH(M, V, 4, K1_GROUP); else if (cpl == 2) K1_LAUNCH(M, V, 2, K1_GROUP); else K1_LAUNCH(M, V, 1, K1_GROUP); }
             if (verify) { if (mode == 0) K1_LAUNCH_C(0, true) else if (mode == 1) K1_LAUNCH_C(1, true) else K1_LAUNCH_C(2, true) }
             else        { if (mode == 0) K1_LAUNCH_C(0, false) else if (mode == 1) K1_LAUNCH_C(1, false) else K1_LAUNCH_C(2, false) }
 #undef K1_LAUNCH_C
@@ -1352,7 +1352,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                     double skew = 0, mx = 0;
                     for (int i = 0; i < nw; i++) {
                         unsigned long long lo = ~0ull, hi = 0;
-                        for (int w = 0; w < (group == K1_GROUP_BIG ? 8 : K1_GROUP / cpl / 64); w++) { lo = std::min(lo, ws[i * 16 + w]); hi = std::max(hi, ws[i * 16 + w]); }
+                        for (int w = 0; w < (group != K1_GROUP ? 8 : K1_GROUP / cpl / 64); w++) { lo = std::min(lo, ws[i * 16 + w]); hi = std::max(hi, ws[i * 16 + w]); }
                         skew += (double)(hi - lo) * 0.01; mx = std::max(mx, (double)(hi - lo) * 0.01);
                     }
                     fprintf(stderr, "[k1 times] wave start skew inside a workgroup: mean %.2f us, max %.2f us\n", skew / nw, mx);

@@ -200,6 +200,8 @@ def test_k1_tile_boxes_selfcheck():
                       {"SLAMHIP_K1_NODEN": "1", "SLAMHIP_K1_VERIFY": "1"},         # tile addresses from the integer coordinates everywhere
                       {"SLAMHIP_K1_GROUP": "2048", "SLAMHIP_K1_VERIFY": "1"},      # groups of 2048 candidates (512 lanes x 4), as large searches use
                       {"SLAMHIP_K1_GROUP": "2048"},
+                      {"SLAMHIP_K1_GROUP": "512", "SLAMHIP_K1_VERIFY": "1"},       # groups of 512 candidates (512 lanes x 1), as small searches use
+                      {"SLAMHIP_K1_GROUP": "512"}, {"SLAMHIP_K1_GROUP": "1024"},
                       {"SLAMHIP_K1_NOBOUNDS": "1", "SLAMHIP_K1_VERIFY": "1"},      # search-mode bounds from the in-kernel reduction
                       {"SLAMHIP_K1_TARGET_WGS": "64", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "64"},
                       {"SLAMHIP_K1_TARGET_WGS": "100000", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "100000", "SLAMHIP_K1_CPL": "1"}):
