@@ -884,19 +884,23 @@ k1_search_tiled(const k1_args a)
     // accumulators back and the last group walk the group minima: five dependent round trips after the slowest workgroup's last
     // gather; now three.)  No fences, no spinning; accumulators, minimum (all ones) and counter (zero) are at rest between launches.
     typedef unsigned long long u64;
-    u64 *acc = a.acc + (size_t)g * GROUP + (size_t)t * CPL;                 // (the candidates of a lane are adjacent)
+    // (slot k of lane t at k * LANES + t: the 64 adds of a wave instruction fall into four consecutive 128-byte lines.  The memory side
+    // performs atomics a line at a time: with a lane's candidates adjacent -- every CPL-th word per instruction, 8 lines at two
+    // candidates per lane, 16 at four -- the adds took twice / four times as long, and spaced 64 bytes apart, one line each, a
+    // 16 384-candidate launch went from 25 to 38 us; measured)
+    u64 *acc = a.acc + (size_t)g * GROUP + (size_t)t;
     u64 tot[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
         const u64 add = (u64)sum[k] | ((u64)((cnt[k] | cnt_all) ? 1u : 0u) << K1_ACC_INMAP) | (1ull << K1_ACC_ARRIVED);
-        tot[k] = __hip_atomic_fetch_add(acc + k, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        tot[k] = __hip_atomic_fetch_add(acc + k * LANES, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
     }
     u64 key = ~0ull;
     unsigned nfin = 0;
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
         if ((unsigned)(tot[k] >> K1_ACC_ARRIVED) == (unsigned)nc) {
-            __hip_atomic_store(acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(acc + k * LANES, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int j = g * GROUP + k * LANES + t;
             if (j < count) {
                 const u64 kk = k1_finish(tot[k] & ((1ull << K1_ACC_INMAP) - 1), (uint32_t)(tot[k] >> K1_ACC_INMAP) & ((1u << (K1_ACC_ARRIVED - K1_ACC_INMAP)) - 1u),
