@@ -560,16 +560,16 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
 {
     if (cs->shard_first == first && cs->shard_count == count) return SLAMHIP_OK;
     slamhip_ctx *ctx = cs->ctx;
-    // Candidates per group -- the candidates that share a tile: 1024 (512 lanes x 2); 2048 (512 lanes x 4) from 49 152 candidates
+    // Candidates per group -- the candidates that share a tile: 1024 (512 lanes x 2); 2048 (512 lanes x 4) from 65 536 candidates
     // on -- a tile then serves twice the candidates, and the theta tails, whose groups widen, are a small part of the launch
     // (measured, 1024 -> 2048, us per launch: 1 M candidates 489 -> 395, 262 144: 152 -> 137, 98 304: 74 -> 64, 81 920: 66 ->
-    // 55, 65 536: 51 -> 51 (4096^2 map: 83 -> 72), 49 152: 45.5 -> 44.6, 32 768: 34.7 -> 34.9; 16 384: 25 -> 33); 512 (512 lanes
+    // 55, 65 536: 51 -> 51 (4096^2 map: 83 -> 72), 49 152: 45.5 -> 44.6 (4096^2: 72 -> 77, 1024^2: 37.1 -> 38.5), 32 768: 34.7 -> 34.9; 16 384: 25 -> 33); 512 (512 lanes
     // x 1) up to 12 288 candidates -- the groups' theta ranges halve, which is worth more there than the tiles' reuse (1024 ->
     // 512: 4096 candidates 22.7 -> 18.8, the simulator's 4000 candidates on a 256^2 map with 400 rays 14.6 -> 13.3, 8192:
     // 23.2 -> 22.8 (1024^2 map: 22.0 -> 19.0), 12 288: 25.7 -> 24.0, but 16 384: 25.3 -> 26.6).
     static const int grp_env = getenv("SLAMHIP_K1_GROUP") ? atoi(getenv("SLAMHIP_K1_GROUP")) : 0;
     const int grp = grp_env == K1_GROUP || grp_env == K1_GROUP_BIG || grp_env == K1_GROUP_SMALL ? grp_env
-                    : count >= 49152 ? K1_GROUP_BIG : count <= 12288 ? K1_GROUP_SMALL : K1_GROUP;
+                    : count >= 65536 ? K1_GROUP_BIG : count <= 12288 ? K1_GROUP_SMALL : K1_GROUP;
     cs->k1_group = grp;
     const int ng = sh_div_up(count, grp);
     cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);
