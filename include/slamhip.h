@@ -299,11 +299,14 @@ int32_t slamhip_comm_unique_id(uint8_t out_id[128]);                            
 int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t id[128], int32_t rank, int32_t n_ranks, slamhip_comm **out);
 int32_t slamhip_comm_destroy(slamhip_comm *comm);
 int32_t slamhip_comm_info(slamhip_comm *comm, int32_t *out_rank, int32_t *out_n_ranks);
-/* One sharded search step (asynchronous): flat candidates [first, first+count) on this rank, then the all-reduce.
- * *d_out_key (optional) = device address where this step's reduced key will be (valid for 64 further steps). */
+/* One sharded search step (asynchronous): flat candidates [first, first+count) on this rank; the keys of up to 16 consecutive
+ * steps are min-all-reduced in one collective (every rank must issue the same steps and call slamhip_comm_wait at the same
+ * places).  *d_out_key (optional) = device address where this step's reduced key will be once the collective of its batch has
+ * run -- after slamhip_comm_wait, or behind a later batch on the communicator's stream -- valid for 64 further steps. */
 int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_comm *comm, const float search_pose[3], int32_t first,
                                           int32_t count, uint64_t **d_out_key);
-/* Wait for every step issued so far; *out_key (optional) = the reduced key of the last one. */
+/* Issues the collective for the steps not yet covered by one, waits for every step issued so far; *out_key (optional) = the
+ * reduced key of the last one.  (A host that needs every scan's winner before the next scan calls it after every step.) */
 int32_t slamhip_comm_wait(slamhip_comm *comm, uint64_t *out_key);
 
 #ifdef __cplusplus

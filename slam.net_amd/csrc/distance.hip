@@ -931,7 +931,10 @@ k1_search_tiled(const k1_args a)
     const u64 best = __hip_atomic_load(a.gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(a.gmin, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *a.key_out = best;
+    // (the key at agent scope and acknowledged: the consumer behind the signal below is another kernel on this GPU -- the collective --
+    // which then needs no system-scope release, i.e. no write-back of the L2, from this thread: ~3 us at the end of every launch)
+    __hip_atomic_store(a.key_out, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.sig) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.best_pose) {                                             // search_pose + offs[index - 1] (:635-637), theta normalised (:746)
         const uint32_t flat = (uint32_t)best;
         float x = a.bx, y = a.by, th = a.bth;
@@ -939,7 +942,7 @@ k1_search_tiled(const k1_args a)
         a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
         a.best_pose[3] = th;                                       // un-normalised, as MonteCarloSearch returns it
     }
-    if (a.sig) __hip_atomic_store(a.sig, a.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.sig) __hip_atomic_store(a.sig, a.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (a.done_flag) {                                             // blocking search: the key into the mailbox, then its completion word
         *(unsigned long long *)(a.done_flag - 15) = best;
         __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -204,7 +204,8 @@ extern "C" int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[
 // event -- so the next search does not wait for the collective of the last one (a ring of key slots keeps them apart),
 // and no interpreter or framework call sits between the kernel and the collective.
 #define SH_COMM_SLOTS 64
-#define SH_COMM_BLOCK 16                 // steps per completion event of the collectives' stream
+#define SH_COMM_BLOCK 32                 // steps per completion event of the collectives' stream
+#define SH_COMM_BATCH_MAX 32             // steps whose keys travel in one all-reduce (slamhip_comm::batch; divides SH_COMM_BLOCK)
 struct slamhip_comm {
     slamhip_ctx *ctx;
     rccl_api api;
@@ -215,6 +216,8 @@ struct slamhip_comm {
     hipEvent_t ev_k1[SH_COMM_SLOTS], ev_ar[SH_COMM_SLOTS];
     bool ar_pending[SH_COMM_SLOTS];
     uint64_t step;
+    int batch;                                     // steps per collective: the keys of `batch` consecutive steps are min-reduced in one call
+    uint64_t flushed;                              // steps whose collective has been issued
     unsigned long long *d_sig;                     // HSA signal memory: the search kernel stores the step number, the collectives' stream waits for it
     bool by_value;
     uint64_t *h_key;                               // pinned
@@ -268,6 +271,18 @@ extern "C" int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t unique_id
     SH_HIP(hipSetDevice(ctx->device));
     slamhip_comm *c = new slamhip_comm();
     c->ctx = ctx; c->rank = rank; c->n_ranks = n_ranks;
+    {   // The collective is latency-bound on the device and costs the host ~15 us per call (stream wait + RCCL's enqueue path):
+        // issued per step it makes a 21 us search step host-bound (25 us per step on one rank).  An asynchronous step therefore
+        // only launches the search; every `batch` steps ONE all-reduce takes the keys of all of them (the slots of a batch are
+        // consecutive), and slamhip_comm_wait flushes what is left.  Every rank issues the same steps and waits at the same
+        // places (as any collective requires), so the batches agree.  SLAMHIP_COMM_BATCH=1: one collective per step.
+        const char *b = getenv("SLAMHIP_COMM_BATCH");
+        int v = b ? atoi(b) : 16;
+        if (v < 1) v = 1;
+        if (v > SH_COMM_BATCH_MAX) v = SH_COMM_BATCH_MAX;
+        while (SH_COMM_BLOCK % v) v--;
+        c->batch = v;
+    }
     int32_t rc = load_rccl(&c->api);
     if (rc == SLAMHIP_OK) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -282,9 +297,13 @@ extern "C" int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t unique_id
         // K1 -> collective dependency: an event pair costs the search stream ~9 us per step on this stack (measured); where
         // the device supports stream memory operations the kernel's last act is the step number into an HSA signal that the
         // collectives' stream waits for -- nothing is inserted into the search stream (SLAMHIP_COMM_DEP=event keeps events)
+        // With the keys of a batch of steps in one collective the dependency is needed once per batch, and an event pair per
+        // batch (~1 us per step at eight steps) beats the signal: the kernel's store into host-visible signal memory must
+        // retire before the launch ends, +3 us per launch (measured on one rank: 25.1 us per step with the signal at one step
+        // per collective, 26.3 at eight; 21.9 us without any collective).  SLAMHIP_COMM_DEP=signal keeps the signal.
         const char *dep = getenv("SLAMHIP_COMM_DEP");
         int can = 0;
-        if (rc == SLAMHIP_OK && !(dep && strcmp(dep, "event") == 0) &&
+        if (rc == SLAMHIP_OK && ((dep && strcmp(dep, "signal") == 0) || (c->batch == 1 && !(dep && strcmp(dep, "event") == 0))) &&
             hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can &&
             hipExtMallocWithFlags((void **)&c->d_sig, 8, hipMallocSignalMemory) == hipSuccess) {
             *c->d_sig = 0ull;                                     // (signal memory is host-visible)
@@ -302,8 +321,27 @@ extern "C" int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t unique_id
     return SLAMHIP_OK;
 }
 
+// The collective for the steps [flushed, step): behind the last of them on the collectives' stream, one min all-reduce over their
+// (consecutive) key slots.
+static int32_t comm_flush(slamhip_comm *c)
+{
+    if (c->flushed == c->step) return SLAMHIP_OK;
+    const int first = (int)(c->flushed % SH_COMM_SLOTS), n = (int)(c->step - c->flushed);       // (a batch never wraps: batch divides the slot count)
+    const int last = first + n - 1;
+    if (c->by_value) SH_HIP(hipStreamWaitValue64(c->stream, c->d_sig, c->step, hipStreamWaitValueGte, ~0ull));
+    else {                                                         // one event pair per batch, behind its last search
+        SH_HIP(hipEventRecord(c->ev_k1[last], c->ctx->stream));
+        SH_HIP(hipStreamWaitEvent(c->stream, c->ev_k1[last], 0));
+    }
+    SH_NCCL(c, c->api.AllReduce(c->d_keys + first, c->d_keys + first, (size_t)n, ncclUint64, ncclMin, c->comm, c->stream));
+    if (last % SH_COMM_BLOCK == SH_COMM_BLOCK - 1) { SH_HIP(hipEventRecord(c->ev_ar[last / SH_COMM_BLOCK], c->stream)); c->ar_pending[last / SH_COMM_BLOCK] = true; }
+    c->flushed = c->step;
+    return SLAMHIP_OK;
+}
+
 // One sharded search step: returns at once; the reduced key of this step will be in *d_out_key (device memory owned by
-// the communicator, valid until SH_COMM_SLOTS (64) further steps have been issued).
+// the communicator, valid until SH_COMM_SLOTS (64) further steps have been issued) once the collective of its batch has run:
+// after slamhip_comm_wait, or behind a later step's batch on the collectives' stream.
 extern "C" int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_comm *c, const float pose[3], int32_t first, int32_t count,
                                                      uint64_t **d_out_key)
 {
@@ -325,16 +363,9 @@ extern "C" int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_com
         SH_TRY(rc);
         signalled = c->by_value && cs->k1_sig_armed;
     } else SH_HIP(hipMemsetAsync(key, 0xFF, sizeof(uint64_t), main));                                   // (a rank without candidates: the neutral key)
-    if (c->by_value) {
-        if (!signalled) SH_HIP(hipStreamWriteValue64(main, c->d_sig, c->step + 1, 0));                   // (fallback kernels, empty shard)
-        SH_HIP(hipStreamWaitValue64(c->stream, c->d_sig, c->step + 1, hipStreamWaitValueGte, ~0ull));
-    } else {
-        SH_HIP(hipEventRecord(c->ev_k1[slot], main));
-        SH_HIP(hipStreamWaitEvent(c->stream, c->ev_k1[slot], 0));
-    }
-    SH_NCCL(c, c->api.AllReduce(key, key, 1, ncclUint64, ncclMin, c->comm, c->stream));
-    if (slot % SH_COMM_BLOCK == SH_COMM_BLOCK - 1) { SH_HIP(hipEventRecord(c->ev_ar[blk], c->stream)); c->ar_pending[blk] = true; }
+    if (c->by_value && !signalled) SH_HIP(hipStreamWriteValue64(main, c->d_sig, c->step + 1, 0));        // (fallback kernels, empty shard)
     c->step++;
+    if (c->step % (uint64_t)c->batch == 0) SH_TRY(comm_flush(c));
     if (d_out_key) *d_out_key = key;
     return SLAMHIP_OK;
 }
@@ -344,6 +375,7 @@ extern "C" int32_t slamhip_comm_wait(slamhip_comm *c, uint64_t *out_key)
 {
     SH_CHECK_ARG(c);
     SH_HIP(hipSetDevice(c->ctx->device));
+    SH_TRY(comm_flush(c));
     if (out_key) {
         if (c->step == 0) SH_FAIL(SLAMHIP_ERR_STATE, "no search step has been issued on this communicator");
         const int slot = (int)((c->step - 1) % SH_COMM_SLOTS);
