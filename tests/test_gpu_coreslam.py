@@ -128,7 +128,9 @@ def test_empty_scan_is_state_error(cs_mod, ctx):
 
 @pytest.mark.parametrize("size,R,K", [(400, 360, 4001), (1024, 1080, 16384), (2048, 1080, 16384),
                                       (512, 360, 70001),       # more than 64 candidate groups: listed theta tails + uniform middle
-                                      (1024, 500, 140000)])
+                                      (1024, 500, 140000),
+                                      (400, 360, 12288), (400, 360, 12289),    # the candidate counts at which the group size changes (512 | 1024 | 2048 candidates per group)
+                                      (256, 200, 65535), (256, 200, 65536)])
 def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
     """BASELINE configs C1/C2/C3 sizes: every candidate's distance and the arg-min vs the C oracle."""
     oc = det
