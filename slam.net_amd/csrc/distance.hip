@@ -9,8 +9,9 @@
 // candidates in theta-sorted order; the arg-min key (distance << 32 | flat index) restores the
 // reference tie-break (first strictly smaller wins, :644,:700).
 //
-// One launch per search (k1_search_tiled).  A workgroup owns 1024 theta-consecutive candidates (a "group") and a
-// chunk = a range of the spatially sorted rays, cut into pieces at ray block boundaries:
+// One launch per search (k1_search_tiled).  A workgroup owns a "group" of 512 / 1024 / 2048 theta-consecutive
+// candidates (by the size of the search) and a chunk = a range of the spatially sorted rays, cut into pieces at ray
+// block boundaries:
 //   prologue  (px,py,c,s) of its candidates (deterministic trigonometry), their min/max bounds, and -- by interval
 //             arithmetic on the reference's very float operations (rounding is monotone, so the box is rigorous)
 //             -- the pixel box every candidate's end points of a piece fall into; from the boxes a list of STEPS:
@@ -19,9 +20,10 @@
 //             rays, boxes at the map border), else bounds-checked global gathers (GLOBAL);
 //   steps     the tile is staged with coalesced 16-byte loads that were issued one step ahead (registers),
 //             then ~14 VALU + 1 ds_read_u16 per point evaluation, no bounds test for SHARED;
-//   epilogue  partial sums are added to per-candidate accumulators with agent-scope atomics; the last workgroup of the
-//             group to arrive (ticket) reads them back, finishes the distances and takes the group arg-min, the
-//             last group the overall arg-min.
+//   epilogue  partial sums are added to per-candidate 64-bit accumulators (sum | in-map count | arrivals) with
+//             agent-scope returning atomics; the lane whose add completes a candidate's arrival count holds its
+//             total, finishes the distance and rests the word; the workgroup minima go through one atomic min, and
+//             the workgroup that completes the finished-candidates counter publishes the overall arg-min.
 // Inputs the fast path cannot take (NaN / huge coordinates, map sides that are not a multiple of 8) run the
 // bounds-checked global-gather kernels (k1_prep_pxcs, k1_distance_global, k1_reduce).
 #include "cs_internal.h"
