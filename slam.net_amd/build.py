@@ -27,22 +27,12 @@ def extra_defs():
     d = []
     if os.environ.get("SLAMHIP_K1_TIMES"):      # developer build: per-workgroup phase stamps in the fused K1 kernel
         d.append("-DK1_TIMES=1")
-    if os.environ.get("SLAMHIP_K1_FAKETRIG"):   # developer experiment only (wrong results): cost of the trigonometry
-        d.append("-DK1_FAKETRIG=1")
     if os.environ.get("SLAMHIP_K4_TIMES"):      # developer build: phase stamps in the Hector matcher
         d.append("-DK4_TIMES=1")
-    if os.environ.get("SLAMHIP_K4_EXP"):        # developer experiments only (wrong results)
-        d.append("-DK4_EXP=%s" % os.environ["SLAMHIP_K4_EXP"])
     if os.environ.get("SLAMHIP_K2_TIMES"):      # developer build: per-workgroup phase stamps in the K2 pixel kernel
         d.append("-DK2_TIMES=1")
     if os.environ.get("SLAMHIP_K2_LDS_RAYS"):   # developer experiment: rays of the K2 pixel kernel's LDS table
         d.append("-DK2_LDS_RAYS=%s" % os.environ["SLAMHIP_K2_LDS_RAYS"])
-    if os.environ.get("SLAMHIP_K2_EXP_CLIP"):   # developer experiment only (wrong results)
-        d.append("-DK2_EXP_CLIP=%s" % os.environ["SLAMHIP_K2_EXP_CLIP"])
-    if os.environ.get("SLAMHIP_K2_EXP_SKIPZ"):  # developer experiment only (wrong results)
-        d.append("-DK2_EXP_SKIPZ=%s" % os.environ["SLAMHIP_K2_EXP_SKIPZ"])
-    if os.environ.get("SLAMHIP_K1_EXP"):        # developer experiments only (wrong results)
-        d.append("-DK1_EXP%s=1" % os.environ["SLAMHIP_K1_EXP"])
     return d
 
 

@@ -84,11 +84,7 @@ __device__ static inline float4 k1_candidate(const float c3[3], float bx, float 
     if (MODE == 1) { x = bx + c3[0]; y = by + c3[1]; th = bth + c3[2]; }
     else           { x = c3[0];      y = c3[1];      th = c3[2]; }
     float s, c;
-#ifdef K1_FAKETRIG
-    s = th * 0.9f; c = 1.0f - th * th * 0.5f;
-#else
     if (SMALL) sh_det_sincosf_small(th, &s, &c); else sh_det_sincosf(th, &s, &c);
-#endif
     float4 q;
     q.x = x * scale + 0.5f;
     q.y = y * scale + 0.5f;
@@ -666,11 +662,7 @@ k1_search_tiled(const k1_args a)
             {   // issue the next step's loads now; nothing in the compute loops below waits on vector memory.  (After the last step
                 // there is no next tile: every lane is idle and every load is skipped -- the last tile used to be fetched again.)
                 const int sn = s + 1 < nsteps ? s + 1 : s;
-#ifdef K1_EXPNOPF
-                K1_PREFETCH(sn, false)                             // developer experiment (wrong results): what the later tiles' loads cost
-#else
                 K1_PREFETCH(sn, s + 1 < nsteps)
-#endif
             }
 #ifdef K1_TIMES
             const unsigned long long ts2 = wall_clock64();

@@ -68,9 +68,6 @@ __device__ static inline float hs_prob(const float *__restrict__ value, int idx)
 
 __device__ static inline float hs_prob_v(float v)
 {
-#if defined(K4_EXP) && K4_EXP == 4
-    return 0.5f + 0.1f * v;                                                // EXPERIMENT (wrong results): no exp, no divide
-#endif
     const float odds = expf(v);                                            // :101
     return odds / (odds + 1.0f);                                           // :102
 }
@@ -89,12 +86,8 @@ __device__ static inline void hs_interp(const hs_level_dev &L, float cx, float c
     // the two taps of a row are adjacent: one 8-byte load each (4-byte aligned is enough for global dwordx2), from the
     // grid of cached probabilities (:97-107 -- the reference caches them per cell and map-update epoch as well)
     float2 r0, r1;
-#if defined(K4_EXP) && K4_EXP == 1
-    r0 = make_float2(cx * 0.001f, 0.1f); r1 = make_float2(0.2f, cy * 0.001f);      // EXPERIMENT (wrong results): no tap loads
-#else
     __builtin_memcpy(&r0, L.prob + idx, sizeof(float2));
     __builtin_memcpy(&r1, L.prob + idx + L.w, sizeof(float2));
-#endif
     const float i0 = r0.x, i1 = r0.y;                                      // :230-231
     const float i2 = r1.x, i3 = r1.y;                                      // :232-233
     const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;            // :235-239
@@ -169,11 +162,7 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
                                   sh_m3x2_scale(L.stm));                   // :139-142
     K4_STAMP_BEGIN
     float s, c;
-#if defined(K4_EXP) && K4_EXP == 3
-    s = pose[2] * 0.9f; c = 1.0f - pose[2] * pose[2] * 0.5f;               // EXPERIMENT (wrong results): no trigonometry
-#else
     sh_det_sincosf(pose[2], &s, &c);
-#endif
     const float sinRot = s * L.stm, cosRot = c * L.stm;                    // :145-146
     K4_STAMP(0)                                                            // transform + trigonometry
     float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };

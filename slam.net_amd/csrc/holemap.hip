@@ -427,9 +427,6 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
     const int R = counters[0], x1 = counters[3], y1 = counters[4];
     if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;       // robot outside the map: nothing is drawn (:509-512)
     int X0 = max(x1 - R, 0), X1 = min(x1 + R, size - 1), Y0 = max(y1 - R, 0), Y1 = min(y1 + R, size - 1);
-#ifdef K2_EXP_CLIP
-    X0 = max(X0, K2_EXP_CLIP); Y0 = max(Y0, K2_EXP_CLIP); X1 = min(X1, size - 1 - K2_EXP_CLIP); Y1 = min(Y1, size - 1 - K2_EXP_CLIP);   // EXPERIMENT (wrong results)
-#endif
     if (threadIdx.x == 0) { s_next_zone = 0; s_next_item = 0; }
     for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
     if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) cand_s[i] = cand_g[i];     // (entries past the valid rays are never addressed)
@@ -451,9 +448,6 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
         if (item >= n_zone) break;
         const int X = x1 - Z + item % side, Y = y1 - Z + item / side;
         if (X < 0 || X >= size || Y < 0 || Y >= size) continue;              // wave-uniform
-#ifdef K2_EXP_SKIPZ
-        if (max(abs(X - x1), abs(Y - y1)) <= K2_EXP_SKIPZ) continue;         // EXPERIMENT (wrong results)
-#endif
         k2_wave_pixel(X, Y, x1, y1, size, byidx, vprof, n_rays, cand, start, map, alpha, sval[wv]);
     }
     K2_STAMP(2)
