@@ -161,7 +161,8 @@ int32_t slamhip_cs_update_holemap_pxcs(slamhip_cs *cs, const float pxcs[4], floa
 /* UpdateObstacleMap + DrawLaserRayOnObstacleMap (:456-490,:540-593) */
 int32_t slamhip_cs_update_obstaclemap(slamhip_cs *cs, const float pose[3], int32_t max_obstacle_hits);
 int32_t slamhip_cs_update_obstaclemap_pxcs(slamhip_cs *cs, const float pxcs[4], int32_t max_obstacle_hits);
-/* number of pixels blended by the last HoleMap update (4 algorithmic bytes each) */
+/* number of pixels blended by the last HoleMap update (4 algorithmic bytes each); after
+ * slamhip_cs_search_and_update the figure is fetched here (this call then waits for the update) */
 int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out_pixels);
 
 /* Diagnostics: with the environment variable SLAMHIP_K1_VERIFY=1 the distance kernel checks every end
@@ -170,7 +171,12 @@ int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out_pixels);
 int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out_failures);
 
 /* Fused configuration C3 (device boundary at CoreSLAMProcessor.cs:732,:750,:751): search, NormalizeAngle
- * (:746) and both map updates in one call; the winning pose never leaves the device between them. */
+ * (:746) and both map updates in one call; the winning pose never leaves the device between them.
+ * Completion: the call returns when the winning pose is back on the host.  The two map updates are enqueued
+ * behind the search on the operator's stream and may still be running; every later call that reads or writes
+ * the maps (the next search, an update, a download, an export, destroy) is ordered behind them, so a caller
+ * sees the reference's sequential semantics -- it only gets the pose ~40 us earlier and can prepare its next scan
+ * meanwhile.  SLAMHIP_FUSED_WAIT_UPDATES=1 restores "return after the updates". */
 int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float search_pose[3], float hole_width,
                                      int32_t quality, int32_t max_obstacle_hits, float out_pose[3],
                                      int32_t *out_dist, int32_t *out_index);

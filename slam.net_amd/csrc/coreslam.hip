@@ -719,7 +719,7 @@ static int32_t finish_holemap(slamhip_cs *cs)
     SH_TRY(sh_publish(cs->ctx, cs->d_k2_counters, 4));
     SH_TRY(sh_host_wait(cs->ctx));
     const int *m = (const int *)cs->ctx->mailbox;                           // [0] longest ray, [1] conflict pixels, [2] blended pixels
-    cs->last_hole_pixels = m[2];
+    cs->last_hole_pixels = m[2]; cs->hole_pixels_pending = false;
     static const bool stats = getenv("SLAMHIP_K2_STATS") != nullptr;        // developer aid
     if (stats) fprintf(stderr, "[slamhip] K2: reach %d px, %d pixels with more than 4 fragments (drawn by the last workgroup), %d blended pixels\n", m[0], m[1], m[2]);
     return SLAMHIP_OK;
@@ -729,7 +729,7 @@ extern "C" int32_t slamhip_cs_update_holemap_pxcs(slamhip_cs *cs, const float px
 {
     SH_CHECK_ARG(cs && pxcs && quality >= 0 && quality <= 256);
     SH_HIP(hipSetDevice(cs->ctx->device));
-    cs->last_hole_pixels = 0;
+    cs->last_hole_pixels = 0; cs->hole_pixels_pending = false;
     if (cs->n_points <= 0) return SLAMHIP_OK;
     SH_TRY(cs_launch_holemap_update(cs, nullptr, make_float4(pxcs[0], pxcs[1], pxcs[2], pxcs[3]), hole_width, quality));
     return finish_holemap(cs);
@@ -766,7 +766,7 @@ int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_w
 {
     SH_CHECK_ARG(cs && pose && quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
     SH_HIP(hipSetDevice(cs->ctx->device));
-    cs->last_hole_pixels = 0;
+    cs->last_hole_pixels = 0; cs->hole_pixels_pending = false;
     if (cs->n_points <= 0) return SLAMHIP_OK;
     SH_TRY(cs_launch_holemap_update(cs, nullptr, pxcs_from_pose(pose, cs->hscale), hole_width, quality));   // :499-502
     SH_TRY(cs_launch_obstacle_update(cs, nullptr, pxcs_from_pose(pose, cs->oscale), max_hits));            // :545-548
@@ -782,6 +782,14 @@ int32_t cs_update_maps_finish(slamhip_cs *cs)
 extern "C" int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out)
 {
     SH_CHECK_ARG(cs && out);
+    if (cs->hole_pixels_pending) {                                  // the fused call returned with the pose: fetch the count now
+        SH_HIP(hipSetDevice(cs->ctx->device));
+        int *h = (int *)(cs->h_key + 8);
+        SH_HIP(hipMemcpyAsync(h, (const int *)cs->d_key + 6, sizeof(int), hipMemcpyDeviceToHost, cs->ctx->stream));
+        SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+        cs->last_hole_pixels = *h;
+        cs->hole_pixels_pending = false;
+    }
     *out = cs->last_hole_pixels;
     return SLAMHIP_OK;
 }
@@ -807,30 +815,47 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
     slamhip_ctx *ctx = cs->ctx;
     // search (:732) -- the launch also leaves the winner's pose, theta normalised (:746-747), on the device -- then both
-    // map updates from that pose (:750-751); one 32-byte result block comes back
+    // map updates from that pose (:750-751).  The call returns when the POSE is known: K1's final arriver stores key and pose
+    // into the mailbox, the updates are already enqueued behind it and run on while the caller prepares its next scan
+    // (everything that reads the maps afterwards -- the next search, a download, an export -- is ordered behind them on the
+    // operator's stream).  Without the mailbox, with per-kernel timing on, or when the search ran on the fallback kernels,
+    // one result block comes back after the updates instead.
+    static const bool wait_updates = getenv("SLAMHIP_FUSED_WAIT_UPDATES") != nullptr;      // (the former behaviour, for comparison)
+    const bool early = !ctx->mail_off && ctx->timing == 0 && !wait_updates;
+    if (early) { cs->k1_done_flag = ctx->mailbox + 15; cs->k1_done_val = ctx->mail_seq + 1; }
     cs->k1_want_pose = true;
     const int32_t rc_s = search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key);
-    cs->k1_want_pose = false;
+    cs->k1_want_pose = false; cs->k1_done_flag = nullptr;
     SH_TRY(rc_s);
+    const bool delivered = early && cs->k1_done_armed && cs->k1_pose_written;
+    if (delivered) (void)sh_mail_seq_next(ctx);
     if (!cs->k1_pose_written)                                    // (fallback search kernels: decode the key in a launch of its own)
         hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
                            cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);
     // :750-751 -- the two maps are independent: the ObstacleMap update's ray walks and cell pass ride on the HoleMap
     // update's two launches as extra workgroups (two dependent launches less per scan); with per-kernel timing on, each
     // update keeps its own launches so that the timers mean what they say
+    int32_t rc_u;
     if (ctx->timing == 0) {
         k3_ride ride;
         cs_obstacle_ride(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits, &ride);
-        SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality, &ride));
+        rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality, &ride);
     } else {
-        SH_TRY(cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality));
-        SH_TRY(cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits));
+        rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality);
+        if (rc_u == SLAMHIP_OK) rc_u = cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits);
     }
-    SH_TRY(sh_publish(ctx, cs->d_key, 8));
-    SH_TRY(sh_host_wait(ctx));
+    if (delivered) {
+        SH_TRY(sh_host_wait(ctx));                               // (the search's word arrives whatever became of the update launches)
+        SH_TRY(rc_u);
+        cs->hole_pixels_pending = true;
+    } else {
+        SH_TRY(rc_u);
+        SH_TRY(sh_publish(ctx, cs->d_key, 8));
+        SH_TRY(sh_host_wait(ctx));
+        cs->last_hole_pixels = ((const int *)ctx->mailbox)[6]; cs->hole_pixels_pending = false;
+    }
     const volatile uint64_t *hk = (const volatile uint64_t *)ctx->mailbox;
     const float *hp = (const float *)(ctx->mailbox + 2);
-    cs->last_hole_pixels = ((const int *)ctx->mailbox)[6];
     const uint64_t key = hk[0];
     if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
     if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);

@@ -80,6 +80,7 @@ struct slamhip_cs {
     int *d_k2_counters;           // [0] longest ray, [1] conflict pixels, [2] blended pixels, [3] x1, [4] y1
     int *d_conflict_pix; int cap_conflict;
     int64_t last_hole_pixels;
+    bool hole_pixels_pending;     // ... still on the device (d_key word 6): slamhip_cs_search_and_update returned with the pose, the updates run on
 
     // ---- K3 ObstacleMap update scratch ---------------------------------------------------------------
     uint32_t *d_o_hits;           // [os*os] endpoint hits this scan

@@ -929,16 +929,20 @@ k1_search_tiled(const k1_args a)
     // which then needs no system-scope release, i.e. no write-back of the L2, from this thread: ~3 us at the end of every launch)
     __hip_atomic_store(a.key_out, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.sig) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float bx = 0.0f, by = 0.0f, bthn = 0.0f;
     if (a.best_pose) {                                             // search_pose + offs[index - 1] (:635-637), theta normalised (:746)
         const uint32_t flat = (uint32_t)best;
-        float x = a.bx, y = a.by, th = a.bth;
-        if (flat > 0) { x = a.bx + a.offs_flat[3 * (flat - 1)]; y = a.by + a.offs_flat[3 * (flat - 1) + 1]; th = a.bth + a.offs_flat[3 * (flat - 1) + 2]; }
-        a.best_pose[0] = x; a.best_pose[1] = y; a.best_pose[2] = sh_normalize_angle(th);
+        float th = a.bth;
+        bx = a.bx; by = a.by;
+        if (flat > 0) { bx = a.bx + a.offs_flat[3 * (flat - 1)]; by = a.by + a.offs_flat[3 * (flat - 1) + 1]; th = a.bth + a.offs_flat[3 * (flat - 1) + 2]; }
+        bthn = sh_normalize_angle(th);
+        a.best_pose[0] = bx; a.best_pose[1] = by; a.best_pose[2] = bthn;
         a.best_pose[3] = th;                                       // un-normalised, as MonteCarloSearch returns it
     }
     if (a.sig) __hip_atomic_store(a.sig, a.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (a.done_flag) {                                             // blocking search: the key into the mailbox, then its completion word
+    if (a.done_flag) {                                             // blocking call: the key -- and the winner's pose when one is asked for -- into the mailbox, then its completion word
         *(unsigned long long *)(a.done_flag - 15) = best;
+        if (a.best_pose) { float *mp = (float *)(a.done_flag - 13); mp[0] = bx; mp[1] = by; mp[2] = bthn; }
         __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     K1_STAMP(9)

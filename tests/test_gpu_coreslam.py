@@ -380,10 +380,34 @@ def test_search_and_update_fused(cs_mod, ctx, det, sim):
     rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, offs)
     rpose[2] = oc.normalize_angle(rpose[2])                                               # :746
     assert idx == rbi and dist == rbd and (pose == rpose).all()
-    oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose)
+    n_px = oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose)
+    # the call returns with the pose while the map updates run on: whatever reads the maps next is ordered behind them
+    assert dev.last_holemap_pixels == n_px
+    assert (dev.holemap_download() == ref_h).all()
+    assert (dev.obstaclemap_download() == ref_o).all()
+    # a second fused scan straight behind the first (its search reads the map the first one's update is still writing)
+    pose2, dist2, idx2 = dev.search_and_update(base, 0.6, 50, 10)
+    rbi2, rpose2, rbd2, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, offs)
+    rpose2[2] = oc.normalize_angle(rpose2[2])
+    assert idx2 == rbi2 and dist2 == rbd2 and (pose2 == rpose2).all()
+    oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose2); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose2)
     assert (dev.holemap_download() == ref_h).all()
     assert (dev.obstaclemap_download() == ref_o).all()
     dev.close()
+
+
+def test_fused_completion_modes():
+    """The fused call and the processor with the result block after the updates (SLAMHIP_FUSED_WAIT_UPDATES=1) and without
+    the host mailbox (SLAMHIP_NO_HOSTWAIT=1: copy + synchronise): same results as the default (pose from K1's final arriver)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "test_search_and_update_fused or test_processor_vs_oracle"
+    for env_extra in ({"SLAMHIP_FUSED_WAIT_UPDATES": "1"}, {"SLAMHIP_NO_HOSTWAIT": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q",
+                            "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, (env_extra, r.stdout.decode(errors="replace")[-3000:])
 
 
 def test_processor_vs_oracle(cs_mod, ctx, det, sim):

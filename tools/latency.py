@@ -4,10 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import slam.net_amd.coreslam as cs, slam.net_amd.sim as sim
 
-def med(f, n=300, warm=30):
+def med(f, n=300, warm=30, idle=None):
     for _ in range(warm): f()
     ts = []
     for _ in range(n):
+        if idle: idle()                  # (a call that returns before all its device work is done: start from an idle device)
         t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
     ts.sort()
     return {"median_us": ts[len(ts) // 2] * 1e6, "p10_us": ts[len(ts) // 10] * 1e6, "p90_us": ts[len(ts) * 9 // 10] * 1e6}
@@ -21,7 +22,8 @@ _, xy = sim.make_scan(segs, traj[-1], R, rng)
 base = (traj[-1] + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
 dev.set_scan(xy); dev.set_offsets(sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0)))
 out = {"search_shard_blocking": med(lambda: dev.search_shard(base, 0, K)),
-       "search_and_update_blocking": med(lambda: dev.search_and_update(base)),
+       "search_and_update_to_pose": med(lambda: dev.search_and_update(base), idle=ctx.synchronize),       # (the map updates run on)
+       "search_and_update_back_to_back": med(lambda: dev.search_and_update(base)),
        "update_holemap_blocking": med(lambda: dev.update_holemap(base)),
        "update_obstaclemap_blocking": med(lambda: dev.update_obstaclemap(base))}
 print(json.dumps(out, indent=1))

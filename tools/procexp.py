@@ -13,7 +13,9 @@ def seg(i):
     rays, xy = scans[i]
     return [cs.ScanSegment(rays, np.zeros(3, np.float32))]
 for i in range(10): proc.Update(seg(i))
+ctx.synchronize()
 t0 = time.perf_counter()
 for i in range(10, 210): proc.Update(seg(10 + i % 60))
+ctx.synchronize()            # (Update returns with the pose; the last scan's map updates belong to the figure)
 dt = (time.perf_counter() - t0) / 200
 print("CoreSLAMProcessor.Update (%d^2, %d candidates): %.1f us per scan" % (size, K, dt * 1e6))

@@ -72,10 +72,15 @@ def main():
     hector_lost_at = None
     for loop, tp in enumerate(traj):
         rays, xy = sim.make_scan(segs, tp, a.rays, rng)
+        # (CoreSLAMProcessor.Update returns with the pose while its map updates run on; the two processors share a stream
+        # here, so each is timed to the completion of its own device work -- the conservative figure, without the overlap
+        # a host gets from preparing its next scan meanwhile)
         t0 = time.perf_counter()
         core.Update([cs.ScanSegment(rays, core.Pose)])                   # :159-160
+        ctx.synchronize()
         t1 = time.perf_counter()
         hect.Update(hs.ScanCloud(xy), hect.MatchPose, loop < 10)         # :179
+        ctx.synchronize()
         t2 = time.perf_counter()
         if loop >= 10:                                                   # steady state only (first calls allocate)
             t_core += t1 - t0
