@@ -59,7 +59,8 @@ def main():
     core = cs.CoreSLAMProcessor(40.0, a.hole_map, a.obstacle_map, start, 0.1, math.radians(10.0), a.iterations, a.threads, ctx=ctx)
     core.HoleWidth = 2.0                                                 # :71
     core.SetSeed(a.seed)
-    hect = hs.HectorSLAMProcessor(40.0 / a.hector_side, (a.hector_side, a.hector_side), start, a.hector_levels, a.threads, ctx=ctx)
+    ctx_h = cs.Context(0)
+    hect = hs.HectorSLAMProcessor(40.0 / a.hector_side, (a.hector_side, a.hector_side), start, a.hector_levels, a.threads, ctx=ctx_h)
     hect.MinDistanceDiffForMapUpdate = 0.4                               # :78-79
     hect.MinAngleDiffForMapUpdate = math.radians(8.0)
     for l, it in enumerate([7, 4, 4, 4][:a.hector_levels]):              # :83-86
@@ -72,15 +73,12 @@ def main():
     hector_lost_at = None
     for loop, tp in enumerate(traj):
         rays, xy = sim.make_scan(segs, tp, a.rays, rng)
-        # (CoreSLAMProcessor.Update returns with the pose while its map updates run on; the two processors share a stream
-        # here, so each is timed to the completion of its own device work -- the conservative figure, without the overlap
-        # a host gets from preparing its next scan meanwhile)
+        # (CoreSLAMProcessor.Update returns with the pose while its map updates run on: the two processors have a context --
+        # a stream -- each, as two independent SLAM instances of a host would, so neither waits for the other's device work)
         t0 = time.perf_counter()
         core.Update([cs.ScanSegment(rays, core.Pose)])                   # :159-160
-        ctx.synchronize()
         t1 = time.perf_counter()
         hect.Update(hs.ScanCloud(xy), hect.MatchPose, loop < 10)         # :179
-        ctx.synchronize()
         t2 = time.perf_counter()
         if loop >= 10:                                                   # steady state only (first calls allocate)
             t_core += t1 - t0
@@ -118,6 +116,7 @@ def main():
     print(json.dumps(out))
     hect.Dispose()
     core.Dispose()
+    ctx_h.close()
     ctx.close()
 
 
