@@ -927,7 +927,8 @@ extern "C" int32_t slamhip_hs_hessian(slamhip_hs *hs, int32_t level, const float
     return SLAMHIP_OK;
 }
 
-extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3])
+// the launches of UpdateByScan on the operator's stream; nothing comes back to the host
+static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
 {
     SH_CHECK_ARG(hs && pose);
     SH_HIP(hipSetDevice(hs->ctx->device));
@@ -984,8 +985,14 @@ extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3]
     }
     SH_HIP(hipGetLastError());
     for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144
-    SH_TRY(sh_publish(ctx, nullptr, 0));
-    return sh_host_wait(ctx);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3])
+{
+    SH_TRY(hs_update_enqueue(hs, pose));
+    SH_TRY(sh_publish(hs->ctx, nullptr, 0));
+    return sh_host_wait(hs->ctx);
 }
 
 // ---- HectorSLAMProcessor (Main/HectorSLAMProcessor.cs) ---------------------------------------------------------------
@@ -1059,8 +1066,13 @@ extern "C" int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int
     if (dist2 > p->min_dist * p->min_dist ||
         deg_diff(p->match_pose[2], p->last_update_pose[2]) > p->min_angle ||   // :108 (radians through DegDiff, as the reference does)
         map_without_matching) {                                           // :109
+        // The grid update returns nothing to the host: it is enqueued and runs on while the caller prepares its next scan --
+        // the next match, a download or an export is ordered behind it on the operator's stream (UpdateTiming :115 is then
+        // the time of the enqueue; SLAMHIP_HS_WAIT_UPDATE=1 waits for the update as before).
+        static const bool wait_update = getenv("SLAMHIP_HS_WAIT_UPDATE") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
-        SH_TRY(slamhip_hs_update_by_scan(p->hs, p->match_pose));          // :112
+        if (wait_update) { SH_TRY(slamhip_hs_update_by_scan(p->hs, p->match_pose)); }   // :112
+        else { SH_TRY(hs_update_enqueue(p->hs, p->match_pose)); }
         const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         p->update_timing = (3.0f * p->update_timing + ms) / 4.0f;         // :115
         memcpy(p->last_update_pose, p->match_pose, sizeof(float) * 3);    // :118

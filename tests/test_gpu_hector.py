@@ -288,3 +288,17 @@ def test_hector_processor_long_run(hs_mod, ctx, det, sim):
     assert math.hypot(err[0], err[1]) < 0.1 and abs(err[2]) < math.radians(1)
     proc.Dispose()
 
+
+
+def test_hector_processor_wait_update_mode():
+    """HectorSLAMProcessor.Update enqueues the grid update and returns; SLAMHIP_HS_WAIT_UPDATE=1 (wait for it, the former
+    behaviour) and SLAMHIP_NO_HOSTWAIT=1 (no host mailbox) must give the same results."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "test_hector_processor_gating or test_hector_processor_long_run"
+    for env_extra in ({"SLAMHIP_HS_WAIT_UPDATE": "1"}, {"SLAMHIP_NO_HOSTWAIT": "1"}):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_hector.py"), "-m", "gpu", "-x", "-q",
+                            "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, (env_extra, r.stdout.decode(errors="replace")[-3000:])
