@@ -263,7 +263,10 @@ int32_t slamhip_hsproc_create(slamhip_ctx *ctx, float map_resolution, int32_t wi
                               const float start_pose[3], int32_t num_depth, slamhip_hsproc **out);
 int32_t slamhip_hsproc_destroy(slamhip_hsproc *p);
 int32_t slamhip_hsproc_reset(slamhip_hsproc *p);                                        /* :131-138 */
-/* Update(scan, poseHintWorld, mapWithoutMatching) (:86-126); *out_map_updated = return value */
+/* Update(scan, poseHintWorld, mapWithoutMatching) (:86-126); *out_map_updated = return value.  The match is waited
+ * for (its pose gates the update); the grid update is enqueued and the call returns -- later calls that touch the
+ * pyramid are ordered behind it on the operator's stream; UpdateTiming (:115) then reports the enqueue.
+ * SLAMHIP_HS_WAIT_UPDATE=1 waits for the update. */
 int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int32_t n_points, const float scan_origin[2],
                               const float pose_hint_world[3], int32_t map_without_matching,
                               int32_t *out_map_updated);
