@@ -21,8 +21,6 @@ void slamhip_set_error(const char *fmt, ...);
 struct slamhip_ctx {
     int device;
     hipStream_t stream;
-    hipStream_t aux_stream;          // side stream for work that overlaps the main kernels (K1 tail kernel)
-    hipEvent_t ev_fork, ev_join;     // main -> aux and aux -> main dependencies
     int num_cus;
     // timing
     uint32_t timing;          // bit mask of timed kernel classes

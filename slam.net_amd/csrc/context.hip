@@ -40,11 +40,12 @@ extern "C" int32_t slamhip_ctx_create(int32_t device, slamhip_ctx **out)
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent);
-    if (e != hipSuccess) { free(c); SH_FAIL(SLAMHIP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        free(c);
+        SH_FAIL(SLAMHIP_ERR_HIP, "context creation failed (stream / pinned mailbox): %s", hipGetErrorString(e));
+    }
     memset(c->mailbox, 0, 64);
     c->mail_off = getenv("SLAMHIP_NO_HOSTWAIT") && atoi(getenv("SLAMHIP_NO_HOSTWAIT"));
     *out = c;
@@ -59,9 +60,6 @@ extern "C" int32_t slamhip_ctx_destroy(slamhip_ctx *c)
     for (int i = 0; i < c->n_pending; i++) { (void)hipEventDestroy(c->pending[i].a); (void)hipEventDestroy(c->pending[i].b); }
     for (int i = 0; i < c->n_pool; i++) (void)hipEventDestroy(c->pool[i]);
     free(c->pending); free(c->pool);
-    (void)hipStreamSynchronize(c->aux_stream);
-    (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
-    (void)hipStreamDestroy(c->aux_stream);
     (void)hipStreamDestroy(c->stream);
     if (c->mailbox) (void)hipHostFree(c->mailbox);
     free(c);
