@@ -396,13 +396,47 @@ def test_search_and_update_fused(cs_mod, ctx, det, sim):
     dev.close()
 
 
+def test_fused_scans_back_to_back(cs_mod, ctx, det, sim):
+    """Twelve scans through set_scan + the fused call with nothing in between that waits for the device: every call
+    returns with its pose while its map updates still run, the next scan's upload and search queue behind them.  Poses
+    scan by scan and both maps at the end equal the oracle's (2048^2: the updates outlast the host's preparation)."""
+    oc = det
+    size, osize, R, K = 2048, 512, 1080, 2048
+    segs = sim.default_field()
+    dev = cs_mod.CoreSlamDevice(ctx, 40.0, size, osize)
+    ref_h = np.full(size * size, 32750, np.uint16)
+    ref_o = np.full((osize, osize), -5, np.int8)
+    rng = sim.PCG32(17)
+    traj = sim.trajectory(18)
+    scans = [sim.make_scan(segs, p, R, rng)[1] for p in traj]
+    for p, xy in zip(traj[:6], scans[:6]):
+        dev.set_scan(xy)
+        dev.update_holemap(p); dev.update_obstaclemap(p)
+        oc.update_holemap(ref_h, size, dev.hole_scale, xy, p); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, p)
+    offs = sim.gaussian_offsets(K - 1, 0.05, math.radians(2.0), seed=9)
+    dev.set_offsets(offs)
+    got = []
+    bases = [(p + np.array([0.02, -0.03, 0.01], np.float32)).astype(np.float32) for p in traj[6:]]
+    for base, xy in zip(bases, scans[6:]):
+        dev.set_scan(xy)
+        got.append(dev.search_and_update(base, 0.6, 50, 10))
+    for (pose, dist, idx), base, xy in zip(got, bases, scans[6:]):
+        rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, offs)
+        rpose[2] = oc.normalize_angle(rpose[2])
+        assert idx == rbi and dist == rbd and (pose == rpose).all()
+        oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose)
+    assert (dev.holemap_download() == ref_h).all()
+    assert (dev.obstaclemap_download() == ref_o).all()
+    dev.close()
+
+
 def test_fused_completion_modes():
     """The fused call and the processor with the result block after the updates (SLAMHIP_FUSED_WAIT_UPDATES=1) and without
     the host mailbox (SLAMHIP_NO_HOSTWAIT=1: copy + synchronise): same results as the default (pose from K1's final arriver)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "test_search_and_update_fused or test_processor_vs_oracle"
+    sel = "test_search_and_update_fused or test_processor_vs_oracle or test_fused_scans_back_to_back"
     for env_extra in ({"SLAMHIP_FUSED_WAIT_UPDATES": "1"}, {"SLAMHIP_NO_HOSTWAIT": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}):
         env = dict(os.environ); env.update(env_extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q",
