@@ -39,6 +39,13 @@ int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words);   // enque
 // (A hipMemcpyAsync right after a mailbox wait takes the runtime's slow path -- it has not seen the stream finish yet -- and the
 // cross-engine dependency delays the first kernel: measured 8 us per scan; with this the per-scan path is launches only.)
 int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flag, uint32_t seq);
+// (the work of the upload's one workgroup of 1024 lanes: also rides on another launch as an extra workgroup, see k_gather_offsets)
+__device__ static inline void sh_upload16_unit(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16, uint32_t *__restrict__ flag, uint32_t seq)
+{
+    for (int i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    __syncthreads();                                               // every lane's loads have returned (its stores depend on them)
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *h_flag, uint32_t seq);
 int32_t sh_host_wait(slamhip_ctx *ctx);                                  // until the last sh_publish of this context has landed
 // (a kernel that is the last of its call may write the mailbox itself: words first, then sh_mail_seq_next() into word 15, released at system scope)

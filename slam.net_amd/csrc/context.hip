@@ -106,9 +106,7 @@ int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words)
 __global__ void __launch_bounds__(1024)
 k_upload16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16, uint32_t *__restrict__ flag, uint32_t seq)
 {
-    for (int i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
-    __syncthreads();                                               // every lane's loads have returned (its stores depend on them)
-    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    sh_upload16_unit(src, dst, n16, flag, seq);
 }
 
 int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flag, uint32_t seq)

@@ -77,8 +77,13 @@ template <bool GEN>
 __global__ void __launch_bounds__(1024)
 k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first, int count, int zero_pos,
                  float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds, int grp,
-                 int gen_n, float gen_sxy, float gen_sth, uint64_t gen_seed, uint64_t gen_stream)
+                 int gen_n, float gen_sxy, float gen_sth, uint64_t gen_seed, uint64_t gen_stream,
+                 const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst, int up_n16, uint32_t *__restrict__ up_flag, uint32_t up_seq)
 {
+    if (up_n16 > 0 && blockIdx.x == gridDim.x - 1) {               // riding along: the scan upload (the two are independent, K1 needs both)
+        sh_upload16_unit(up_src, up_dst, up_n16, up_flag, up_seq);
+        return;
+    }
     __shared__ float red[16][6];
     float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
     for (int jj = threadIdx.x; jj < grp; jj += 1024) {            // (grp = 1024 or 2048 candidates per group)
@@ -284,7 +289,8 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->cap_points = cap;
         cs->scan_in_flight = false;
     }
-    if (cs->scan_in_flight) {                           // the previous copy has left the staging block
+    if (cs->upload_pending) cs->upload_pending = false; // (the staged scan was never consumed: nothing was launched, the block is ours)
+    else if (cs->scan_in_flight) {                      // the previous copy has left the staging block
         if (!cs->ctx->mail_off) SH_TRY(sh_flag_wait(cs->ctx, (volatile uint32_t *)cs->h_key + 30, cs->upload_seq));
         else SH_HIP(hipEventSynchronize(cs->ev_scan));
         cs->scan_in_flight = false;
@@ -383,15 +389,28 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     // (a blocking call that returned through the mailbox leaves a stream the runtime has not yet seen finish; the copy takes
     // its immediate path only on a stream the runtime knows to be idle: one query lets it find out)
     if (!cs->ctx->mail_off) {
-        // the upload is a launch that pulls the staging block and then tells the host (h_key word 30) that it may be refilled
-        cs->upload_seq++;
-        SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, (used + 15) & ~(size_t)15, (uint32_t *)cs->h_key + 30, cs->upload_seq));
+        // The upload is a launch that pulls the staging block and then tells the host (h_key word 30) that it may be refilled.
+        // It is left pending: the first launch that reads the scan issues it (cs_flush_scan) -- or the candidate gather of the
+        // coming search carries it as an extra workgroup (ensure_shard): one launch and one launch boundary less per scan in the
+        // processor's flow (upload -> gather -> K1 -> ...).
+        cs->upload_pending = true;
+        cs->upload_bytes = (used + 15) & ~(size_t)15;
     } else {
         SH_HIP(hipMemcpyAsync(cs->d_scan_blob, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
         SH_HIP(hipEventRecord(cs->ev_scan, cs->ctx->stream));
+        cs->scan_in_flight = true;
     }
-    cs->scan_in_flight = true;
     cs->n_points = n;
+    return SLAMHIP_OK;
+}
+
+int32_t cs_flush_scan(slamhip_cs *cs)
+{
+    if (!cs->upload_pending) return SLAMHIP_OK;
+    cs->upload_pending = false;
+    cs->upload_seq++;
+    SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, cs->upload_bytes, (uint32_t *)cs->h_key + 30, cs->upload_seq));
+    cs->scan_in_flight = true;
     return SLAMHIP_OK;
 }
 
@@ -574,20 +593,29 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
     const int ng = sh_div_up(count, grp);
     cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);
     cs->k1_layout_dirty = true;
+    // a pending scan upload rides on the gather launch as one more workgroup
+    const int up_wg = cs->upload_pending ? 1 : 0;
+    const uint4 *up_src = nullptr; uint4 *up_dst = nullptr; int up_n16 = 0; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
+    if (up_wg) {
+        cs->upload_pending = false;
+        up_src = (const uint4 *)cs->h_scan_blob; up_dst = (uint4 *)cs->d_scan_blob; up_n16 = (int)(cs->upload_bytes / 16);
+        up_flag = (uint32_t *)cs->h_key + 30; up_seq = ++cs->upload_seq;
+        cs->scan_in_flight = true;
+    }
     if (cs->offs_on_device_sorted) {
         // flat candidates first .. first+count-1 = the un-jittered pose (flat 0) and jitters in ascending dtheta
         const int n = cs->n_offs;
         const int zero_pos = first == 0 ? (count - 1 < n / 2 ? count - 1 : n / 2) : -1;
         if (cs->gen_pending && first == 0 && count == n + 1) {
             cs->gen_pending = false;
-            hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng), dim3(1024), 0, ctx->stream,
+            hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
-                               n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream);
+                               n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream, up_src, up_dst, up_n16, up_flag, up_seq);
         } else {
             SH_TRY(flush_generate(cs));
-            hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(1024), 0, ctx->stream,
+            hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
-                               0, 0.f, 0.f, (uint64_t)0, (uint64_t)0);
+                               0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq);
         }
         // the jitters are the strata of N(0, sigma): group ranges from the quantile function (layout balance only)
         for (int g = 0; g < ng; g++) {
@@ -619,9 +647,9 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             cs->h_grp_dxy[(size_t)g] = fmaxf(hi[0] - lo[0], hi[1] - lo[1]) * cs->hscale;
         }
         SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng), dim3(1024), 0, ctx->stream,
+        hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                            cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds, grp,
-                           0, 0.f, 0.f, (uint64_t)0, (uint64_t)0);
+                           0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq);
         SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
     }
     SH_HIP(hipGetLastError());

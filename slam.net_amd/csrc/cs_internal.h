@@ -25,6 +25,8 @@ struct slamhip_cs {
     int n_points, cap_points;
     void *d_scan_blob, *h_scan_blob;  // one device block / one pinned staging block for all per-scan uploads
     hipEvent_t ev_scan; bool scan_in_flight;
+    bool upload_pending; size_t upload_bytes;   // set_scan filled the staging block; the upload is launched by the first consumer (cs_flush_scan),
+                                                // or rides on the candidate gather's launch when one comes first (ensure_shard)
     float2 *d_pts;                // original order: K2/K3 are ray-order dependent
     float2 *d_pts_sorted;         // spatially sorted copy for K1 (integer sum: any order is exact)
     int4 *d_ray_blk;              // per sorted ray: (first ray of its block, one past its last, block index, 0)
@@ -89,6 +91,8 @@ struct slamhip_cs {
 
 // distance.hip
 int32_t cs_alloc_candidates(slamhip_cs *cs, int count);
+// launches the scan upload that slamhip_cs_set_scan left pending (every launch that reads the scan calls it first)
+int32_t cs_flush_scan(slamhip_cs *cs);
 int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int count, bool want_dist, bool cand_sane,
                            uint64_t *key_dst);
 // holemap.hip

@@ -1220,6 +1220,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 {
     slamhip_ctx *ctx = cs->ctx;
     if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
+    SH_TRY(cs_flush_scan(cs));
     static const int force_global = env_int("SLAMHIP_K1_GLOBAL", 0);
     static const int verify = env_int("SLAMHIP_K1_VERIFY", 0);
     static const int tile_kb = env_int("SLAMHIP_K1_TILE_KB", 60);

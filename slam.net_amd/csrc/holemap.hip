@@ -551,6 +551,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     slamhip_ctx *ctx = cs->ctx;
     const int n = cs->n_points;
     if (n <= 0) return SLAMHIP_OK;
+    SH_TRY(cs_flush_scan(cs));
     if (n > cs->cap_rays) {
         if (cs->d_rays) (void)hipFree(cs->d_rays);
         if (cs->d_k2_cand) (void)hipFree(cs->d_k2_cand);

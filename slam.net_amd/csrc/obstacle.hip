@@ -60,6 +60,7 @@ int32_t cs_launch_obstacle_update(slamhip_cs *cs, const float *d_pose, float4 h_
     slamhip_ctx *ctx = cs->ctx;
     const int n = cs->n_points;
     if (n <= 0) return SLAMHIP_OK;
+    SH_TRY(cs_flush_scan(cs));
     const int cells = cs->os * cs->os;
     sh_timer t(ctx, SLAMHIP_K_CS_OBSTACLE);
     // a walk stays in the map for at most `size` iterations (one major-axis step each): iterations 0 .. size
