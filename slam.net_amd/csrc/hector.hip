@@ -50,6 +50,7 @@ struct slamhip_hs {
     int n_points, cap_points;
     float2 *d_pts; float origin[2];
     float *h_pts; hipEvent_t ev_pts; bool pts_in_flight;   // pinned staging of the scan: one async copy (or upload launch), no wait in set_scan
+    bool upload_pending; size_t upload_bytes;              // set_scan filled the staging block; the first launch that reads the points issues the upload (hs_flush_scan) -- a single match pulls the block itself
     uint32_t upload_seq;                                   // upload launches issued; the launch stores it behind the staged points (h_pts + 2 * cap) when it has read them
     float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
     // K5 line tables, per level: lines by index, lines sorted by (direction class, slope bucket), bucket starts, header
@@ -242,7 +243,8 @@ __device__ static inline void hs_step(const float sums[9], float est[3])
 template <int BDIM>
 __global__ void __launch_bounds__(BDIM)
 k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float3 hint1,
-         float *__restrict__ out, int only_level, int iters_override, uint32_t *mail, uint32_t mail_seq)
+         float *__restrict__ out, int only_level, int iters_override, uint32_t *mail, uint32_t mail_seq,
+         const float2 *up_src, float2 *up_dst, uint32_t *up_flag, uint32_t up_seq)
 {
     __shared__ double red[16 * 9 + 9];
     const int b = blockIdx.x;
@@ -250,10 +252,25 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
     if (hints) { est_w[0] = hints[3 * b]; est_w[1] = hints[3 * b + 1]; est_w[2] = hints[3 * b + 2]; }
     const bool pre_ok = n <= HS_PRE * BDIM;
     float2 pre[HS_PRE];
+    if (up_src) {
+        // A single match on a freshly set scan (one workgroup, n <= HS_PRE * BDIM): the points come straight from the pinned
+        // staging block -- this launch IS the scan upload.  Every lane keeps its points in registers for the iterations and
+        // stores them to the device copy for the launches that follow (grid update); the stores depend on the loads, so after
+        // the barrier the staging block has been read and the host may refill it.
 #pragma unroll
-    for (int u = 0; u < HS_PRE; u++) {
-        const int i = threadIdx.x + u * BDIM;
-        pre[u] = (pre_ok && i < n) ? pts[i] : make_float2(0.f, 0.f);
+        for (int u = 0; u < HS_PRE; u++) {
+            const int i = threadIdx.x + u * BDIM;
+            pre[u] = i < n ? up_src[i] : make_float2(0.f, 0.f);
+            if (i < n) up_dst[i] = pre[u];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(up_flag, up_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+#pragma unroll
+        for (int u = 0; u < HS_PRE; u++) {
+            const int i = threadIdx.x + u * BDIM;
+            pre[u] = (pre_ok && i < n) ? pts[i] : make_float2(0.f, 0.f);
+        }
     }
     if (n > 0) {                                                           // :66 (else: hint returned, :83)
         const int l_hi = only_level >= 0 ? only_level : A.n - 1;
@@ -810,21 +827,33 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
         hs->pts_in_flight = false;
     }
     uint32_t *up_flag = (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points);
-    if (hs->pts_in_flight) {                            // the previous copy has left the staging block
+    if (hs->upload_pending) hs->upload_pending = false; // (the staged scan was never consumed: nothing was launched, the block is ours)
+    else if (hs->pts_in_flight) {                       // the previous copy has left the staging block
         if (!hs->ctx->mail_off) SH_TRY(sh_flag_wait(hs->ctx, up_flag, hs->upload_seq));
         else SH_HIP(hipEventSynchronize(hs->ev_pts));
         hs->pts_in_flight = false;
     }
     memcpy(hs->h_pts, xy, sizeof(float) * 2 * (size_t)n);
-    if (!hs->ctx->mail_off) {                           // (see slamhip_cs_set_scan: the per-scan path is launches only)
-        hs->upload_seq++;
-        SH_TRY(sh_upload(hs->ctx, hs->h_pts, hs->d_pts, (sizeof(float) * 2 * (size_t)n + 15) & ~(size_t)15, up_flag, hs->upload_seq));
+    if (!hs->ctx->mail_off) {                           // (see slamhip_cs_set_scan: the per-scan path is launches only, and the upload is left pending)
+        hs->upload_pending = true;
+        hs->upload_bytes = (sizeof(float) * 2 * (size_t)n + 15) & ~(size_t)15;
     } else {
         SH_HIP(hipMemcpyAsync(hs->d_pts, hs->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, hs->ctx->stream));
         SH_HIP(hipEventRecord(hs->ev_pts, hs->ctx->stream));
+        hs->pts_in_flight = true;
     }
-    hs->pts_in_flight = true;
     hs->n_points = n;
+    return SLAMHIP_OK;
+}
+
+// launches the scan upload that slamhip_hs_set_scan left pending (every launch that reads the points calls it first)
+static int32_t hs_flush_scan(slamhip_hs *hs)
+{
+    if (!hs->upload_pending) return SLAMHIP_OK;
+    hs->upload_pending = false;
+    hs->upload_seq++;
+    SH_TRY(sh_upload(hs->ctx, hs->h_pts, hs->d_pts, hs->upload_bytes, (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points), hs->upload_seq));
+    hs->pts_in_flight = true;
     return SLAMHIP_OK;
 }
 
@@ -846,6 +875,15 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     SH_TRY(ensure_io(hs, 6 * B));
     float *d_in = hs->d_io, *d_out = hs->d_io + 3 * (size_t)B;
     const bool mail1 = B == 1 && !ctx->mail_off;                          // one match: the kernel itself delivers the pose to the host
+    // ... and pulls a freshly set scan from the staging block itself (k4_match): no upload launch in the per-scan chain
+    const bool pull = B == 1 && hs->upload_pending && hs->n_points > 0 && hs->n_points <= HS_PRE * 1024;
+    const float2 *up_src = nullptr; float2 *up_dst = nullptr; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
+    if (pull) {
+        hs->upload_pending = false;
+        up_src = (const float2 *)hs->h_pts; up_dst = hs->d_pts; up_flag = (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points);
+        up_seq = ++hs->upload_seq;
+        hs->pts_in_flight = true;
+    } else SH_TRY(hs_flush_scan(hs));
     if (B > 1) {
         memcpy(hs->h_io, hints, sizeof(float) * 3 * (size_t)B);
         SH_HIP(hipMemcpyAsync(d_in, hs->h_io, sizeof(float) * 3 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
@@ -857,10 +895,11 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
         if (B <= 64)
             hipLaunchKernelGGL(k4_match<1024>, dim3(B), dim3(1024), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
                                B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters,
-                               mail1 ? ctx->mailbox : (uint32_t *)nullptr, mail1 ? sh_mail_seq_next(ctx) : 0u);
+                               mail1 ? ctx->mailbox : (uint32_t *)nullptr, mail1 ? sh_mail_seq_next(ctx) : 0u, up_src, up_dst, up_flag, up_seq);
         else
             hipLaunchKernelGGL(k4_match<256>, dim3(B), dim3(256), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
-                               (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters, (uint32_t *)nullptr, 0u);
+                               (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters, (uint32_t *)nullptr, 0u,
+                               (const float2 *)nullptr, (float2 *)nullptr, (uint32_t *)nullptr, 0u);
     }
     SH_HIP(hipGetLastError());
 #ifdef K4_TIMES
@@ -915,6 +954,7 @@ extern "C" int32_t slamhip_hs_hessian(slamhip_hs *hs, int32_t level, const float
     SH_HIP(hipSetDevice(hs->ctx->device));
     slamhip_ctx *ctx = hs->ctx;
     SH_TRY(ensure_io(hs, 32));
+    SH_TRY(hs_flush_scan(hs));
     memcpy(hs->h_io, pose_map, sizeof(float) * 3);
     SH_HIP(hipMemcpyAsync(hs->d_io, hs->h_io, sizeof(float) * 3, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k4_hessian, dim3(1), dim3(256), 0, ctx->stream, levels_arg(hs), level, hs->d_pts, hs->n_points,
@@ -947,6 +987,7 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
         A.lv[l].mark_occ = L.curr_update_index + 2;                       // :117
     }
     if (n > 0) {
+        SH_TRY(hs_flush_scan(hs));
         if (n > hs->cap_lines || !hs->d_k5_hdr) {
             (void)hipFree(hs->d_k5_byidx); (void)hipFree(hs->d_k5_cand); (void)hipFree(hs->d_k5_start); (void)hipFree(hs->d_k5_hdr);
             hs->d_k5_byidx = hs->d_k5_cand = nullptr; hs->d_k5_start = hs->d_k5_hdr = nullptr; hs->cap_lines = 0;
