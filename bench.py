@@ -325,6 +325,24 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
                                                     "search_evals_per_s": 16384 / dt,
                                                     "us_to_pose_idle_device_median": float(np.median(lat)) * 1e6}
     d3.close()
+    # the same through the CoreSLAMProcessor.Update mirror (CoreSLAMProcessor.cs:717-752): host scan (polar ranges) -> cartesian
+    # cloud, sort + upload, 16 384 candidates generated on the device, search, both map updates, pose back -- 200 scans along the
+    # trajectory, the last scan's map updates inside the timed region
+    traj = sim.trajectory(80)
+    rngp = sim.PCG32(5)
+    pscans = [sim.make_scan(segs, p, 1080, rngp)[0] for p in traj]
+    proc = cs.CoreSLAMProcessor(40.0, 2048, 512, traj[0], 0.1, math.radians(10.0), 16383 // 64, 64, ctx=ctx)
+    zero = np.zeros(3, np.float32)
+    for i in range(10):
+        proc.Update([cs.ScanSegment(pscans[i], zero)])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(200):
+        proc.Update([cs.ScanSegment(pscans[10 + i % 60], zero)])
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / 200
+    out["coreslam_processor_update_2048_map_1080_rays_16384_candidates"] = {"us_per_scan": dt * 1e6, "scans_per_s": 1.0 / dt}
+    proc.Dispose()
     # C4: Hector Gauss-Newton match, 3-level 2048^2 pyramid, 1080 rays
     rep = hs.MapRepMultiMap(40.0 / 2048, (2048, 2048), 3, ctx=ctx)
     rng = sim.PCG32(3)
