@@ -55,7 +55,8 @@ namespace CoreSLAM
 
         /// <summary>Seed of the candidate generator (new: the reference seeds from entropy).</summary>
         public ulong Seed { get; set; } = 0x5EED5EEDUL;
-        /// <summary>Refresh the managed map mirrors after every Update (source compatibility; costs the PCIe copies).</summary>
+        /// <summary>Refresh the managed map mirrors after every Update (source compatibility; costs the PCIe copies, and the
+        /// downloads wait for the map updates that Update would otherwise leave running while the host prepares its next scan).</summary>
         public bool MirrorMaps { get; set; } = true;
 
         public CoreSLAMProcessor(float physicalMapSize, int holeMapSize, int obstacleMapSize, Vector3 startPose,
@@ -122,7 +123,9 @@ namespace CoreSLAM
                 }
                 scanNumber++;
                 lastOdometryPose = odometry;                                        // :745
-                // search (:732), NormalizeAngle (:746) and both map updates (:750-751): one call, one 32-byte read-back
+                // search (:732), NormalizeAngle (:746) and both map updates (:750-751): one call.  It returns when the pose is
+                // on the host; the map updates are enqueued behind the search and finish ~40 us later -- every later call that
+                // touches the maps (the next search, the mirrors' downloads below) is ordered behind them on the device
                 Native.Check(Native.slamhip_cs_search_and_update(cs.Ptr, search, HoleWidth, Quality, MaxObstacleHits,
                                                                  out Vector3 found, out _, out _));
                 Pose = found;
