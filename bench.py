@@ -9,6 +9,15 @@ all rays from LDS-staged HoleMap tiles, per-candidate accumulation and arg-min);
 per-rank packed (distance << 32 | index) keys are min-all-reduced over RCCL (one 8-byte all-reduce per step).  All inputs (map, scan, jitter list) are resident in HBM
 before the timed region.  Weak scaling: per-GPU candidates are fixed as N grows.
 
+N > 1 reports the PER-SCAN form in `value`: every step is one blocking slamhip_cs_search_allreduce -- K1, the collective and the
+hand-over of the reduced key to the host, one behind the other, because the SLAM loop needs the winner of a scan before it can
+update the maps (CoreSLAMProcessor.cs:732 -> :750).  The overlapped form (the keys of 16 steps per collective on a second
+stream, nothing waits per step) and the latency of the bare collective are measured after the timed region and reported in
+`multi_gpu`.
+
+Timed region (N = 1): barrier + device synchronise, t0, K x one C call (the launch), one event record, ONE device synchronise,
+t1 -- event creation, the first event's record and every other synchronisation sit outside.
+
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
@@ -110,25 +119,29 @@ def main():
         if world > 1:
             dist.all_reduce(key, op=dist.ReduceOp.MIN)             # one 8-byte RCCL min all-reduce per step
 
-    # N > 1: the library's own communicator (slamhip_comm_*): a step is ONE C call -- K1 on the operator's stream; the packed
-    # keys of 16 consecutive steps are min-all-reduced in one RCCL call on the communicator's stream behind one event, so the
-    # following searches overlap the collective and no interpreter / c10d work sits between them (per step: +1.3 us over a
-    # search without a collective on one rank, 25.2 -> 23.2 us against one collective per step).  It is checked against
-    # the torch.distributed path on this very workload first; any failure or disagreement on any rank falls back to
-    # that path (SLAMHIP_BENCH_COLLECTIVE=torch forces it; "lib1" exercises the library path on a single rank).
+    def step_torch_per_scan():                                     # ... and the reduced key on the host before the next step
+        step_torch()
+        return int(key.item())
+
+    # N > 1: the library's own communicator (slamhip_comm_*).  It is checked against the torch.distributed path on this very
+    # workload first -- the blocking per-scan call and the asynchronous batched one; any failure or disagreement on any rank
+    # falls back to torch.distributed (SLAMHIP_BENCH_COLLECTIVE=torch forces it; "lib1" exercises the library path on one rank).
     coll = os.environ.get("SLAMHIP_BENCH_COLLECTIVE", "lib")
     comm = None
     collective = "none"
+    collective_ranks = 1
     if (world > 1 and backend == "nccl" and coll == "lib") or (world == 1 and coll == "lib1"):
         ok = 1
         try:
             comm = D.LibComm(ctx, rank, world)
+            k_sync = comm.search_allreduce(dev, base, first, count)
             lib_step = comm.bind_step(dev, base, first, count)
             lib_step()
             k_lib = comm.wait()
             step_torch()
             ctx.synchronize(); torch.cuda.synchronize()
-            ok = int(k_lib == int(key.item()))
+            ok = int(k_lib == int(key.item()) and k_sync == k_lib)
+            collective_ranks = comm.info()[1]
         except Exception as e:                                     # noqa: BLE001 -- any failure means "use the torch path"
             print("bench.py: library communicator unavailable on rank %d (%s); using torch.distributed" % (rank, e), file=sys.stderr)
             ok = 0
@@ -139,12 +152,18 @@ def main():
         if not ok and comm is not None:
             comm.close(); comm = None
     if comm is not None:
-        step = lib_step
-        collective = "rccl ncclAllReduce(min, uint64): one 8-byte key per step, the keys of 16 steps per call, issued by libslamhip on its own stream (overlaps the following searches)"
+        step = comm.bind_search_allreduce(dev, base, first, count)   # per scan: blocking, returns the reduced key
+        step_overlapped = lib_step
+        collective = ("rccl ncclAllReduce(min, uint64, 1) issued by libslamhip (slamhip_cs_search_allreduce): per scan, on the operator's "
+                      "stream behind K1, reduced key handed to the host before the next step")
+    elif world > 1:
+        step = step_torch_per_scan
+        step_overlapped = step_torch
+        collective = "%s all_reduce(min, 8 B) per scan via torch.distributed, reduced key read by the host before the next step" % ("rccl" if backend == "nccl" else backend)
+        collective_ranks = dist.get_world_size()
     else:
         step = step_torch
-        if world > 1:
-            collective = "%s all_reduce(min, 8 B)/step via torch.distributed" % ("rccl" if backend == "nccl" else backend)
+        step_overlapped = None
 
     def sync_all():
         ctx.synchronize()
@@ -152,44 +171,75 @@ def main():
             comm.synchronize()
         torch.cuda.synchronize()
 
+    final_key = None
     for _ in range(max(a.warmup, 1)):
-        step()
+        final_key = step()
     sync_all()
-    # K1's average launch duration for the roofline figure.  A step is exactly one K1 launch, so two HIP events on the
-    # operator's stream around the timed region give it without touching the region (per-launch event pairs cost ~8 us per
-    # step on this stack and would depress `value`) -- at N = 1, and at N > 1 when the library issues the collective on its
-    # own stream (the operator's stream then carries K1 launches only).  With the torch.distributed path the stream also
-    # carries the all-reduce, so K1 is timed per launch in a short pass AFTER the timed region instead.
-    two_events = (world == 1 or comm is not None) and not a.no_kernel_timing
+    # K1's average launch duration for the roofline figure.  At N = 1 a step is exactly one K1 launch, so two HIP events on the
+    # operator's stream around the timed region give it (per-launch event pairs cost ~8 us per step on this stack and would
+    # depress `value`); the first is recorded BEFORE t0.  At N > 1 the timed region's stream also carries the collective and the
+    # hand-over, so K1 is timed in the overlapped pass after the region (library path: the operator's stream carries K1 only)
+    # or per launch in a short pass of its own (torch.distributed path).
+    two_events = world == 1 and not a.no_kernel_timing
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    if world > 1:
-        dist.barrier()
-    sync_all()
     # (the interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a full collection is a
     # pause of tens of milliseconds -- it once landed in a loop of 100 blocking calls and read as 440 us per call instead of 70)
     gc.collect()
     gc.disable()
-    t0 = time.perf_counter()
-    if two_events:
-        with torch.cuda.stream(ext):
-            ev0.record()
-    for _ in range(a.steps):
-        step()
-    if two_events:
-        with torch.cuda.stream(ext):
-            ev1.record()
-    sync_all()
     if world > 1:
         dist.barrier()
     sync_all()
+    if two_events:
+        ev0.record(ext)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        final_key = step()
+    if two_events:
+        ev1.record(ext)
+    torch.cuda.synchronize()                # (the whole device: the library's streams included)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if comm is None:
+        final_key = int(key.item())
     k1_ms, k1_n = (0.0, 0)
-    if not a.no_kernel_timing:
-        if two_events:
-            k1_ms, k1_n = ev0.elapsed_time(ev1), a.steps
-        else:
+    k1_how = "two HIP events on the operator's stream around the timed region"
+    if two_events:
+        k1_ms, k1_n = ev0.elapsed_time(ev1), a.steps
+    multi = None
+    if world > 1 or comm is not None:
+        # ---- after the timed region: the overlapped form, K1's launch time, the bare collective ----------------------
+        n_ov = max(a.steps, 100)
+        if comm is not None:
+            comm.set_batch(16)
+        for _ in range(5):
+            step_overlapped()
+        sync_all()
+        if world > 1:
+            dist.barrier()
+        sync_all()
+        gc.disable()
+        ev_ok = comm is not None and not a.no_kernel_timing
+        if ev_ok:
+            ev0.record(ext)
+        t1 = time.perf_counter()
+        for _ in range(n_ov):
+            step_overlapped()
+        if ev_ok:
+            ev1.record(ext)
+        sync_all()
+        if world > 1:
+            dist.barrier()
+        dt_ov = time.perf_counter() - t1
+        gc.enable()
+        if ev_ok:
+            k1_ms, k1_n = ev0.elapsed_time(ev1), n_ov
+            k1_how = "two HIP events on the operator's stream around the overlapped pass (that stream carries K1 launches only)"
+        elif not a.no_kernel_timing:
+            k1_how = "per-launch HIP event pairs, 50 launches after the timed region"
             ctx.timing_reset()
             ctx.timing_enable(1 << capi.K_CS_DISTANCE)
             for _ in range(50):
@@ -197,11 +247,31 @@ def main():
             sync_all()
             k1_ms, k1_n = ctx.timing_get(capi.K_CS_DISTANCE)
             ctx.timing_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_key = comm.wait() if comm is not None else int(key.item())
+        ar_us = None
+        if comm is not None:
+            ar_us = comm.allreduce_probe(200)
+        elif world > 1:                                            # the torch.distributed collective, events on torch's stream
+            for _ in range(3):
+                dist.all_reduce(key, op=dist.ReduceOp.MIN)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(100):
+                dist.all_reduce(key, op=dist.ReduceOp.MIN)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_us = e0.elapsed_time(e1) * 1e3 / 100
+        if world > 1:
+            t = torch.tensor([elapsed, dt_ov, ar_us if ar_us is not None else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, dt_ov, ar_max = float(t[0].item()), float(t[1].item()), float(t[2].item())
+            ar_us = ar_max if ar_us is not None else None
+        multi = {"per_scan_us_per_step": elapsed / a.steps * 1e6,
+                 "overlapped_us_per_step": dt_ov / n_ov * 1e6, "overlapped_evals_per_s": float(K_total) * n_ov / dt_ov,
+                 "overlapped_steps": n_ov,
+                 "overlapped_form": ("keys of 16 steps per ncclAllReduce on the communicator's own stream behind one event" if comm is not None
+                                     else "search + all_reduce enqueued per step, nothing read back per step"),
+                 "allreduce_us": ar_us, "collective_ranks": collective_ranks}
 
     if rank == 0:
         evals = float(K_total) * a.steps
@@ -211,10 +281,14 @@ def main():
         if k1_n > 0:
             avg_s = (k1_ms / k1_n) * 1e-3
             achieved = a.cands * bytes_per_eval / avg_s / 1e9
+            traffic, traffic_src = pmc_traffic(a)
+            peak_m, peak_src = measured_peak()
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(a), "peak_measured": measured_peak(),
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                    "peak_measured": peak_m, "peak_measured_source": peak_src,
                     "kernel": "k1_search_tiled", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
-                    "bytes_per_launch": a.cands * bytes_per_eval}
+                    "bytes_per_launch": a.cands * bytes_per_eval,
+                    "timing": k1_how}
         out = {
             "metric": "candidate-pose distance evals/sec on 2048^2 map, 1080-ray scan, 1/2/4/8 GPU",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -223,20 +297,28 @@ def main():
             "config": {"workload": "CoreSLAM Monte-Carlo distance search, %dx%d HoleMap, %d rays, %d candidates/GPU/step"
                                    % (a.size, a.size, a.rays, a.cands),
                        "map": a.size, "rays": a.rays, "candidates_per_gpu": a.cands, "candidates_total": K_total,
-                       "collective": collective,
+                       "collective": collective, "collective_ranks": collective_ranks,
+                       "timed_region": ("%d steps, each one launch; one device synchronise inside" % a.steps) if world == 1 else
+                                       ("%d steps, each K1 + all-reduce + reduced key back on the host (per scan)" % a.steps),
                        "best_index": final_key & 0xFFFFFFFF, "best_distance": final_key >> 32},
             "roofline": roof,
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
+        checks = []
         if world == 1 and not a.no_extras:
             # the other configurations of BASELINE.json and larger candidate counts, measured in this very process AFTER the
-            # timed region (they are not part of `value`): a few seconds in all
+            # timed region (they are not part of `value`): a few seconds in all.  `checks` collects, per configuration, the
+            # inputs and the GPU's answer; the CPU leg below compares them with the oracle (the only place it is used).
             try:
-                out["other_workloads"] = other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval)
+                out["other_workloads"] = other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks)
             except Exception as e:                                 # noqa: BLE001 -- extras must never cost the headline line
                 out["other_workloads"] = {"error": repr(e)}
             gc.enable()
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs, final_key)
+            out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs, final_key, checks)
+            if "other_workloads" in out and "error" not in out["other_workloads"]:
+                out["other_workloads"]["winners_match_oracle"] = out["cpu_baseline"].pop("other_workloads_match", None)
         print(json.dumps(out))
         sys.stdout.flush()
     if comm is not None:
@@ -247,7 +329,7 @@ def main():
         dist.destroy_process_group()
 
 
-def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
+def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
     """Secondary figures, same process, after the headline's timed region: the headline search at larger candidate counts
     (the launch is latency-bound at 16 384 candidates: these show the kernel's throughput), and BASELINE.json's other
     configurations -- C2 (1024^2 map, 16 384 candidates), C3 (search + HoleMap / ObstacleMap update fused, one blocking
@@ -290,22 +372,43 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
             d.update_holemap(p, 0.6, 50)
         _, s_xy = sim.make_scan(segs, traj[-1], rays, rng)
         d.set_scan(s_xy)
+        d._bench_xy = s_xy                                         # (kept for the parity records)
         return d, (traj[-1] + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
 
+    def search_check(name, d, pose, offs):
+        """the blocking search's answer + everything the CPU leg needs to repeat it with the oracle"""
+        _, dist_, idx_ = d.search(pose)
+        checks.append({"name": name, "pix": d.holemap_download(), "size": d.hole_size, "scale": d.hole_scale, "xy": d._bench_xy,
+                       "base": pose, "offs": offs, "gpu": (int(idx_), int(dist_))})
+
     d2, b2 = mapped(1024)
-    d2.set_offsets(sim.gaussian_offsets(16383, 0.1, math.radians(10.0), seed=42))
+    o2 = sim.gaussian_offsets(16383, 0.1, math.radians(10.0), seed=42)
+    d2.set_offsets(o2)
     out["c2_search_1024_map_16384_candidates"] = time_search(d2, b2, 16384, 200)
+    search_check("c2", d2, b2, o2)
     d2.close()
+    # C5: 262 144 candidates over 8 GPUs on a 4096^2 map = 32 768 per GPU: rank 0's block of the flat list is timed, and the
+    # min over the eight blocks' keys (this GPU playing every rank in turn) is the winner the CPU leg checks
     d5, b5 = mapped(4096)
-    d5.set_offsets(sim.gaussian_offsets(32767, 0.1, math.radians(10.0), seed=42))
+    o5 = sim.gaussian_offsets(262143, 0.1, math.radians(10.0), seed=42)
+    d5.set_offsets(o5)
     out["c5_one_gpu_share_4096_map_32768_candidates"] = time_search(d5, b5, 32768, 100)
+    keys5 = [d5.search_shard(b5, 32768 * r, 32768) for r in range(8)]
+    k5 = min(keys5)
+    checks.append({"name": "c5_8_shards_of_262144", "pix": d5.holemap_download(), "size": d5.hole_size, "scale": d5.hole_scale, "xy": d5._bench_xy,
+                   "base": b5, "offs": o5, "gpu": (int(k5 & 0xFFFFFFFF), int(k5 >> 32))})
     d5.close()
     # C3: one call per scan = search (16 384 candidates) + HoleMap update + ObstacleMap update.  The call returns when the
     # winner's pose is back (K1's final arriver delivers it); the map updates are enqueued behind the search and run on, and
     # the next call's search is ordered behind them.  us_per_scan: 100 calls back to back INCLUDING the last call's updates
     # (synchronised inside the timed region); us_to_pose: one call on an idle device, until it returns.
     d3, b3 = mapped(2048)
-    d3.set_offsets(sim.gaussian_offsets(16383, 0.1, math.radians(10.0), seed=42))
+    o3 = sim.gaussian_offsets(16383, 0.1, math.radians(10.0), seed=42)
+    d3.set_offsets(o3)
+    pix_before = d3.holemap_download()
+    pose3, dist3, idx3 = d3.search_and_update(b3)                  # the first fused scan, kept for the CPU leg's check
+    checks.append({"name": "c3_fused", "pix": pix_before, "size": d3.hole_size, "scale": d3.hole_scale, "xy": d3._bench_xy, "base": b3,
+                   "offs": o3, "gpu": (int(idx3), int(dist3)), "pose": np.asarray(pose3, np.float32), "pix_after": d3.holemap_download()})
     for _ in range(5):
         d3.search_and_update(b3)
     ctx.synchronize()
@@ -321,9 +424,31 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval):
         d3.search_and_update(b3)
         lat.append(time.perf_counter() - t1)
     ctx.synchronize()
+    # the same with the host mirrors a source-compatible C# shim keeps (HoleMap.Pixels is read directly, HoleMap.cs:27,
+    # Simulation/MainWindow.xaml.cs:229): after every scan the HoleMap rectangle the scan touched (slamhip_cs_holemap_mirror) and
+    # the whole ObstacleMap come back -- and, for comparison, the whole HoleMap (8 MiB at 2048^2)
+    mirror = d3.holemap_download()
+    d3.holemap_mirror(mirror)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        d3.search_and_update(b3)
+        rect = d3.holemap_mirror(mirror)
+        d3.obstaclemap_download()
+    ctx.synchronize()
+    dt_m = (time.perf_counter() - t0) / 50
+    t0 = time.perf_counter()
+    for _ in range(20):
+        d3.search_and_update(b3)
+        d3.holemap_download()
+        d3.obstaclemap_download()
+    ctx.synchronize()
+    dt_f = (time.perf_counter() - t0) / 20
+    mirror_ok = bool((mirror == d3.holemap_download()).all())
     out["c3_fused_search_and_map_updates_2048"] = {"us_per_scan": dt * 1e6, "scans_per_s": 1.0 / dt,
                                                     "search_evals_per_s": 16384 / dt,
-                                                    "us_to_pose_idle_device_median": float(np.median(lat)) * 1e6}
+                                                    "us_to_pose_idle_device_median": float(np.median(lat)) * 1e6,
+                                                    "us_per_scan_with_mirror": dt_m * 1e6, "us_per_scan_with_full_downloads": dt_f * 1e6,
+                                                    "mirror_rect_x0_y0_x1_y1": list(rect), "mirror_equals_full_download": mirror_ok}
     d3.close()
     # the same through the CoreSLAMProcessor.Update mirror (CoreSLAMProcessor.cs:717-752): host scan (polar ranges) -> cartesian
     # cloud, sort + upload, 16 384 candidates generated on the device, search, both map updates, pose back -- 200 scans along the
@@ -389,10 +514,10 @@ def pmc_traffic(a):
                 t = json.load(f)
             w = t["workload"]
             if (w["map"], w["rays"], w["candidates_per_gpu"]) == (a.size, a.rays, a.cands):
-                return int(t["hbm_bytes_per_launch_gfx950_corrected"])
+                return int(t["hbm_bytes_per_launch_gfx950_corrected"]), "replayed from %s (a separate rocprofv3 --pmc run of this command, not this run)" % os.path.relpath(path, ROOT)
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def measured_peak():
@@ -400,16 +525,22 @@ def measured_peak():
     the ceiling the hardware delivers, next to the 8 TB/s specification `peak` is quoted from.  GB/s or null."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_hbm_probe.json")) as f:
-            return float(json.load(f)["4_GiB"]["sum_GBps_read"])
+            return float(json.load(f)["4_GiB"]["sum_GBps_read"]), "replayed from profiles/r01_hbm_probe.json (tools/hbm_probe.py, round 1; not measured in this run)"
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(a, dev, xy, base, offs, gpu_key):
+def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=()):
     """The reference's ParallelWorker-structured CPU search (oracle/cpu_baseline.c, kind = "port": the C#
-    reference cannot run here) on the SAME map / scan / candidates, bounded to ~a.cpu_seconds of CPU work."""
+    reference cannot run here) on the SAME map / scan / candidates, bounded to ~a.cpu_seconds of CPU work at
+    T = min(nproc, 64) threads, plus short runs at T = 1 and T = 4 and BASELINE.json's config C1 (400^2 map,
+    360 rays, 1000 iterations per thread; Simulation/MainWindow.xaml.cs:69) at T = 1, 4, nproc.
+    `value` is total evaluations / total seconds of the long run (the mean; thread wake-ups make a few scans
+    slow: the per-scan median is reported beside it).  This is also where the GPU's winners are compared with
+    the oracle: the headline's and those of the other configurations (`checks`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c as oc
+    import slam.net_amd.sim as sim
     oc.set_trig_mode(oc.TRIG_DET)
     pix = dev.holemap_download()
     # WaitHandle.WaitAll caps the reference's ParallelWorker at 64 threads (BaseSLAM/ParallelWorker.cs:115)
@@ -426,11 +557,60 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key):
     # parity spot-check on the full candidate list of the GPU step (single oracle pass, ~0.1 s)
     rbi, _, rbd, _ = oc.search(pix, dev.hole_size, dev.hole_scale, xy, base, offs)
     same = bool(((rbd << 32) | rbi) == gpu_key)
+
+    def short_run(pix_, size_, scale_, xy_, base_, offs_, T_, iters_, seconds):
+        s_, e_, _, _ = oc.cpu_baseline_search(pix_, size_, scale_, xy_, base_, offs_, T_, iters_, 3)        # warm-up: 3 scans
+        sc = max(int(seconds / max(s_ / 3, 1e-6)), 20)
+        s_, e_, _, _, per_ = oc.cpu_baseline_search_timed(pix_, size_, scale_, xy_, base_, offs_, T_, iters_, sc)
+        return {"evals_per_s": e_ / s_, "median_scan": (e_ / sc) / float(np.median(per_)), "scans": sc, "seconds": round(s_, 2),
+                "iterations_per_thread": iters_}
+
+    sweep = {}
+    for Ts in (1, 4):
+        if Ts < T:
+            sweep["T%d" % Ts] = short_run(pix, dev.hole_size, dev.hole_scale, xy, base, offs, Ts, max(n // Ts // 16, 1), 2.5)
+    # config C1: the reference's own CPU-runnable case -- map built by 30 oracle mapping updates (the GPU plays no part)
+    c1 = {}
+    try:
+        size1, R1, it1 = 400, 360, 1000
+        scale1 = size1 / 40.0
+        pix1 = np.full(size1 * size1, 32750, np.uint16)
+        segs = sim.default_field()
+        rng = sim.PCG32(1234)
+        traj = sim.trajectory(31)
+        for p in traj[:-1]:
+            _, xy1 = sim.make_scan(segs, p, R1, rng)
+            oc.update_holemap(pix1, size1, scale1, xy1, p, 0.6, 50)
+        _, xy1 = sim.make_scan(segs, traj[-1], R1, rng)
+        base1 = (traj[-1] + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
+        for Ts in sorted(set([1, 4, T])):
+            offs1 = sim.gaussian_offsets(Ts * it1, 0.1, math.radians(10.0), seed=42)
+            c1["T%d" % Ts] = short_run(pix1, size1, scale1, xy1, base1, offs1, Ts, it1, 2.5)
+    except Exception as e:                                         # noqa: BLE001
+        c1 = {"error": repr(e)}
+    # the other configurations' winners (bench.other_workloads collected the inputs and the GPU's answers)
+    match = {}
+    for c in checks:
+        try:
+            obi, opose, obd, _ = oc.search(c["pix"], c["size"], c["scale"], c["xy"], c["base"], c["offs"])
+            ok = (int(obi), int(obd)) == c["gpu"]
+            if "pose" in c:                                        # fused search + update: pose and the HoleMap after the update
+                opose[2] = oc.normalize_angle(opose[2])
+                ok = ok and bool((np.asarray(opose, np.float32) == c["pose"]).all())
+                ref = c["pix"].copy()
+                oc.update_holemap(ref, c["size"], c["scale"], c["xy"], opose)
+                ok = ok and bool((ref == c["pix_after"]).all())
+            match[c["name"]] = bool(ok)
+        except Exception as e:                                     # noqa: BLE001
+            match[c["name"]] = repr(e)
     return {"value": evals2 / secs2, "unit": "evals/s", "cores": T, "kind": "port",
             "sample": "%d scans x %d threads x (%d jitters + base) on the same map/scan/candidates, %.1f s"
                       % (scans, T, iters, secs2),
+            "value_is": "mean over the sample (total evaluations / total seconds); median_scan and p95_scan are per-scan rates",
             "median_scan": (evals2 / scans) / float(np.median(per)), "p95_scan": (evals2 / scans) / float(np.percentile(per, 95)),
-            "argmin_matches_gpu": same}
+            "argmin_matches_gpu": same,
+            "threads_sweep_headline": sweep, "c1_400_map_360_rays_1000_iterations_per_thread": c1,
+            "other_workloads_match": match}
 
 
 if __name__ == "__main__":

@@ -55,8 +55,10 @@ namespace CoreSLAM
 
         /// <summary>Seed of the candidate generator (new: the reference seeds from entropy).</summary>
         public ulong Seed { get; set; } = 0x5EED5EEDUL;
-        /// <summary>Refresh the managed map mirrors after every Update (source compatibility; costs the PCIe copies, and the
-        /// downloads wait for the map updates that Update would otherwise leave running while the host prepares its next scan).</summary>
+        /// <summary>Refresh the managed map mirrors after every Update (source compatibility).  The HoleMap mirror copies only the
+        /// bounding rectangle of the scan just drawn (slamhip_cs_holemap_mirror), the ObstacleMap is small and comes whole; the
+        /// copies wait for the map updates that Update would otherwise leave running while the host prepares its next scan
+        /// (bench.py, other_workloads: us_per_scan_with_mirror against us_per_scan).</summary>
         public bool MirrorMaps { get; set; } = true;
 
         public CoreSLAMProcessor(float physicalMapSize, int holeMapSize, int obstacleMapSize, Vector3 startPose,
@@ -93,7 +95,7 @@ namespace CoreSLAM
             Pose = startPose;
             lastOdometryPose = Vector3.Zero;
             scanCount = 0;
-            if (MirrorMaps) { HoleMap.Download(); ObstacleMap.Download(); }
+            if (MirrorMaps) { HoleMap.Mirror(); ObstacleMap.Download(); }
         }
 
         /// <summary>Use this jitter list (n x (dx, dy, dtheta), flat thread-major order) instead of generated ones.</summary>
@@ -151,7 +153,7 @@ namespace CoreSLAM
                     Native.Check(Native.slamhip_cs_update_obstaclemap(cs.Ptr, Pose, MaxObstacleHits));         // :751
                 }
             }
-            if (MirrorMaps) { HoleMap.Download(); ObstacleMap.Download(); }
+            if (MirrorMaps) { HoleMap.Mirror(); ObstacleMap.Download(); }
         }
 
         // ScanSegmentsToCloud (:187-207): every segment's rays in the frame of the last odometry pose.

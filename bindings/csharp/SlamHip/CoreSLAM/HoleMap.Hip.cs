@@ -1,7 +1,8 @@
 // CoreSLAM.HoleMap on the GPU: the public surface of the reference class (CoreSLAM/HoleMap.cs:10-56) with the pixels
 // living in device memory.  `Pixels` stays a managed ushort[] because callers read it directly
-// (Simulation/MainWindow.xaml.cs:229): it is a MIRROR, refreshed by Download() -- which CoreSLAMProcessor.Update calls
-// after every scan when MirrorMaps is set (the default, for source compatibility).
+// (Simulation/MainWindow.xaml.cs:229): it is a MIRROR, refreshed by Download() (everything) or Mirror() (the rectangle
+// the scans since the last refresh touched) -- CoreSLAMProcessor.Update calls Mirror() after every scan when MirrorMaps is
+// set (the default, for source compatibility).
 using System;
 using SlamHip;
 
@@ -33,6 +34,16 @@ namespace CoreSLAM
         {
             fixed (ushort* p = Pixels)
                 Native.Check(Native.slamhip_cs_holemap_download(cs.Ptr, p, (nuint)Pixels.Length));
+        }
+
+        /// <summary>Bring Pixels up to date by copying only what the updates since the last Mirror()/Download() call can have
+        /// changed: the bounding rectangle of the scans drawn (the update kernel keeps it on the device).  The whole map on the
+        /// first call and after Reset/Upload.  This is what CoreSLAMProcessor.Update calls when MirrorMaps is set.</summary>
+        public unsafe void Mirror()
+        {
+            int* rect = stackalloc int[4];
+            fixed (ushort* p = Pixels)
+                Native.Check(Native.slamhip_cs_holemap_mirror(cs.Ptr, p, (nuint)Pixels.Length, rect));
         }
 
         /// <summary>Replace the device pixels with Pixels (restoring a saved map).</summary>

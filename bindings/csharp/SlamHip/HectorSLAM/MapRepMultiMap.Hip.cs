@@ -61,21 +61,15 @@ namespace HectorSLAM.Main
             foreach (OccGridMap m in Maps) m.mirrorStale = true;
         }
 
-        // the scan most recently handed to the device: matching and updating with the same ScanCloud uploads it once
-        private ScanCloud deviceScan;
-        private int deviceScanCount = -1;
-
+        // The reference reads the scan at call time (ScanMatcher.cs:149-195, OccGridMap.cs:114-239): a caller may refill one
+        // ScanCloud in place, or change its Pose, between two calls.  Every call therefore hands the scan to the library again --
+        // slamhip_hs_set_scan is a host memcpy into a pinned staging block; the upload itself is deferred to the first kernel that
+        // reads the points, so matching and then updating with one scan still uploads it once per call pair at most.
         internal unsafe void SetScan(ScanCloud scan)
         {
-            if (ReferenceEquals(scan, deviceScan) && scan.Points.Count == deviceScanCount) return;
             fixed (Vector2* p = CollectionsMarshal.AsSpan(scan.Points))
                 Native.Check(Native.slamhip_hs_set_scan(Pyramid.Ptr, p, scan.Points.Count, new Vector2(scan.Pose.X, scan.Pose.Y)));
-            deviceScan = scan;
-            deviceScanCount = scan.Points.Count;
         }
-
-        /// <summary>Forget the cached scan (call after mutating a ScanCloud's Points in place).</summary>
-        public void InvalidateScan() => deviceScan = null;
 
         public void SetUpdateFactorFree(float factor)                    // MapRepMultiMap.cs:83-89
         {

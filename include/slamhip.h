@@ -18,7 +18,16 @@
  *     library copies in/out and never retains them.  Device memory lives behind opaque handles.
  *   - a handle is single-caller (like the reference objects: ParallelWorker.Work is "blocking,
  *     non-reentrant", BaseSLAM/ParallelWorker.cs:95); different handles may be used from different
- *     threads.  Calls block until the result is on the host unless the name ends in _async.
+ *     threads, also handles that share one slamhip_ctx: the context's completion mailbox is guarded
+ *     by a lock, so the blocking calls of such handles take turns (they share one HIP stream
+ *     anyway); give each thread its own context if they should overlap.
+ *   - calls block until their RESULT is on the host unless the name ends in _async.  Two calls
+ *     return as soon as the result the caller reads is there while work that returns nothing is
+ *     still running on the device: slamhip_cs_search_and_update / slamhip_csproc_update (back with
+ *     the pose; the two map updates run on) and slamhip_hsproc_update (the grid update runs on).
+ *     Every later call on the same context is ordered behind that work, so the caller sees the
+ *     reference's sequential semantics.  A blocking wait polls a pinned word for up to ~300 us and
+ *     then sleeps in hipStreamSynchronize.
  *   - float poses are (x [m], y [m], theta [rad]) = System.Numerics.Vector3; points are
  *     System.Numerics.Vector2 (8 B); LogOddsCell is {int32 UpdateIndex; float Value} (8 B).
  *   - there is no CPU fallback: every compute entry point launches HIP kernels on gfx950.
@@ -103,6 +112,11 @@ int32_t slamhip_cs_reset(slamhip_cs *cs, int32_t unmapped_obstacle_hits);
 /* HoleMap.Pixels (HoleMap.cs:27): ushort[Size*Size] row-major.  n_pixels must equal Size*Size. */
 int32_t slamhip_cs_holemap_upload(slamhip_cs *cs, const uint16_t *pixels, size_t n_pixels);
 int32_t slamhip_cs_holemap_download(slamhip_cs *cs, uint16_t *pixels, size_t n_pixels);
+/* Live HoleMap.Pixels (HoleMap.cs:27; callers read the array directly, Simulation/MainWindow.xaml.cs:229) at the price of what
+ * changed: copies into the caller's full-size array only the bounding rectangle of the scans drawn since the previous mirror call
+ * (everything on the first call and after reset / upload).  out_rect (optional) = {x0, y0, x1, y1} inclusive, or {0, 0, -1, -1}
+ * when nothing changed.  `pixels` must be the array the previous mirror call filled. */
+int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pixels, size_t n_pixels, int32_t out_rect[4]);
 /* HoleMap.GetPackedPixels (HoleMap.cs:44-55): 4-bit packing done on the device; n_bytes = Size*Size/2 */
 int32_t slamhip_cs_holemap_download_packed(slamhip_cs *cs, uint8_t *packed, size_t n_bytes);
 /* ObstacleMap.Pixels (ObstacleMap.cs:31): sbyte[Size,Size], [y,x] row-major */
@@ -317,6 +331,18 @@ int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_comm *comm, co
 /* Issues the collective for the steps not yet covered by one, waits for every step issued so far; *out_key (optional) = the
  * reduced key of the last one.  (A host that needs every scan's winner before the next scan calls it after every step.) */
 int32_t slamhip_comm_wait(slamhip_comm *comm, uint64_t *out_key);
+/* Steps per collective of the asynchronous form (1 .. 32; default 16).  Waits for the steps issued so far; every rank calls it
+ * at the same place. */
+int32_t slamhip_comm_set_batch(slamhip_comm *comm, int32_t steps);
+/* One sharded search step, BLOCKING -- the per-scan form: CoreSLAMProcessor.Update needs the winner (CoreSLAMProcessor.cs:732,
+ * the arg-min of :695-705) before it updates the maps (:750-751).  K1 over this rank's block, ncclAllReduce(min, uint64, 1)
+ * and the hand-over of the reduced key to the host sit on the operator's stream, one behind the other (no second stream, no
+ * event).  *out_key = min over all ranks of (distance << 32 | flat index).  Every rank makes the same call. */
+int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *comm, const float search_pose[3], int32_t first,
+                                    int32_t count, uint64_t *out_key);
+/* Latency of the exchange step alone: `iters` 8-byte min all-reduces back to back; *out_us = device microseconds per
+ * collective.  Every rank makes the same call (measurement aid for the scaling curve). */
+int32_t slamhip_comm_allreduce_probe(slamhip_comm *comm, int32_t iters, float *out_us);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,7 @@ def _declare(L):
         "slamhip_cs_holemap_upload": (i32, [vp, u16p, sz]),
         "slamhip_cs_holemap_download": (i32, [vp, u16p, sz]),
         "slamhip_cs_holemap_download_packed": (i32, [vp, u8p, sz]),
+        "slamhip_cs_holemap_mirror": (i32, [vp, u16p, sz, ip]),
         "slamhip_cs_obstaclemap_upload": (i32, [vp, i8p, sz]),
         "slamhip_cs_obstaclemap_download": (i32, [vp, i8p, sz]),
         "slamhip_cs_set_scan": (i32, [vp, fp, i32]),
@@ -139,6 +140,9 @@ def _declare(L):
         "slamhip_comm_info": (i32, [vp, ip, ip]),
         "slamhip_cs_search_allreduce_async": (i32, [vp, vp, fp, i32, i32, C.POINTER(C.c_void_p)]),
         "slamhip_comm_wait": (i32, [vp, C.POINTER(C.c_uint64)]),
+        "slamhip_comm_set_batch": (i32, [vp, i32]),
+        "slamhip_cs_search_allreduce": (i32, [vp, vp, fp, i32, i32, u64p]),
+        "slamhip_comm_allreduce_probe": (i32, [vp, i32, fp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -111,6 +111,14 @@ class CoreSlamDevice:
         capi.call("slamhip_cs_holemap_download_packed", self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size)
         return out
 
+    def holemap_mirror(self, pixels):
+        """Brings `pixels` (the uint16[Size*Size] array the previous mirror call filled) up to date in place by copying only
+        the rectangle the updates since then touched; returns (x0, y0, x1, y1) inclusive, or (0, 0, -1, -1)."""
+        assert pixels.dtype == np.uint16 and pixels.size == self.hole_size * self.hole_size and pixels.flags.c_contiguous
+        rect = np.zeros(4, np.int32)
+        capi.call("slamhip_cs_holemap_mirror", self._h, pixels.ctypes.data_as(C.POINTER(C.c_uint16)), pixels.size, capi.iptr(rect))
+        return tuple(int(v) for v in rect)
+
     def obstaclemap_upload(self, pixels):
         p = np.ascontiguousarray(pixels, np.int8).reshape(-1)
         capi.call("slamhip_cs_obstaclemap_upload", self._h, p.ctypes.data_as(C.POINTER(C.c_int8)), p.size)

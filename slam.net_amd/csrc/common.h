@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <limits.h>
+#include <pthread.h>
 #include "../../include/slamhip.h"
 
 void slamhip_set_error(const char *fmt, ...);
@@ -31,9 +32,23 @@ struct slamhip_ctx {
     // mailbox: 64 B of pinned, device-visible host memory.  A blocking call ends its launches with sh_publish (copies up
     // to 15 result words here, then stores the call's sequence number into word 15) and waits in sh_host_wait for that
     // word: no device-to-host copy, no stream synchronisation (measured: 8 us less per call than copy + hipStreamSynchronize).
+    // The mailbox and its sequence counter are shared by every operator object of the context: a call that uses them holds
+    // `mail_lock` (recursive) from the moment it takes its sequence number until it has read its result words, so handles of
+    // one context may be driven from different threads (slamhip.h) -- their blocking calls then take turns, as they do on the
+    // context's one stream anyway.
     uint32_t *mailbox; uint32_t mail_seq; bool mail_off;
+    pthread_mutex_t mail_lock;
+};
+// RAII guard of slamhip_ctx::mail_lock (see there)
+struct sh_mail_guard {
+    slamhip_ctx *ctx;
+    explicit sh_mail_guard(slamhip_ctx *c) : ctx(c) { pthread_mutex_lock(&ctx->mail_lock); }
+    ~sh_mail_guard() { pthread_mutex_unlock(&ctx->mail_lock); }
+    sh_mail_guard(const sh_mail_guard &) = delete;
+    sh_mail_guard &operator=(const sh_mail_guard &) = delete;
 };
 int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words);   // enqueue; returns after the launch
+int32_t sh_publish_seq(slamhip_ctx *ctx, const void *d_src, int n_words, uint32_t seq);   // ... with a sequence number taken earlier (sh_mail_seq_next)
 // Per-scan upload as a launch: one workgroup pulls `bytes` (a multiple of 16) from a pinned staging block over PCIe and then
 // stores `seq` into the pinned word `h_flag`; sh_flag_wait(h_flag, seq) tells the host that the staging block may be refilled.
 // (A hipMemcpyAsync right after a mailbox wait takes the runtime's slow path -- it has not seen the stream finish yet -- and the

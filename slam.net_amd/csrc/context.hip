@@ -1,6 +1,7 @@
 // context.hip -- library / context entry points of include/slamhip.h (gfx950 only).
 #include "common.h"
 #include <stdlib.h>
+#include <time.h>
 
 static thread_local char g_err[512] = "";
 
@@ -47,6 +48,13 @@ extern "C" int32_t slamhip_ctx_create(int32_t device, slamhip_ctx **out)
         SH_FAIL(SLAMHIP_ERR_HIP, "context creation failed (stream / pinned mailbox): %s", hipGetErrorString(e));
     }
     memset(c->mailbox, 0, 64);
+    {
+        pthread_mutexattr_t at;
+        pthread_mutexattr_init(&at);
+        pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&c->mail_lock, &at);
+        pthread_mutexattr_destroy(&at);
+    }
     c->mail_off = getenv("SLAMHIP_NO_HOSTWAIT") && atoi(getenv("SLAMHIP_NO_HOSTWAIT"));
     *out = c;
     return SLAMHIP_OK;
@@ -62,6 +70,7 @@ extern "C" int32_t slamhip_ctx_destroy(slamhip_ctx *c)
     free(c->pending); free(c->pool);
     (void)hipStreamDestroy(c->stream);
     if (c->mailbox) (void)hipHostFree(c->mailbox);
+    pthread_mutex_destroy(&c->mail_lock);
     free(c);
     return SLAMHIP_OK;
 }
@@ -92,8 +101,12 @@ __global__ void k_publish(const uint32_t *__restrict__ src, int n_words, uint32_
 
 int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words)
 {
+    return sh_publish_seq(ctx, d_src, n_words, sh_mail_seq_next(ctx));
+}
+
+int32_t sh_publish_seq(slamhip_ctx *ctx, const void *d_src, int n_words, uint32_t seq)
+{
     SH_CHECK_ARG(n_words >= 0 && n_words <= 15 && (d_src || n_words == 0));
-    const uint32_t seq = sh_mail_seq_next(ctx);
     if (ctx->mail_off) {                                           // (SLAMHIP_NO_HOSTWAIT=1: the copy + synchronise form)
         if (n_words > 0) SH_HIP(hipMemcpyAsync(ctx->mailbox, d_src, sizeof(uint32_t) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
         return SLAMHIP_OK;
@@ -117,20 +130,30 @@ int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes
     return SLAMHIP_OK;
 }
 
+// Waits until *flag has reached `val` (sequence numbers only grow: the comparison is wrap-safe, and a later number that
+// landed first also ends the wait).  The host polls the pinned word for up to ~300 us -- a blocking call's device latency is
+// tens of microseconds, and a stream synchronisation costs 15-20 us on this stack -- and then hands the wait to
+// hipStreamSynchronize: a long-running or faulted stream no longer pins a core or is reported late.
+static inline bool sh_flag_reached(volatile uint32_t *flag, uint32_t val)
+{
+    return (int32_t)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - val) >= 0;
+}
 int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val)
 {
-    for (long spins = 0;; spins++) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return SLAMHIP_OK;
-        if ((spins & 0xfffff) == 0xfffff) {                        // every ~million polls: is the stream in trouble, or idle without the word?
-            const hipError_t e = hipStreamQuery(ctx->stream);
-            if (e == hipSuccess) {
-                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return SLAMHIP_OK;
-                SH_FAIL(SLAMHIP_ERR_HIP, "the stream is idle but the completion word never arrived");
-            }
-            if (e != hipErrorNotReady) SH_HIP(e);
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spins = 1;; spins++) {
+        if (sh_flag_reached(flag, val)) return SLAMHIP_OK;
+        if ((spins & 0x3ff) == 0) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 300000L) break;
         }
         __builtin_ia32_pause();
     }
+    SH_HIP(hipStreamSynchronize(ctx->stream));                     // (reports a device fault)
+    if (sh_flag_reached(flag, val)) return SLAMHIP_OK;
+    SH_FAIL(SLAMHIP_ERR_HIP, "the stream is idle but the completion word never arrived");
 }
 
 int32_t sh_host_wait(slamhip_ctx *ctx)

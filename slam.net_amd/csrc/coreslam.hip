@@ -201,6 +201,7 @@ extern "C" int32_t slamhip_cs_reset(slamhip_cs *cs, int32_t unmapped)
     hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, cs->ctx->stream, cs->d_hole, n,
                        (uint16_t)((0 + 65500) / 2));                       // :169 (TS_OBSTACLE + TS_NO_OBSTACLE) / 2
     SH_HIP(hipMemsetAsync(cs->d_obst, (int)(uint8_t)(int8_t)unmapped, (size_t)cs->os * cs->os, cs->ctx->stream)); // :170
+    SH_TRY(cs_holemap_dirty_set(cs, true));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     return SLAMHIP_OK;
 }
@@ -211,6 +212,7 @@ extern "C" int32_t slamhip_cs_holemap_upload(slamhip_cs *cs, const uint16_t *pix
     SH_CHECK_ARG(cs && pix && n == (size_t)cs->hs * cs->hs);
     SH_HIP(hipSetDevice(cs->ctx->device));
     SH_HIP(hipMemcpyAsync(cs->d_hole, pix, n * sizeof(uint16_t), hipMemcpyHostToDevice, cs->ctx->stream));
+    SH_TRY(cs_holemap_dirty_set(cs, true));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     return SLAMHIP_OK;
 }
@@ -222,6 +224,33 @@ extern "C" int32_t slamhip_cs_holemap_download(slamhip_cs *cs, uint16_t *pix, si
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     return SLAMHIP_OK;
 }
+// Live `HoleMap.Pixels` (HoleMap.cs:27; read directly by Simulation/MainWindow.xaml.cs:229) at the price of what changed: every
+// HoleMap update leaves the bounding square of its scan in a device-side dirty rectangle; this call fetches the rectangle, copies
+// only those rows and columns into the caller's full-size array and rests the rectangle.  `pix` must be the array the previous
+// mirror call (or a full download) filled; the first call after create / reset / upload copies the whole map.
+extern "C" int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pix, size_t n, int32_t out_rect[4])
+{
+    SH_CHECK_ARG(cs && pix && n == (size_t)cs->hs * cs->hs);
+    slamhip_ctx *ctx = cs->ctx;
+    SH_HIP(hipSetDevice(ctx->device));
+    int r[4];
+    {
+        sh_mail_guard lock(ctx);
+        SH_TRY(sh_publish(ctx, cs->d_hole_dirty, 4));
+        SH_TRY(cs_holemap_dirty_set(cs, false));                   // (behind the publish on the stream; later updates are behind this)
+        SH_TRY(sh_host_wait(ctx));
+        memcpy(r, (const void *)ctx->mailbox, sizeof(r));
+    }
+    if (r[2] >= r[0] && r[3] >= r[1]) {
+        const size_t pitch = (size_t)cs->hs * sizeof(uint16_t), ofs = (size_t)r[1] * cs->hs + (size_t)r[0];
+        SH_HIP(hipMemcpy2DAsync(pix + ofs, pitch, cs->d_hole + ofs, pitch, (size_t)(r[2] - r[0] + 1) * sizeof(uint16_t), (size_t)(r[3] - r[1] + 1),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        SH_HIP(hipStreamSynchronize(ctx->stream));
+    } else { r[0] = r[1] = 0; r[2] = r[3] = -1; }
+    if (out_rect) memcpy(out_rect, r, sizeof(r));
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_cs_holemap_download_packed(slamhip_cs *cs, uint8_t *packed, size_t n_bytes)
 {
     SH_CHECK_ARG(cs && packed && n_bytes == ((size_t)cs->hs * cs->hs) / 2);
@@ -407,9 +436,10 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
 int32_t cs_flush_scan(slamhip_cs *cs)
 {
     if (!cs->upload_pending) return SLAMHIP_OK;
+    // (the upload state is committed once the launch that carries it is in the stream: on an error the scan stays pending)
+    SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, cs->upload_bytes, (uint32_t *)cs->h_key + 30, cs->upload_seq + 1));
     cs->upload_pending = false;
     cs->upload_seq++;
-    SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, cs->upload_bytes, (uint32_t *)cs->h_key + 30, cs->upload_seq));
     cs->scan_in_flight = true;
     return SLAMHIP_OK;
 }
@@ -418,6 +448,7 @@ int32_t cs_flush_scan(slamhip_cs *cs)
 static int32_t finish_distance(slamhip_cs *cs, int K, int32_t *out_dist, int32_t *out_best_index, int32_t *out_best_dist)
 {
     slamhip_ctx *ctx = cs->ctx;
+    sh_mail_guard lock(ctx);
     uint64_t key;
     if (out_dist) {
         SH_HIP(hipMemcpyAsync(cs->h_key, cs->d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -596,11 +627,9 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
     // a pending scan upload rides on the gather launch as one more workgroup
     const int up_wg = cs->upload_pending ? 1 : 0;
     const uint4 *up_src = nullptr; uint4 *up_dst = nullptr; int up_n16 = 0; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
-    if (up_wg) {
-        cs->upload_pending = false;
+    if (up_wg) {                                                   // (committed below, once the gather launch is in the stream)
         up_src = (const uint4 *)cs->h_scan_blob; up_dst = (uint4 *)cs->d_scan_blob; up_n16 = (int)(cs->upload_bytes / 16);
-        up_flag = (uint32_t *)cs->h_key + 30; up_seq = ++cs->upload_seq;
-        cs->scan_in_flight = true;
+        up_flag = (uint32_t *)cs->h_key + 30; up_seq = cs->upload_seq + 1;
     }
     if (cs->offs_on_device_sorted) {
         // flat candidates first .. first+count-1 = the un-jittered pose (flat 0) and jitters in ascending dtheta
@@ -650,9 +679,15 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                            cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds, grp,
                            0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq);
+        const hipError_t le = hipGetLastError();
+        if (le == hipSuccess && up_wg) { cs->upload_pending = false; cs->upload_seq = up_seq; cs->scan_in_flight = true; }
+        SH_HIP(le);
         SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
+        cs->shard_first = first; cs->shard_count = count;
+        return SLAMHIP_OK;
     }
     SH_HIP(hipGetLastError());
+    if (up_wg) { cs->upload_pending = false; cs->upload_seq = up_seq; cs->scan_in_flight = true; }
     cs->shard_first = first; cs->shard_count = count;
     return SLAMHIP_OK;
 }
@@ -679,16 +714,18 @@ extern "C" int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float pose[3], 
 {
     SH_CHECK_ARG(cs && out_key);
     slamhip_ctx *ctx = cs->ctx;
+    sh_mail_guard lock(ctx);
     if (!ctx->mail_off) {
         // the launch ends with the key and the completion word into the mailbox (tiled kernel), or a publish launch
-        // follows the fallback kernels
-        cs->k1_done_flag = ctx->mailbox + 15; cs->k1_done_val = ctx->mail_seq + 1;
+        // follows the fallback kernels.  The sequence number is taken when the kernel is armed: the value K1 stores is the value
+        // waited for, whatever publishes in between; the fallback's publish launch reuses it.
+        const uint32_t seq = sh_mail_seq_next(ctx);
+        cs->k1_done_flag = ctx->mailbox + 15; cs->k1_done_val = seq;
         const int32_t rc = search_enqueue(cs, pose, first, count, cs->d_key);
         cs->k1_done_flag = nullptr;
         SH_TRY(rc);
-        if (cs->k1_done_armed) (void)sh_mail_seq_next(ctx);
-        else SH_TRY(sh_publish(ctx, cs->d_key, 2));
-        SH_TRY(sh_host_wait(ctx));
+        if (!cs->k1_done_armed) SH_TRY(sh_publish_seq(ctx, cs->d_key, 2, seq));
+        SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));
         *out_key = *(volatile uint64_t *)ctx->mailbox;
         return SLAMHIP_OK;
     }
@@ -744,6 +781,7 @@ static float4 pxcs_from_pose(const float pose[3], float scale)
 
 static int32_t finish_holemap(slamhip_cs *cs)
 {
+    sh_mail_guard lock(cs->ctx);
     SH_TRY(sh_publish(cs->ctx, cs->d_k2_counters, 4));
     SH_TRY(sh_host_wait(cs->ctx));
     const int *m = (const int *)cs->ctx->mailbox;                           // [0] longest ray, [1] conflict pixels, [2] blended pixels
@@ -776,6 +814,7 @@ extern "C" int32_t slamhip_cs_update_obstaclemap_pxcs(slamhip_cs *cs, const floa
     SH_CHECK_ARG(cs && pxcs && max_hits >= -128 && max_hits <= 127);
     SH_HIP(hipSetDevice(cs->ctx->device));
     if (cs->n_points <= 0) return SLAMHIP_OK;
+    sh_mail_guard lock(cs->ctx);
     SH_TRY(cs_launch_obstacle_update(cs, nullptr, make_float4(pxcs[0], pxcs[1], pxcs[2], pxcs[3]), max_hits));
     SH_TRY(sh_publish(cs->ctx, nullptr, 0));
     return sh_host_wait(cs->ctx);
@@ -850,13 +889,14 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     // one result block comes back after the updates instead.
     static const bool wait_updates = getenv("SLAMHIP_FUSED_WAIT_UPDATES") != nullptr;      // (the former behaviour, for comparison)
     const bool early = !ctx->mail_off && ctx->timing == 0 && !wait_updates;
-    if (early) { cs->k1_done_flag = ctx->mailbox + 15; cs->k1_done_val = ctx->mail_seq + 1; }
+    sh_mail_guard lock(ctx);
+    const uint32_t seq = sh_mail_seq_next(ctx);                    // (taken when K1 is armed; the result block's publish reuses it otherwise)
+    if (early) { cs->k1_done_flag = ctx->mailbox + 15; cs->k1_done_val = seq; }
     cs->k1_want_pose = true;
     const int32_t rc_s = search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key);
     cs->k1_want_pose = false; cs->k1_done_flag = nullptr;
     SH_TRY(rc_s);
     const bool delivered = early && cs->k1_done_armed && cs->k1_pose_written;
-    if (delivered) (void)sh_mail_seq_next(ctx);
     if (!cs->k1_pose_written)                                    // (fallback search kernels: decode the key in a launch of its own)
         hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
                            cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);
@@ -873,13 +913,15 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
         if (rc_u == SLAMHIP_OK) rc_u = cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits);
     }
     if (delivered) {
-        SH_TRY(sh_host_wait(ctx));                               // (the search's word arrives whatever became of the update launches)
+        SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));       // (the search's word arrives whatever became of the update launches)
         SH_TRY(rc_u);
         cs->hole_pixels_pending = true;
     } else {
         SH_TRY(rc_u);
-        SH_TRY(sh_publish(ctx, cs->d_key, 8));
-        SH_TRY(sh_host_wait(ctx));
+        // (K1 armed but without the pose -- it then stored `seq` with the key alone: the result block follows under a fresh number)
+        const uint32_t seq2 = early && cs->k1_done_armed ? sh_mail_seq_next(ctx) : seq;
+        SH_TRY(sh_publish_seq(ctx, cs->d_key, 8, seq2));
+        if (ctx->mail_off) SH_TRY(sh_host_wait(ctx)); else SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq2));
         cs->last_hole_pixels = ((const int *)ctx->mailbox)[6]; cs->hole_pixels_pending = false;
     }
     const volatile uint64_t *hk = (const volatile uint64_t *)ctx->mailbox;

@@ -81,6 +81,7 @@ struct slamhip_cs {
     int *d_k2_start;                            // [4 x 1024 + 1] first table entry of every bucket
     int *d_k2_counters;           // [0] longest ray, [1] conflict pixels, [2] blended pixels, [3] x1, [4] y1
     int *d_conflict_pix; int cap_conflict;
+    int *d_hole_dirty;            // [4] x0, y0, x1, y1 (inclusive): pixels the HoleMap updates may have changed since the last slamhip_cs_holemap_mirror
     int64_t last_hole_pixels;
     bool hole_pixels_pending;     // ... still on the device (d_key word 6): slamhip_cs_search_and_update returned with the pose, the updates run on
 
@@ -97,6 +98,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                            uint64_t *key_dst);
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);
+int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all);   // the dirty rectangle := the whole map / empty (enqueued on the operator's stream)
 void    cs_holemap_free(slamhip_cs *cs);
 int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality, int32_t max_hits);
 int32_t cs_update_maps_finish(slamhip_cs *cs);

@@ -221,6 +221,8 @@ struct slamhip_comm {
     unsigned long long *d_sig;                     // HSA signal memory: the search kernel stores the step number, the collectives' stream waits for it
     bool by_value;
     uint64_t *h_key;                               // pinned
+    uint64_t *d_sync_key;                          // the blocking step's key (slamhip_cs_search_allreduce)
+    bool async_dirty;                              // asynchronous steps issued since the last slamhip_comm_wait
 };
 
 static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
@@ -257,7 +259,7 @@ extern "C" int32_t slamhip_comm_destroy(slamhip_comm *c)
     if (c->comm) c->api.CommDestroy(c->comm);
     for (int i = 0; i < SH_COMM_SLOTS; i++) { if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]); if (c->ev_ar[i]) (void)hipEventDestroy(c->ev_ar[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    (void)hipFree(c->d_keys);
+    (void)hipFree(c->d_keys); (void)hipFree(c->d_sync_key);
     if (c->d_sig) (void)hipFree(c->d_sig);
     if (c->h_key) (void)hipHostFree(c->h_key);
     if (c->api.lib) dlclose(c->api.lib);
@@ -289,6 +291,7 @@ extern "C" int32_t slamhip_comm_create(slamhip_ctx *ctx, const uint8_t unique_id
         if (e == hipSuccess) e = hipMalloc(&c->d_keys, sizeof(uint64_t) * SH_COMM_SLOTS);
         if (e == hipSuccess) e = hipMemset(c->d_keys, 0xFF, sizeof(uint64_t) * SH_COMM_SLOTS);
         if (e == hipSuccess) e = hipHostMalloc(&c->h_key, 64);
+        if (e == hipSuccess) e = hipMalloc(&c->d_sync_key, 16);
         for (int i = 0; i < SH_COMM_SLOTS && e == hipSuccess; i++) {
             e = hipEventCreateWithFlags(&c->ev_k1[i], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ar[i], hipEventDisableTiming);
@@ -365,6 +368,7 @@ extern "C" int32_t slamhip_cs_search_allreduce_async(slamhip_cs *cs, slamhip_com
     } else SH_HIP(hipMemsetAsync(key, 0xFF, sizeof(uint64_t), main));                                   // (a rank without candidates: the neutral key)
     if (c->by_value && !signalled) SH_HIP(hipStreamWriteValue64(main, c->d_sig, c->step + 1, 0));        // (fallback kernels, empty shard)
     c->step++;
+    c->async_dirty = true;
     if (c->step % (uint64_t)c->batch == 0) SH_TRY(comm_flush(c));
     if (d_out_key) *d_out_key = key;
     return SLAMHIP_OK;
@@ -383,7 +387,74 @@ extern "C" int32_t slamhip_comm_wait(slamhip_comm *c, uint64_t *out_key)
     }
     SH_HIP(hipStreamSynchronize(c->stream));
     SH_HIP(hipStreamSynchronize(c->ctx->stream));
+    c->async_dirty = false;
     if (out_key) *out_key = *c->h_key;
+    return SLAMHIP_OK;
+}
+
+// Steps per collective of the asynchronous form (1 .. 32, rounded down to a divisor of 32; default 16 or SLAMHIP_COMM_BATCH).
+// Waits for the steps issued so far first; every rank must make the same call at the same place.
+extern "C" int32_t slamhip_comm_set_batch(slamhip_comm *c, int32_t steps)
+{
+    SH_CHECK_ARG(c && steps >= 1);
+    SH_TRY(slamhip_comm_wait(c, nullptr));
+    int v = steps > SH_COMM_BATCH_MAX ? SH_COMM_BATCH_MAX : steps;
+    while (SH_COMM_BLOCK % v) v--;
+    // (a batch never wraps the ring of key slots: restart the step count at a batch boundary -- every slot is idle after the wait)
+    c->step = c->flushed = 0;
+    for (int i = 0; i < SH_COMM_SLOTS; i++) c->ar_pending[i] = false;
+    if (c->by_value) *c->d_sig = 0ull;
+    c->batch = v;
+    return SLAMHIP_OK;
+}
+
+// One sharded search step, BLOCKING: the per-scan form of the SLAM loop, which needs the winner before it can update the maps
+// (CoreSLAMProcessor.cs:732 -> :750).  Nothing can overlap the exchange here, so everything sits on the operator's stream --
+// K1 over this rank's block, ncclAllReduce(min, uint64, 1) behind it (no event, no second stream), then the publish launch that
+// hands the reduced key to the host through the context's mailbox.  *out_key = the reduced key.  Every rank makes the same call.
+extern "C" int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *c, const float pose[3], int32_t first, int32_t count,
+                                               uint64_t *out_key)
+{
+    SH_CHECK_ARG(cs && c && pose && out_key && cs->ctx == c->ctx && count >= 0);
+    slamhip_ctx *ctx = c->ctx;
+    SH_HIP(hipSetDevice(ctx->device));
+    if (c->async_dirty) SH_TRY(slamhip_comm_wait(c, nullptr));    // (collectives of one communicator are issued from one stream at a time)
+    sh_mail_guard lock(ctx);
+    if (count > 0) SH_TRY(slamhip_cs_search_shard_async(cs, pose, first, count, c->d_sync_key));
+    else SH_HIP(hipMemsetAsync(c->d_sync_key, 0xFF, sizeof(uint64_t), ctx->stream));                     // (a rank without candidates: the neutral key)
+    SH_NCCL(c, c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, ctx->stream));
+    SH_TRY(sh_publish(ctx, c->d_sync_key, 2));
+    SH_TRY(sh_host_wait(ctx));
+    *out_key = *(volatile uint64_t *)ctx->mailbox;
+    return SLAMHIP_OK;
+}
+
+// Latency of the exchange step alone: `iters` 8-byte min all-reduces back to back on the communicator's stream between two
+// events; *out_us = microseconds per collective (device time, no search in front).  Every rank makes the same call.
+extern "C" int32_t slamhip_comm_allreduce_probe(slamhip_comm *c, int32_t iters, float *out_us)
+{
+    SH_CHECK_ARG(c && iters >= 1 && out_us);
+    SH_HIP(hipSetDevice(c->ctx->device));
+    SH_TRY(slamhip_comm_wait(c, nullptr));
+    hipEvent_t a = nullptr, b = nullptr;
+    SH_HIP(hipEventCreate(&a));
+    hipError_t e = hipEventCreate(&b);
+    if (e != hipSuccess) { (void)hipEventDestroy(a); SH_HIP(e); }
+    int32_t rc = SLAMHIP_OK;
+    (void)hipMemsetAsync(c->d_sync_key, 0xFF, 16, c->stream);
+    for (int w = 0; w < 3 && rc == SLAMHIP_OK; w++)                // (warm-up: RCCL sets up its channels on first use)
+        if (c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, c->stream) != ncclSuccess) rc = SLAMHIP_ERR_RCCL;
+    (void)hipEventRecord(a, c->stream);
+    for (int i = 0; i < iters && rc == SLAMHIP_OK; i++)
+        if (c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, c->stream) != ncclSuccess) rc = SLAMHIP_ERR_RCCL;
+    (void)hipEventRecord(b, c->stream);
+    e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (rc != SLAMHIP_OK) SH_FAIL(SLAMHIP_ERR_RCCL, "ncclAllReduce failed in the latency probe");
+    SH_HIP(e);
+    *out_us = ms * 1000.0f / (float)iters;
     return SLAMHIP_OK;
 }
 

@@ -850,9 +850,10 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
 static int32_t hs_flush_scan(slamhip_hs *hs)
 {
     if (!hs->upload_pending) return SLAMHIP_OK;
+    // (the upload state is committed once the launch that carries it is in the stream: on an error the scan stays pending)
+    SH_TRY(sh_upload(hs->ctx, hs->h_pts, hs->d_pts, hs->upload_bytes, (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points), hs->upload_seq + 1));
     hs->upload_pending = false;
     hs->upload_seq++;
-    SH_TRY(sh_upload(hs->ctx, hs->h_pts, hs->d_pts, hs->upload_bytes, (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points), hs->upload_seq));
     hs->pts_in_flight = true;
     return SLAMHIP_OK;
 }
@@ -872,17 +873,16 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
 {
     SH_HIP(hipSetDevice(hs->ctx->device));
     slamhip_ctx *ctx = hs->ctx;
+    sh_mail_guard lock(ctx);                                              // (the mailbox is the context's: common.h)
     SH_TRY(ensure_io(hs, 6 * B));
     float *d_in = hs->d_io, *d_out = hs->d_io + 3 * (size_t)B;
     const bool mail1 = B == 1 && !ctx->mail_off;                          // one match: the kernel itself delivers the pose to the host
     // ... and pulls a freshly set scan from the staging block itself (k4_match): no upload launch in the per-scan chain
     const bool pull = B == 1 && hs->upload_pending && hs->n_points > 0 && hs->n_points <= HS_PRE * 1024;
     const float2 *up_src = nullptr; float2 *up_dst = nullptr; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
-    if (pull) {
-        hs->upload_pending = false;
+    if (pull) {                                                           // (committed below, once the launch is in the stream)
         up_src = (const float2 *)hs->h_pts; up_dst = hs->d_pts; up_flag = (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points);
-        up_seq = ++hs->upload_seq;
-        hs->pts_in_flight = true;
+        up_seq = hs->upload_seq + 1;
     } else SH_TRY(hs_flush_scan(hs));
     if (B > 1) {
         memcpy(hs->h_io, hints, sizeof(float) * 3 * (size_t)B);
@@ -902,6 +902,7 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
                                (const float2 *)nullptr, (float2 *)nullptr, (uint32_t *)nullptr, 0u);
     }
     SH_HIP(hipGetLastError());
+    if (pull) { hs->upload_pending = false; hs->upload_seq = up_seq; hs->pts_in_flight = true; }
 #ifdef K4_TIMES
     {
         static int calls = 0;
@@ -1031,6 +1032,8 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
 
 extern "C" int32_t slamhip_hs_update_by_scan(slamhip_hs *hs, const float pose[3])
 {
+    SH_CHECK_ARG(hs);
+    sh_mail_guard lock(hs->ctx);
     SH_TRY(hs_update_enqueue(hs, pose));
     SH_TRY(sh_publish(hs->ctx, nullptr, 0));
     return sh_host_wait(hs->ctx);

@@ -228,7 +228,7 @@ __device__ static inline bool k2_hit(const k2_cand c, int a, int b)
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
            k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, int *__restrict__ start,
-           int *__restrict__ counters, int *__restrict__ total_out, const k3_ride ride)
+           int *__restrict__ counters, int *__restrict__ total_out, int *__restrict__ dirty, const k3_ride ride)
 {
     if (blockIdx.x > 0) {                                          // riding along: the ray walks of the ObstacleMap update
         k3_rays_unit((blockIdx.x - 1) * 16 + (threadIdx.x >> 6), threadIdx.x & 63, ride.pts, ride.n_points, ride.size, ride.scale,
@@ -300,7 +300,14 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     if (t == 0) {
         counters[0] = s_R; counters[1] = 0; counters[2] = s_total;
         if (total_out) *total_out = s_total;
-        counters[3] = sh_f2i(q.x); counters[4] = sh_f2i(q.y);
+        const int x1 = sh_f2i(q.x), y1 = sh_f2i(q.y);
+        counters[3] = x1; counters[4] = y1;
+        // the pixels this update can change lie in the scan's bounding square (the pixel kernel's very bounds): the partial
+        // host mirror (slamhip_cs_holemap_mirror) copies the union of these squares since its last call
+        if (dirty && s_total > 0 && x1 >= 0 && x1 < size && y1 >= 0 && y1 < size) {
+            dirty[0] = min(dirty[0], max(x1 - s_R, 0)); dirty[1] = min(dirty[1], max(y1 - s_R, 0));
+            dirty[2] = max(dirty[2], min(x1 + s_R, size - 1)); dirty[3] = max(dirty[3], min(y1 + s_R, size - 1));
+        }
     }
 }
 
@@ -532,13 +539,21 @@ int32_t cs_holemap_alloc(slamhip_cs *cs)
     SH_HIP(hipMalloc(&cs->d_k2_start, sizeof(int) * (4 * K2_NBUCK + 1)));
     cs->cap_conflict = (int)(npix < (1u << 22) ? npix : (1u << 22));
     SH_HIP(hipMalloc(&cs->d_conflict_pix, sizeof(int) * (size_t)cs->cap_conflict));
+    SH_HIP(hipMalloc(&cs->d_hole_dirty, sizeof(int) * 4));
+    return cs_holemap_dirty_set(cs, true);
+}
+
+int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all)
+{
+    SH_HIP(hipMemsetD32Async((hipDeviceptr_t)cs->d_hole_dirty, all ? 0 : cs->hs, 2, cs->ctx->stream));
+    SH_HIP(hipMemsetD32Async((hipDeviceptr_t)(cs->d_hole_dirty + 2), all ? cs->hs - 1 : -1, 2, cs->ctx->stream));
     return SLAMHIP_OK;
 }
 
 void cs_holemap_free(slamhip_cs *cs)
 {
     (void)hipFree(cs->d_rays); (void)hipFree(cs->d_k2_cand); (void)hipFree(cs->d_k2_vprof); (void)hipFree(cs->d_k2_start);
-    (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_conflict_pix);
+    (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_conflict_pix); (void)hipFree(cs->d_hole_dirty);
 }
 
 // ride != nullptr: the ObstacleMap update (prepared by cs_obstacle_ride) travels in the same two launches
@@ -565,7 +580,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     }
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
     hipLaunchKernelGGL(k2_prepare, dim3(1 + ride_rays), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, ride);
+                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty, ride);
     // One round of resident workgroups (a second round would start when the first drains: measured 51 -> 42 us at
     // 2048^2 together with the per-workgroup work counter): what the occupancy calculator says fits, times the CUs.
     static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;

@@ -83,6 +83,39 @@ class LibComm:
             capi.check(fn(*args))
         return step
 
+    def search_allreduce(self, dev, pose, first, count):
+        """One sharded search step, blocking (the per-scan form): K1, the 8-byte min all-reduce and the hand-over of the reduced
+        key on the operator's stream; returns the reduced key."""
+        k = C.c_uint64()
+        capi.call("slamhip_cs_search_allreduce", dev._h, self._h, capi.fptr(np.ascontiguousarray(pose, np.float32)), int(first), int(count), C.byref(k))
+        return int(k.value)
+
+    def bind_search_allreduce(self, dev, pose, first, count):
+        """The blocking step with its arguments bound once: a zero-argument function returning the reduced key."""
+        self._pose_b = np.ascontiguousarray(pose, np.float32)
+        k = C.c_uint64()
+        args = (dev._h, self._h, capi.fptr(self._pose_b), int(first), int(count), C.byref(k))
+        fn = capi.lib().slamhip_cs_search_allreduce
+
+        def step():
+            capi.check(fn(*args))
+            return int(k.value)
+        return step
+
+    def set_batch(self, steps):
+        capi.call("slamhip_comm_set_batch", self._h, int(steps))
+
+    def allreduce_probe(self, iters=200):
+        """Device microseconds per 8-byte min all-reduce (no search in front); every rank calls it."""
+        us = C.c_float()
+        capi.call("slamhip_comm_allreduce_probe", self._h, int(iters), C.byref(us))
+        return float(us.value)
+
+    def info(self):
+        r, n = C.c_int32(), C.c_int32()
+        capi.call("slamhip_comm_info", self._h, C.byref(r), C.byref(n))
+        return int(r.value), int(n.value)
+
     def wait(self):
         """Waits for every step issued so far; returns the reduced key of the last one."""
         k = C.c_uint64()

@@ -625,3 +625,284 @@ def test_lib_comm_single_rank(cs_mod, ctx, sim):
     finally:
         comm.close()
         dev.close()
+
+
+# ---- round 3: the BASELINE configurations at their own sizes, the host mirror, threads, two GPUs -------------------------
+def _mapped_dev(cs_mod, ctx, sim, size, R, updates, osize=None):
+    segs = sim.default_field()
+    dev = cs_mod.CoreSlamDevice(ctx, 40.0, size, osize or max(size // 4, 1))
+    rng = sim.PCG32(1234)
+    traj = sim.trajectory(updates + 1)
+    for p in traj[:-1]:
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy)
+        dev.update_holemap(p, 0.6, 50)
+    _, xy = sim.make_scan(segs, traj[-1], R, rng)
+    base = (traj[-1] + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
+    return dev, segs, rng, xy, base
+
+
+def test_c5_4096_map_262144_candidates_eight_shards(cs_mod, ctx, det, sim):
+    """BASELINE config C5 at its own size: 4096^2 HoleMap, 1080 rays, 262 144 candidates in eight blocks of 32 768 (one per
+    GPU of the 8-GPU configuration; this GPU plays every rank in turn).  Every distance of rank 0's block, every block's key and
+    the min over the eight keys -- what the RCCL min all-reduce delivers -- equal the oracle's single search of the whole list."""
+    oc = det
+    size, R, K, n = 4096, 1080, 262144, 8
+    dev, segs, rng, xy, base = _mapped_dev(cs_mod, ctx, sim, size, R, 10)
+    pix = dev.holemap_download()
+    offs = sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=42)
+    dev.set_scan(xy)
+    dev.set_offsets(offs)
+    rbi, rpose, rbd, rall = oc.search(pix, size, dev.hole_scale, xy, base, offs)
+    keys = []
+    for r in range(n):
+        first, count = K * r // n, K * (r + 1) // n - K * r // n
+        assert count == 32768
+        k = dev.search_shard(base, first, count)
+        blk = rall[first:first + count]
+        j = int(np.argmin(blk))                                    # (first strictly smaller wins: argmin returns the first minimum)
+        assert (k >> 32, k & 0xFFFFFFFF) == (int(blk[j]), first + j), r
+        keys.append(k)
+    pose, dist, idx = dev.pose_from_key(base, min(keys))
+    assert idx == rbi and dist == rbd and (pose == rpose).all()
+    # every distance of one GPU's share (rank 0's block: the base pose and the first 32 767 jitters)
+    poses = np.vstack([base[None], base[None] + offs[:32767]]).astype(np.float32)
+    d, bi, bd = dev.distance_poses(poses)
+    assert (d == rall[:32768]).all()
+    assert dev.selfcheck_failures == 0
+    dev.close()
+
+
+def test_c3_fused_at_bench_size(cs_mod, ctx, det, sim):
+    """BASELINE config C3 as bench.py times it: the fused search + HoleMap / ObstacleMap update at 2048^2 with 1080 rays and
+    16 384 candidates, four consecutive scans (each search reads the map the previous call's update wrote): winner, pose and
+    both maps equal the oracle's after every scan."""
+    oc = det
+    size, osize, R, K = 2048, 512, 1080, 16384
+    dev, segs, rng, xy, base = _mapped_dev(cs_mod, ctx, sim, size, R, 12, osize)
+    ref_h = dev.holemap_download()
+    ref_o = dev.obstaclemap_download()
+    offs = sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=42)
+    dev.set_offsets(offs)
+    traj = sim.trajectory(18)
+    est = base.copy()
+    for i in range(4):
+        if i > 0:
+            _, xy = sim.make_scan(segs, traj[12 + i], R, rng)
+        dev.set_scan(xy)
+        search = (est + np.array([0.01 * i, -0.005 * i, 0.002 * i], np.float32)).astype(np.float32)
+        pose, dist, idx = dev.search_and_update(search, 0.6, 50, 10)
+        rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, search, offs)
+        rpose[2] = oc.normalize_angle(rpose[2])
+        assert idx == rbi and dist == rbd and (pose == rpose).all(), i
+        n_px = oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose, 0.6, 50)
+        oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose, 10)
+        assert dev.last_holemap_pixels == n_px
+        assert (dev.holemap_download() == ref_h).all(), i
+        assert (dev.obstaclemap_download() == ref_o).all(), i
+        est = np.asarray(pose, np.float32)
+    dev.close()
+
+
+def test_holemap_partial_mirror(cs_mod, ctx, sim):
+    """slamhip_cs_holemap_mirror (live HoleMap.Pixels at the price of what changed): after every update the mirror -- brought up
+    to date by copying the scan's bounding rectangle only -- equals a full download; the rectangle is smaller than the map; a
+    second call without an update copies nothing; reset and upload make everything dirty again."""
+    size, R = 1024, 720
+    segs = sim.default_field()
+    dev = make_dev(cs_mod, ctx, size, 64)
+    rng = sim.PCG32(8)
+    mirror = np.zeros(size * size, np.uint16)
+    assert dev.holemap_mirror(mirror) == (0, 0, size - 1, size - 1)           # first call: everything
+    assert (mirror == 32750).all()
+    assert dev.holemap_mirror(mirror) == (0, 0, -1, -1)
+    small = 0
+    for k, p in enumerate(sim.trajectory(10, step=(0.35, 0.2, 0.05))):
+        pose = (p + np.array([-6.0 + k, 4.0 - k, 0.0], np.float32)).astype(np.float32)     # wander: the rectangles move
+        _, xy = sim.make_scan(segs, pose, R, rng)
+        dev.set_scan(xy * (0.35 if k % 3 == 0 else 1.0))                      # (some short scans: small rectangles)
+        dev.update_holemap(pose, 0.6, 50)
+        if k % 2:                                                              # sometimes two updates between mirror calls: the union
+            dev.update_holemap((pose + np.array([1.5, -1.0, 0.3], np.float32)).astype(np.float32), 0.6, 50)
+        x0, y0, x1, y1 = dev.holemap_mirror(mirror)
+        assert 0 <= x0 <= x1 < size and 0 <= y0 <= y1 < size
+        small += (x1 - x0 + 1) * (y1 - y0 + 1) < size * size
+        assert (mirror == dev.holemap_download()).all(), k
+    assert small > 0
+    # the fused call's update marks its rectangle too
+    dev.set_offsets(sim.gaussian_offsets(255))
+    dev.search_and_update(np.array([20.0, 20.0, 0.0], np.float32), 0.6, 50, 10)
+    dev.holemap_mirror(mirror)
+    assert (mirror == dev.holemap_download()).all()
+    dev.reset()
+    assert dev.holemap_mirror(mirror) == (0, 0, size - 1, size - 1) and (mirror == 32750).all()
+    up = np.arange(size * size, dtype=np.uint32).astype(np.uint16)
+    dev.holemap_upload(up)
+    assert dev.holemap_mirror(mirror) == (0, 0, size - 1, size - 1) and (mirror == up).all()
+    dev.close()
+
+
+def test_two_handles_one_context_two_threads(cs_mod, ctx, det, sim):
+    """Handles that share a context may be driven from different threads (slamhip.h): their blocking calls deliver results
+    through the context's one mailbox, under its lock.  Two operator objects with different maps / scans / lists are hammered
+    from two threads; every call must return ITS answer."""
+    import threading
+    oc = det
+    segs = sim.default_field()
+    devs, wants, args = [], [], []
+    for t, (size, R, K) in enumerate(((256, 200, 700), (512, 360, 1500))):
+        dev = make_dev(cs_mod, ctx, size, 64)
+        rng = sim.PCG32(40 + t)
+        for p in sim.trajectory(4):
+            _, xy = sim.make_scan(segs, p, R, rng)
+            dev.set_scan(xy)
+            dev.update_holemap(p)
+        pix = dev.holemap_download()
+        base = (sim.trajectory(5)[-1] + np.array([0.02 * t, -0.01, 0.01], np.float32)).astype(np.float32)
+        _, xy = sim.make_scan(segs, base, R, rng)
+        offs = sim.gaussian_offsets(K - 1, seed=3 + t)
+        dev.set_scan(xy)
+        dev.set_offsets(offs)
+        rbi, rpose, rbd, _ = oc.search(pix, size, dev.hole_scale, xy, base, offs)
+        devs.append(dev); wants.append((rbi, rbd, rpose)); args.append(base)
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(300):
+                pose, dist, idx = devs[i].search(args[i])
+                if (idx, dist) != wants[i][:2] or not (pose == wants[i][2]).all():
+                    errors.append((i, idx, dist))
+                    return
+        except Exception as e:                                     # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    for d in devs:
+        d.close()
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_group_two_gpus(det, sim):
+    """slamhip_group_* on TWO devices (skipped on a one-GPU box): the candidates are block-sharded over the GPUs, the packed keys
+    go through one grouped ncclAllReduce(min) over xGMI, the map updates are replicated -- winner, pose and both replicas' maps
+    equal the oracle's."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import ctypes as C
+    import slam.net_amd.capi as capi
+    import slam.net_amd.coreslam as cs_mod
+    oc = det
+    size, R, K = 1024, 1080, 16384
+    segs = sim.default_field()
+    rng = sim.PCG32(77)
+    g = C.c_void_p()
+    dev_ids = (C.c_int32 * 2)(0, 1)
+    capi.call("slamhip_group_create", dev_ids, 2, C.c_float(40.0), size, 64, C.byref(g))
+    try:
+        capi.call("slamhip_group_reset", g, -5)
+        ref = np.full(size * size, 32750, np.uint16)
+        scale = size / 40.0
+        for p in sim.trajectory(6)[:-1]:
+            _, xy = sim.make_scan(segs, p, R, rng)
+            capi.call("slamhip_group_set_scan", g, capi.fptr(capi.f32(xy)), xy.shape[0])
+            capi.call("slamhip_group_update_maps", g, capi.fptr(capi.f32(p)), C.c_float(0.6), 50, 60)
+            oc.update_holemap(ref, size, scale, xy, p, 0.6, 50)
+        pose = sim.trajectory(6)[-1]
+        _, xy = sim.make_scan(segs, pose, R, rng)
+        base = (pose + np.array([0.02, -0.03, 0.01], np.float32)).astype(np.float32)
+        offs = sim.gaussian_offsets(K - 1)
+        capi.call("slamhip_group_set_scan", g, capi.fptr(capi.f32(xy)), xy.shape[0])
+        capi.call("slamhip_group_set_offsets", g, capi.fptr(capi.f32(offs)), offs.shape[0])
+        rbi, rpose, rbd, _ = oc.search(ref, size, scale, xy, base, offs)
+        for _ in range(3):
+            out_pose = np.zeros(3, np.float32)
+            dist, idx = C.c_int32(), C.c_int32()
+            capi.call("slamhip_group_search", g, capi.fptr(base), capi.fptr(out_pose), C.byref(dist), C.byref(idx))
+            assert idx.value == rbi and dist.value == rbd and (out_pose == rpose).all()
+        for r in range(2):                                         # the replicas hold the same, oracle-equal map
+            h = C.c_void_p()
+            capi.call("slamhip_group_cs", g, r, C.byref(h))
+            pix = np.empty(size * size, np.uint16)
+            capi.call("slamhip_cs_holemap_download", h, pix.ctypes.data_as(C.POINTER(C.c_uint16)), pix.size)
+            assert (pix == ref).all(), r
+    finally:
+        capi.call("slamhip_group_destroy", g)
+
+
+def test_bench_two_gpus_rccl():
+    """bench.py --gpus 2 under torch.distributed.run with RCCL (skipped on a one-GPU box): the library's communicator must be the
+    one that ran (`collective` names libslamhip, two ranks seen by RCCL), and the winner over 2 x 4096 candidates equals that of
+    one rank searching all 8192."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "20", "--warmup", "3", "--size", "1024", "--map-updates", "8", "--no-cpu-baseline"]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--cands", "4096"] + common,
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r2.returncode == 0, r2.stderr.decode(errors="replace")[-3000:]
+    j2 = json.loads([l for l in r2.stdout.decode().splitlines() if l.startswith("{")][0])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--cands", "8192", "--no-extras"] + common,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r1.returncode == 0, r1.stderr.decode(errors="replace")[-3000:]
+    j1 = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert j2["n_gpus"] == 2 and "libslamhip" in j2["config"]["collective"], j2["config"]["collective"]
+    assert j2["config"]["collective_ranks"] == 2 and j2["multi_gpu"]["collective_ranks"] == 2
+    assert (j2["config"]["best_index"], j2["config"]["best_distance"]) == (j1["config"]["best_index"], j1["config"]["best_distance"])
+    assert j2["multi_gpu"]["allreduce_us"] > 0 and j2["multi_gpu"]["overlapped_evals_per_s"] > 0 and j2["value"] > 0
+
+
+def test_lib_comm_blocking_step_single_rank(cs_mod, ctx, sim):
+    """slamhip_cs_search_allreduce (the per-scan form: K1, the collective and the key's hand-over on one stream) on a one-rank
+    communicator, mixed with the asynchronous batched form and a changed batch size: always the key of the blocking search."""
+    import slam.net_amd.distributed as D
+    size, R, K = 512, 360, 5000
+    dev = make_dev(cs_mod, ctx, size, 64)
+    segs = sim.default_field()
+    rng = sim.PCG32(5)
+    for p in sim.trajectory(6):
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy)
+        dev.update_holemap(p)
+    base = sim.trajectory(7)[-1]
+    dev.set_offsets(sim.gaussian_offsets(K - 1))
+    comm = D.LibComm(ctx, 0, 1)
+    try:
+        assert comm.info() == (0, 1)
+        for first, count in ((0, K), (K // 3, K - K // 3), (K - 1, 1)):
+            want = dev.search_shard(base, first, count)
+            assert comm.search_allreduce(dev, base, first, count) == want
+            step = comm.bind_step(dev, base, first, count)
+            for batch in (1, 16, 5):
+                comm.set_batch(batch)
+                for _ in range(7):
+                    step()
+                assert comm.search_allreduce(dev, base, first, count) == want     # (waits for the asynchronous steps first)
+                for _ in range(3):
+                    step()
+                assert comm.wait() == want
+            bstep = comm.bind_search_allreduce(dev, base, first, count)
+            assert [bstep() for _ in range(5)] == [want] * 5
+        assert comm.search_allreduce(dev, base, 0, 0) == 2 ** 64 - 1           # a rank without candidates: the neutral key
+        assert comm.allreduce_probe(20) > 0
+    finally:
+        comm.close()
+        dev.close()
