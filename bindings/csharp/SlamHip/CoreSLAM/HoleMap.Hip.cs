@@ -26,7 +26,9 @@ namespace CoreSLAM
             this.cs = cs;
             Size = sizePixels;
             Scale = scale;
-            Pixels = new ushort[sizePixels * sizePixels];
+            // (on the pinned object heap: the address never changes, so the library page-locks the array once for its partial
+            // mirror copies -- slamhip_cs_holemap_mirror)
+            Pixels = GC.AllocateArray<ushort>(sizePixels * sizePixels, pinned: true);
         }
 
         /// <summary>Refresh Pixels from the device (2 bytes per pixel over PCIe: 8 MiB at 2048 x 2048).</summary>

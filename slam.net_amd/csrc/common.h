@@ -88,3 +88,18 @@ __host__ __device__ static inline int32_t sh_wsub(int32_t a, int32_t b) { return
 __host__ __device__ static inline int32_t sh_wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 __host__ __device__ static inline int32_t sh_sign(int32_t a) { return (a > 0) - (a < 0); }
 __host__ __device__ static inline int32_t sh_abs(int32_t a) { return a < 0 ? sh_wsub(0, a) : a; }
+
+// One value for the whole wavefront, fetched by ONE lane per loop iteration (`EXPR` typically draws a work item from an LDS
+// counter).  The lane is chosen through an opaque asm, once per evaluation: with `if (lane == 0) k = ...; k = readfirstlane(k);`
+// at the head of a persistent loop whose body ends in another `if (lane == 0)` (a pixel's store), the compiler threads the tail's
+// knowledge "lane != 0" into the next iteration's head and the structuriser then lets the lanes 1..63 run ahead of lane 0 -- the
+// readfirstlane sees the wrong first lane (a zero), the wavefront re-draws the same item for ever (seen on gfx950 / ROCm 7.2
+// after an unrelated edit of the loop's body; found with rocgdb).  The asm's result cannot be correlated with `lane`.
+#define SH_WAVE_FETCH(dst, EXPR)                                                                    \
+    {                                                                                               \
+        int leader_;                                                                                \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(leader_)); \
+        int v_ = 0;                                                                                 \
+        if (leader_ == 0) v_ = (EXPR);                                                              \
+        (dst) = __builtin_amdgcn_readfirstlane(v_);                                                 \
+    }

@@ -143,6 +143,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_verify);
     (void)hipFree(cs->d_k1_gmin); (void)hipFree(cs->d_k1_acc);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
+    if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
     cs_holemap_free(cs);
     cs_obstacle_free(cs);
     delete cs;
@@ -242,9 +243,26 @@ extern "C" int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pix, size
         memcpy(r, (const void *)ctx->mailbox, sizeof(r));
     }
     if (r[2] >= r[0] && r[3] >= r[1]) {
-        const size_t pitch = (size_t)cs->hs * sizeof(uint16_t), ofs = (size_t)r[1] * cs->hs + (size_t)r[0];
-        SH_HIP(hipMemcpy2DAsync(pix + ofs, pitch, cs->d_hole + ofs, pitch, (size_t)(r[2] - r[0] + 1) * sizeof(uint16_t), (size_t)(r[3] - r[1] + 1),
-                                hipMemcpyDeviceToHost, ctx->stream));
+        // The mirror array is page-locked on its first use (a strided copy into pageable memory goes row by row through the
+        // runtime's staging buffer: 2.1 ms for a 1713 x 1713 rectangle, against 0.23 ms for the whole 2048^2 map in one piece).
+        // A managed caller keeps the array at a fixed address (pinned object heap / GCHandle), as the C# shim's HoleMap does.
+        static const bool no_reg = getenv("SLAMHIP_MIRROR_NOREG") != nullptr;
+        if (!no_reg && (cs->mirror_reg != (void *)pix || cs->mirror_reg_bytes != n * sizeof(uint16_t))) {
+            if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
+            cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0;
+            if (hipHostRegister(pix, n * sizeof(uint16_t), hipHostRegisterDefault) == hipSuccess) { cs->mirror_reg = pix; cs->mirror_reg_bytes = n * sizeof(uint16_t); }
+            else (void)hipGetLastError();                          // (not registrable: the copy below still works, slowly)
+        }
+        const size_t pitch = (size_t)cs->hs * sizeof(uint16_t);
+        const size_t rows = (size_t)(r[3] - r[1] + 1), cols = (size_t)(r[2] - r[0] + 1);
+        if (cols * 4 >= (size_t)cs->hs * 3) {                      // nearly full rows: whole rows in one linear copy
+            const size_t ofs = (size_t)r[1] * cs->hs;
+            SH_HIP(hipMemcpyAsync(pix + ofs, cs->d_hole + ofs, rows * pitch, hipMemcpyDeviceToHost, ctx->stream));
+            r[0] = 0; r[2] = cs->hs - 1;
+        } else {
+            const size_t ofs = (size_t)r[1] * cs->hs + (size_t)r[0];
+            SH_HIP(hipMemcpy2DAsync(pix + ofs, pitch, cs->d_hole + ofs, pitch, cols * sizeof(uint16_t), rows, hipMemcpyDeviceToHost, ctx->stream));
+        }
         SH_HIP(hipStreamSynchronize(ctx->stream));
     } else { r[0] = r[1] = 0; r[2] = r[3] = -1; }
     if (out_rect) memcpy(out_rect, r, sizeof(r));

@@ -81,6 +81,7 @@ struct slamhip_cs {
     int *d_k2_start;                            // [4 x 1024 + 1] first table entry of every bucket
     int *d_k2_counters;           // [0] longest ray, [1] conflict pixels, [2] blended pixels, [3] x1, [4] y1
     int *d_conflict_pix; int cap_conflict;
+    void *mirror_reg; size_t mirror_reg_bytes;   // the caller's mirror array, page-locked on first use (slamhip_cs_holemap_mirror)
     int *d_hole_dirty;            // [4] x0, y0, x1, y1 (inclusive): pixels the HoleMap updates may have changed since the last slamhip_cs_holemap_mirror
     int64_t last_hole_pixels;
     bool hole_pixels_pending;     // ... still on the device (d_key word 6): slamhip_cs_search_and_update returned with the pose, the updates run on

@@ -227,7 +227,8 @@ __device__ static inline bool k2_hit(const k2_cand c, int a, int b)
 // a valid ray blends exactly one pixel, :404,:431), [3] x1, [4] y1, [5] robot inside the map
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
-           k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, int *__restrict__ start,
+           k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, k2_vprof *__restrict__ vprof_sorted,
+           int *__restrict__ start,
            int *__restrict__ counters, int *__restrict__ total_out, int *__restrict__ dirty, const k3_ride ride)
 {
     if (blockIdx.x > 0) {                                          // riding along: the ray walks of the ObstacleMap update
@@ -245,7 +246,9 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     const float4 q = k2_pxcs(d_pose, h_pxcs, scale);
     int my_R = 0, my_total = 0;
     k2_byidx keep[2];                                              // a thread's first two rays stay in registers for the second pass (scans of up to 2048 rays)
+    k2_vprof keepv[2];
     keep[0].flags = 0; keep[1].flags = 0;
+    memset(keepv, 0, sizeof(keepv));
     for (int i = t, it = 0; i < n; i += 1024, it++) {
         const cs_ray r = k2_make_ray(pts[i], size, q, scale, hole_width);
         k2_byidx e; e.dxc = r.dxc; e.sdyc = r.smin * r.dyc; e.lim2 = r.lim2;
@@ -255,6 +258,7 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
         if (r.valid) {
             k2_vprof vp; vp.derrorv = r.derrorv; vp.incv = r.incv; vp.lim2 = r.lim2; vp.lim1 = r.lim1;
             vprof[i] = vp;
+            if (it == 0) keepv[0] = vp; else if (it == 1) keepv[1] = vp;
             const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
             const float tt = r.dxc > 0 ? (float)e.sdyc / (float)r.dxc : 0.0f;
             atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
@@ -295,6 +299,7 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
             const int pos = atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
             k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
             cand[pos] = c;
+            vprof_sorted[pos] = it == 0 ? keepv[0] : it == 1 ? keepv[1] : vprof[i];      // the V-profiles in table order, for the lane-per-pixel lookups
         }
     }
     if (t == 0) {
@@ -314,9 +319,11 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
 // One wavefront draws one pixel: lanes test the candidate rays, hits are rank-sorted by ray index and blended in that
 // order; the robot's pixel (step 0 of every ray) and its closest neighbours (more than 64 candidates) scan all rays in
 // index order.  `sval` is 64 ints of LDS private to the wavefront.
-template <typename CT>
-__device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int size, const k2_byidx *__restrict__ byidx,
-                                            const k2_vprof *__restrict__ vprof, int n_rays, CT cand, const int *start,
+// (byidx / cand / vprof_sorted: LDS when the scan's tables fit, else global; vprof: by ray index, global -- read only by the
+// all-rays scan, for a pixel inside a ray's hole zone)
+template <typename T, typename CT, typename BT, typename VT>
+__device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int size, BT byidx,
+                                            const k2_vprof *__restrict__ vprof, VT vprof_sorted, int n_rays, CT cand, const int *start,
                                             uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int lane = threadIdx.x & 63;
@@ -345,7 +352,7 @@ __device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int si
                     int x = -1;
                     if (smaj != 0) x = aa * smaj; else if (aa == 0) x = 0;
                     k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
-                    if (x == 0 ? bb == 0 : (x > 0 && k2_hit<long long>(c, x, bb))) {
+                    if (x == 0 ? bb == 0 : (x > 0 && k2_hit<T>(c, x, bb))) {
                         hit = true;
                         v = x <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[i], x);
                     }
@@ -375,7 +382,7 @@ __device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int si
         if (ci >= 0) {
             const k2_cand c = cand[ci];
             const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
-            if (k2_hit<long long>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], aa); }
+            if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof_sorted[ci], aa); }
         }
         const unsigned long long mask = __ballot(hit);
         if (mask) {
@@ -403,22 +410,185 @@ __device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int si
     if (lane == 0) map[ptr] = pix;
 }
 
-// lane per pixel over the bounding square of the scan (persistent grid; a wavefront takes 64 pixels of one row).
-// The bucket table and -- when it fits (LDS_TABLE) -- the candidate table live in LDS: a pixel's lookup is a chain of
-// dependent small reads (bucket bounds -> candidates -> map), which global-memory latency would dominate.
+// ---- the pixel kernel ------------------------------------------------------------------------------------------------
+// Work is proportional to what is DRAWN, not to the scan's bounding square (round 2 visited every pixel of the square: ~4 M
+// lanes for ~0.64 M blended pixels at 2048^2).  Two tiers around the robot, by Chebyshev distance r (step x of a ray lies at
+// r = x exactly: the walk takes at most one minor step per major step):
+//   T1  r < K2_ZONE (48)   pixel-centric, wavefronts: tens to a thousand rays cross a pixel near the robot, a handful at r = 47.
+//                          Pixels are numbered from the centre outwards (k2_ring_pixel); a wavefront takes one pixel (r < rB), two
+//                          (rB <= r < rC: 32 lanes test the candidate rays of each) or four (16 lanes each): lanes test the candidates,
+//                          hits are rank-sorted by ray index through LDS and blended in that order by the group's first lane.
+//   T3  r >= K2_ZONE       one lane per (ray, step): the lane computes its pixel from the closed form of the walk.  Beyond the step
+//                          x_free of its ray -- from which on no other ray's walk can share a pixel with it: two walks of a class
+//                          that meet at major offset x have slopes within 1 / x of each other, and x_free comes from the ray's
+//                          nearest neighbours in the slope-sorted table -- the pixel has exactly one hit and is blended at once.
+//                          Below it (and on the diagonals, where the two classes of a quadrant meet) the lane asks, like a pixel-
+//                          centric lane would, which rays draw the pixel; the lane of the LOWEST ray index among them owns it and
+//                          blends all hits in ray order, the other hitting rays' lanes drop it.  The lookup is a function of the
+//                          pixel alone, so every lane that lands on a pixel sees the same hit list and exactly one of them owns it.
+// Pixels with more hits than a T3 lane orders go to the conflict list (drawn by the last workgroup, one wavefront per pixel).
+// The bucket table, the sorted ray table, the V-profiles (in table order), the rays by index and x_free live in LDS: a pixel's
+// lookup is a chain of dependent small reads (bucket bounds -> candidates -> V-profile -> map), which global-memory latency
+// would dominate.
 #ifndef K2_LDS_RAYS
-#define K2_LDS_RAYS 3072
+#define K2_LDS_RAYS 2640               // largest scan whose tables fit the LDS: 16.4 KB of buckets + 52 B per ray + the kernel's static 4 KB <= 160 KB
 #endif
+#define K2_XF_WALK 16                  // buckets searched on either side of a ray's own for its nearest slope neighbours
+#define K2_XF_MAXPOP 8                 // a bucket with more rays than this counts as "a neighbour at distance zero"
+static_assert((K2_XF_WALK - 1) * (2.0 / K2_NBUCK) * K2_ZONE > 1.0, "no neighbour within the walk: every T3 step is free");
 #ifdef K2_TIMES
 // developer instrumentation (build with SLAMHIP_K2_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
 __device__ unsigned long long g_k2_times[512 * 8];
 #define K2_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 512) g_k2_times[blockIdx.x * 8 + (k)] = wall_clock64(); }
+__device__ unsigned long long g_k2_sub[512 * 16 * 8];   // per wavefront: [0] T1 time [1] T1 items [2] - [3] - [4] T3 time [5] T3 items [6] longest item [7] its kind * 65536 + index
+#define K2_ITEM_T0 const unsigned long long it0_ = wall_clock64();
+#define K2_ITEM_T1(kind, idx) { if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) { unsigned long long *p_ = g_k2_sub + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8; \
+        const unsigned long long d_ = wall_clock64() - it0_; p_[2 * (kind)] += d_; p_[2 * (kind) + 1] += 1; if (d_ > p_[6]) { p_[6] = d_; p_[7] = (unsigned long long)(kind) * 65536ull + (unsigned long long)((idx) & 65535); } } }
 #else
 #define K2_STAMP(k) {}
+#define K2_ITEM_T0
+#define K2_ITEM_T1(kind, idx)
 #endif
+
+// Which rays draw the pixel at offset (dx, dy) from the robot?  Up to H hits, kept sorted by ray index (compile-time
+// subscripts: the lists stay in registers); `min_ray` = the lowest hitting ray index, also when the list overflowed.
+template <typename T, int H, typename CT, typename VT>
+__device__ static inline void k2_lookup(CT cand, VT vprof_sorted, const int *start, int dx, int dy,
+                                        int (&hidx)[H], int (&hval)[H], int &nh, bool &overflow, int &min_ray)
+{
+    int cls[2], a[2], b[2];
+    const int ncls = rs_classes(dx, dy, cls, a, b);
+    nh = 0; overflow = false; min_ray = 0x7fffffff;
+    for (int k = 0; k < ncls; k++) {
+        int lo, hi;
+        rs_range(start, cls[k], a[k], b[k], 0.0f, lo, hi);
+        for (int ci = lo; ci < hi; ci++) {
+            const k2_cand c = cand[ci];
+            if (!k2_hit<T>(c, a[k], b[k])) continue;
+            min_ray = c.ray < min_ray ? c.ray : min_ray;
+            if (nh == H) { overflow = true; continue; }            // (keep scanning: the owner is the lowest index of ALL hits)
+            const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof_sorted[ci], a[k]);
+            int posn = 0;
+#pragma unroll
+            for (int s = 0; s < H; s++) if (s < nh && hidx[s] < c.ray) posn++;
+#pragma unroll
+            for (int s = H - 1; s >= 1; s--) if (s > posn && s <= nh) { hidx[s] = hidx[s - 1]; hval[s] = hval[s - 1]; }
+#pragma unroll
+            for (int s = 0; s < H; s++) if (s == posn) { hidx[s] = c.ray; hval[s] = v; }
+            nh++;
+        }
+    }
+}
+
+// pixel number i of the zone, counted from the robot's pixel outwards: ring r (Chebyshev distance r) holds the numbers
+// (2r-1)^2 .. (2r+1)^2 - 1, walked along its four sides
+__device__ static inline void k2_ring_pixel(int i, int &ddx, int &ddy)
+{
+    ddx = 0; ddy = 0;
+    if (i <= 0) return;
+    int r = (int)((sqrtf((float)i) + 1.0f) * 0.5f);
+    if ((2 * r - 1) * (2 * r - 1) > i) r--; else if ((2 * r + 1) * (2 * r + 1) <= i) r++;
+    const int o = i - (2 * r - 1) * (2 * r - 1), side = o / (2 * r), p = o - side * 2 * r;      // 8r pixels: four sides of 2r
+    ddx = side == 0 ? -r + p : side == 1 ? r : side == 2 ? r - p : -r;
+    ddy = side == 0 ? -r : side == 1 ? -r + p : side == 2 ? r : r - p;
+}
+
+// One wavefront draws G > 1 pixels (numbers pix0 .. pix0 + G - 1 of the zone), 64 / G lanes each.  A pixel with more candidates
+// than its lanes (or the robot's own pixel) sends the whole item down the one-pixel path, pixel after pixel.
+template <typename T, int G, typename CT, typename BT, typename VT>
+__device__ static inline void k2_wave_group(int pix0, int n_pix, int x1, int y1, int size, BT byidx, const k2_vprof *__restrict__ vprof,
+                                            VT vps, int n_rays, CT cand, const int *start, uint16_t *__restrict__ map, int alpha, int *sval)
+{
+    constexpr int W = 64 / G;
+    const int lane = threadIdx.x & 63, g = lane / W, l = lane - g * W;
+    int ddx, ddy;
+    k2_ring_pixel(pix0 + g, ddx, ddy);
+    const int X = x1 + ddx, Y = y1 + ddy;
+    const bool valid = pix0 + g < n_pix && X >= 0 && X < size && Y >= 0 && Y < size;
+    int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
+    int ncls = 0, nc = 0;
+    if (valid) {
+        ncls = rs_classes(ddx, ddy, cls, a, b);
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (k < ncls) { rs_range(start, cls[k], a[k], b[k], 0.0f, lo[k], hi[k]); nc += hi[k] - lo[k]; }
+    }
+    if (__ballot(valid && (ncls == 0 || nc > W)) != 0ull) {
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) {
+            const int Xg = __builtin_amdgcn_readlane(X, gg * W), Yg = __builtin_amdgcn_readlane(Y, gg * W);
+            const int vg = __builtin_amdgcn_readlane(valid ? 1 : 0, gg * W);
+            if (vg) k2_wave_pixel<T>(Xg, Yg, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval);
+        }
+        return;
+    }
+    const int ptr = Y * size + X;
+    uint16_t pix = 0;
+    if (valid && l == 0) pix = map[ptr];                           // requested now, needed after the ranking
+    int ci = -1, kk = 0;
+    if (l < hi[0] - lo[0]) { ci = lo[0] + l; kk = 0; }
+    else if (ncls > 1 && l - (hi[0] - lo[0]) < hi[1] - lo[1]) { ci = lo[1] + l - (hi[0] - lo[0]); kk = 1; }
+    bool hit = false;
+    int idx = 0x7fffffff, v = 0;
+    if (ci >= 0) {
+        const k2_cand c = cand[ci];
+        const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
+        if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[ci], aa); }
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0ull) return;
+    int rank = 0;
+    for (unsigned long long m = mask; m; m &= m - 1) {             // rank among the hits of the lane's own pixel
+        const int src = __ffsll((long long)m) - 1;
+        const int oi = __builtin_amdgcn_readlane(idx, src);
+        rank += (hit && (src / W) == g && oi < idx) ? 1 : 0;
+    }
+    if (hit) sval[g * W + rank] = v;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long gm = (W == 32 ? 0xffffffffull : 0xffffull) << (g * W);
+    const int nh = __popcll(mask & gm);
+    if (valid && l == 0 && nh > 0) {
+        bool stable = false;
+        int last_v = 0;
+        for (int k0 = 0; k0 < nh; k0 += 4) {                       // (four values per LDS read: the read's latency is the loop's)
+            const int4 q = *(const int4 *)&sval[g * W + k0];
+            const int vv4[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (k0 + k < nh && !(stable && vv4[k] == last_v)) {
+                const uint16_t np = k2_blend(pix, vv4[k], alpha);
+                stable = np == pix; pix = np; last_v = vv4[k];
+            }
+        }
+        map[ptr] = pix;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// smallest slope distance between ray `ci` (slope tt) and the other rays of bucket `bucket` (absolute bucket number), or `gap`
+// if that is smaller; a crowded bucket counts as distance zero
+__device__ static inline float k2_bucket_gap(const int *start, const k2_cand *cand_s, int bucket, int ci, float tt, float gap)
+{
+    const int lo = start[bucket], hi = start[bucket + 1];
+    if (hi - lo > K2_XF_MAXPOP) return 0.0f;
+    for (int j = lo; j < hi; j++) if (j != ci) {
+        const k2_cand o = cand_s[j];
+        const float to = o.dxc > 0 ? (float)o.sdyc / (float)o.dxc : 0.0f;
+        gap = fminf(gap, fabsf(tt - to));
+    }
+    return gap;
+}
+
+// dynamic LDS of the pixel kernel: the bucket table, then -- when the scan's tables fit (LDS_TABLE) -- the sorted ray table, the
+// V-profiles in table order and the rays by index (16 bytes per ray each) and x_free (4 bytes per ray)
+#define K2_LDS_FIXED ((4 * K2_NBUCK + 4) * 4)
+static inline size_t k2_lds_bytes(bool lds_table, int n_rays) { return (size_t)K2_LDS_FIXED + (lds_table ? (size_t)52 * (size_t)((n_rays + 3) & ~3) : 0); }
+
+// a T3 work item as a lane holds it between its fetch (the pixel's load is issued there) and its turn
+struct k2_t3 { int ptr, dx, dy, ray, ci, x, lim2; bool free; uint16_t pix; };
+
 template <bool LDS_TABLE, typename T>
 __global__ void __launch_bounds__(1024)
-k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof, const k2_cand *__restrict__ cand_g, int n_rays,
+k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vprof, const k2_vprof *__restrict__ vprof_sorted_g,
+          const k2_cand *__restrict__ cand_g, int n_rays,
           const int *__restrict__ start_g, int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
           int *__restrict__ conflict_pix, int cap_conflict, int n_pix_wgs, const k3_ride ride)
 {
@@ -426,90 +596,155 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
         k3_apply_cell(((int)blockIdx.x - n_pix_wgs) * 1024 + threadIdx.x, ride.map, ride.n_cells, ride.hits, ride.nohit, ride.max_hits);
         return;
     }
-    __shared__ int start[4 * K2_NBUCK + 1];
-    __shared__ __attribute__((aligned(16))) k2_cand cand_s[LDS_TABLE ? K2_LDS_RAYS : 1];
-    __shared__ int sval[16][64];
-    __shared__ int s_last, s_next_zone, s_next_item;
+    extern __shared__ __attribute__((aligned(16))) char k2_smem[];
+    int *start = (int *)k2_smem;
+    const int n4 = (n_rays + 3) & ~3;
+    k2_cand *cand_s = (k2_cand *)(k2_smem + K2_LDS_FIXED);
+    k2_vprof *vprof_s = (k2_vprof *)(cand_s + (LDS_TABLE ? n4 : 0));
+    k2_byidx *byidx_s = (k2_byidx *)(vprof_s + (LDS_TABLE ? n4 : 0));
+    int *xfree_s = (int *)(byidx_s + (LDS_TABLE ? n4 : 0));
+    __shared__ __attribute__((aligned(16))) int sval[16][64];
+    __shared__ int s_last, s_nextA, s_nextB;
     K2_STAMP(0)
     const int R = counters[0], x1 = counters[3], y1 = counters[4];
     if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;       // robot outside the map: nothing is drawn (:509-512)
-    int X0 = max(x1 - R, 0), X1 = min(x1 + R, size - 1), Y0 = max(y1 - R, 0), Y1 = min(y1 + R, size - 1);
-    if (threadIdx.x == 0) { s_next_zone = 0; s_next_item = 0; }
+    if (threadIdx.x == 0) { s_nextA = 0; s_nextB = 0; }
     for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
-    if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) cand_s[i] = cand_g[i];     // (entries past the valid rays are never addressed)
+    if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) { cand_s[i] = cand_g[i]; vprof_s[i] = vprof_sorted_g[i]; byidx_s[i] = byidx_g[i]; }   // (table entries past the valid rays are never addressed)
     __syncthreads();
+    const int n_valid = start[4 * K2_NBUCK];
+    if (LDS_TABLE && R >= K2_ZONE) {
+        // x_free of every ray: the gap to its nearest neighbours in slope among the rays of its class -- its own bucket and the
+        // nearest occupied bucket on either side (buckets are ordered by slope); float slopes carry an error below 1e-7 each
+        for (int ci = threadIdx.x; ci < n_valid; ci += 1024) {
+            const k2_cand me = cand_s[ci];
+            const int cls = ci < start[2 * K2_NBUCK] ? (ci < start[K2_NBUCK] ? 0 : 1) : (ci < start[3 * K2_NBUCK] ? 2 : 3);
+            const float tt = me.dxc > 0 ? (float)me.sdyc / (float)me.dxc : 0.0f;       // (as k2_prepare bucketed it)
+            const int b0 = rs_bucket(tt), base = cls * K2_NBUCK;
+            float gap = k2_bucket_gap(start, cand_s, base + b0, ci, tt, 3.0e38f);
+            for (int d = 1; d <= K2_XF_WALK && b0 - d >= 0; d++) if (start[base + b0 - d + 1] > start[base + b0 - d]) { gap = k2_bucket_gap(start, cand_s, base + b0 - d, ci, tt, gap); break; }
+            for (int d = 1; d <= K2_XF_WALK && b0 + d < K2_NBUCK; d++) if (start[base + b0 + d + 1] > start[base + b0 + d]) { gap = k2_bucket_gap(start, cand_s, base + b0 + d, ci, tt, gap); break; }
+            // no walk of another ray shares a pixel with this one at a step x with (gap - 3e-7) * x > 1
+            xfree_s[ci] = gap > 1.0e-6f ? (gap < 1.0f ? (int)(1.0f / (gap - 3.0e-7f)) + 2 : 3) : 0x7fffffff;
+        }
+        __syncthreads();
+    }
     K2_STAMP(1)
     const k2_cand *cand = LDS_TABLE ? cand_s : cand_g;
+    const k2_vprof *vps = LDS_TABLE ? vprof_s : vprof_sorted_g;
+    const k2_byidx *byidx = LDS_TABLE ? byidx_s : byidx_g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // Work items are dealt to the workgroups round-robin (every workgroup gets pixels from all over the square) and
-    // inside a workgroup to whichever wavefront is free (an LDS counter): the cost of an item depends on how many
-    // rays cross its pixels, and a workgroup is only as fast as its slowest wavefront.
-    // (1) the zone around the robot (Chebyshev distance <= Z): one wavefront per pixel
-    const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R;
-    const int side = 2 * Z + 1, n_zone = side * side;
+    // Work items are dealt to the workgroups round-robin and inside a workgroup to whichever wavefront is free (an LDS
+    // counter): an item costs what its pixels' hit lists cost, and a workgroup is only as fast as its slowest wavefront.
+    // T1: the zone, from the centre outwards (the closer to the robot, the more rays cross a pixel: the longest items start
+    // first).  About n / (2 pi r) rays cross a pixel at distance r, and a pixel has a fifth more candidates than that: two pixels
+    // per wavefront from rB on (~26 candidates for 32 lanes), four from rC on (~13 for 16 lanes).
+    const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R, n_pix = (2 * Z + 1) * (2 * Z + 1);
+    int rB = (8 * n_valid + 1079) / 1080, rC = (16 * n_valid + 1079) / 1080;
+    rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB; rC = rC < rB ? rB : rC > K2_ZONE ? K2_ZONE : rC;
+#ifdef K2_DBG_RB
+    rB = K2_DBG_RB; rC = rC < rB ? rB : rC;
+#endif
+#ifdef K2_DBG_RC
+    rC = K2_DBG_RC;
+#endif
+    const int pA = min((2 * rB - 1) * (2 * rB - 1), n_pix), pB = min((2 * rC - 1) * (2 * rC - 1), n_pix);
+    const int nA = pA, nB = (pB - pA + 1) / 2, nC = (n_pix - pB + 3) / 4;
     for (;;) {
-        int k = 0;
-        if (lane == 0) k = atomicAdd(&s_next_zone, 1);
-        k = __builtin_amdgcn_readfirstlane(k);
+        int k;
+        SH_WAVE_FETCH(k, atomicAdd(&s_nextA, 1))
         const int item = blockIdx.x + k * n_pix_wgs;
-        if (item >= n_zone) break;
-        const int X = x1 - Z + item % side, Y = y1 - Z + item / side;
-        if (X < 0 || X >= size || Y < 0 || Y >= size) continue;              // wave-uniform
-        k2_wave_pixel(X, Y, x1, y1, size, byidx, vprof, n_rays, cand, start, map, alpha, sval[wv]);
+        if (item >= nA + nB + nC) break;
+        K2_ITEM_T0
+        if (item < nA) {                                           // one pixel for the whole wavefront
+            int ddx, ddy;
+            k2_ring_pixel(item, ddx, ddy);
+            const int X = x1 + ddx, Y = y1 + ddy;
+            if (X >= 0 && X < size && Y >= 0 && Y < size) k2_wave_pixel<T>(X, Y, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
+        } else if (item < nA + nB) k2_wave_group<T, 2>(pA + 2 * (item - nA), pB, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
+        else k2_wave_group<T, 4>(pB + 4 * (item - nA - nB), n_pix, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
+        K2_ITEM_T1(0, item)
     }
     K2_STAMP(2)
-    // (2) the rest of the bounding square: one lane per pixel, a wavefront takes 64 pixels of one row
-    const int tiles_x = (X1 - X0 + 64) / 64, items = R > 0 ? tiles_x * (Y1 - Y0 + 1) : 0;
-    for (;;) {
-        int k = 0;
-        if (lane == 0) k = atomicAdd(&s_next_item, 1);
-        k = __builtin_amdgcn_readfirstlane(k);
-        const int item = blockIdx.x + k * n_pix_wgs;
-        if (item >= items) break;
-        const int row = item / tiles_x, tx = item - row * tiles_x;
-        const int X = X0 + tx * 64 + lane, Y = Y0 + row;
-        if (X > X1) continue;
-        const int dx = X - x1, dy = Y - y1;
-        if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K2_ZONE) continue;     // (1)'s pixels
-        const int ptr = Y * size + X;
-        const uint16_t pix_in = map[ptr];                          // requested now, needed after the search (no other lane touches this pixel)
-        int cls[2], a[2], b[2];
-        const int ncls = rs_classes(dx, dy, cls, a, b);
-        int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh = 0;
-        bool overflow = false;
-        for (int k = 0; k < ncls; k++) {
-            int lo, hi;
-            rs_range(start, cls[k], a[k], b[k], 0.0f, lo, hi);
-            for (int ci = lo; ci < hi; ci++) {
-                const k2_cand c = cand[ci];
-                if (!k2_hit<T>(c, a[k], b[k])) continue;
-                const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], a[k]);
-                if (nh == K2_MAXHIT) { overflow = true; break; }
-                // insert by ray index (the list stays sorted; compile-time subscripts keep it in registers)
-                int posn = 0;
-#pragma unroll
-                for (int s = 0; s < K2_MAXHIT; s++) if (s < nh && hidx[s] < c.ray) posn++;
-#pragma unroll
-                for (int s = K2_MAXHIT - 1; s >= 1; s--) if (s > posn && s <= nh) { hidx[s] = hidx[s - 1]; hval[s] = hval[s - 1]; }
-#pragma unroll
-                for (int s = 0; s < K2_MAXHIT; s++) if (s == posn) { hidx[s] = c.ray; hval[s] = v; }
-                nh++;
-            }
-            if (overflow) break;
-        }
-        if (overflow) {
-            const int slot = __hip_atomic_fetch_add(&counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (slot < cap_conflict) __hip_atomic_store(&conflict_pix[slot], ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (nh > 0) {
-            uint16_t pix = pix_in;
-#pragma unroll
-            for (int s = 0; s < K2_MAXHIT; s++) if (s < nh) pix = k2_blend(pix, hval[s], alpha);
-            map[ptr] = pix;
-        }
+    // T3: one lane per (ray, step) beyond the zone, ray = an entry of the sorted table, steps in blocks of 64.  Software
+    // pipeline: an item's pixel is requested when the item is fetched, one iteration before its turn -- the map sits in HBM /
+    // Infinity Cache, a microsecond away.
+    const int nblk = R >= K2_ZONE ? (R - K2_ZONE) / 64 + 1 : 0;      // steps K2_ZONE .. R
+    const int n_t3 = nblk * n_valid;
+    const float rcp_nv = __builtin_amdgcn_rcpf((float)(n_valid > 0 ? n_valid : 1));
+#define K2_FETCH(it, more_)                                                                              \
+    {                                                                                                   \
+        int k_;                                                                                         \
+        SH_WAVE_FETCH(k_, atomicAdd(&s_nextB, 1))                                                       \
+        const int item_ = blockIdx.x + k_ * n_pix_wgs;                                                  \
+        (it).ptr = -1;                                                                                  \
+        more_ = item_ < n_t3;                                                                           \
+        if (more_) {                                                                                    \
+            int blk_ = (int)((float)item_ * rcp_nv);       /* item / n_valid (item < 2^24: settled exactly below) */ \
+            int ci_ = item_ - blk_ * n_valid;                                                           \
+            if (ci_ < 0) { blk_--; ci_ += n_valid; } else if (ci_ >= n_valid) { blk_++; ci_ -= n_valid; } \
+            const k2_cand me_ = cand[ci_];                 /* (uniform: an LDS broadcast) */             \
+            const int x_ = K2_ZONE + blk_ * 64 + lane;                                                  \
+            if (x_ <= me_.dxc) {                                                                        \
+                const int cls_ = ci_ < start[2 * K2_NBUCK] ? (ci_ < start[K2_NBUCK] ? 0 : 1) : (ci_ < start[3 * K2_NBUCK] ? 2 : 3); \
+                const int dyc_ = me_.sdyc < 0 ? -me_.sdyc : me_.sdyc;                                   \
+                const T N_ = (T)2 * dyc_ * x_ - me_.dxc, D_ = (T)2 * me_.dxc;                           \
+                int m_ = 0;                                                                             \
+                if (N_ > 0) {      /* m(x) = min(x, ceil(N / D)), the closed form of the error recurrence (:394-396, :433-441) */ \
+                    T q_;                                                                               \
+                    if (sizeof(T) == 4) {  /* N < 2^29: a float estimate is within one of the quotient; settled exactly */ \
+                        q_ = (T)((float)N_ * __builtin_amdgcn_rcpf((float)D_));                         \
+                        if (q_ * D_ < N_) q_++;                                                         \
+                        if (q_ * D_ < N_) q_++;                                                         \
+                        if ((q_ - 1) * D_ >= N_) q_--;                                                  \
+                        if ((q_ - 1) * D_ >= N_) q_--;                                                  \
+                    } else q_ = (N_ + D_ - 1) / D_;                                                     \
+                    m_ = q_ < (T)x_ ? (int)q_ : x_;                                                     \
+                }                                                                                       \
+                const int b_ = me_.sdyc < 0 ? -m_ : m_, a_ = (cls_ & 1) ? -x_ : x_;                     \
+                (it).dx = cls_ < 2 ? a_ : b_; (it).dy = cls_ < 2 ? b_ : a_;                             \
+                (it).ray = me_.ray; (it).ci = ci_; (it).x = x_; (it).lim2 = me_.lim2;                   \
+                (it).free = LDS_TABLE && m_ != x_ && x_ >= xfree_s[ci_];   /* (m == x: a diagonal pixel, where the quadrant's other class draws too) */ \
+                (it).ptr = (y1 + (it).dy) * size + (x1 + (it).dx);         /* (step pixels of a clipped ray lie inside the map) */ \
+                (it).pix = map[(it).ptr];                                                               \
+            }                                                                                           \
+        }                                                                                               \
     }
-    // (3) pixels with more than K2_MAXHIT hits, queued by (2): the last workgroup to finish draws them, one wavefront
-    //     per pixel.  Queue entries are published write-through and the count is an agent-scope atomic; every wave
-    //     drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
+    k2_t3 cur, nxt;
+    cur.ptr = -1; cur.dx = cur.dy = cur.ray = cur.ci = cur.x = cur.lim2 = 0; cur.free = false; cur.pix = 0; nxt = cur;
+    bool more = false;
+    if (n_t3 > 0) K2_FETCH(cur, more)
+    while (more) {
+        K2_ITEM_T0
+        K2_FETCH(nxt, more)
+        if (cur.ptr >= 0) {
+            if (cur.free) {                                        // the only ray that draws this pixel
+                const int v = cur.x <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[cur.ci], cur.x);
+                map[cur.ptr] = k2_blend(cur.pix, v, alpha);
+            } else {
+                int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh, min_ray;
+                bool overflow;
+                k2_lookup<T, K2_MAXHIT>(cand, vps, start, cur.dx, cur.dy, hidx, hval, nh, overflow, min_ray);
+                if (min_ray == cur.ray) {                          // the owner
+                    if (overflow) {
+                        const int slot = __hip_atomic_fetch_add(&counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (slot < cap_conflict) __hip_atomic_store(&conflict_pix[slot], cur.ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        uint16_t pix = cur.pix;
+#pragma unroll
+                        for (int s2 = 0; s2 < K2_MAXHIT; s2++) if (s2 < nh) pix = k2_blend(pix, hval[s2], alpha);
+                        map[cur.ptr] = pix;
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        K2_ITEM_T1(2, 0)
+    }
+#undef K2_FETCH
+    // pixels with more hits than a lane orders, queued above: the last workgroup to finish draws them, one wavefront
+    // per pixel.  Queue entries are published write-through and the count is an agent-scope atomic; every wave
+    // drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
     K2_STAMP(3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -526,7 +761,7 @@ k2_pixels(const k2_byidx *__restrict__ byidx, const k2_vprof *__restrict__ vprof
     if (n_conf > cap_conflict) n_conf = cap_conflict;
     for (int item = wv; item < n_conf; item += 16) {
         const int ptr = __hip_atomic_load(&conflict_pix[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k2_wave_pixel(ptr % size, ptr / size, x1, y1, size, byidx, vprof, n_rays, cand, start, map, alpha, sval[wv]);
+        k2_wave_pixel<T>(ptr % size, ptr / size, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
     }
 }
 
@@ -575,24 +810,26 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         const int cap = n + n / 4 + 64;
         SH_HIP(hipMalloc(&cs->d_rays, sizeof(k2_byidx) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_k2_cand, sizeof(k2_cand) * (size_t)cap));
-        SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_vprof) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_vprof) * 2 * (size_t)cap));      // by ray index | in table order
         cs->cap_rays = cap;
     }
     sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
     hipLaunchKernelGGL(k2_prepare, dim3(1 + ride_rays), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty, ride);
+                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, (k2_vprof *)cs->d_k2_vprof + cs->cap_rays, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty, ride);
     // One round of resident workgroups (a second round would start when the first drains: measured 51 -> 42 us at
     // 2048^2 together with the per-workgroup work counter): what the occupancy calculator says fits, times the CUs.
     static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
 #define K2_PIXELS(L, T) {                                                                                                   \
         static int per_cu = 0;                                                                                              \
-        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2_pixels<L, T>, 1024, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2_pixels<L, T>, 1024, k2_lds_bytes(L, L ? K2_LDS_RAYS : 0)) != hipSuccess || per_cu < 1)) per_cu = 1; \
         const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;                                                              \
         const int grid = grid_env > 0 ? grid_env : (L ? 1 : per_cu < 2 ? per_cu : 2) * cus;   /* (with the LDS table one workgroup per CU measured best) */ \
         static bool told = false;                                                                                           \
         if (!told && getenv("SLAMHIP_K2_STATS")) { told = true; fprintf(stderr, "[slamhip] K2 pixel kernel: %d workgroups (%d per CU x %d CUs)\n", grid, per_cu, ctx->num_cus); } \
-        hipLaunchKernelGGL((k2_pixels<L, T>), dim3(grid + ride_cells), dim3(1024), 0, ctx->stream, (const k2_byidx *)cs->d_rays, \
-                           (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
+        static bool attr_set = false;                                                                                       \
+        if (!attr_set) { attr_set = true; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(true, K2_LDS_RAYS)); } \
+        hipLaunchKernelGGL((k2_pixels<L, T>), dim3(grid + ride_cells), dim3(1024), k2_lds_bytes(L, n), ctx->stream, (const k2_byidx *)cs->d_rays, \
+                           (const k2_vprof *)cs->d_k2_vprof, (const k2_vprof *)cs->d_k2_vprof + cs->cap_rays, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
                            cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }
     if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }
     else                  { if (cs->hs <= 16384) K2_PIXELS(false, int) else K2_PIXELS(false, long long) }
@@ -609,7 +846,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
             unsigned long long t0 = ~0ull, t1 = 0;
             int nb = 0;
             for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8]) { nb++; t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 5]); }
-            static const char *nm[5] = { "tables", "zone", "outer", "drain", "ticket" };
+            static const char *nm[5] = { "tables", "T1", "T3", "drain", "ticket" };
             double acc[5] = { 0 }, mx[5] = { 0 }, smax = 0;
             for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8]) {
                 for (int k = 0; k < 5; k++) { const double d = (double)(h[i * 8 + k + 1] - h[i * 8 + k]) * 0.01; acc[k] += d; mx[k] = std::max(mx[k], d); }
@@ -618,8 +855,26 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
             fprintf(stderr, "[k2 times] %d workgroups, span %.2f us; first thread of each workgroup, mean (max):", nb, (double)(t1 - t0) * 0.01);
             for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f (%.2f) |", nm[k], acc[k] / std::max(nb, 1), mx[k]);
             fprintf(stderr, " last workgroup starts at %.2f us\n", smax);
+            std::vector<unsigned long long> sb(512 * 16 * 8);
+            (void)hipMemcpyFromSymbol(sb.data(), HIP_SYMBOL(g_k2_sub), sizeof(unsigned long long) * sb.size());
+            double tt[3] = { 0, 0, 0 }, cn[3] = { 0, 0, 0 }, wmax[3] = { 0, 0, 0 };
+            struct top { double d; int kind, idx, wg, wv; };
+            std::vector<top> tops;
+            for (int w = 0; w < 512 * 16; w++) {
+                for (int k = 0; k < 3; k++) { tt[k] += (double)sb[w * 8 + 2 * k] * 0.01; cn[k] += (double)sb[w * 8 + 2 * k + 1]; wmax[k] = std::max(wmax[k], (double)sb[w * 8 + 2 * k] * 0.01); }
+                if (sb[w * 8 + 6]) tops.push_back({ (double)sb[w * 8 + 6] * 0.01, (int)(sb[w * 8 + 7] >> 16), (int)(sb[w * 8 + 7] & 65535), w / 16, w % 16 });
+            }
+            std::sort(tops.begin(), tops.end(), [](const top &a, const top &b) { return a.d > b.d; });
+            fprintf(stderr, "[k2 times] per item, mean us (items; busiest wavefront's total): T1 %.2f (%.0f; %.2f) | T2 %.2f (%.0f; %.2f) | T3 %.2f (%.0f; %.2f)\n",
+                    tt[0] / std::max(cn[0], 1.0), cn[0], wmax[0], tt[1] / std::max(cn[1], 1.0), cn[1], wmax[1], tt[2] / std::max(cn[2], 1.0), cn[2], wmax[2]);
+            for (size_t i = 0; i < tops.size() && i < 12; i++) fprintf(stderr, "   longest items: %.2f us tier %d item %d (wg %d wave %d)\n", tops[i].d, tops[i].kind + 1, tops[i].idx, tops[i].wg, tops[i].wv);
         }
-        if (calls == 11) { std::vector<unsigned long long> z(512 * 8, 0ull); (void)hipStreamSynchronize(ctx->stream); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2_times), z.data(), sizeof(unsigned long long) * z.size()); }
+        if (calls == 11) {
+            std::vector<unsigned long long> z(512 * 16 * 8, 0ull);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2_times), z.data(), sizeof(unsigned long long) * 512 * 8);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2_sub), z.data(), sizeof(unsigned long long) * z.size());
+        }
     }
 #endif
     return SLAMHIP_OK;

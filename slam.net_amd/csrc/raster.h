@@ -35,9 +35,12 @@ __device__ static inline void rs_range(const int *start, int cls, int a, int b, 
 // classes of a cell at offset (dx, dy) from the start cell; a diagonal cell has two; the start cell itself none
 __device__ static inline int rs_classes(int dx, int dy, int cls[2], int a[2], int b[2])
 {
+    // (no run-time subscripts: with `cls[n++] = ...` the compiler kept the three arrays in scratch memory -- a memory round
+    // trip at the head of every pixel's lookup)
     const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-    int n = 0;
-    if (adx >= ady && adx > 0) { cls[n] = dx > 0 ? 0 : 1; a[n] = adx; b[n] = dy; n++; }
-    if (ady >= adx && ady > 0) { cls[n] = dy > 0 ? 2 : 3; a[n] = ady; b[n] = dx; n++; }
-    return n;
+    const bool cx = adx >= ady && adx > 0, cy = ady >= adx && ady > 0;
+    const int clsx = dx > 0 ? 0 : 1, clsy = dy > 0 ? 2 : 3;
+    cls[0] = cx ? clsx : clsy; a[0] = cx ? adx : ady; b[0] = cx ? dy : dx;
+    cls[1] = clsy;             a[1] = ady;            b[1] = dx;              // (the second class of a diagonal cell)
+    return (cx ? 1 : 0) + (cy ? 1 : 0);
 }
