@@ -166,7 +166,7 @@ __device__ static inline cs_ray k2_make_ray(const float2 p, int size, const floa
 // descending half (x <= lim1) never carries, and on the ascending half the carry fires on the first J steps only:
 // before-correction error of step i while every step carries = u0 + i*g + d*(i-1), negative iff i*(g+d) < d - u0.
 static_assert(TS_OBSTACLE < TS_NO_OBSTACLE, "k2_pixval_closed assumes a falling V-profile");
-__device__ static inline int k2_pixval_closed(const k2_vprof p, int x)
+__device__ static __forceinline__ int k2_pixval_closed(const k2_vprof p, int x)
 {
     if (x <= p.lim2) return TS_NO_OBSTACLE;
     const int d = p.derrorv;
@@ -199,7 +199,7 @@ __device__ static inline int k2_pixval_closed(const k2_vprof p, int x)
     return TS_NO_OBSTACLE + (n1 - j) * p.incv + f;                             // sincv = -1 (:374)
 }
 
-__device__ static inline uint16_t k2_blend(uint16_t pix, int pixval, int alpha)
+__device__ static __forceinline__ uint16_t k2_blend(uint16_t pix, int pixval, int alpha)
 {
     return (uint16_t)(sh_wadd(sh_wmul(256 - alpha, (int)pix), sh_wmul(alpha, pixval)) >> 8);   // :431
 }
@@ -208,7 +208,7 @@ __device__ static inline uint16_t k2_blend(uint16_t pix, int pixval, int alpha)
 // T = int for maps up to 16384 pixels a side -- 2*dyc*a < 2^29 -- else long long: 64-bit multiplies are several
 // quarter-rate instructions each)
 template <typename T>
-__device__ static inline bool k2_hit(const k2_cand c, int a, int b)
+__device__ static __forceinline__ bool k2_hit(const k2_cand c, int a, int b)
 {
     if (a > c.dxc) return false;
     const int B = b < 0 ? -b : b, dyc = c.sdyc < 0 ? -c.sdyc : c.sdyc;
@@ -322,7 +322,7 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
 // (byidx / cand / vprof_sorted: LDS when the scan's tables fit, else global; vprof: by ray index, global -- read only by the
 // all-rays scan, for a pixel inside a ray's hole zone)
 template <typename T, typename CT, typename BT, typename VT>
-__device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int size, BT byidx,
+__device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, int size, BT byidx,
                                             const k2_vprof *__restrict__ vprof, VT vprof_sorted, int n_rays, CT cand, const int *start,
                                             uint16_t *__restrict__ map, int alpha, int *sval)
 {
@@ -418,24 +418,20 @@ __device__ static inline void k2_wave_pixel(int X, int Y, int x1, int y1, int si
 //                          Pixels are numbered from the centre outwards (k2_ring_pixel); a wavefront takes one pixel (r < rB), two
 //                          (rB <= r < rC: 32 lanes test the candidate rays of each) or four (16 lanes each): lanes test the candidates,
 //                          hits are rank-sorted by ray index through LDS and blended in that order by the group's first lane.
-//   T3  r >= K2_ZONE       one lane per (ray, step): the lane computes its pixel from the closed form of the walk.  Beyond the step
-//                          x_free of its ray -- from which on no other ray's walk can share a pixel with it: two walks of a class
-//                          that meet at major offset x have slopes within 1 / x of each other, and x_free comes from the ray's
-//                          nearest neighbours in the slope-sorted table -- the pixel has exactly one hit and is blended at once.
-//                          Below it (and on the diagonals, where the two classes of a quadrant meet) the lane asks, like a pixel-
-//                          centric lane would, which rays draw the pixel; the lane of the LOWEST ray index among them owns it and
-//                          blends all hits in ray order, the other hitting rays' lanes drop it.  The lookup is a function of the
-//                          pixel alone, so every lane that lands on a pixel sees the same hit list and exactly one of them owns it.
+//   T3  r >= K2_ZONE       one lane per (ray, step): the lane computes its pixel from the closed form of the walk and asks, like a
+//                          pixel-centric lane would, which rays can draw that pixel -- one contiguous range of the slope-sorted
+//                          table.  Out here rays are more than a pixel apart: nearly always the range holds the lane's own ray and
+//                          nothing else, and the pixel is blended at once.  Otherwise (and on the diagonals, where the two classes
+//                          of a quadrant meet) the candidates are tested; the lane of the LOWEST ray index among the hits owns the
+//                          pixel and blends all hits in ray order, the other hitting rays' lanes drop it.  The lookup is a function
+//                          of the pixel alone, so every lane that lands on a pixel sees the same hit list and exactly one owns it.
 // Pixels with more hits than a T3 lane orders go to the conflict list (drawn by the last workgroup, one wavefront per pixel).
-// The bucket table, the sorted ray table, the V-profiles (in table order), the rays by index and x_free live in LDS: a pixel's
+// The bucket table, the sorted ray table, the V-profiles (in table order) and the rays by index live in LDS: a pixel's
 // lookup is a chain of dependent small reads (bucket bounds -> candidates -> V-profile -> map), which global-memory latency
 // would dominate.
 #ifndef K2_LDS_RAYS
-#define K2_LDS_RAYS 2640               // largest scan whose tables fit the LDS: 16.4 KB of buckets + 52 B per ray + the kernel's static 4 KB <= 160 KB
+#define K2_LDS_RAYS 2880               // largest scan whose tables fit the LDS: 16.4 KB of buckets + 48 B per ray + the kernel's static 4 KB <= 160 KB
 #endif
-#define K2_XF_WALK 16                  // buckets searched on either side of a ray's own for its nearest slope neighbours
-#define K2_XF_MAXPOP 8                 // a bucket with more rays than this counts as "a neighbour at distance zero"
-static_assert((K2_XF_WALK - 1) * (2.0 / K2_NBUCK) * K2_ZONE > 1.0, "no neighbour within the walk: every T3 step is free");
 #ifdef K2_TIMES
 // developer instrumentation (build with SLAMHIP_K2_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
 __device__ unsigned long long g_k2_times[512 * 8];
@@ -453,7 +449,7 @@ __device__ unsigned long long g_k2_sub[512 * 16 * 8];   // per wavefront: [0] T1
 // Which rays draw the pixel at offset (dx, dy) from the robot?  Up to H hits, kept sorted by ray index (compile-time
 // subscripts: the lists stay in registers); `min_ray` = the lowest hitting ray index, also when the list overflowed.
 template <typename T, int H, typename CT, typename VT>
-__device__ static inline void k2_lookup(CT cand, VT vprof_sorted, const int *start, int dx, int dy,
+__device__ static __forceinline__ void k2_lookup(CT cand, VT vprof_sorted, const int *start, int dx, int dy,
                                         int (&hidx)[H], int (&hval)[H], int &nh, bool &overflow, int &min_ray)
 {
     int cls[2], a[2], b[2];
@@ -482,7 +478,7 @@ __device__ static inline void k2_lookup(CT cand, VT vprof_sorted, const int *sta
 
 // pixel number i of the zone, counted from the robot's pixel outwards: ring r (Chebyshev distance r) holds the numbers
 // (2r-1)^2 .. (2r+1)^2 - 1, walked along its four sides
-__device__ static inline void k2_ring_pixel(int i, int &ddx, int &ddy)
+__device__ static __forceinline__ void k2_ring_pixel(int i, int &ddx, int &ddy)
 {
     ddx = 0; ddy = 0;
     if (i <= 0) return;
@@ -493,27 +489,28 @@ __device__ static inline void k2_ring_pixel(int i, int &ddx, int &ddy)
     ddy = side == 0 ? -r : side == 1 ? -r + p : side == 2 ? r : r - p;
 }
 
-// One wavefront draws G > 1 pixels (numbers pix0 .. pix0 + G - 1 of the zone), 64 / G lanes each.  A pixel with more candidates
-// than its lanes (or the robot's own pixel) sends the whole item down the one-pixel path, pixel after pixel.
-template <typename T, int G, typename CT, typename BT, typename VT>
-__device__ static inline void k2_wave_group(int pix0, int n_pix, int x1, int y1, int size, BT byidx, const k2_vprof *__restrict__ vprof,
-                                            VT vps, int n_rays, CT cand, const int *start, uint16_t *__restrict__ map, int alpha, int *sval)
+// One wavefront draws G = 1 << lg pixels (numbers pix0 .. pix0 + G - 1 of the zone), W = 64 / G lanes each.  A pixel with more
+// candidates than its lanes -- and every G = 1 item -- goes down the one-pixel path, pixel after pixel: ONE call site for it (the
+// kernel's code is executed once or twice per wavefront, from a cold instruction cache: its size is latency; nine inlined copies
+// of the one-pixel path made a 47 KB kernel that ran 10 us slower than the 20 KB one).
+template <typename T, typename CT, typename BT, typename VT>
+__device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg, int x1, int y1, int size, BT byidx, const k2_vprof *__restrict__ vprof,
+                                                     VT vps, int n_rays, CT cand, const int *start, uint16_t *__restrict__ map, int alpha, int *sval)
 {
-    constexpr int W = 64 / G;
-    const int lane = threadIdx.x & 63, g = lane / W, l = lane - g * W;
+    const int W = 64 >> lg, G = 1 << lg;
+    const int lane = threadIdx.x & 63, g = lane >> (6 - lg), l = lane & (W - 1);
     int ddx, ddy;
     k2_ring_pixel(pix0 + g, ddx, ddy);
     const int X = x1 + ddx, Y = y1 + ddy;
     const bool valid = pix0 + g < n_pix && X >= 0 && X < size && Y >= 0 && Y < size;
     int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
     int ncls = 0, nc = 0;
-    if (valid) {
+    if (valid && lg > 0) {
         ncls = rs_classes(ddx, ddy, cls, a, b);
 #pragma unroll
         for (int k = 0; k < 2; k++) if (k < ncls) { rs_range(start, cls[k], a[k], b[k], 0.0f, lo[k], hi[k]); nc += hi[k] - lo[k]; }
     }
-    if (__ballot(valid && (ncls == 0 || nc > W)) != 0ull) {
-#pragma unroll
+    if (lg == 0 || __ballot(valid && (ncls == 0 || nc > W)) != 0ull) {
         for (int gg = 0; gg < G; gg++) {
             const int Xg = __builtin_amdgcn_readlane(X, gg * W), Yg = __builtin_amdgcn_readlane(Y, gg * W);
             const int vg = __builtin_amdgcn_readlane(valid ? 1 : 0, gg * W);
@@ -540,11 +537,11 @@ __device__ static inline void k2_wave_group(int pix0, int n_pix, int x1, int y1,
     for (unsigned long long m = mask; m; m &= m - 1) {             // rank among the hits of the lane's own pixel
         const int src = __ffsll((long long)m) - 1;
         const int oi = __builtin_amdgcn_readlane(idx, src);
-        rank += (hit && (src / W) == g && oi < idx) ? 1 : 0;
+        rank += (hit && (src >> (6 - lg)) == g && oi < idx) ? 1 : 0;
     }
     if (hit) sval[g * W + rank] = v;
     __builtin_amdgcn_wave_barrier();
-    const unsigned long long gm = (W == 32 ? 0xffffffffull : 0xffffull) << (g * W);
+    const unsigned long long gm = (lg == 1 ? 0xffffffffull : 0xffffull) << (g * W);
     const int nh = __popcll(mask & gm);
     if (valid && l == 0 && nh > 0) {
         bool stable = false;
@@ -563,27 +560,13 @@ __device__ static inline void k2_wave_group(int pix0, int n_pix, int x1, int y1,
     __builtin_amdgcn_wave_barrier();
 }
 
-// smallest slope distance between ray `ci` (slope tt) and the other rays of bucket `bucket` (absolute bucket number), or `gap`
-// if that is smaller; a crowded bucket counts as distance zero
-__device__ static inline float k2_bucket_gap(const int *start, const k2_cand *cand_s, int bucket, int ci, float tt, float gap)
-{
-    const int lo = start[bucket], hi = start[bucket + 1];
-    if (hi - lo > K2_XF_MAXPOP) return 0.0f;
-    for (int j = lo; j < hi; j++) if (j != ci) {
-        const k2_cand o = cand_s[j];
-        const float to = o.dxc > 0 ? (float)o.sdyc / (float)o.dxc : 0.0f;
-        gap = fminf(gap, fabsf(tt - to));
-    }
-    return gap;
-}
-
 // dynamic LDS of the pixel kernel: the bucket table, then -- when the scan's tables fit (LDS_TABLE) -- the sorted ray table, the
-// V-profiles in table order and the rays by index (16 bytes per ray each) and x_free (4 bytes per ray)
+// V-profiles in table order and the rays by index (16 bytes per ray each)
 #define K2_LDS_FIXED ((4 * K2_NBUCK + 4) * 4)
-static inline size_t k2_lds_bytes(bool lds_table, int n_rays) { return (size_t)K2_LDS_FIXED + (lds_table ? (size_t)52 * (size_t)((n_rays + 3) & ~3) : 0); }
+static inline size_t k2_lds_bytes(bool lds_table, int n_rays) { return (size_t)K2_LDS_FIXED + (lds_table ? (size_t)48 * (size_t)((n_rays + 3) & ~3) : 0); }
 
 // a T3 work item as a lane holds it between its fetch (the pixel's load is issued there) and its turn
-struct k2_t3 { int ptr, dx, dy, ray, ci, x, lim2; bool free; uint16_t pix; };
+struct k2_t3 { int ptr, dx, dy, ray, ci, lim2; uint16_t pix; };
 
 template <bool LDS_TABLE, typename T>
 __global__ void __launch_bounds__(1024)
@@ -602,7 +585,6 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
     k2_cand *cand_s = (k2_cand *)(k2_smem + K2_LDS_FIXED);
     k2_vprof *vprof_s = (k2_vprof *)(cand_s + (LDS_TABLE ? n4 : 0));
     k2_byidx *byidx_s = (k2_byidx *)(vprof_s + (LDS_TABLE ? n4 : 0));
-    int *xfree_s = (int *)(byidx_s + (LDS_TABLE ? n4 : 0));
     __shared__ __attribute__((aligned(16))) int sval[16][64];
     __shared__ int s_last, s_nextA, s_nextB;
     K2_STAMP(0)
@@ -612,23 +594,8 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
     for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
     if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) { cand_s[i] = cand_g[i]; vprof_s[i] = vprof_sorted_g[i]; byidx_s[i] = byidx_g[i]; }   // (table entries past the valid rays are never addressed)
     __syncthreads();
+    K2_STAMP(6)
     const int n_valid = start[4 * K2_NBUCK];
-    if (LDS_TABLE && R >= K2_ZONE) {
-        // x_free of every ray: the gap to its nearest neighbours in slope among the rays of its class -- its own bucket and the
-        // nearest occupied bucket on either side (buckets are ordered by slope); float slopes carry an error below 1e-7 each
-        for (int ci = threadIdx.x; ci < n_valid; ci += 1024) {
-            const k2_cand me = cand_s[ci];
-            const int cls = ci < start[2 * K2_NBUCK] ? (ci < start[K2_NBUCK] ? 0 : 1) : (ci < start[3 * K2_NBUCK] ? 2 : 3);
-            const float tt = me.dxc > 0 ? (float)me.sdyc / (float)me.dxc : 0.0f;       // (as k2_prepare bucketed it)
-            const int b0 = rs_bucket(tt), base = cls * K2_NBUCK;
-            float gap = k2_bucket_gap(start, cand_s, base + b0, ci, tt, 3.0e38f);
-            for (int d = 1; d <= K2_XF_WALK && b0 - d >= 0; d++) if (start[base + b0 - d + 1] > start[base + b0 - d]) { gap = k2_bucket_gap(start, cand_s, base + b0 - d, ci, tt, gap); break; }
-            for (int d = 1; d <= K2_XF_WALK && b0 + d < K2_NBUCK; d++) if (start[base + b0 + d + 1] > start[base + b0 + d]) { gap = k2_bucket_gap(start, cand_s, base + b0 + d, ci, tt, gap); break; }
-            // no walk of another ray shares a pixel with this one at a step x with (gap - 3e-7) * x > 1
-            xfree_s[ci] = gap > 1.0e-6f ? (gap < 1.0f ? (int)(1.0f / (gap - 3.0e-7f)) + 2 : 3) : 0x7fffffff;
-        }
-        __syncthreads();
-    }
     K2_STAMP(1)
     const k2_cand *cand = LDS_TABLE ? cand_s : cand_g;
     const k2_vprof *vps = LDS_TABLE ? vprof_s : vprof_sorted_g;
@@ -638,9 +605,10 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
     // counter): an item costs what its pixels' hit lists cost, and a workgroup is only as fast as its slowest wavefront.
     // T1: the zone, from the centre outwards (the closer to the robot, the more rays cross a pixel: the longest items start
     // first).  About n / (2 pi r) rays cross a pixel at distance r, and a pixel has a fifth more candidates than that: two pixels
-    // per wavefront from rB on (~26 candidates for 32 lanes), four from rC on (~13 for 16 lanes).
+    // per wavefront from rB on (~17 candidates for 32 lanes), four from rC on (~7 for 16 lanes) -- a pixel with more candidates
+    // than its lanes sends the whole item down the one-pixel path, which costs as much as the pixels it holds.
     const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R, n_pix = (2 * Z + 1) * (2 * Z + 1);
-    int rB = (8 * n_valid + 1079) / 1080, rC = (16 * n_valid + 1079) / 1080;
+    int rB = (12 * n_valid + 1079) / 1080, rC = (28 * n_valid + 1079) / 1080;
     rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB; rC = rC < rB ? rB : rC > K2_ZONE ? K2_ZONE : rC;
 #ifdef K2_DBG_RB
     rB = K2_DBG_RB; rC = rC < rB ? rB : rC;
@@ -656,33 +624,37 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
         const int item = blockIdx.x + k * n_pix_wgs;
         if (item >= nA + nB + nC) break;
         K2_ITEM_T0
-        if (item < nA) {                                           // one pixel for the whole wavefront
-            int ddx, ddy;
-            k2_ring_pixel(item, ddx, ddy);
-            const int X = x1 + ddx, Y = y1 + ddy;
-            if (X >= 0 && X < size && Y >= 0 && Y < size) k2_wave_pixel<T>(X, Y, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
-        } else if (item < nA + nB) k2_wave_group<T, 2>(pA + 2 * (item - nA), pB, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
-        else k2_wave_group<T, 4>(pB + 4 * (item - nA - nB), n_pix, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
+        int pix0 = item, lim = n_pix, lg = 0;
+        if (item >= nA + nB) { pix0 = pB + 4 * (item - nA - nB); lg = 2; }
+        else if (item >= nA) { pix0 = pA + 2 * (item - nA); lim = pB; lg = 1; }
+        k2_wave_group<T>(pix0, lim, lg, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
         K2_ITEM_T1(0, item)
     }
     K2_STAMP(2)
     // T3: one lane per (ray, step) beyond the zone, ray = an entry of the sorted table, steps in blocks of 64.  Software
     // pipeline: an item's pixel is requested when the item is fetched, one iteration before its turn -- the map sits in HBM /
     // Infinity Cache, a microsecond away.
+    // The rays are dealt to the XCDs by SECTOR -- XCD s (workgroup b runs on XCD b % 8) draws the s-th eighth of the sorted table, a
+    // contiguous range of directions: a ray's pixels share their 128-byte lines with its neighbours' (at r = 600 px adjacent rays
+    // are 3.5 px apart), and a line must meet ONE L2.  Dealt round-robin over all workgroups, every XCD fetched and wrote back
+    // every line: eight times the traffic, and the tier ran at the speed of the fabric.
     const int nblk = R >= K2_ZONE ? (R - K2_ZONE) / 64 + 1 : 0;      // steps K2_ZONE .. R
-    const int n_t3 = nblk * n_valid;
-    const float rcp_nv = __builtin_amdgcn_rcpf((float)(n_valid > 0 ? n_valid : 1));
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_in_xcd = (n_pix_wgs - xcd + 7) >> 3;
+    const int c0 = (int)(((long long)n_valid * xcd) >> 3), n_sec = (int)(((long long)n_valid * (xcd + 1)) >> 3) - c0;
+    const int n_t3 = nblk * n_sec;
+    const float rcp_nv = __builtin_amdgcn_rcpf((float)(n_sec > 0 ? n_sec : 1));
 #define K2_FETCH(it, more_)                                                                              \
     {                                                                                                   \
         int k_;                                                                                         \
         SH_WAVE_FETCH(k_, atomicAdd(&s_nextB, 1))                                                       \
-        const int item_ = blockIdx.x + k_ * n_pix_wgs;                                                  \
+        const int item_ = wg_in_xcd + k_ * wgs_in_xcd;                                                  \
         (it).ptr = -1;                                                                                  \
         more_ = item_ < n_t3;                                                                           \
         if (more_) {                                                                                    \
-            int blk_ = (int)((float)item_ * rcp_nv);       /* item / n_valid (item < 2^24: settled exactly below) */ \
-            int ci_ = item_ - blk_ * n_valid;                                                           \
-            if (ci_ < 0) { blk_--; ci_ += n_valid; } else if (ci_ >= n_valid) { blk_++; ci_ -= n_valid; } \
+            int blk_ = (int)((float)item_ * rcp_nv);       /* item / n_sec (item < 2^24: settled exactly below) */ \
+            int ci_ = item_ - blk_ * n_sec;                                                             \
+            if (ci_ < 0) { blk_--; ci_ += n_sec; } else if (ci_ >= n_sec) { blk_++; ci_ -= n_sec; }     \
+            ci_ += c0;                                                                                  \
             const k2_cand me_ = cand[ci_];                 /* (uniform: an LDS broadcast) */             \
             const int x_ = K2_ZONE + blk_ * 64 + lane;                                                  \
             if (x_ <= me_.dxc) {                                                                        \
@@ -692,34 +664,42 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
                 int m_ = 0;                                                                             \
                 if (N_ > 0) {      /* m(x) = min(x, ceil(N / D)), the closed form of the error recurrence (:394-396, :433-441) */ \
                     T q_;                                                                               \
-                    if (sizeof(T) == 4) {  /* N < 2^29: a float estimate is within one of the quotient; settled exactly */ \
+                    if (sizeof(T) == 4) {  /* N < 2^29, D < 2^16: the float estimate of floor(N / D) is within one; one multiply settles it */ \
                         q_ = (T)((float)N_ * __builtin_amdgcn_rcpf((float)D_));                         \
-                        if (q_ * D_ < N_) q_++;                                                         \
-                        if (q_ * D_ < N_) q_++;                                                         \
-                        if ((q_ - 1) * D_ >= N_) q_--;                                                  \
-                        if ((q_ - 1) * D_ >= N_) q_--;                                                  \
+                        T r_ = N_ - q_ * D_;                                                            \
+                        if (r_ < 0) { q_--; r_ += D_; } else if (r_ >= D_) { q_++; r_ -= D_; }          \
+                        q_ += r_ > 0 ? 1 : 0;                      /* ceil */                            \
                     } else q_ = (N_ + D_ - 1) / D_;                                                     \
                     m_ = q_ < (T)x_ ? (int)q_ : x_;                                                     \
                 }                                                                                       \
                 const int b_ = me_.sdyc < 0 ? -m_ : m_, a_ = (cls_ & 1) ? -x_ : x_;                     \
                 (it).dx = cls_ < 2 ? a_ : b_; (it).dy = cls_ < 2 ? b_ : a_;                             \
-                (it).ray = me_.ray; (it).ci = ci_; (it).x = x_; (it).lim2 = me_.lim2;                   \
-                (it).free = LDS_TABLE && m_ != x_ && x_ >= xfree_s[ci_];   /* (m == x: a diagonal pixel, where the quadrant's other class draws too) */ \
+                (it).ray = me_.ray; (it).ci = ci_; (it).lim2 = me_.lim2;                                \
                 (it).ptr = (y1 + (it).dy) * size + (x1 + (it).dx);         /* (step pixels of a clipped ray lie inside the map) */ \
                 (it).pix = map[(it).ptr];                                                               \
             }                                                                                           \
         }                                                                                               \
     }
     k2_t3 cur, nxt;
-    cur.ptr = -1; cur.dx = cur.dy = cur.ray = cur.ci = cur.x = cur.lim2 = 0; cur.free = false; cur.pix = 0; nxt = cur;
+    cur.ptr = -1; cur.dx = cur.dy = cur.ray = cur.ci = cur.lim2 = 0; cur.pix = 0; nxt = cur;
     bool more = false;
     if (n_t3 > 0) K2_FETCH(cur, more)
     while (more) {
         K2_ITEM_T0
         K2_FETCH(nxt, more)
         if (cur.ptr >= 0) {
-            if (cur.free) {                                        // the only ray that draws this pixel
-                const int v = cur.x <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[cur.ci], cur.x);
+            // Out here rays are more than a pixel apart: nearly every pixel's candidate range holds its own ray and nothing else
+            // -- then it is blended at once (no hit test, no ordering).  A diagonal pixel (the quadrant's other class draws there
+            // too) or a range with company goes through the full lookup.
+            const int adx = cur.dx < 0 ? -cur.dx : cur.dx, ady = cur.dy < 0 ? -cur.dy : cur.dy;
+            int lo = 0, hi = 2;
+            if (adx != ady) {
+                const bool xm = adx > ady;
+                rs_range(start, xm ? (cur.dx > 0 ? 0 : 1) : (cur.dy > 0 ? 2 : 3), xm ? adx : ady, xm ? cur.dy : cur.dx, 0.0f, lo, hi);
+            }
+            if (hi - lo == 1) {
+                const int a = adx > ady ? adx : ady;
+                const int v = a <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[cur.ci], a);
                 map[cur.ptr] = k2_blend(cur.pix, v, alpha);
             } else {
                 int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh, min_ray;
@@ -855,6 +835,8 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
             fprintf(stderr, "[k2 times] %d workgroups, span %.2f us; first thread of each workgroup, mean (max):", nb, (double)(t1 - t0) * 0.01);
             for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f (%.2f) |", nm[k], acc[k] / std::max(nb, 1), mx[k]);
             fprintf(stderr, " last workgroup starts at %.2f us\n", smax);
+            { double a6 = 0, a7 = 0; int nn = 0; for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 6]) { a6 += (double)(h[i * 8 + 6] - h[i * 8]) * 0.01; a7 += (double)(h[i * 8 + 7] - h[i * 8 + 6]) * 0.01; nn++; }
+              fprintf(stderr, "[k2 times] inside tables: loads + first barrier %.2f us | x_free (thread 0) %.2f us\n", a6 / std::max(nn, 1), a7 / std::max(nn, 1)); }
             std::vector<unsigned long long> sb(512 * 16 * 8);
             (void)hipMemcpyFromSymbol(sb.data(), HIP_SYMBOL(g_k2_sub), sizeof(unsigned long long) * sb.size());
             double tt[3] = { 0, 0, 0 }, cn[3] = { 0, 0, 0 }, wmax[3] = { 0, 0, 0 };
