@@ -201,6 +201,7 @@ extern "C" int32_t slamhip_cs_reset(slamhip_cs *cs, int32_t unmapped)
     const size_t n = (size_t)cs->hs * cs->hs;
     hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, cs->ctx->stream, cs->d_hole, n,
                        (uint16_t)((0 + 65500) / 2));                       // :169 (TS_OBSTACLE + TS_NO_OBSTACLE) / 2
+    SH_TRY(cs_obstacle_flush(cs));
     SH_HIP(hipMemsetAsync(cs->d_obst, (int)(uint8_t)(int8_t)unmapped, (size_t)cs->os * cs->os, cs->ctx->stream)); // :170
     SH_TRY(cs_holemap_dirty_set(cs, true));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
@@ -286,6 +287,7 @@ extern "C" int32_t slamhip_cs_obstaclemap_upload(slamhip_cs *cs, const int8_t *p
 {
     SH_CHECK_ARG(cs && pix && n == (size_t)cs->os * cs->os);
     SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_TRY(cs_obstacle_flush(cs));
     SH_HIP(hipMemcpyAsync(cs->d_obst, pix, n, hipMemcpyHostToDevice, cs->ctx->stream));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     return SLAMHIP_OK;
@@ -294,6 +296,7 @@ extern "C" int32_t slamhip_cs_obstaclemap_download(slamhip_cs *cs, int8_t *pix, 
 {
     SH_CHECK_ARG(cs && pix && n == (size_t)cs->os * cs->os);
     SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_TRY(cs_obstacle_flush(cs));                                 // (the fused call's cell pass trails one scan behind: obstacle_dev.h)
     SH_HIP(hipMemcpyAsync(pix, cs->d_obst, n, hipMemcpyDeviceToHost, cs->ctx->stream));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     return SLAMHIP_OK;
@@ -805,7 +808,7 @@ static int32_t finish_holemap(slamhip_cs *cs)
     const int *m = (const int *)cs->ctx->mailbox;                           // [0] longest ray, [1] conflict pixels, [2] blended pixels
     cs->last_hole_pixels = m[2]; cs->hole_pixels_pending = false;
     static const bool stats = getenv("SLAMHIP_K2_STATS") != nullptr;        // developer aid
-    if (stats) fprintf(stderr, "[slamhip] K2: reach %d px, %d pixels with more than 4 fragments (drawn by the last workgroup), %d blended pixels\n", m[0], m[1], m[2]);
+    if (stats) fprintf(stderr, "[slamhip] K2: reach %d px, %d blended pixels\n", m[0], m[2]);
     return SLAMHIP_OK;
 }
 
@@ -815,7 +818,7 @@ extern "C" int32_t slamhip_cs_update_holemap_pxcs(slamhip_cs *cs, const float px
     SH_HIP(hipSetDevice(cs->ctx->device));
     cs->last_hole_pixels = 0; cs->hole_pixels_pending = false;
     if (cs->n_points <= 0) return SLAMHIP_OK;
-    SH_TRY(cs_launch_holemap_update(cs, nullptr, make_float4(pxcs[0], pxcs[1], pxcs[2], pxcs[3]), hole_width, quality));
+    SH_TRY(cs_launch_holemap_update(cs, nullptr, make_float4(pxcs[0], pxcs[1], pxcs[2], pxcs[3]), make_float4(0, 0, 0, 0), hole_width, quality));
     return finish_holemap(cs);
 }
 
@@ -853,7 +856,7 @@ int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_w
     SH_HIP(hipSetDevice(cs->ctx->device));
     cs->last_hole_pixels = 0; cs->hole_pixels_pending = false;
     if (cs->n_points <= 0) return SLAMHIP_OK;
-    SH_TRY(cs_launch_holemap_update(cs, nullptr, pxcs_from_pose(pose, cs->hscale), hole_width, quality));   // :499-502
+    SH_TRY(cs_launch_holemap_update(cs, nullptr, pxcs_from_pose(pose, cs->hscale), make_float4(0, 0, 0, 0), hole_width, quality));   // :499-502
     SH_TRY(cs_launch_obstacle_update(cs, nullptr, pxcs_from_pose(pose, cs->oscale), max_hits));            // :545-548
     return SLAMHIP_OK;
 }
@@ -918,16 +921,14 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     if (!cs->k1_pose_written)                                    // (fallback search kernels: decode the key in a launch of its own)
         hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
                            cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);
-    // :750-751 -- the two maps are independent: the ObstacleMap update's ray walks and cell pass ride on the HoleMap
-    // update's two launches as extra workgroups (two dependent launches less per scan); with per-kernel timing on, each
-    // update keeps its own launches so that the timers mean what they say
+    // :750-751 -- the two maps are independent: the ObstacleMap update rides on the HoleMap update's ONE launch as extra
+    // workgroups -- this scan's ray walks, and the cell pass of the previous scan (obstacle_dev.h); with per-kernel timing on,
+    // each update keeps its own launches so that the timers mean what they say
     int32_t rc_u;
     if (ctx->timing == 0) {
-        k3_ride ride;
-        cs_obstacle_ride(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits, &ride);
-        rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality, &ride);
+        rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality, true, max_hits);
     } else {
-        rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), hole_width, quality);
+        rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality);
         if (rc_u == SLAMHIP_OK) rc_u = cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits);
     }
     if (delivered) {

@@ -87,8 +87,10 @@ struct slamhip_cs {
     bool hole_pixels_pending;     // ... still on the device (d_key word 6): slamhip_cs_search_and_update returned with the pose, the updates run on
 
     // ---- K3 ObstacleMap update scratch ---------------------------------------------------------------
-    uint32_t *d_o_hits;           // [os*os] endpoint hits this scan
-    uint8_t *d_o_nohit;           // [os*os] noHitMap (CoreSLAMProcessor.cs:26,:133)
+    uint32_t *d_o_hits[2];        // [os*os] endpoint hits of a scan; two sets: the fused path's cell pass trails one scan behind its ray walks (obstacle_dev.h)
+    uint8_t *d_o_nohit[2];        // [os*os] noHitMap (CoreSLAMProcessor.cs:26,:133)
+    int obst_buf;                 // the set the next ray walks use
+    bool obst_pending; int obst_pend_buf, obst_pend_max_hits;   // a cell pass not yet applied to d_obst
 };
 
 // distance.hip
@@ -104,8 +106,12 @@ void    cs_holemap_free(slamhip_cs *cs);
 int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality, int32_t max_hits);
 int32_t cs_update_maps_finish(slamhip_cs *cs);
 struct k3_ride;
-int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float hole_width, int quality, const k3_ride *ride = nullptr);
+// with_obstacle: the ObstacleMap update of the same scan and pose rides along (or follows in launches of its own when it cannot)
+int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float4 h_pxcs_obst, float hole_width, int quality,
+                                 bool with_obstacle = false, int max_hits = 0);
 void cs_obstacle_ride(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, int max_hits, k3_ride *out);
+void cs_obstacle_ride_commit(slamhip_cs *cs, const k3_ride *ride, int max_hits);   // after the carrying launch is in the stream
+int32_t cs_obstacle_flush(slamhip_cs *cs);                        // applies a pending cell pass (before anything reads or writes the ObstacleMap)
 // obstacle.hip
 int32_t cs_obstacle_alloc(slamhip_cs *cs);
 void    cs_obstacle_free(slamhip_cs *cs);

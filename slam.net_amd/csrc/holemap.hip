@@ -4,21 +4,21 @@
 // ClipRay (:320-345).  The reference draws ray after ray with a read-modify-write blend
 //     pix = (ushort)(((256 - alpha) * pix + alpha * pixval) >> 8)                     (:431)
 // which does not commute for different pixval, so a pixel touched by several rays must see their
-// fragments in ray order.  The update is PIXEL-centric (a gather, no atomics on the map,
-// no per-pixel scratch): a pixel asks which rays draw it, then blends their values in ray order.
-//   prepare  one workgroup: per ray the literal float/int arithmetic of :519-530, :361-399 (clip, major axis,
-//            V-profile parameters) -> ray table; rays are counting-sorted into 4 direction classes (major axis
-//            and its sign) x 1024 buckets of signed slope (minor / major)
-//   pixels   one lane per pixel of the scan's bounding square: step x of a ray lies at major offset x and minor
-//            offset m(x) = min(x, max(0, ceil((2*dyc*x - dxc) / (2*dxc)))) (closed form of the error
-//            recurrence :394-396,:433-441; tests/test_closed_forms.py), and |m(x) - slope*x| <= 1/2, so only
-//            rays of the pixel's class with slope in [(b-1)/a, (b+1)/a] can draw pixel (major a, minor b): a
-//            contiguous range of the sorted table, tested exactly.  Up to 4 hits are sorted by ray index in
-//            registers and blended; a pixel with more goes to the conflict list
-//            (same launch) one wavefront per pixel for the neighbourhood of the robot (every ray passes there) and,
-//            in the last workgroup to finish, for the conflict list: lanes test the candidate rays, hits are
-//            rank-sorted by ray index and blended in that order; the few pixels with more than 64 candidates scan
-//            all rays in index order
+// fragments in ray order.  No atomics on the map and no per-pixel scratch: every pixel has exactly one
+// writer, which knows all the rays that draw the pixel and blends their values in ray order.  ONE launch per update
+// (k2_pixels<BUILD>; scans of more than K2_LDS_RAYS rays: k2_prepare + k2_pixels<!BUILD>):
+//   tables   every workgroup, in LDS: per ray the literal float/int arithmetic of :519-530, :361-399 (clip, major axis,
+//            V-profile parameters); rays are counting-sorted into 4 direction classes (major axis and its sign) x 1024
+//            buckets of signed slope (minor / major).  Step x of a ray lies at major offset x and minor offset
+//            m(x) = min(x, max(0, ceil((2*dyc*x - dxc) / (2*dxc)))) (closed form of the error recurrence :394-396,
+//            :433-441; tests/test_closed_forms.py), and |m(x) - slope*x| <= 1/2, so only rays of a pixel's class with
+//            slope in [(b-1/2)/a, (b+1/2)/a] can draw the pixel at (major a, minor b): one contiguous range of the table.
+//   zone     (Chebyshev distance < 48 from the robot, where tens to a thousand rays cross a pixel) pixel-centric,
+//            one / two / four pixels per wavefront: lanes test the candidate rays, hits are rank-sorted by ray index and
+//            blended in that order; the few pixels with more than 64 candidates scan all rays in index order
+//   beyond   one lane per (ray, step): work is proportional to what is drawn, not to the scan's bounding square.  The lane
+//            looks up who else draws its pixel; the lowest ray index among the hits owns the pixel (see k2_pixels)
+//   last     pixels with more hits than a lane orders are queued and drawn by the last workgroup to finish
 // All integer arithmetic wraps like C# unchecked int; float->int follows cvttss2si (sh_f2i).
 // Deviations from the reference (all in exception / platform-dependent territory; the CPU checker used by the tests does the same):
 //   D1 non-representable pixel coordinates (NaN/inf, e.g. zero-range point) skip the ray;
@@ -227,15 +227,11 @@ __device__ static __forceinline__ bool k2_hit(const k2_cand c, int a, int b)
 // a valid ray blends exactly one pixel, :404,:431), [3] x1, [4] y1, [5] robot inside the map
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
-           k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof, k2_vprof *__restrict__ vprof_sorted,
+           k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof,
            int *__restrict__ start,
            int *__restrict__ counters, int *__restrict__ total_out, int *__restrict__ dirty, const k3_ride ride)
 {
-    if (blockIdx.x > 0) {                                          // riding along: the ray walks of the ObstacleMap update
-        k3_rays_unit((blockIdx.x - 1) * 16 + (threadIdx.x >> 6), threadIdx.x & 63, ride.pts, ride.n_points, ride.size, ride.scale,
-                     ride.d_pose, ride.h_pxcs, ride.hits, ride.nohit, ride.chunks_per_ray);
-        return;
-    }
+    (void)ride;
     __shared__ int hist[4 * K2_NBUCK];
     __shared__ int wsum[16];
     __shared__ int s_R, s_total;
@@ -246,9 +242,7 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     const float4 q = k2_pxcs(d_pose, h_pxcs, scale);
     int my_R = 0, my_total = 0;
     k2_byidx keep[2];                                              // a thread's first two rays stay in registers for the second pass (scans of up to 2048 rays)
-    k2_vprof keepv[2];
     keep[0].flags = 0; keep[1].flags = 0;
-    memset(keepv, 0, sizeof(keepv));
     for (int i = t, it = 0; i < n; i += 1024, it++) {
         const cs_ray r = k2_make_ray(pts[i], size, q, scale, hole_width);
         k2_byidx e; e.dxc = r.dxc; e.sdyc = r.smin * r.dyc; e.lim2 = r.lim2;
@@ -258,7 +252,6 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
         if (r.valid) {
             k2_vprof vp; vp.derrorv = r.derrorv; vp.incv = r.incv; vp.lim2 = r.lim2; vp.lim1 = r.lim1;
             vprof[i] = vp;
-            if (it == 0) keepv[0] = vp; else if (it == 1) keepv[1] = vp;
             const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
             const float tt = r.dxc > 0 ? (float)e.sdyc / (float)r.dxc : 0.0f;
             atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
@@ -299,7 +292,6 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
             const int pos = atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
             k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
             cand[pos] = c;
-            vprof_sorted[pos] = it == 0 ? keepv[0] : it == 1 ? keepv[1] : vprof[i];      // the V-profiles in table order, for the lane-per-pixel lookups
         }
     }
     if (t == 0) {
@@ -319,11 +311,10 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
 // One wavefront draws one pixel: lanes test the candidate rays, hits are rank-sorted by ray index and blended in that
 // order; the robot's pixel (step 0 of every ray) and its closest neighbours (more than 64 candidates) scan all rays in
 // index order.  `sval` is 64 ints of LDS private to the wavefront.
-// (byidx / cand / vprof_sorted: LDS when the scan's tables fit, else global; vprof: by ray index, global -- read only by the
-// all-rays scan, for a pixel inside a ray's hole zone)
+// (byidx / cand / vprof: LDS when the kernel made the scan's tables itself, else global; vprof goes by ray index)
 template <typename T, typename CT, typename BT, typename VT>
 __device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, int size, BT byidx,
-                                            const k2_vprof *__restrict__ vprof, VT vprof_sorted, int n_rays, CT cand, const int *start,
+                                            VT vprof, int n_rays, CT cand, const int *start,
                                             uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int lane = threadIdx.x & 63;
@@ -382,7 +373,7 @@ __device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y
         if (ci >= 0) {
             const k2_cand c = cand[ci];
             const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
-            if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof_sorted[ci], aa); }
+            if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], aa); }
         }
         const unsigned long long mask = __ballot(hit);
         if (mask) {
@@ -430,7 +421,7 @@ __device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y
 // lookup is a chain of dependent small reads (bucket bounds -> candidates -> V-profile -> map), which global-memory latency
 // would dominate.
 #ifndef K2_LDS_RAYS
-#define K2_LDS_RAYS 2880               // largest scan whose tables fit the LDS: 16.4 KB of buckets + 48 B per ray + the kernel's static 4 KB <= 160 KB
+#define K2_LDS_RAYS 2400               // largest scan whose tables fit the LDS: 2 x 16.4 KB of buckets + 48 B per ray + the kernel's static 4 KB <= 160 KB
 #endif
 #ifdef K2_TIMES
 // developer instrumentation (build with SLAMHIP_K2_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
@@ -449,7 +440,7 @@ __device__ unsigned long long g_k2_sub[512 * 16 * 8];   // per wavefront: [0] T1
 // Which rays draw the pixel at offset (dx, dy) from the robot?  Up to H hits, kept sorted by ray index (compile-time
 // subscripts: the lists stay in registers); `min_ray` = the lowest hitting ray index, also when the list overflowed.
 template <typename T, int H, typename CT, typename VT>
-__device__ static __forceinline__ void k2_lookup(CT cand, VT vprof_sorted, const int *start, int dx, int dy,
+__device__ static __forceinline__ void k2_lookup(CT cand, VT vprof, const int *start, int dx, int dy,
                                         int (&hidx)[H], int (&hval)[H], int &nh, bool &overflow, int &min_ray)
 {
     int cls[2], a[2], b[2];
@@ -463,7 +454,7 @@ __device__ static __forceinline__ void k2_lookup(CT cand, VT vprof_sorted, const
             if (!k2_hit<T>(c, a[k], b[k])) continue;
             min_ray = c.ray < min_ray ? c.ray : min_ray;
             if (nh == H) { overflow = true; continue; }            // (keep scanning: the owner is the lowest index of ALL hits)
-            const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof_sorted[ci], a[k]);
+            const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], a[k]);
             int posn = 0;
 #pragma unroll
             for (int s = 0; s < H; s++) if (s < nh && hidx[s] < c.ray) posn++;
@@ -494,7 +485,7 @@ __device__ static __forceinline__ void k2_ring_pixel(int i, int &ddx, int &ddy)
 // kernel's code is executed once or twice per wavefront, from a cold instruction cache: its size is latency; nine inlined copies
 // of the one-pixel path made a 47 KB kernel that ran 10 us slower than the 20 KB one).
 template <typename T, typename CT, typename BT, typename VT>
-__device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg, int x1, int y1, int size, BT byidx, const k2_vprof *__restrict__ vprof,
+__device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg, int x1, int y1, int size, BT byidx,
                                                      VT vps, int n_rays, CT cand, const int *start, uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int W = 64 >> lg, G = 1 << lg;
@@ -514,7 +505,7 @@ __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg
         for (int gg = 0; gg < G; gg++) {
             const int Xg = __builtin_amdgcn_readlane(X, gg * W), Yg = __builtin_amdgcn_readlane(Y, gg * W);
             const int vg = __builtin_amdgcn_readlane(valid ? 1 : 0, gg * W);
-            if (vg) k2_wave_pixel<T>(Xg, Yg, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval);
+            if (vg) k2_wave_pixel<T>(Xg, Yg, x1, y1, size, byidx, vps, n_rays, cand, start, map, alpha, sval);
         }
         return;
     }
@@ -529,7 +520,7 @@ __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg
     if (ci >= 0) {
         const k2_cand c = cand[ci];
         const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
-        if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[ci], aa); }
+        if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[c.ray], aa); }
     }
     const unsigned long long mask = __ballot(hit);
     if (mask == 0ull) return;
@@ -560,46 +551,145 @@ __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg
     __builtin_amdgcn_wave_barrier();
 }
 
-// dynamic LDS of the pixel kernel: the bucket table, then -- when the scan's tables fit (LDS_TABLE) -- the sorted ray table, the
-// V-profiles in table order and the rays by index (16 bytes per ray each)
+// dynamic LDS of the pixel kernel: the bucket table; when the kernel builds the scan's tables itself (BUILD) the buckets'
+// running positions, the sorted ray table, the V-profiles in table order and the rays by index (16 bytes per ray each)
 #define K2_LDS_FIXED ((4 * K2_NBUCK + 4) * 4)
-static inline size_t k2_lds_bytes(bool lds_table, int n_rays) { return (size_t)K2_LDS_FIXED + (lds_table ? (size_t)48 * (size_t)((n_rays + 3) & ~3) : 0); }
+static inline size_t k2_lds_bytes(bool build, int n_rays) { return (size_t)K2_LDS_FIXED + (build ? (size_t)4 * K2_NBUCK * 4 + (size_t)48 * (size_t)((n_rays + 3) & ~3) : 0); }
 
 // a T3 work item as a lane holds it between its fetch (the pixel's load is issued there) and its turn
-struct k2_t3 { int ptr, dx, dy, ray, ci, lim2; uint16_t pix; };
+struct k2_t3 { int ptr, dx, dy, ray, lim2; uint16_t pix; };
 
-template <bool LDS_TABLE, typename T>
+// what the kernel needs of the scan when it makes the tables itself
+struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; };
+
+// BUILD: ONE launch per HoleMap update.  Every workgroup makes the scan's ray tables itself, in LDS -- per ray the literal
+// arithmetic of :519-530 / :361-399 (k2_make_ray), a counting sort into 4 direction classes x 1024 slope buckets -- instead of
+// reading what a one-workgroup k2_prepare launch left in memory: 1080 rays are a microsecond of arithmetic for 1024 lanes, the
+// separate launch was 7.5 us plus a launch boundary.  (The order of the rays inside a bucket differs from workgroup to workgroup
+// -- LDS atomics -- so nothing that is shared out between workgroups goes by table position: T3 deals RAY INDICES.)
+// !BUILD (scans of more than K2_LDS_RAYS rays): k2_prepare's tables are read from memory.
+template <bool BUILD, typename T>
 __global__ void __launch_bounds__(1024)
-k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vprof, const k2_vprof *__restrict__ vprof_sorted_g,
+k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vprof_g,
           const k2_cand *__restrict__ cand_g, int n_rays,
           const int *__restrict__ start_g, int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
           int *__restrict__ conflict_pix, int cap_conflict, int n_pix_wgs, const k3_ride ride)
 {
-    if ((int)blockIdx.x >= n_pix_wgs) {                            // riding along: the cell pass of the ObstacleMap update
-        k3_apply_cell(((int)blockIdx.x - n_pix_wgs) * 1024 + threadIdx.x, ride.map, ride.n_cells, ride.hits, ride.nohit, ride.max_hits);
+    if ((int)blockIdx.x >= n_pix_wgs) {                            // riding along: the ObstacleMap update (obstacle_dev.h)
+        const int rb = (int)blockIdx.x - n_pix_wgs;
+        if (rb < ride.ray_blocks) k3_rays_unit(rb * 16 + (threadIdx.x >> 6), threadIdx.x & 63, ride.pts, ride.n_points, ride.size, ride.scale,
+                                               ride.d_pose, ride.h_pxcs, ride.hits, ride.nohit, ride.chunks_per_ray);
+        else k3_apply_cell((rb - ride.ray_blocks) * 1024 + threadIdx.x, ride.map, ride.n_cells, ride.cell_hits, ride.cell_nohit, ride.cell_max_hits);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char k2_smem[];
     int *start = (int *)k2_smem;
     const int n4 = (n_rays + 3) & ~3;
-    k2_cand *cand_s = (k2_cand *)(k2_smem + K2_LDS_FIXED);
-    k2_vprof *vprof_s = (k2_vprof *)(cand_s + (LDS_TABLE ? n4 : 0));
-    k2_byidx *byidx_s = (k2_byidx *)(vprof_s + (LDS_TABLE ? n4 : 0));
+    int *pos_s = (int *)(k2_smem + K2_LDS_FIXED);
+    k2_cand *cand_s = (k2_cand *)(pos_s + (BUILD ? 4 * K2_NBUCK : 0));
+    k2_vprof *vprof_s = (k2_vprof *)(cand_s + (BUILD ? n4 : 0));
+    k2_byidx *byidx_s = (k2_byidx *)(vprof_s + (BUILD ? n4 : 0));
     __shared__ __attribute__((aligned(16))) int sval[16][64];
-    __shared__ int s_last, s_nextA, s_nextB;
+    __shared__ int s_last, s_nextA, s_nextB, s_R, s_total, wsum[16];
     K2_STAMP(0)
-    const int R = counters[0], x1 = counters[3], y1 = counters[4];
-    if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;       // robot outside the map: nothing is drawn (:509-512)
-    if (threadIdx.x == 0) { s_nextA = 0; s_nextB = 0; }
-    for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
-    if (LDS_TABLE) for (int i = threadIdx.x; i < n_rays; i += 1024) { cand_s[i] = cand_g[i]; vprof_s[i] = vprof_sorted_g[i]; byidx_s[i] = byidx_g[i]; }   // (table entries past the valid rays are never addressed)
-    __syncthreads();
-    K2_STAMP(6)
-    const int n_valid = start[4 * K2_NBUCK];
+    int R, x1, y1, n_valid;
+    if (BUILD) {
+        const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
+        constexpr int RPT = (K2_LDS_RAYS + 1023) / 1024;            // rays per thread
+        float2 p_next = make_float2(0.f, 0.f);
+        if (t < n_rays) p_next = sc.pts[t];                         // (a thread's next point is requested one iteration ahead)
+        const float4 q = k2_pxcs(sc.d_pose, sc.h_pxcs, sc.scale);
+        for (int i = t; i < 4 * K2_NBUCK; i += 1024) start[i] = 0;  // (the histogram, then the bucket table)
+        if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; }
+        __syncthreads();
+        int bkt[RPT];                                               // a ray's bucket (class * 1024 + slope bucket), -1: not valid
+        int my_R = 0, my_total = 0;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) bkt[k] = -1;
+#pragma unroll 1
+        for (int it = 0; it * 1024 < n_rays; it++) {                // (rolled: k2_make_ray is kilobytes of code, fetched once per launch)
+            const int i = t + it * 1024;
+            int bb = -1;
+            const float2 p = p_next;
+            if (i + 1024 < n_rays) p_next = sc.pts[i + 1024];
+            if (i < n_rays) {
+                const cs_ray r = k2_make_ray(p, size, q, sc.scale, sc.hole_width);
+                k2_byidx ee; ee.dxc = r.dxc; ee.sdyc = r.smin * r.dyc; ee.lim2 = r.lim2;
+                ee.flags = (r.valid ? 1 : 0) | (r.major_x ? 2 : 0) | ((r.smaj + 1) << 2);
+                byidx_s[i] = ee;
+                if (r.valid) {
+                    k2_vprof vv; vv.derrorv = r.derrorv; vv.incv = r.incv; vv.lim2 = r.lim2; vv.lim1 = r.lim1;
+                    vprof_s[i] = vv;
+                    const float tt = r.dxc > 0 ? (float)ee.sdyc / (float)r.dxc : 0.0f;
+                    bb = (r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3)) * K2_NBUCK + rs_bucket(tt);
+                    atomicAdd(&start[bb], 1);
+                    my_R = max(my_R, r.dxc);
+                    my_total += r.dxc + 1;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RPT; k++) if (k == it) bkt[k] = bb;
+        }
+        for (int off = 32; off > 0; off >>= 1) {                   // one LDS atomic per wave, not per ray (same address)
+            my_R = max(my_R, __shfl_down(my_R, off, 64));
+            my_total += __shfl_down(my_total, off, 64);
+        }
+        if (lane_ == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_total, my_total); }
+        __syncthreads();
+        {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
+            int v[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = start[4 * t + k]; sum += v[k]; }
+            int incl = sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane_ >= off) incl += o;
+            }
+            if (lane_ == 63) wsum[wid] = incl;
+            __syncthreads();                                       // (every thread has read its bins: they may be overwritten)
+            int base = incl - sum;
+            for (int w = 0; w < wid; w++) base += wsum[w];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { start[4 * t + k] = base; pos_s[4 * t + k] = base; base += v[k]; }
+            if (t == 1023) start[4 * K2_NBUCK] = base;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < RPT; it++) {
+            const int i = t + it * 1024;
+            if (i < n_rays && bkt[it] >= 0) {
+                const k2_byidx ee = byidx_s[i];                    // (this thread's own store)
+                const int pos = atomicAdd(&pos_s[bkt[it]], 1);
+                k2_cand c; c.dxc = ee.dxc; c.sdyc = ee.sdyc; c.lim2 = ee.lim2; c.ray = i;
+                cand_s[pos] = c;
+            }
+        }
+        R = s_R; x1 = sh_f2i(q.x); y1 = sh_f2i(q.y);
+        if (blockIdx.x == 0 && t == 0) {                           // what the host reads: reach, blended pixels, the robot's pixel
+            counters[0] = R; counters[2] = s_total; counters[3] = x1; counters[4] = y1;
+            if (sc.total_out) *sc.total_out = s_total;
+            // the pixels this update can change lie in the scan's bounding square: the partial host mirror
+            // (slamhip_cs_holemap_mirror) copies the union of these squares since its last call
+            if (sc.dirty && s_total > 0 && x1 >= 0 && x1 < size && y1 >= 0 && y1 < size) {
+                sc.dirty[0] = min(sc.dirty[0], max(x1 - R, 0)); sc.dirty[1] = min(sc.dirty[1], max(y1 - R, 0));
+                sc.dirty[2] = max(sc.dirty[2], min(x1 + R, size - 1)); sc.dirty[3] = max(sc.dirty[3], min(y1 + R, size - 1));
+            }
+        }
+        __syncthreads();
+        n_valid = start[4 * K2_NBUCK];
+        if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;   // robot outside the map: nothing is drawn (:509-512)
+    } else {
+        R = counters[0]; x1 = counters[3]; y1 = counters[4];
+        if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;   // robot outside the map: nothing is drawn (:509-512)
+        if (threadIdx.x == 0) { s_nextA = 0; s_nextB = 0; }
+        for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
+        __syncthreads();
+        n_valid = start[4 * K2_NBUCK];
+    }
     K2_STAMP(1)
-    const k2_cand *cand = LDS_TABLE ? cand_s : cand_g;
-    const k2_vprof *vps = LDS_TABLE ? vprof_s : vprof_sorted_g;
-    const k2_byidx *byidx = LDS_TABLE ? byidx_s : byidx_g;
+    const k2_cand *cand = BUILD ? cand_s : cand_g;
+    const k2_vprof *vps = BUILD ? vprof_s : vprof_g;
+    const k2_byidx *byidx = BUILD ? byidx_s : byidx_g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // Work items are dealt to the workgroups round-robin and inside a workgroup to whichever wavefront is free (an LDS
     // counter): an item costs what its pixels' hit lists cost, and a workgroup is only as fast as its slowest wavefront.
@@ -610,12 +700,6 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
     const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R, n_pix = (2 * Z + 1) * (2 * Z + 1);
     int rB = (12 * n_valid + 1079) / 1080, rC = (28 * n_valid + 1079) / 1080;
     rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB; rC = rC < rB ? rB : rC > K2_ZONE ? K2_ZONE : rC;
-#ifdef K2_DBG_RB
-    rB = K2_DBG_RB; rC = rC < rB ? rB : rC;
-#endif
-#ifdef K2_DBG_RC
-    rC = K2_DBG_RC;
-#endif
     const int pA = min((2 * rB - 1) * (2 * rB - 1), n_pix), pB = min((2 * rC - 1) * (2 * rC - 1), n_pix);
     const int nA = pA, nB = (pB - pA + 1) / 2, nC = (n_pix - pB + 3) / 4;
     for (;;) {
@@ -627,20 +711,19 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
         int pix0 = item, lim = n_pix, lg = 0;
         if (item >= nA + nB) { pix0 = pB + 4 * (item - nA - nB); lg = 2; }
         else if (item >= nA) { pix0 = pA + 2 * (item - nA); lim = pB; lg = 1; }
-        k2_wave_group<T>(pix0, lim, lg, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
+        k2_wave_group<T>(pix0, lim, lg, x1, y1, size, byidx, vps, n_rays, cand, start, map, alpha, sval[wv]);
         K2_ITEM_T1(0, item)
     }
     K2_STAMP(2)
     // T3: one lane per (ray, step) beyond the zone, ray = an entry of the sorted table, steps in blocks of 64.  Software
     // pipeline: an item's pixel is requested when the item is fetched, one iteration before its turn -- the map sits in HBM /
     // Infinity Cache, a microsecond away.
-    // The rays are dealt to the XCDs by SECTOR -- XCD s (workgroup b runs on XCD b % 8) draws the s-th eighth of the sorted table, a
-    // contiguous range of directions: a ray's pixels share their 128-byte lines with its neighbours' (at r = 600 px adjacent rays
-    // are 3.5 px apart), and a line must meet ONE L2.  Dealt round-robin over all workgroups, every XCD fetched and wrote back
-    // every line: eight times the traffic, and the tier ran at the speed of the fabric.
+    // Rays are dealt BY INDEX (a scan's rays come in order of their angle: neighbours in index are neighbours in direction), and to
+    // the XCDs by sector -- XCD s (workgroup b runs on XCD b % 8) draws the s-th eighth of the scan: a ray's pixels share their
+    // 128-byte lines with its neighbours' (at r = 600 px adjacent rays are 3.5 px apart), and a line should meet one L2.
     const int nblk = R >= K2_ZONE ? (R - K2_ZONE) / 64 + 1 : 0;      // steps K2_ZONE .. R
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_in_xcd = (n_pix_wgs - xcd + 7) >> 3;
-    const int c0 = (int)(((long long)n_valid * xcd) >> 3), n_sec = (int)(((long long)n_valid * (xcd + 1)) >> 3) - c0;
+    const int c0 = (int)(((long long)n_rays * xcd) >> 3), n_sec = (int)(((long long)n_rays * (xcd + 1)) >> 3) - c0;
     const int n_t3 = nblk * n_sec;
     const float rcp_nv = __builtin_amdgcn_rcpf((float)(n_sec > 0 ? n_sec : 1));
 #define K2_FETCH(it, more_)                                                                              \
@@ -652,13 +735,13 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
         more_ = item_ < n_t3;                                                                           \
         if (more_) {                                                                                    \
             int blk_ = (int)((float)item_ * rcp_nv);       /* item / n_sec (item < 2^24: settled exactly below) */ \
-            int ci_ = item_ - blk_ * n_sec;                                                             \
-            if (ci_ < 0) { blk_--; ci_ += n_sec; } else if (ci_ >= n_sec) { blk_++; ci_ -= n_sec; }     \
-            ci_ += c0;                                                                                  \
-            const k2_cand me_ = cand[ci_];                 /* (uniform: an LDS broadcast) */             \
+            int ri_ = item_ - blk_ * n_sec;                                                             \
+            if (ri_ < 0) { blk_--; ri_ += n_sec; } else if (ri_ >= n_sec) { blk_++; ri_ -= n_sec; }     \
+            ri_ += c0;                                                                                  \
+            const k2_byidx me_ = byidx[ri_];               /* (uniform: an LDS broadcast) */             \
             const int x_ = K2_ZONE + blk_ * 64 + lane;                                                  \
-            if (x_ <= me_.dxc) {                                                                        \
-                const int cls_ = ci_ < start[2 * K2_NBUCK] ? (ci_ < start[K2_NBUCK] ? 0 : 1) : (ci_ < start[3 * K2_NBUCK] ? 2 : 3); \
+            if ((me_.flags & 1) && x_ <= me_.dxc) {                                                     \
+                const int smaj_ = ((me_.flags >> 2) & 3) - 1;                                           \
                 const int dyc_ = me_.sdyc < 0 ? -me_.sdyc : me_.sdyc;                                   \
                 const T N_ = (T)2 * dyc_ * x_ - me_.dxc, D_ = (T)2 * me_.dxc;                           \
                 int m_ = 0;                                                                             \
@@ -672,16 +755,16 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
                     } else q_ = (N_ + D_ - 1) / D_;                                                     \
                     m_ = q_ < (T)x_ ? (int)q_ : x_;                                                     \
                 }                                                                                       \
-                const int b_ = me_.sdyc < 0 ? -m_ : m_, a_ = (cls_ & 1) ? -x_ : x_;                     \
-                (it).dx = cls_ < 2 ? a_ : b_; (it).dy = cls_ < 2 ? b_ : a_;                             \
-                (it).ray = me_.ray; (it).ci = ci_; (it).lim2 = me_.lim2;                                \
+                const int b_ = me_.sdyc < 0 ? -m_ : m_, a_ = smaj_ < 0 ? -x_ : x_;                      \
+                (it).dx = (me_.flags & 2) ? a_ : b_; (it).dy = (me_.flags & 2) ? b_ : a_;               \
+                (it).ray = ri_; (it).lim2 = me_.lim2;                                                   \
                 (it).ptr = (y1 + (it).dy) * size + (x1 + (it).dx);         /* (step pixels of a clipped ray lie inside the map) */ \
                 (it).pix = map[(it).ptr];                                                               \
             }                                                                                           \
         }                                                                                               \
     }
     k2_t3 cur, nxt;
-    cur.ptr = -1; cur.dx = cur.dy = cur.ray = cur.ci = cur.lim2 = 0; cur.pix = 0; nxt = cur;
+    cur.ptr = -1; cur.dx = cur.dy = cur.ray = cur.lim2 = 0; cur.pix = 0; nxt = cur;
     bool more = false;
     if (n_t3 > 0) K2_FETCH(cur, more)
     while (more) {
@@ -699,7 +782,7 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
             }
             if (hi - lo == 1) {
                 const int a = adx > ady ? adx : ady;
-                const int v = a <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[cur.ci], a);
+                const int v = a <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[cur.ray], a);
                 map[cur.ptr] = k2_blend(cur.pix, v, alpha);
             } else {
                 int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh, min_ray;
@@ -739,9 +822,12 @@ k2_pixels(const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vpr
     if (!s_last) return;
     int n_conf = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n_conf > cap_conflict) n_conf = cap_conflict;
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&counters[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (at rest between launches, like the ticket)
+    if (threadIdx.x == 0) counters[5] = n_conf;                     // (developer statistics: SLAMHIP_K2_STATS)
     for (int item = wv; item < n_conf; item += 16) {
         const int ptr = __hip_atomic_load(&conflict_pix[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k2_wave_pixel<T>(ptr % size, ptr / size, x1, y1, size, byidx, vprof, vps, n_rays, cand, start, map, alpha, sval[wv]);
+        k2_wave_pixel<T>(ptr % size, ptr / size, x1, y1, size, byidx, vps, n_rays, cand, start, map, alpha, sval[wv]);
     }
 }
 
@@ -771,18 +857,21 @@ void cs_holemap_free(slamhip_cs *cs)
     (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_conflict_pix); (void)hipFree(cs->d_hole_dirty);
 }
 
-// ride != nullptr: the ObstacleMap update (prepared by cs_obstacle_ride) travels in the same two launches
-int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, float hole_width, int quality, const k3_ride *ride_in)
+// with_obstacle: the ObstacleMap update of this scan rides on the launch (obstacle_dev.h); scans too large for the in-kernel
+// tables take k2_prepare + the pixel kernel, and their ObstacleMap update its own launches
+int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, float4 h_pxcs_obst, float hole_width, int quality,
+                                 bool with_obstacle, int max_hits)
 {
-    k3_ride ride;
-    if (ride_in) ride = *ride_in; else memset(&ride, 0, sizeof(ride));
-    const int ride_rays = ride.n_blocks ? sh_div_up(ride.n_points * ride.chunks_per_ray, 16) : 0;
-    const int ride_cells = ride.n_blocks ? sh_div_up(ride.n_cells, 1024) : 0;
     slamhip_ctx *ctx = cs->ctx;
     const int n = cs->n_points;
     if (n <= 0) return SLAMHIP_OK;
     SH_TRY(cs_flush_scan(cs));
-    if (n > cs->cap_rays) {
+    static const bool two_launch = getenv("SLAMHIP_K2_TWO_LAUNCHES") != nullptr;          // (tests: the large-scan path on ordinary scans)
+    const bool build = n <= K2_LDS_RAYS && !two_launch;
+    k3_ride ride;
+    memset(&ride, 0, sizeof(ride));
+    if (with_obstacle && build) cs_obstacle_ride(cs, d_pose, h_pxcs_obst, max_hits, &ride);
+    if (!build && n > cs->cap_rays) {
         if (cs->d_rays) (void)hipFree(cs->d_rays);
         if (cs->d_k2_cand) (void)hipFree(cs->d_k2_cand);
         if (cs->d_k2_vprof) (void)hipFree(cs->d_k2_vprof);
@@ -790,31 +879,40 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         const int cap = n + n / 4 + 64;
         SH_HIP(hipMalloc(&cs->d_rays, sizeof(k2_byidx) * (size_t)cap));
         SH_HIP(hipMalloc(&cs->d_k2_cand, sizeof(k2_cand) * (size_t)cap));
-        SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_vprof) * 2 * (size_t)cap));      // by ray index | in table order
+        SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_vprof) * (size_t)cap));
         cs->cap_rays = cap;
     }
-    sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
-    hipLaunchKernelGGL(k2_prepare, dim3(1 + ride_rays), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                       hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, (k2_vprof *)cs->d_k2_vprof + cs->cap_rays, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty, ride);
-    // One round of resident workgroups (a second round would start when the first drains: measured 51 -> 42 us at
-    // 2048^2 together with the per-workgroup work counter): what the occupancy calculator says fits, times the CUs.
-    static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
-#define K2_PIXELS(L, T) {                                                                                                   \
-        static int per_cu = 0;                                                                                              \
-        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2_pixels<L, T>, 1024, k2_lds_bytes(L, L ? K2_LDS_RAYS : 0)) != hipSuccess || per_cu < 1)) per_cu = 1; \
-        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;                                                              \
-        const int grid = grid_env > 0 ? grid_env : (L ? 1 : per_cu < 2 ? per_cu : 2) * cus;   /* (with the LDS table one workgroup per CU measured best) */ \
-        static bool told = false;                                                                                           \
-        if (!told && getenv("SLAMHIP_K2_STATS")) { told = true; fprintf(stderr, "[slamhip] K2 pixel kernel: %d workgroups (%d per CU x %d CUs)\n", grid, per_cu, ctx->num_cus); } \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) { attr_set = true; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(true, K2_LDS_RAYS)); } \
-        hipLaunchKernelGGL((k2_pixels<L, T>), dim3(grid + ride_cells), dim3(1024), k2_lds_bytes(L, n), ctx->stream, (const k2_byidx *)cs->d_rays, \
-                           (const k2_vprof *)cs->d_k2_vprof, (const k2_vprof *)cs->d_k2_vprof + cs->cap_rays, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
-                           cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }
-    if (n <= K2_LDS_RAYS) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }
-    else                  { if (cs->hs <= 16384) K2_PIXELS(false, int) else K2_PIXELS(false, long long) }
+    k2_scan sc;
+    sc.pts = cs->d_pts; sc.scale = cs->hscale; sc.hole_width = hole_width; sc.d_pose = d_pose; sc.h_pxcs = h_pxcs;
+    sc.total_out = (int *)cs->d_key + 6; sc.dirty = cs->d_hole_dirty;
+    {
+        sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
+        if (!build) {
+            k3_ride none;
+            memset(&none, 0, sizeof(none));
+            hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
+                               hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty, none);
+        }
+        // One round of resident workgroups, one per CU (a second round would start when the first drains; with the tables in LDS
+        // one workgroup per CU measured best).
+        static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
+        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        const int grid = grid_env > 0 ? grid_env : build ? cus : 2 * cus;
+#define K2_PIXELS(B, T) {                                                                                                   \
+            static bool attr_set = false;                                                                                   \
+            if (!attr_set) { attr_set = true; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); } \
+            hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid + ride.ray_blocks + ride.cell_blocks), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_byidx *)cs->d_rays, \
+                               (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
+                               cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }
+        if (build) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }
+        else       { if (cs->hs <= 16384) K2_PIXELS(false, int) else K2_PIXELS(false, long long) }
 #undef K2_PIXELS
+    }
     SH_HIP(hipGetLastError());
+    if (with_obstacle) {
+        if (build) cs_obstacle_ride_commit(cs, &ride, max_hits);
+        else SH_TRY(cs_launch_obstacle_update(cs, d_pose, h_pxcs_obst, max_hits));
+    }
 #ifdef K2_TIMES
     {
         static int calls = 0;
@@ -835,8 +933,6 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
             fprintf(stderr, "[k2 times] %d workgroups, span %.2f us; first thread of each workgroup, mean (max):", nb, (double)(t1 - t0) * 0.01);
             for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f (%.2f) |", nm[k], acc[k] / std::max(nb, 1), mx[k]);
             fprintf(stderr, " last workgroup starts at %.2f us\n", smax);
-            { double a6 = 0, a7 = 0; int nn = 0; for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 6]) { a6 += (double)(h[i * 8 + 6] - h[i * 8]) * 0.01; a7 += (double)(h[i * 8 + 7] - h[i * 8 + 6]) * 0.01; nn++; }
-              fprintf(stderr, "[k2 times] inside tables: loads + first barrier %.2f us | x_free (thread 0) %.2f us\n", a6 / std::max(nn, 1), a7 / std::max(nn, 1)); }
             std::vector<unsigned long long> sb(512 * 16 * 8);
             (void)hipMemcpyFromSymbol(sb.data(), HIP_SYMBOL(g_k2_sub), sizeof(unsigned long long) * sb.size());
             double tt[3] = { 0, 0, 0 }, cn[3] = { 0, 0, 0 }, wmax[3] = { 0, 0, 0 };

@@ -1,15 +1,17 @@
 // obstacle_dev.h -- the two steps of the ObstacleMap update (K3) as device functions: obstacle.hip launches them as
-// kernels of their own; the fused search + update rides them on the two HoleMap launches (extra workgroups of
-// k2_prepare / k2_pixels, holemap.hip), which saves two dependent launches per scan.
+// kernels of their own; the fused search + update rides them on the HoleMap update's ONE launch (extra workgroups of
+// k2_pixels, holemap.hip): the ray walks of this scan, and the cell pass of the PREVIOUS scan -- the two steps of one scan
+// need a launch boundary between them, so the per-scan scratch (hits, noHit) is double-buffered and the cell pass trails one
+// scan behind; whoever reads or writes the ObstacleMap flushes it first (cs_obstacle_flush).  No launch of its own per scan.
 #pragma once
 #include "common.h"
 #include "det_trig.h"
 
 struct k3_ride {
-    int n_blocks;                      // extra 1024-thread workgroups carrying K3 work (0: none)
+    int ray_blocks, cell_blocks;       // extra 1024-thread workgroups: this scan's ray walks, the pending cell pass (0: none)
     const float2 *pts; int n_points, size; float scale; const float *d_pose; float4 h_pxcs;
-    uint32_t *hits; uint8_t *nohit; int chunks_per_ray;
-    int8_t *map; int n_cells, max_hits;
+    uint32_t *hits; uint8_t *nohit; int chunks_per_ray;                   // this scan's scratch
+    int8_t *map; int n_cells; uint32_t *cell_hits; uint8_t *cell_nohit; int cell_max_hits;   // the pending pass: its scratch, its MaxObstacleHits
 };
 
 // one wavefront per (ray, 64 iterations of the walk): w = ray * chunks_per_ray + chunk, one lane per iteration

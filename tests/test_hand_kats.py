@@ -1,0 +1,218 @@
+"""Known answers derived BY HAND from the C# text of the reference -- not from either restatement in oracle/.
+
+The reference ships no tests or fixtures (SLAM.sln:6-15) and cannot be built in this image, so the oracle is "parity
+unpinned" against the C# itself.  These cases are a third, human-checkable anchor: every expected number below was
+worked out with pencil-and-paper arithmetic from CoreSLAM/CoreSLAMProcessor.cs:320-443 (ClipRay,
+DrawLaserRayOnHoleMap), :496-534 (UpdateHoleMap) and HectorSLAM/Map/OccGridMap.cs:114-239; the working is written out
+in the comments so that a reader can follow it against the C# without running anything.  The C oracle, the NumPy
+oracle and (on the GPU box) the HIP kernels must all reproduce them.
+
+Conventions used in the working: C# `int / int` truncates toward zero; `(int)float` truncates toward zero;
+TS_NO_OBSTACLE = 65500, TS_OBSTACLE = 0 (:21-22); a fresh HoleMap holds (0 + 65500) / 2 = 32750 (:169).
+"""
+import numpy as np
+import pytest
+
+SIZE = 16
+FRESH = 32750
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ray A -- x-major, inside the map, the whole V-profile visible, alpha = 128.
+#   DrawLaserRayOnHoleMap(x1=8, y1=8, x2=14, y2=8, xp=12, yp=8, value=0, alpha=128), Size 16
+#   :365-366 nothing to clip.  :368-374 dx=6 dy=0 dxc=6 dyc=0 incptrx=+1 incptry=0*16=0 sincv=Sign(0-65500)=-1
+#   :377 dx>dy -> derrorv=|xp-x2|=|12-14|=2
+#   :394-399 error=2*0-6=-6 horiz=0 diago=-12 errorv=2/2=1 incv=-65500/2=-32750 incerrorv=-65500-2*(-32750)=0
+#   :401 ptr=8*16+8=136, pixval=65500
+#   x=0,1,2: x > dx-2*derrorv = 2 is false               -> pixval 65500
+#   x=3: 3>2 and 3<=dx-derrorv=4 -> pixval+=incv = 32750; errorv=1 (not > 2)
+#   x=4: 4<=4                   -> pixval = 0
+#   x=5: else branch            -> pixval-=incv = 32750; errorv-=0 = 1 (not < 0)
+#   x=6:                        -> pixval = 65500
+#   error stays -6 (+= horiz = 0): no step in y; pixels ptr 136..142
+#   blend :431 with alpha 128 on 32750: (128*32750 + 128*pixval) >> 8
+#       65500 -> 12 576 000 >> 8 = 49125;  32750 -> 8 384 000 >> 8 = 32750;  0 -> 4 192 000 >> 8 = 16375
+RAY_A = dict(args=(8, 8, 14, 8, 12, 8, 0, 128),
+             want={136: 49125, 137: 49125, 138: 49125, 139: 32750, 140: 16375, 141: 32750, 142: 49125})
+
+# Ray B -- y-major after the swap of :381-387, clipped at the top edge with a NEGATIVE truncating division, alpha = 128.
+#   Draw(x1=8, y1=8, x2=15, y2=18, xp=14, yp=16, value=0, alpha=128)
+#   :365 ClipRay(16, ref x2c=15, ref y2c=18, 8, 8): 0 <= 15 < 16 -> untouched
+#   :366 ClipRay(16, ref y2c=18, ref x2c=15, 8, 8): 18 >= 16, 18 != 8 ->
+#        x2c += (15-8)*(16-1-18)/(18-8) = 7*(-3)/10 = -21/10 = -2 (toward zero; floor would give -3) -> x2c=13, y2c=15
+#   :368-374 dx=7 dy=10 dxc=|13-8|=5 dyc=|15-8|=7 incptrx=+1 incptry=+16 sincv=-1
+#   :377 dx>dy false -> dx=10, (dxc,dyc)=(7,5), (incptrx,incptry)=(16,1), derrorv=|yp-y2|=|16-18|=2
+#   :394-399 error=2*5-7=3 horiz=10 diago=2*(5-7)=-4 errorv=1 incv=-32750 incerrorv=0;  ptr=136
+#   hole starts at x > dx-2*derrorv = 6: only x=7 (<= dx-derrorv = 8) -> pixval 32750; x=0..6 -> 65500
+#   walk (blend at ptr, then error>0 ? ptr+=incptry(1), error+=diago : error+=horiz; then ptr+=incptrx(16)):
+#     x=0 ptr=136 e=3  -> 137,e=-1 -> 153 | x=1 ptr=153 e=-1 -> e=9 -> 169 | x=2 ptr=169 e=9 -> 170,e=5 -> 186
+#     x=3 ptr=186 e=5  -> 187,e=1  -> 203 | x=4 ptr=203 e=1  -> 204,e=-3 -> 220 | x=5 ptr=220 e=-3 -> e=7 -> 236
+#     x=6 ptr=236 e=7  -> 237,e=3  -> 253 | x=7 ptr=253 = 15*16+13: the clipped end point (13,15)
+RAY_B = dict(args=(8, 8, 15, 18, 14, 16, 0, 128),
+             want={136: 49125, 153: 49125, 169: 49125, 186: 49125, 203: 49125, 220: 49125, 236: 49125, 253: 32750})
+
+# Ray C -- x-major towards -x, clipped at the left edge (quotient 0 by truncation), derrorv = 3 so that incv has a
+# remainder and the rising half of the V takes its carry, alpha = 64.
+#   Draw(x1=9, y1=5, x2=-2, y2=2, xp=1, yp=3, value=0, alpha=64)
+#   :365 ClipRay(16, ref x2c=-2, ref y2c=2, 9, 5): -2 < 0, -2 != 9 -> y2c += (2-5)*(-(-2))/(-2-9) = (-6)/(-11) = 0 -> y2c=2, x2c=0
+#   :366 y2c=2 in range.   dx=11 dy=3 dxc=9 dyc=3 incptrx=-1 incptry=-16 sincv=-1;  dx>dy -> derrorv=|1-(-2)|=3
+#   error=2*3-9=-3 horiz=6 diago=2*(3-9)=-12 errorv=3/2=1 incv=-65500/3=-21833 incerrorv=-65500-3*(-21833)=-1;  ptr=5*16+9=89
+#   thresholds: dx-2*derrorv=5, dx-derrorv=8
+#     x=0 ptr=89 65500 e=-3->3 ->88 | x=1 ptr=88 65500 e=3 -> 72,e=-9 ->71 | x=2 ptr=71 65500 e=-9->-3 ->70
+#     x=3 ptr=70 65500 e=-3->3 ->69 | x=4 ptr=69 65500 e=3 -> 53,e=-9 ->52 | x=5 ptr=52 65500 (5>5 false) e=-9->-3 ->51
+#     x=6 ptr=51 pixval=65500-21833=43667 errorv=1-1=0 (not > 3)          e=-3->3 ->50
+#     x=7 ptr=50 pixval=21834 errorv=-1                                    e=3 -> 34,e=-9 ->33
+#     x=8 ptr=33 pixval=1 errorv=-2                                        e=-9->-3 ->32
+#     x=9 ptr=32 (9>8: rising half) pixval=1+21833=21834, errorv=-2-(-1)=-1 < 0 -> pixval-=sincv = 21835, errorv=2
+#   blend alpha 64 on 32750: (192*32750 + 64*pixval) >> 8, 192*32750 = 6 288 000
+#     65500: 10 480 000/256 = 40937.5 -> 40937 | 43667: 9 082 688/256 = 35479.25 -> 35479 | 21834: 7 685 376/256 = 30021
+#     1: 6 288 064/256 = 24562.75 -> 24562     | 21835: 7 685 440/256 = 30021.25 -> 30021
+RAY_C = dict(args=(9, 5, -2, 2, 1, 3, 0, 64),
+             want={89: 40937, 88: 40937, 71: 40937, 70: 40937, 69: 40937, 52: 40937, 51: 35479, 50: 30021, 33: 24562, 32: 30021})
+
+# Rays A then B on ONE map: pixel 136 (the robot's) is drawn twice, in ray order (:431 does not commute):
+#   after A: 49125; B blends 65500 onto it: (128*49125 + 128*65500) >> 8 = 14 672 000 >> 8 = 57312 (.5 dropped)
+A_THEN_B_136 = 57312
+
+
+def _expect(want):
+    m = np.full(SIZE * SIZE, FRESH, np.uint16)
+    for k, v in want.items():
+        m[k] = v
+    return m
+
+
+@pytest.mark.parametrize("ray", [RAY_A, RAY_B, RAY_C], ids=["A", "B", "C"])
+def test_hand_rays_c_oracle(oc, ray):
+    pix = np.full(SIZE * SIZE, FRESH, np.uint16)
+    oc.draw_ray_holemap(pix, SIZE, *ray["args"])
+    assert (pix == _expect(ray["want"])).all(), np.flatnonzero(pix != _expect(ray["want"]))
+
+
+@pytest.mark.parametrize("ray", [RAY_A, RAY_B, RAY_C], ids=["A", "B", "C"])
+def test_hand_rays_numpy_oracle(npo, ray):
+    x1, y1, x2, y2, xp, yp, value, alpha = ray["args"]
+    frags = npo.ray_fragments(SIZE, x1, y1, x2, y2, xp, yp, value)
+    pix = np.full(SIZE * SIZE, FRESH, np.uint16)
+    for ptr, pixval in frags:
+        pix[ptr] = npo.blend(int(pix[ptr]), pixval, alpha)
+    assert (pix == _expect(ray["want"])).all()
+
+
+def test_hand_clip_quotients(oc):
+    # the two truncating divisions worked out above
+    assert oc.clip_ray(16, 18, 15, 8, 8) == (True, 15, 13)            # ray B, second ClipRay: x2c 15 -> 13, y2c 18 -> 15
+    assert oc.clip_ray(16, -2, 2, 9, 5) == (True, 0, 2)               # ray C, first ClipRay: (-6)/(-11) = 0
+
+
+def test_hand_ray_order_c_oracle(oc):
+    pix = np.full(SIZE * SIZE, FRESH, np.uint16)
+    oc.draw_ray_holemap(pix, SIZE, *RAY_A["args"])
+    oc.draw_ray_holemap(pix, SIZE, *RAY_B["args"])
+    want = _expect({**RAY_A["want"], **RAY_B["want"]})
+    want[136] = A_THEN_B_136
+    assert (pix == want).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same two rays through UpdateHoleMap (:496-534), so that the float part is covered too -- with numbers that are exact
+# in binary32, or whose truncation is far from an integer:
+#   map 16 px over 8 m -> Scale 2;  Pose (4, 4, 0) -> px = py = 4*2 + 0.5 = 8.5, c = cos(0)*2 = 2, s = 0;  x1 = y1 = 8
+#   HoleWidth 2.0 m, Quality 128
+#   point (2, 0):  x2p = 2*2 - 0*0 = 4, y2p = 0; xp = (int)12.5 = 12, yp = (int)8.5 = 8; dist = 4;
+#                  add = 2.0*2/2/4 = 0.5 -> x2p = 6 -> x2 = (int)14.5 = 14, y2 = 8                       == ray A
+#   point (3, 4):  x2p = 6, y2p = 8; xp = (int)14.5 = 14, yp = (int)16.5 = 16; dist = sqrt(36 + 64) = 10;
+#                  add = 2/10 = 0.2 -> x2p = 6*1.2 = 7.2(0000005), y2p = 9.6(000001) -> x2 = (int)15.7 = 15, y2 = (int)18.1 = 18   == ray B
+UPDATE_XY = np.array([[2.0, 0.0], [3.0, 4.0]], np.float32)
+UPDATE_POSE = np.array([4.0, 4.0, 0.0], np.float32)
+
+
+def _update_want():
+    want = _expect({**RAY_A["want"], **RAY_B["want"]})
+    want[136] = A_THEN_B_136
+    return want
+
+
+def test_hand_update_c_oracle(oc):
+    pix = np.full(SIZE * SIZE, FRESH, np.uint16)
+    n = oc.update_holemap(pix, SIZE, 2.0, UPDATE_XY, UPDATE_POSE, 2.0, 128)
+    assert (pix == _update_want()).all()
+    assert n == 7 + 8                                                  # steps 0..dxc of each ray blend one pixel each (:404)
+
+
+@pytest.mark.gpu
+def test_hand_update_hip():
+    import slam.net_amd.coreslam as cs
+    ctx = cs.Context(0)
+    dev = cs.CoreSlamDevice(ctx, 8.0, SIZE, 16)
+    assert dev.hole_scale == 2.0
+    dev.set_scan(UPDATE_XY)
+    dev.update_holemap(UPDATE_POSE, 2.0, 128)
+    assert dev.last_holemap_pixels == 15
+    assert (dev.holemap_download() == _update_want()).all()
+    dev.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Hector: one cell that a scan first marks FREE and then OCCUPIED (OccGridMap.cs:192-218).
+#   8 x 8 grid, cell length 1 m -> ScaleToMap 1 (MapProperties);  robot pose (2, 3, 0), scan origin (0, 0):
+#   :120-123 poseTransform = R(0) * T(2,3) * S(1) = [1 0; 0 1; 2 3];  :126-127 begin = Round((0,0)*M) = (2,3)
+#   scan points, in this order:  (4, 0) -> end (6,3);   (2, 0) -> end (4,3)
+#   scan 1 (currUpdateIndex 0 -> markFree 1, markOcc 2), all cells start (Value 0, UpdateIndex -1):
+#     ray 1: abs_dx=4 >= abs_dy=0: Bresenham2D(4, 0, 2, +1, 0, 3*8+2=26): free 26, then i=0..2: 27, 28, 29  (abs_da - 1 = 3 steps:
+#            the end point is not drawn as free);  :189 occ(30): -1 < 2, not == 1 -> Value = 0 + lo, index 2
+#     ray 2: Bresenham2D(2, 0, 1, +1, 0, 26): free 26 (index 1 < 1 false: skipped), i=0: 27 (skipped);
+#            occ(28): index 1 < 2 and == markFree -> Value = (lf) - lf = 0 exactly, then + lo -> lo, index 2
+#     after scan 1: 26, 27, 29 = (lf, 1); 28, 30 = (lo, 2).   currUpdateIndex = 3
+#   scan 2, the same scan (markFree 4, markOcc 5):
+#     ray 1: free 26 -> lf + lf, 27 -> lf + lf, 28: index 2 < 4 -> lo + lf (index 4), 29 -> lf + lf;  occ(30) -> lo + lo (index 5)
+#     ray 2: 26, 27 skipped;  occ(28): index 4 < 5 and == markFree -> Value = ((lo + lf) - lf) + lo, index 5
+#   -- in binary32 (lo + lf) - lf need not give lo back: the expected value is formed below with exactly these three
+#   IEEE operations in this order (NumPy float32 scalars as the calculator), from the implementation's own lf, lo.
+def _hector_expected(lf, lo):
+    lf, lo = np.float32(lf), np.float32(lo)
+    want = {i: (np.float32(0.0), -1) for i in range(64)}
+    want[26] = (np.float32(lf + lf), 4)
+    want[27] = (np.float32(lf + lf), 4)
+    want[29] = (np.float32(lf + lf), 4)
+    want[30] = (np.float32(lo + lo), 5)
+    want[28] = (np.float32(np.float32(np.float32(lo + lf) - lf) + lo), 5)
+    return want
+
+
+HECTOR_XY = np.array([[4.0, 0.0], [2.0, 0.0]], np.float32)
+HECTOR_POSE = np.array([2.0, 3.0, 0.0], np.float32)
+
+
+def test_hand_hector_free_then_occupied_c_oracle(oc):
+    g = oc.Grid(1.0, 8, 8)
+    lf, lo = g.logodds
+    assert abs(lf - (-0.40546510)) < 1e-6 and abs(lo - 2.1972246) < 1e-6      # log(0.4/0.6), log(0.9/0.1) (:24-25, :88-92)
+    g.update_by_scan(HECTOR_XY, HECTOR_POSE)
+    c = g.cells
+    assert (c["update_index"][[26, 27, 29]] == 1).all() and (c["value"][[26, 27, 29]] == np.float32(lf)).all()
+    assert (c["update_index"][[28, 30]] == 2).all() and (c["value"][[28, 30]] == np.float32(lo)).all()
+    g.update_by_scan(HECTOR_XY, HECTOR_POSE)
+    c = g.cells
+    for i, (v, idx) in _hector_expected(lf, lo).items():
+        assert c["update_index"][i] == idx and c["value"][i] == v, i
+    g.close()
+
+
+@pytest.mark.gpu
+def test_hand_hector_free_then_occupied_hip(oc):
+    import slam.net_amd.coreslam as cs
+    import slam.net_amd.hector as hs
+    g = oc.Grid(1.0, 8, 8)
+    lf, lo = g.logodds
+    g.close()
+    ctx = cs.Context(0)
+    rep = hs.MapRepMultiMap(1.0, (8, 8), 1, ctx=ctx)
+    for _ in range(2):
+        rep.UpdateByScan(hs.ScanCloud(HECTOR_XY), HECTOR_POSE)
+    c = rep.Maps[0].GetCells()
+    for i, (v, idx) in _hector_expected(lf, lo).items():
+        assert c["update_index"][i] == idx and c["value"][i] == v, i
+    rep.close()
+    ctx.close()

@@ -1,20 +1,41 @@
 #!/bin/bash
-# rocprofv3 passes over the headline benchmark (run on the GPU box, e.g. gpurun -- 'bash tools/prof_bench.sh r02'):
-#   1. --kernel-trace --stats            per-kernel durations (the K1 average must agree with bench.py's own HIP-event figure)
-#   2. --kernel-trace --pmc FETCH_SIZE   \  HBM-side traffic of the dominant kernel, one counter set per pass
-#   3. --kernel-trace --pmc WRITE_SIZE   /  (MI355X_MICROARCH.md: FETCH_SIZE costs 3 of the 4 TCC slots)
-#   4. --kernel-trace --pmc TCC_HIT TCC_MISS
-# Output: gpurun_out/<tag>/prof/{stats,fetch,write,tcc}; tools/prof_summary.py turns it into profiles/<tag>_*.
-tag=${1:-r02}
+# rocprofv3 passes over the headline benchmark (run on the GPU box, e.g. gpurun -- 'bash tools/prof_bench.sh r03'):
+#   stats      --kernel-trace --stats            per-kernel durations (the K1 average must agree with bench.py's own HIP-event figure)
+#   stats262k  the same at 262 144 candidates per launch (the size at which K1 passes half the HBM roofline)
+#   fetch / write / tcc   --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT TCC_MISS: HBM-side traffic of the dominant kernel, one counter
+#              set per pass (MI355X_MICROARCH.md: FETCH_SIZE costs 3 of the 4 TCC slots)
+#   sq1 / sq2  --pmc SQ_* (8 SQ slots per pass): waves, busy / wave cycles, VALU / SALU / LDS / VMEM instruction counts, wait
+#              cycles, LDS bank conflicts -- the VALU-bound / latency-bound split of K1
+#   k2*        the same counters for the HoleMap update (tools/prof_k2.py: 40 updates at 2048^2)
+# Counter passes never carry --stats or any trace domain but --kernel-trace (gpurun refuses such combinations).
+# Output: gpurun_out/<tag>/prof/*; tools/prof_summary.py turns it into profiles/<tag>_*.
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag/prof
-mkdir -p $out
+rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python3 $root/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- $cmd > $out/stats_bench.json 2> $out/stats.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $cmd > $out/fetch_bench.json 2> $out/fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- $cmd > $out/write_bench.json 2> $out/write.log
-rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS --output-format csv -d $out/tcc -o tcc -- $cmd > $out/tcc_bench.json 2> $out/tcc.log
+bench="python3 $root/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras"
+SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"
+SQ2="SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"
+run() { name=$1; shift; timeout 300 rocprofv3 "$@" > $out/$name.out 2> $out/$name.log; }
+run stats     --kernel-trace --stats --output-format csv -d $out/stats -o stats -- $bench
+run stats262k --kernel-trace --stats --output-format csv -d $out/stats262k -o stats -- $bench --cands 262144 --steps 50
+run fetch     --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- $bench
+run write     --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- $bench
+run tcc       --kernel-trace --pmc TCC_HIT TCC_MISS --output-format csv -d $out/tcc -o p -- $bench
+run sq1       --kernel-trace --pmc $SQ1 --output-format csv -d $out/sq1 -o p -- $bench
+run sq2       --kernel-trace --pmc $SQ2 --output-format csv -d $out/sq2 -o p -- $bench
+run sq1_262k  --kernel-trace --pmc $SQ1 --output-format csv -d $out/sq1_262k -o p -- $bench --cands 262144 --steps 50
+k2="python3 $root/tools/prof_k2.py"
+run k2stats   --kernel-trace --stats --output-format csv -d $out/k2stats -o stats -- $k2
+run k2fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/k2fetch -o p -- $k2
+run k2write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/k2write -o p -- $k2
+run k2tcc     --kernel-trace --pmc TCC_HIT TCC_MISS --output-format csv -d $out/k2tcc -o p -- $k2
+run k2sq1     --kernel-trace --pmc $SQ1 --output-format csv -d $out/k2sq1 -o p -- $k2
+run k2sq2     --kernel-trace --pmc $SQ2 --output-format csv -d $out/k2sq2 -o p -- $k2
 cd $root
-python3 bench.py > $out/bench.json 2> $out/bench.err
-find $out -name "*.csv" | head -20
+timeout 600 python3 bench.py > $out/bench.json 2> $out/bench.err
+# keep what travels back small: the per-dispatch counter CSVs are summarised here, the raw files stay on the box
+python3 tools/prof_summary.py $tag --collect
+find $out -name "*.csv" -size +200k -delete
+ls $out | head -40

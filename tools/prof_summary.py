@@ -1,8 +1,18 @@
 """Turn the rocprofv3 passes of tools/prof_bench.sh into the committed profile files.
-usage: python tools/prof_summary.py r02   (reads gpurun_out/r02/prof, writes profiles/r02_*)"""
-import collections, csv, glob, json, os, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    python tools/prof_summary.py r03 --collect    on the GPU box, at the end of prof_bench.sh: reads the raw per-dispatch CSVs under
+                                                  gpurun_out/r03/prof and writes gpurun_out/r03/prof/collected.json (small: it
+                                                  travels back with gpurun_out, the raw counter files do not)
+    python tools/prof_summary.py r03              here: collected.json -> profiles/r03_*
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag, "prof")
 dst = os.path.join(root, "profiles")
@@ -13,60 +23,150 @@ def find(sub, pattern):
     return hits[0] if hits else None
 
 
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
 def pmc(sub):
-    """mean counter value per dispatch, per kernel"""
+    """mean counter value per dispatch, per kernel (all dispatches of the run)"""
     f = find(sub, "*counter_collection.csv")
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    disp = collections.defaultdict(set)
     if not f:
         return {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
-    return {k: {c: v / max(len(disp[k]), 1) for c, v in cs.items()} for k, cs in agg.items()}
+    return {k: dict({c: v / max(len(disp[k]), 1) for c, v in cs.items()}, dispatches=len(disp[k])) for k, cs in agg.items()}
 
 
-# 1. per-kernel statistics
-stats = find("stats", "*kernel_stats.csv")
-rows = list(csv.DictReader(open(stats))) if stats else []
-with open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w") as f:
-    if rows:
-        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
-        w.writeheader()
-        w.writerows(rows)
-k1 = next((r for r in rows if "k1_search_tiled" in r["Name"]), None)
+def stats(sub):
+    f = find(sub, "*kernel_stats.csv")
+    return list(csv.DictReader(open(f))) if f else []
 
-# 2. the bench lines of the runs
-bench = {}
-for name in ("bench", "stats_bench", "fetch_bench"):
-    p = os.path.join(src, name + ".json")
+
+def bench_line(name):
+    p = os.path.join(src, name)
     if os.path.exists(p):
         for line in open(p):
             if line.startswith("{"):
-                bench[name] = json.loads(line)
-if "bench" in bench:
-    json.dump(bench["bench"], open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
+                return json.loads(line)
+    return None
+
+
+if "--collect" in sys.argv:
+    out = {"stats": stats("stats"), "stats262k": stats("stats262k"), "k2stats": stats("k2stats")}
+    for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2"):
+        out[sub] = pmc(sub)
+    for name in ("bench.json", "stats.out", "stats262k.out", "fetch.out", "sq1.out"):
+        out["line_" + name] = bench_line(name)
+    json.dump(out, open(os.path.join(src, "collected.json"), "w"))
+    print("collected ->", os.path.join(src, "collected.json"))
+    sys.exit(0)
+
+c = json.load(open(os.path.join(src, "collected.json")))
+
+
+def write_stats(rows, name):
+    with open(os.path.join(dst, name), "w") as f:
+        if rows:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+            w.writeheader()
+            w.writerows(rows)
+
+
+def k1_of(d):
+    return next((k for k in d if "k1_search_tiled" in k), None)
+
+
+# 1. per-kernel statistics: headline run, 262 144-candidate run, the HoleMap update run
+write_stats(c["stats"], tag + "_bench_kernel_stats.csv")
+write_stats(c["stats262k"], tag + "_bench_262144_kernel_stats.csv")
+write_stats(c["k2stats"], tag + "_k2_kernel_stats.csv")
+k1row = next((r for r in c["stats"] if "k1_search_tiled" in r["Name"]), None)
+k1row262 = next((r for r in c["stats262k"] if "k1_search_tiled" in r["Name"]), None)
+
+# 2. the bench line of the plain run
+if c.get("line_bench.json"):
+    json.dump(c["line_bench.json"], open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
 
 # 3. HBM-side traffic of K1
-fetch, write, tcc = pmc("fetch"), pmc("write"), pmc("tcc")
-k1name = next((k for k in fetch if "k1_search_tiled" in k), None)
-if k1name:
-    fs = fetch[k1name].get("FETCH_SIZE", 0.0)          # KB per dispatch
-    ws = write.get(k1name, {}).get("WRITE_SIZE", 0.0)
-    cfg = bench.get("fetch_bench", bench.get("bench", {})).get("config", {})
-    out = {
-        "kernel": k1name,
+fetch, write, tcc = c["fetch"], c["write"], c["tcc"]
+k1 = k1_of(fetch)
+if k1:
+    fs = fetch[k1].get("FETCH_SIZE", 0.0)          # KB per dispatch
+    ws = write.get(k1, {}).get("WRITE_SIZE", 0.0)
+    cfg = (c.get("line_fetch.out") or c.get("line_bench.json") or {}).get("config", {})
+    json.dump({
+        "kernel": k1,
         "workload": {"map": cfg.get("map"), "rays": cfg.get("rays"), "candidates_per_gpu": cfg.get("candidates_per_gpu")},
-        "command": "tools/prof_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT TCC_MISS (separate passes) -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline",
+        "command": "tools/prof_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT TCC_MISS (separate passes) -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras",
         "FETCH_SIZE_KB_per_launch": fs, "WRITE_SIZE_KB_per_launch": ws,
         "hbm_bytes_per_launch_raw": (fs + ws) * 1024.0,
         "hbm_bytes_per_launch_gfx950_corrected": (2.0 * fs + ws) * 1024.0,
         "note": "FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM): the tile staging loads are 16 B per lane, so the corrected figure doubles the read side.  Infinity-Cache hits are counted: this is L2 <-> fabric traffic, not DRAM traffic (the 8 MiB map is cache resident).  The write side is the per-candidate accumulator atomics, performed at the memory side (uncalibrated).",
-        "TCC_HIT_per_launch": tcc.get(k1name, {}).get("TCC_HIT"), "TCC_MISS_per_launch": tcc.get(k1name, {}).get("TCC_MISS"),
-        "k1_avg_ns_rocprof_stats": float(k1["AverageNs"]) if k1 else None,
-        "k1_avg_us_hip_events_same_run": bench.get("stats_bench", {}).get("roofline", {}).get("avg_launch_us"),
-    }
-    json.dump(out, open(os.path.join(dst, tag + "_k1_traffic.json"), "w"), indent=1)
-json.dump({"fetch": fetch, "write": write, "tcc": tcc}, open(os.path.join(dst, tag + "_bench_pmc_per_kernel.json"), "w"), indent=1)
-print("wrote profiles/%s_*; K1 rocprof avg %s ns" % (tag, k1["AverageNs"] if k1 else "?"))
+        "TCC_HIT_per_launch": tcc.get(k1, {}).get("TCC_HIT"), "TCC_MISS_per_launch": tcc.get(k1, {}).get("TCC_MISS"),
+        "k1_avg_ns_rocprof_stats": float(k1row["AverageNs"]) if k1row else None,
+        "k1_avg_us_hip_events_same_run": (c.get("line_stats.out") or {}).get("roofline", {}).get("avg_launch_us"),
+    }, open(os.path.join(dst, tag + "_k1_traffic.json"), "w"), indent=1)
+
+
+# 4. SQ counters of K1: where the cycles of a launch go
+def sq_summary(s1, s2, kernel, avg_ns):
+    a, b = s1.get(kernel, {}), s2.get(kernel, {}) if s2 else {}
+    if not a:
+        return None
+    waves = a.get("SQ_WAVES", 0.0)
+    wc = a.get("SQ_WAVE_CYCLES", 0.0)
+    out = {"kernel": kernel, "dispatches_averaged": a.get("dispatches"), "avg_launch_ns_rocprof_stats": avg_ns,
+           "per_launch": {k: v for k, v in {**a, **b}.items() if k != "dispatches"}}
+    d = {}
+    if waves:
+        d["wave_cycles_per_wave_quad"] = wc / waves
+        d["valu_instructions_per_wave"] = a.get("SQ_INSTS_VALU", 0.0) / waves
+        d["salu_instructions_per_wave"] = a.get("SQ_INSTS_SALU", 0.0) / waves
+        d["lds_instructions_per_wave"] = a.get("SQ_INSTS_LDS", 0.0) / waves
+    if wc:
+        d["fraction_of_wave_cycles_issuing_valu"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
+        d["fraction_of_wave_cycles_stalled_at_issue"] = a.get("SQ_WAIT_INST_ANY", 0.0) / wc
+        if b:
+            d["fraction_of_wave_cycles_waiting_waitcnt_or_barrier"] = b.get("SQ_WAIT_ANY", 0.0) / wc
+            d["fraction_of_wave_cycles_issuing_any"] = b.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+    if b and b.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_fraction_of_lds_cycles"] = b.get("SQ_LDS_BANK_CONFLICT", 0.0) / b["SQ_LDS_IDX_ACTIVE"]
+    if avg_ns and a.get("SQ_INSTS_VALU"):
+        # 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU quad-cycles on average
+        d["valu_busy_us_per_simd_if_evenly_spread"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / 2.1e3
+        d["note"] = "quad-cycle counters (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*) count 4-cycle units (MI355X_MICROARCH.md); the busy estimate assumes 2.1 GHz"
+    out["derived"] = d
+    return out
+
+
+k1s = k1_of(c["sq1"])
+if k1s:
+    json.dump({
+        "command": "tools/prof_bench.sh: rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes) -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras [--cands 262144 --steps 50]",
+        "headline_16384_candidates": sq_summary(c["sq1"], c["sq2"], k1s, float(k1row["AverageNs"]) if k1row else None),
+        "at_262144_candidates": sq_summary(c["sq1_262k"], None, k1_of(c["sq1_262k"]) or "", float(k1row262["AverageNs"]) if k1row262 else None),
+    }, open(os.path.join(dst, tag + "_k1_sq.json"), "w"), indent=1)
+
+# 5. the HoleMap update: traffic and SQ counters of its kernel(s)
+k2 = next((k for k in c["k2sq1"] if "k2_pixels" in k), None)
+if k2:
+    k2row = next((r for r in c["k2stats"] if "k2_pixels" in r["Name"]), None)
+    fs = c["k2fetch"].get(k2, {}).get("FETCH_SIZE", 0.0)
+    ws = c["k2write"].get(k2, {}).get("WRITE_SIZE", 0.0)
+    json.dump({
+        "command": "tools/prof_bench.sh: rocprofv3 ... -- python3 tools/prof_k2.py (40 HoleMap updates, 2048^2 map, 1080 rays)",
+        "traffic": {"FETCH_SIZE_KB_per_launch": fs, "WRITE_SIZE_KB_per_launch": ws,
+                    "hbm_bytes_per_launch_gfx950_corrected_upper": (2.0 * fs + ws) * 1024.0, "hbm_bytes_per_launch_raw": (fs + ws) * 1024.0,
+                    "algorithmic_bytes_per_update": "4 B per blended pixel: ~2.56 MB at 640 k pixels",
+                    "TCC_HIT_per_launch": c["k2tcc"].get(k2, {}).get("TCC_HIT"), "TCC_MISS_per_launch": c["k2tcc"].get(k2, {}).get("TCC_MISS"),
+                    "note": "the pixel reads are 2-byte gathers, not wide coalesced loads: the x2 read-side correction of the guide is an upper bound here"},
+        "sq": sq_summary(c["k2sq1"], c["k2sq2"], k2, float(k2row["AverageNs"]) if k2row else None),
+    }, open(os.path.join(dst, tag + "_k2_counters.json"), "w"), indent=1)
+
+json.dump({k: c[k] for k in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2")},
+          open(os.path.join(dst, tag + "_bench_pmc_per_kernel.json"), "w"), indent=1)
+print("wrote profiles/%s_*; K1 rocprof avg %s ns (262144 candidates: %s ns)" % (tag, k1row["AverageNs"] if k1row else "?", k1row262["AverageNs"] if k1row262 else "?"))
