@@ -511,30 +511,93 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
             L.prob[cell] = hs_prob_v(v);
         }
     }
-    // (2) the rest of the bounding square: one lane per cell, a wavefront takes 64 cells of one row
-    const int X0 = max(bx - R, 0), X1 = min(bx + R, L.w - 1), Y0 = max(by - R, 0), Y1 = min(by + R, L.h - 1);
-    const int tiles_x = (X1 - X0 + 64) / 64, items = (R > 0 && X1 >= X0 && Y1 >= Y0) ? tiles_x * (Y1 - Y0 + 1) : 0;
-    for (int item = gw; item < items; item += nw) {
-        const int row = item / tiles_x, tx = item - row * tiles_x;
-        const int X = X0 + tx * 64 + lane, Y = Y0 + row;
-        if (X > X1) continue;
-        const int dx = X - bx, dy = Y - by;
-        if (max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) < K5_ZONE) continue;     // (1)'s cells
-        int cls[2], a[2], b[2];
-        const int ncls = rs_classes(dx, dy, cls, a, b);
-        int first_free = 0x7fffffff, first_occ = 0x7fffffff;
-        for (int k = 0; k < ncls; k++) {
-            int lo, hi;
-            rs_range(start, cls[k], a[k], b[k], 0.5f, lo, hi);
-            for (int ci = lo; ci < hi; ci++) {
-                const k5_line c = cand[ci];
-                const int h = k5_hit(c, a[k], b[k]);
-                if (h == 1) first_free = min(first_free, c.ray);
-                else if (h == 2) first_occ = min(first_occ, c.ray);
+    // (2) beyond the zone: one lane per (line, step) -- work proportional to the cells the scan touches, not to the scan's
+    //     bounding square (rounds 1-2 visited every cell of the square: ~5 M lanes for ~1.1 M touched cells over three levels of
+    //     a 2048^2 pyramid).  Step i of a line lies at major offset i (its Chebyshev distance from the begin cell) and minor
+    //     offset floor((da / 2 + i * db) / da) (:220-239; k5_hit is the same closed form), the end cell at i = da.  The lane
+    //     asks, like a cell-centric lane would, which lines touch its cell -- one contiguous range of the slope-sorted table;
+    //     nearly always the range holds the lane's own line and nothing else, and the cell is updated at once.  Otherwise the
+    //     candidates are tested and the lane of the LOWEST line index among the touching lines owns the cell (every touching
+    //     line has a lane on it, and all of them see the same candidates): it applies the transitions, the others drop it.
+    //     Lines are dealt by table position (adjacent positions: adjacent directions), to the XCDs by sector: a line's cells
+    //     share their 128-byte rows with its neighbours'.
+    if (R < K5_ZONE) return;
+    const int nblk = (R - K5_ZONE) / 64 + 1;
+    const int wg_l = (int)blockIdx.x - L.wg0;                              // workgroup within the level
+    const int xcd = wg_l & 7, wgs_x = (L.wgn - xcd + 7) >> 3, wg_x = wg_l >> 3;
+    const int c0 = (int)(((long long)nv * xcd) >> 3), n_sec = (int)(((long long)nv * (xcd + 1)) >> 3) - c0;
+    const int items = nblk * n_sec;
+    // (software pipeline: a cell's value and update index are requested when its item is fetched, one iteration before its
+    // turn -- the three arrays of a 2048^2 level are 48 MB, a microsecond away)
+    struct k5_item { int cell, dx, dy, ray, end; float v; int u; };
+#define K5_FETCH(it, item_)                                                                         \
+    {                                                                                               \
+        (it).cell = -1;                                                                             \
+        if ((item_) < items) {                                                                      \
+            const int blk_ = (item_) / n_sec, ci0_ = c0 + ((item_) - blk_ * n_sec);                 \
+            const k5_line me_ = cand[ci0_];                /* (uniform: a broadcast) */              \
+            const int i_ = K5_ZONE + blk_ * 64 + lane;                                              \
+            if (i_ <= me_.da) {                                                                     \
+                const int db_ = me_.sdb < 0 ? -me_.sdb : me_.sdb;                                   \
+                const int e_ = me_.da / 2 + i_ * db_;      /* (maps <= 32768 a side: < 2^31) */      \
+                int m_;                                                                             \
+                if (L.w <= 2048 && L.h <= 2048) {          /* e < 2^24: the float estimate of e / da is within one; settled exactly */ \
+                    m_ = (int)((float)e_ * __builtin_amdgcn_rcpf((float)me_.da));                   \
+                    const int r_ = e_ - m_ * me_.da;                                                \
+                    if (r_ < 0) m_--; else if (r_ >= me_.da) m_++;                                  \
+                } else m_ = e_ / me_.da;                                                            \
+                const int smaj_ = ((me_.flags >> 2) & 3) - 1;                                       \
+                const int am_ = smaj_ < 0 ? -i_ : i_, bm_ = me_.sdb < 0 ? -m_ : m_;                 \
+                (it).dx = (me_.flags & 2) ? am_ : bm_; (it).dy = (me_.flags & 2) ? bm_ : am_;       \
+                (it).ray = me_.ray; (it).end = i_ == me_.da;                                        \
+                (it).cell = (by + (it).dy) * L.w + (bx + (it).dx);                                  \
+                (it).v = L.value[(it).cell]; (it).u = L.upd[(it).cell];                             \
+            }                                                                                       \
+        }                                                                                           \
+    }
+    k5_item cur, nxt;
+    cur.cell = -1; cur.dx = cur.dy = cur.ray = cur.end = cur.u = 0; cur.v = 0.f; nxt = cur;
+    int item = wg_x * 16 + wv;
+    K5_FETCH(cur, item)
+    for (; item < items; item += wgs_x * 16) {
+        K5_FETCH(nxt, item + wgs_x * 16)
+        if (cur.cell >= 0) {
+            const int dx = cur.dx, dy = cur.dy;
+            const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+            int first_free = 0x7fffffff, first_occ = 0x7fffffff;
+            int lo = 0, hi = 2;
+            if (adx != ady) {                                              // (a diagonal cell: the quadrant's other class touches it too)
+                const bool xm = adx > ady;
+                rs_range(start, xm ? (dx > 0 ? 0 : 1) : (dy > 0 ? 2 : 3), xm ? adx : ady, xm ? dy : dx, 0.5f, lo, hi);
+            }
+            bool mine = true;
+            if (hi - lo == 1) { if (cur.end) first_occ = cur.ray; else first_free = cur.ray; }
+            else {
+                int cls[2], a[2], b[2];
+                const int ncls = rs_classes(dx, dy, cls, a, b);
+                for (int k = 0; k < ncls; k++) {
+                    rs_range(start, cls[k], a[k], b[k], 0.5f, lo, hi);
+                    for (int ci = lo; ci < hi; ci++) {
+                        const k5_line c = cand[ci];
+                        const int h = k5_hit(c, a[k], b[k]);
+                        if (h == 1) first_free = min(first_free, c.ray);
+                        else if (h == 2) first_occ = min(first_occ, c.ray);
+                    }
+                }
+                mine = min(first_free, first_occ) == cur.ray;              // else another line's lane owns this cell
+            }
+            if (mine) {
+                float v = cur.v;
+                int u = cur.u;
+                k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
+                L.value[cur.cell] = v;
+                L.upd[cur.cell] = u;
+                L.prob[cur.cell] = hs_prob_v(v);
             }
         }
-        if (first_free != 0x7fffffff || first_occ != 0x7fffffff) k5_apply(L, Y * L.w + X, first_free, first_occ, lo_free, lo_occ);
+        cur = nxt;
     }
+#undef K5_FETCH
 }
 
 __global__ void k5_fill_cells(float *value, int32_t *upd, float *prob, size_t n)
@@ -1004,16 +1067,22 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
         // all levels in every launch (MapRepMultiMap.cs:76)
         hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
                            hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);
-        {   // 512 workgroups (two per CU), shared out over the levels by cell count
+        {   // ONE round of resident workgroups (two per CU: 512), shared out over the levels by the work they hold -- the cells a
+            // scan touches, which halve from level to level (the zone around the begin cell is the same on every level: a floor
+            // of 1/16 each).  (Round 2 shared them out by cell count with a floor of 1/8: 551 workgroups, i.e. a second round that
+            // started when the first drained -- half of the kernel's 35 us.)
+            static const int wgs_env = getenv("SLAMHIP_K5_WGS") ? atoi(getenv("SLAMHIP_K5_WGS")) : 512;
             double tot = 0.0;
-            for (int l = 0; l < hs->n_levels; l++) tot += (double)hs->lv[l].w * hs->lv[l].h;
-            int first = 0;
+            for (int l = 0; l < hs->n_levels; l++) tot += (double)hs->lv[l].w + (double)hs->lv[l].h;
+            int first = 0, left = wgs_env;
             for (int l = 0; l < hs->n_levels; l++) {
-                static const int wgs_env = getenv("SLAMHIP_K5_WGS") ? atoi(getenv("SLAMHIP_K5_WGS")) : 512;
-                int k = (int)((double)wgs_env * ((double)hs->lv[l].w * hs->lv[l].h) / tot);
-                if (k < wgs_env / 8) k = wgs_env / 8;
+                const int floor_k = wgs_env / 16 > 0 ? wgs_env / 16 : 1;
+                int k = (int)((double)wgs_env * ((double)hs->lv[l].w + (double)hs->lv[l].h) / tot);
+                if (k < floor_k) k = floor_k;
+                const int must_leave = (hs->n_levels - 1 - l) * floor_k;   // (the levels still to come keep their floor)
+                if (k > left - must_leave) k = left - must_leave > 1 ? left - must_leave : 1;
                 A.lv[l].wg0 = first; A.lv[l].wgn = k;
-                first += k;
+                first += k; left -= k;
             }
             cgrid_x = first;
         }

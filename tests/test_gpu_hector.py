@@ -182,12 +182,19 @@ def test_match_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R, iters):
             want = oc.match_pyramid(ref, xy, hint, iters, n_threads=T)
             assert abs(got[0] - want[0]) < POS_TOL and abs(got[1] - want[1]) < POS_TOL, (hint, T, got, want)
             assert abs(math.remainder(float(got[2]) - float(want[2]), 2 * math.pi)) < ANG_TOL, (hint, T, got, want)
-    # H / dTr at a fixed map pose (single level API) within fp32 summation noise
+    # H / dTr at a fixed map pose (single level API) within fp32 summation noise.  The entries are binary32 sums of ~R
+    # products whose order differs from the reference's thread chunks (ScanMatcher.cs:149-195); an entry's error scales with
+    # the sum of the magnitudes of its terms, i.e. with the LARGEST entry of the matrix (the small off-diagonal entries are
+    # differences of large sums), not with the entry itself.  Measured on MI355X (tools: 8 poses, 400^2 and 2048^2):
+    # <= 7e-7 of the largest entry -- the same as the reference's own spread between 1 and 4 threads (<= 7e-7 for H, 1.7e-6
+    # for dTr).  The bound below is 4e-6 of the largest entry.
     rep.set_scan(scan)
-    est_map = ref[0].map_pose(hints[1])
-    H, d = rep.Maps[0].Hessian(est_map)
-    Hr, dr = ref[0].hessian(xy, est_map, 1)
-    assert np.allclose(H, Hr, rtol=2e-4, atol=1e-3) and np.allclose(d, dr, rtol=2e-4, atol=1e-2)
+    for hint in hints:
+        est_map = ref[0].map_pose(hint)
+        H, d = rep.Maps[0].Hessian(est_map)
+        Hr, dr = ref[0].hessian(xy, est_map, 1)
+        assert np.abs(H - Hr).max() <= 4e-6 * np.abs(Hr).max(), (hint, np.abs(H - Hr).max(), np.abs(Hr).max())
+        assert np.abs(d - dr).max() <= 4e-6 * max(np.abs(dr).max(), 1.0), (hint, np.abs(d - dr).max(), np.abs(dr).max())
     # MatchData(OccGridMap) on one level (:64-84)
     got = matcher.MatchData(rep.Maps[1], scan, hints[1])
     want = ref[1].match(xy, hints[1], iters[1], 1)
@@ -201,7 +208,7 @@ def test_match_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R, iters):
     far = np.array([500.0, 500.0, 0.3], np.float32)
     got = matcher.MatchData(rep, scan, far)
     want = oc.match_pyramid(ref, xy, far, iters, 1)
-    assert np.allclose(got, want, atol=1e-3)
+    assert (np.asarray(got) == np.asarray(want)).all()                 # (no iteration moves it: the same float transforms there and back)
     rep.close()
 
 
