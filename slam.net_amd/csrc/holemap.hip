@@ -560,7 +560,7 @@ static inline size_t k2_lds_bytes(bool build, int n_rays) { return (size_t)K2_LD
 struct k2_t3 { int ptr, dx, dy, ray, lim2; uint16_t pix; };
 
 // what the kernel needs of the scan when it makes the tables itself
-struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; };
+struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, rc_num; };
 
 // BUILD: ONE launch per HoleMap update.  Every workgroup makes the scan's ray tables itself, in LDS -- per ray the literal
 // arithmetic of :519-530 / :361-399 (k2_make_ray), a counting sort into 4 direction classes x 1024 slope buckets -- instead of
@@ -698,7 +698,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     // per wavefront from rB on (~17 candidates for 32 lanes), four from rC on (~7 for 16 lanes) -- a pixel with more candidates
     // than its lanes sends the whole item down the one-pixel path, which costs as much as the pixels it holds.
     const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R, n_pix = (2 * Z + 1) * (2 * Z + 1);
-    int rB = (12 * n_valid + 1079) / 1080, rC = (28 * n_valid + 1079) / 1080;
+    int rB = (sc.rb_num * n_valid + 1079) / 1080, rC = (sc.rc_num * n_valid + 1079) / 1080;
     rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB; rC = rC < rB ? rB : rC > K2_ZONE ? K2_ZONE : rC;
     const int pA = min((2 * rB - 1) * (2 * rB - 1), n_pix), pB = min((2 * rC - 1) * (2 * rC - 1), n_pix);
     const int nA = pA, nB = (pB - pA + 1) / 2, nC = (n_pix - pB + 3) / 4;
@@ -885,6 +885,8 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     k2_scan sc;
     sc.pts = cs->d_pts; sc.scale = cs->hscale; sc.hole_width = hole_width; sc.d_pose = d_pose; sc.h_pxcs = h_pxcs;
     sc.total_out = (int *)cs->d_key + 6; sc.dirty = cs->d_hole_dirty;
+    static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, rc_env = getenv("SLAMHIP_K2_RC") ? atoi(getenv("SLAMHIP_K2_RC")) : 28;
+    sc.rb_num = rb_env; sc.rc_num = rc_env;                        // (radii, per 1080 rays, from which a wavefront takes two / four zone pixels)
     {
         sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
         if (!build) {

@@ -627,6 +627,48 @@ def test_lib_comm_single_rank(cs_mod, ctx, sim):
         dev.close()
 
 
+def test_holemap_large_scan_path():
+    """The HoleMap update of scans too large for the in-kernel tables (more than 2400 rays: k2_prepare + the pixel kernel reading
+    its tables from memory, the ObstacleMap update in launches of its own), forced on the ordinary test scans with
+    SLAMHIP_K2_TWO_LAUNCHES=1: same maps, same fused results.  (Natively the path runs in the 3000- and 4097-ray cases below and
+    in the soak.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SLAMHIP_K2_TWO_LAUNCHES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "holemap_golden or holemap_vs_oracle or holemap_unordered or holemap_degenerate or search_and_update_fused or fused_scans or partial_mirror"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+
+
+def test_holemap_more_rays_than_lds_tables(cs_mod, ctx, det, sim):
+    """3000 rays (> K2_LDS_RAYS): the update takes the two-launch path by itself, the ObstacleMap update rides nowhere."""
+    oc = det
+    size, osize, R = 1024, 256, 3000
+    segs = sim.default_field()
+    dev = cs_mod.CoreSlamDevice(ctx, 40.0, size, osize)
+    ref_h = np.full(size * size, 32750, np.uint16)
+    ref_o = np.full((osize, osize), -5, np.int8)
+    rng = sim.PCG32(61)
+    for p in sim.trajectory(4, step=(0.3, 0.1, 0.2)):
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy)
+        dev.update_holemap(p); dev.update_obstaclemap(p)
+        oc.update_holemap(ref_h, size, dev.hole_scale, xy, p); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, p)
+    assert (dev.holemap_download() == ref_h).all() and (dev.obstaclemap_download() == ref_o).all()
+    dev.set_offsets(sim.gaussian_offsets(999))
+    base = sim.trajectory(5, step=(0.3, 0.1, 0.2))[-1]
+    for _ in range(2):                                                  # fused: search + both updates, twice in a row
+        pose, dist, idx = dev.search_and_update(base, 0.6, 50, 10)
+        rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, sim.gaussian_offsets(999))
+        rpose[2] = oc.normalize_angle(rpose[2])
+        assert idx == rbi and dist == rbd and (pose == rpose).all()
+        oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose)
+    assert (dev.holemap_download() == ref_h).all() and (dev.obstaclemap_download() == ref_o).all()
+    dev.close()
+
+
 # ---- round 3: the BASELINE configurations at their own sizes, the host mirror, threads, two GPUs -------------------------
 def _mapped_dev(cs_mod, ctx, sim, size, R, updates, osize=None):
     segs = sim.default_field()
