@@ -358,25 +358,29 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     std::vector<uint64_t> &keys = cs->h_sort_keys;                 // (kept between scans: no allocation per scan)
     keys.resize((size_t)n);
     const float cell = 64.0f / cs->hscale;          // metres per 64 px
+    // (one pass over the points makes the keys and the histograms of all three 11-bit digits: a digit whose histogram has a single
+    // occupied bin -- a scan spans few 64-pixel cells, the high digits are equal -- needs no pass of its own)
+    static thread_local unsigned cnt3[3][2048];
+    memset(cnt3, 0, sizeof(cnt3));
     for (int i = 0; i < n; i++) {
         const float X = xy[2 * i], Y = xy[2 * i + 1];
         if (!(fabsf(X) < 1.0e9f) || !(fabsf(Y) < 1.0e9f)) sane = false;
         float gx = X / cell + 32768.0f, gy = Y / cell + 32768.0f;
         uint32_t ux = gx > 0.0f ? (gx < 65535.0f ? (uint32_t)gx : 65535u) : 0u;
         uint32_t uy = gy > 0.0f ? (gy < 65535.0f ? (uint32_t)gy : 65535u) : 0u;
-        keys[i] = ((uint64_t)(part1by1(ux) | (part1by1(uy) << 1)) << 32) | (uint32_t)i;
+        const uint32_t code = part1by1(ux) | (part1by1(uy) << 1);
+        keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
+        cnt3[0][code & 2047u]++; cnt3[1][(code >> 11) & 2047u]++; cnt3[2][code >> 22]++;
     }
-    {   // LSD radix sort on the 32-bit Morton code (3 stable passes of 11 bits; ties keep ray order): std::sort was
+    {   // LSD radix sort on the 32-bit Morton code (up to 3 stable passes of 11 bits; ties keep ray order): std::sort was
         // most of this function's time at ~1000 rays
         std::vector<uint64_t> &tmp = cs->h_sort_tmp;
         tmp.resize((size_t)n);
         uint64_t *src = keys.data(), *dst = tmp.data();
         for (int pass = 0; pass < 3; pass++) {
             const int shift = 32 + 11 * pass;
-            unsigned cnt[2048];
-            memset(cnt, 0, sizeof(cnt));
-            for (int i = 0; i < n; i++) cnt[(src[i] >> shift) & 2047u]++;
-            if (cnt[(src[0] >> shift) & 2047u] == (unsigned)n) continue;      // every key in one bin (a scan spans few 64-pixel cells: the high digits are equal)
+            unsigned *cnt = cnt3[pass];
+            if (cnt[(src[0] >> shift) & 2047u] == (unsigned)n) continue;      // every key in one bin
             unsigned sum = 0;
             for (int k = 0; k < 2048; k++) { const unsigned c = cnt[k]; cnt[k] = sum; sum += c; }
             for (int i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
