@@ -3,7 +3,8 @@
 The reference ships no tests or fixtures (SLAM.sln:6-15) and cannot be built in this image, so the oracle is "parity
 unpinned" against the C# itself.  These cases are a third, human-checkable anchor: every expected number below was
 worked out with pencil-and-paper arithmetic from CoreSLAM/CoreSLAMProcessor.cs:320-443 (ClipRay,
-DrawLaserRayOnHoleMap), :496-534 (UpdateHoleMap) and HectorSLAM/Map/OccGridMap.cs:114-239; the working is written out
+DrawLaserRayOnHoleMap), :496-534 (UpdateHoleMap), :226-259 (CalculateDistanceSISD), :456-490 / :540-593
+(DrawLaserRayOnObstacleMap, UpdateObstacleMap) and HectorSLAM/Map/OccGridMap.cs:114-239; the working is written out
 in the comments so that a reader can follow it against the C# without running anything.  The C oracle, the NumPy
 oracle and (on the GPU box) the HIP kernels must all reproduce them.
 
@@ -215,4 +216,88 @@ def test_hand_hector_free_then_occupied_hip(oc):
     for i, (v, idx) in _hector_expected(lf, lo).items():
         assert c["update_index"][i] == idx and c["value"][i] == v, i
     rep.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CalculateDistanceSISD (CoreSLAMProcessor.cs:226-259) by hand: 8 x 8 HoleMap over 4 m (Scale 2), Pixels[y*8 + x] = 1000*y + 10*x
+#   pose (1.0, 1.5, 0): px = 1.0*2 + 0.5 = 2.5, py = 1.5*2 + 0.5 = 3.5, c = cos(0)*2 = 2, s = 0          (:232-235)
+#   point ( 0.5 , 0.25): x = (int)(2.5 + 2*0.5 - 0) = 3,  y = (int)(3.5 + 0 + 2*0.25) = 4   -> Pixels[4*8+3] = 4030
+#   point (-2.0 , 0   ): x = (int)(2.5 - 4.0) = (int)(-1.5) = -1                            -> outside (:244): not summed, not counted
+#   point (-1.2 , 0   ): x = (int)(2.5 - 2.4000001) = (int)0.0999999 = 0, y = (int)3.5 = 3  -> Pixels[3*8+0] = 3000
+#   point (-1.3 , 0   ): x = (int)(2.5 - 2.5999999) = (int)(-0.0999999) = 0 (truncation TOWARDS ZERO: in the map), y = 3 -> 3000
+#   sum = 10030, nb_points = 3 > 0  ->  (int)((10030 * 1024) / cloud.Points.Count) = 10 270 720 / 4 = 2 567 680   (divides by ALL points, :253)
+DIST_PIX = (1000 * np.arange(8)[:, None] + 10 * np.arange(8)[None, :]).astype(np.uint16).reshape(-1)
+DIST_XY = np.array([[0.5, 0.25], [-2.0, 0.0], [-1.2, 0.0], [-1.3, 0.0]], np.float32)
+DIST_PXCS = np.array([[2.5, 3.5, 2.0, 0.0]], np.float32)
+DIST_WANT = 2567680
+
+
+def test_hand_distance_c_oracle(oc):
+    d, bi, bd = oc.distance_batch_pxcs(DIST_PIX, 8, DIST_XY, DIST_PXCS)
+    assert d[0] == DIST_WANT and (bi, bd) == (0, DIST_WANT)
+    assert (oc.pose_to_pxcs([1.0, 1.5, 0.0], 2.0) == DIST_PXCS[0]).all()
+
+
+@pytest.mark.gpu
+def test_hand_distance_hip():
+    import slam.net_amd.coreslam as cs
+    ctx = cs.Context(0)
+    dev = cs.CoreSlamDevice(ctx, 4.0, 8, 8)
+    dev.holemap_upload(DIST_PIX)
+    dev.set_scan(DIST_XY)
+    d, bi, bd = dev.distance_pxcs(DIST_PXCS)
+    assert d[0] == DIST_WANT and bd == DIST_WANT
+    d2, _, _ = dev.distance_poses(np.array([[1.0, 1.5, 0.0]], np.float32))
+    assert d2[0] == DIST_WANT
+    dev.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UpdateObstacleMap / DrawLaserRayOnObstacleMap (:456-490, :540-593) by hand: 8 x 8 ObstacleMap over 4 m (Scale 2), MaxObstacleHits 10
+#   pose (0.25, 0.25, 0): px = py = 0.25*2 + 0.5 = 1.0, c = 2, s = 0; x1 = y1 = 1
+#   two identical points (2.0, 1.0): x2 = (int)(1 + 2*2.0) = 5, y2 = (int)(1 + 2*1.0) = 3
+#   ray (1,1) -> (5,3): dx = 4 sx = 1 dy = 2 sy = 1, err = (dx > dy ? dx : -dy) / 2 = 2
+#     (1,1) noHit; e2 = 2:  2 > -4 -> err = 0, x = 2;   2 < 2 false
+#     (2,1) noHit; e2 = 0:  0 > -4 -> err = -2, x = 3;  0 < 2 -> err = 2, y = 2
+#     (3,2) noHit; e2 = 2:          err = 0, x = 4;     2 < 2 false
+#     (4,2) noHit; e2 = 0:          err = -2, x = 5;    0 < 2 -> err = 2, y = 3
+#     (5,3) == end: Pixels[3,5] < 10 ? ++ : nothing
+#   start map: -5 everywhere (UnmappedObstacleHits), but [y=1,x=2] = 3, [2,3] = 0, [3,5] = 9
+#   first ray: [3,5] 9 -> 10;  second ray (same cells): [3,5] = 10 is not < 10: stays (:474-477, "k hits saturate")
+#   decay over the noHit cells (:576-592): [1,1] -5 -> -4;  [1,2] 3 -> 2;  [2,3] 0 stays 0;  [2,4] -5 -> -4;  the end cell is not noHit: 10
+def _obst_start():
+    m = np.full((8, 8), -5, np.int8)
+    m[1, 2] = 3; m[2, 3] = 0; m[3, 5] = 9
+    return m
+
+
+def _obst_want():
+    m = np.full((8, 8), -5, np.int8)
+    m[1, 1] = -4; m[1, 2] = 2; m[2, 3] = 0; m[2, 4] = -4; m[3, 5] = 10
+    return m
+
+
+OBST_XY = np.array([[2.0, 1.0], [2.0, 1.0]], np.float32)
+OBST_POSE = np.array([0.25, 0.25, 0.0], np.float32)
+
+
+def test_hand_obstaclemap_c_oracle(oc):
+    m = _obst_start()
+    oc.update_obstaclemap(m, 8, 2.0, OBST_XY, OBST_POSE, 10)
+    assert (m == _obst_want()).all(), m
+
+
+@pytest.mark.gpu
+def test_hand_obstaclemap_hip():
+    import slam.net_amd.coreslam as cs
+    ctx = cs.Context(0)
+    dev = cs.CoreSlamDevice(ctx, 4.0, 8, 8)
+    assert dev.obst_scale == 2.0
+    dev.obstaclemap_upload(_obst_start())
+    dev.set_scan(OBST_XY)
+    dev.update_obstaclemap(OBST_POSE, 10)
+    assert (dev.obstaclemap_download() == _obst_want()).all()
+    dev.close()
     ctx.close()
