@@ -453,26 +453,119 @@ __device__ static inline int k5_wave_min(int x)
     return x;
 }
 
-// persistent grid over the bounding squares of the lines of all levels
-template <bool LDS_TABLE>
-__global__ void __launch_bounds__(1024)
-k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
+// all levels in ONE launch.  BUILD (scans of up to K5_LDS_LINES points): every workgroup makes the line tables of ITS level
+// itself, in LDS -- the transform of :133-134 per point, the counting sort by (direction class, slope bucket) -- instead of
+// reading what a k5_prepare launch left in memory (5 us plus a launch boundary for a microsecond of arithmetic).  The order of
+// the lines inside a bucket then differs from workgroup to workgroup (LDS atomics), so the work that is shared out between
+// workgroups goes by LINE INDEX (byidx), never by table position.
+#define K5_LDS_FIXED ((4 * RS_NBUCK + 4) * 4)
+static inline size_t k5_lds_bytes(bool build, int n) { return (size_t)K5_LDS_FIXED + (build ? (size_t)4 * RS_NBUCK * 4 + (size_t)32 * (size_t)((n + 3) & ~3) : 0); }
+template <bool BUILD>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox, float oy,
+         const k5_line *__restrict__ byidx_all, const k5_line *__restrict__ cand_all,
          const int *__restrict__ start_all, const int *__restrict__ hdr_all, float lo_free, float lo_occ)
 {
-    __shared__ int start[4 * RS_NBUCK + 1];
-    __shared__ __attribute__((aligned(16))) k5_line cand_s[LDS_TABLE ? K5_LDS_LINES : 1];
-    // workgroups are shared out over the levels in proportion to their cell counts (host: wg0, wgn)
+    extern __shared__ __attribute__((aligned(16))) char k5_smem[];
+    int *start = (int *)k5_smem;
+    int *pos_s = (int *)(k5_smem + K5_LDS_FIXED);
+    const int n4 = (n_pts + 3) & ~3;
+    k5_line *cand_s = (k5_line *)(pos_s + (BUILD ? 4 * RS_NBUCK : 0));
+    k5_line *byidx_s = cand_s + (BUILD ? n4 : 0);
+    __shared__ int wsum[16];
+    __shared__ int s_R, s_nv, s_first;
+    // workgroups are shared out over the levels (host: wg0, wgn)
     int lvl = 0;
     for (int l = 1; l < A.n; l++) if ((int)blockIdx.x >= A.lv[l].wg0) lvl = l;
     const k5_level &L = A.lv[lvl];
-    const k5_line *cand_g = cand_all + (size_t)lvl * cap;
-    const int *start_g = start_all + (size_t)lvl * (4 * RS_NBUCK + 1), *hdr = hdr_all + lvl * K5_HDR;
-    const int bx = hdr[0], by = hdr[1], R = hdr[2], nv = hdr[3];
-    if (nv == 0) return;
-    for (int i = threadIdx.x; i <= 4 * RS_NBUCK; i += 1024) start[i] = start_g[i];
-    if (LDS_TABLE) for (int i = threadIdx.x; i < nv; i += 1024) cand_s[i] = cand_g[i];
-    __syncthreads();
-    const k5_line *cand = LDS_TABLE ? cand_s : cand_g;
+    int bx, by, R, nv, first_line;
+    if (BUILD) {
+        const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
+        constexpr int RPT = (K5_LDS_LINES + 1023) / 1024;
+        float2 p_next = make_float2(0.f, 0.f);
+        if (t < n_pts) p_next = pts[t];
+        for (int i = t; i < 4 * RS_NBUCK; i += 1024) start[i] = 0;          // (the histogram, then the bucket table)
+        if (t == 0) { s_R = 0; s_nv = 0; s_first = 0x7fffffff; }
+        __syncthreads();
+        float bxf, byf;
+        sh_v2_transform(ox, oy, L.t, &bxf, &byf);                          // :126
+        bx = sh_f2i(rintf(bxf)); by = sh_f2i(rintf(byf));                  // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
+        int bkt[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) bkt[k] = -1;
+        int my_R = 0, my_nv = 0, my_first = 0x7fffffff;
+#pragma unroll 1
+        for (int it = 0; it * 1024 < n_pts; it++) {
+            const int i = t + it * 1024;
+            int bb = -1;
+            const float2 p = p_next;
+            if (i + 1024 < n_pts) p_next = pts[i + 1024];
+            if (i < n_pts) {
+                float exf, eyf;
+                sh_v2_transform(p.x, p.y, L.t, &exf, &eyf);                // :133
+                const int ex = sh_f2i(rintf(exf)), ey = sh_f2i(rintf(eyf));    // :134
+                const bool same = (bx == ex) & (by == ey);                 // :137
+                const bool inside = (bx >= 0) & (by >= 0) & (bx < L.w) & (by < L.h) & (ex >= 0) & (ey >= 0) & (ex < L.w) & (ey < L.h);   // :158-161
+                k5_line e; e.da = 0; e.sdb = 0; e.ray = i; e.flags = 0;
+                if (!same && inside) {
+                    const int dx = ex - bx, dy = ey - by;
+                    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+                    const bool major_x = adx >= ady;                       // :175
+                    e.da = major_x ? adx : ady;
+                    e.sdb = major_x ? dy : dx;                             // minor extent with its sign (:169-170)
+                    const int smaj = sh_sign(major_x ? dx : dy);
+                    e.flags = 1 | (major_x ? 2 : 0) | ((smaj + 1) << 2);
+                    bb = rs_class(major_x, smaj) * RS_NBUCK + rs_bucket((float)e.sdb / (float)e.da);
+                    atomicAdd(&start[bb], 1);
+                    my_R = max(my_R, e.da);
+                    my_nv++;
+                    my_first = min(my_first, i);
+                }
+                byidx_s[i] = e;
+            }
+#pragma unroll
+            for (int k = 0; k < RPT; k++) if (k == it) bkt[k] = bb;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            my_R = max(my_R, __shfl_down(my_R, off, 64)); my_nv += __shfl_down(my_nv, off, 64); my_first = min(my_first, __shfl_down(my_first, off, 64));
+        }
+        if (lane_ == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_nv, my_nv); atomicMin(&s_first, my_first); }
+        __syncthreads();
+        {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
+            int v[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = start[4 * t + k]; sum += v[k]; }
+            int incl = sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane_ >= off) incl += o;
+            }
+            if (lane_ == 63) wsum[wid] = incl;
+            __syncthreads();                                               // (every thread has read its bins)
+            int base = incl - sum;
+            for (int w = 0; w < wid; w++) base += wsum[w];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { start[4 * t + k] = base; pos_s[4 * t + k] = base; base += v[k]; }
+            if (t == 1023) start[4 * RS_NBUCK] = base;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < RPT; it++) {
+            const int i = t + it * 1024;
+            if (i < n_pts && bkt[it] >= 0) cand_s[atomicAdd(&pos_s[bkt[it]], 1)] = byidx_s[i];      // (this thread's own store)
+        }
+        R = s_R; nv = s_nv; first_line = s_first;
+        __syncthreads();
+        if (nv == 0) return;
+    } else {
+        const int *start_g = start_all + (size_t)lvl * (4 * RS_NBUCK + 1), *hdr = hdr_all + lvl * K5_HDR;
+        bx = hdr[0]; by = hdr[1]; R = hdr[2]; nv = hdr[3]; first_line = hdr[4];
+        if (nv == 0) return;
+        for (int i = threadIdx.x; i <= 4 * RS_NBUCK; i += 1024) start[i] = start_g[i];
+        __syncthreads();
+    }
+    const k5_line *cand = BUILD ? cand_s : cand_all + (size_t)lvl * cap;
+    const k5_line *byidx = BUILD ? byidx_s : byidx_all + (size_t)lvl * cap;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gw = ((int)blockIdx.x - L.wg0) * 16 + wv, nw = L.wgn * 16;
     // (1) the zone around the begin cell, where a cell has many candidate lines: one wavefront per cell, one candidate
@@ -487,7 +580,7 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
         float v = L.value[cell];                                           // (requested now, needed after the search)
         int u = L.upd[cell];
         int first_free = 0x7fffffff, first_occ = 0x7fffffff;
-        if (dx == 0 && dy == 0) first_free = hdr[4];
+        if (dx == 0 && dy == 0) first_free = first_line;
         else {
             int cls[2], a[2], b[2];
             const int ncls = rs_classes(dx, dy, cls, a, b);
@@ -519,13 +612,13 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
     //     nearly always the range holds the lane's own line and nothing else, and the cell is updated at once.  Otherwise the
     //     candidates are tested and the lane of the LOWEST line index among the touching lines owns the cell (every touching
     //     line has a lane on it, and all of them see the same candidates): it applies the transitions, the others drop it.
-    //     Lines are dealt by table position (adjacent positions: adjacent directions), to the XCDs by sector: a line's cells
-    //     share their 128-byte rows with its neighbours'.
+    //     Lines are dealt by index (a scan's points come in order of their angle), to the XCDs by sector: a line's cells share
+    //     their 128-byte rows with its neighbours'.
     if (R < K5_ZONE) return;
     const int nblk = (R - K5_ZONE) / 64 + 1;
     const int wg_l = (int)blockIdx.x - L.wg0;                              // workgroup within the level
     const int xcd = wg_l & 7, wgs_x = (L.wgn - xcd + 7) >> 3, wg_x = wg_l >> 3;
-    const int c0 = (int)(((long long)nv * xcd) >> 3), n_sec = (int)(((long long)nv * (xcd + 1)) >> 3) - c0;
+    const int c0 = (int)(((long long)n_pts * xcd) >> 3), n_sec = (int)(((long long)n_pts * (xcd + 1)) >> 3) - c0;
     const int items = nblk * n_sec;
     // (software pipeline: a cell's value and update index are requested when its item is fetched, one iteration before its
     // turn -- the three arrays of a 2048^2 level are 48 MB, a microsecond away)
@@ -535,9 +628,9 @@ k5_cells(k5_arg A, int cap, const k5_line *__restrict__ cand_all,
         (it).cell = -1;                                                                             \
         if ((item_) < items) {                                                                      \
             const int blk_ = (item_) / n_sec, ci0_ = c0 + ((item_) - blk_ * n_sec);                 \
-            const k5_line me_ = cand[ci0_];                /* (uniform: a broadcast) */              \
+            const k5_line me_ = byidx[ci0_];               /* (uniform: a broadcast) */              \
             const int i_ = K5_ZONE + blk_ * 64 + lane;                                              \
-            if (i_ <= me_.da) {                                                                     \
+            if ((me_.flags & 1) && i_ <= me_.da) {                                                                     \
                 const int db_ = me_.sdb < 0 ? -me_.sdb : me_.sdb;                                   \
                 const int e_ = me_.da / 2 + i_ * db_;      /* (maps <= 32768 a side: < 2^31) */      \
                 int m_;                                                                             \
@@ -1064,9 +1157,6 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
         }
         int cgrid_x = 0;
         sh_timer t(ctx, SLAMHIP_K_HS_UPDATE);
-        // all levels in every launch (MapRepMultiMap.cs:76)
-        hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
-                           hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);
         {   // ONE round of resident workgroups (two per CU: 512), shared out over the levels by the work they hold -- the cells a
             // scan touches, which halve from level to level (the zone around the begin cell is the same on every level: a floor
             // of 1/16 each).  (Round 2 shared them out by cell count with a floor of 1/8: 551 workgroups, i.e. a second round that
@@ -1087,12 +1177,21 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
             cgrid_x = first;
         }
         const dim3 cgrid(cgrid_x);
-        if (n <= K5_LDS_LINES)
-            hipLaunchKernelGGL(k5_cells<true>, cgrid, dim3(1024), 0, ctx->stream, A, hs->cap_lines,
-                               (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start, (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
+        static const bool two_launch = getenv("SLAMHIP_K5_TWO_LAUNCHES") != nullptr;       // (tests: the large-scan path on ordinary scans)
+        const bool build = n <= K5_LDS_LINES && !two_launch;
+        static bool attr_set = false;
+        if (!attr_set) { attr_set = true; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k5_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds_bytes(true, K5_LDS_LINES)); }
+        if (!build)      // all levels in every launch (MapRepMultiMap.cs:76)
+            hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
+                               hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);
+        if (build)
+            hipLaunchKernelGGL(k5_cells<true>, cgrid, dim3(1024), k5_lds_bytes(true, n), ctx->stream, A, hs->cap_lines, (const float2 *)hs->d_pts, n,
+                               hs->origin[0], hs->origin[1], (const k5_line *)hs->d_k5_byidx, (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start,
+                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
         else
-            hipLaunchKernelGGL(k5_cells<false>, cgrid, dim3(1024), 0, ctx->stream, A, hs->cap_lines,
-                               (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start, (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
+            hipLaunchKernelGGL(k5_cells<false>, cgrid, dim3(1024), k5_lds_bytes(false, n), ctx->stream, A, hs->cap_lines, (const float2 *)hs->d_pts, n,
+                               hs->origin[0], hs->origin[1], (const k5_line *)hs->d_k5_byidx, (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start,
+                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
     }
     SH_HIP(hipGetLastError());
     for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144

@@ -312,9 +312,9 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
 // order; the robot's pixel (step 0 of every ray) and its closest neighbours (more than 64 candidates) scan all rays in
 // index order.  `sval` is 64 ints of LDS private to the wavefront.
 // (byidx / cand / vprof: LDS when the kernel made the scan's tables itself, else global; vprof goes by ray index)
-template <typename T, typename CT, typename BT, typename VT>
+template <typename T, typename CT, typename BT, typename VT, typename ST>
 __device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, int size, BT byidx,
-                                            VT vprof, int n_rays, CT cand, const int *start,
+                                            VT vprof, int n_rays, CT cand, const ST *start,
                                             uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int lane = threadIdx.x & 63;
@@ -439,8 +439,8 @@ __device__ unsigned long long g_k2_sub[512 * 16 * 8];   // per wavefront: [0] T1
 
 // Which rays draw the pixel at offset (dx, dy) from the robot?  Up to H hits, kept sorted by ray index (compile-time
 // subscripts: the lists stay in registers); `min_ray` = the lowest hitting ray index, also when the list overflowed.
-template <typename T, int H, typename CT, typename VT>
-__device__ static __forceinline__ void k2_lookup(CT cand, VT vprof, const int *start, int dx, int dy,
+template <typename T, int H, typename CT, typename VT, typename ST>
+__device__ static __forceinline__ void k2_lookup(CT cand, VT vprof, const ST *start, int dx, int dy,
                                         int (&hidx)[H], int (&hval)[H], int &nh, bool &overflow, int &min_ray)
 {
     int cls[2], a[2], b[2];
@@ -484,9 +484,9 @@ __device__ static __forceinline__ void k2_ring_pixel(int i, int &ddx, int &ddy)
 // candidates than its lanes -- and every G = 1 item -- goes down the one-pixel path, pixel after pixel: ONE call site for it (the
 // kernel's code is executed once or twice per wavefront, from a cold instruction cache: its size is latency; nine inlined copies
 // of the one-pixel path made a 47 KB kernel that ran 10 us slower than the 20 KB one).
-template <typename T, typename CT, typename BT, typename VT>
+template <typename T, typename CT, typename BT, typename VT, typename ST>
 __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg, int x1, int y1, int size, BT byidx,
-                                                     VT vps, int n_rays, CT cand, const int *start, uint16_t *__restrict__ map, int alpha, int *sval)
+                                                     VT vps, int n_rays, CT cand, const ST *start, uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int W = 64 >> lg, G = 1 << lg;
     const int lane = threadIdx.x & 63, g = lane >> (6 - lg), l = lane & (W - 1);
@@ -551,10 +551,13 @@ __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg
     __builtin_amdgcn_wave_barrier();
 }
 
-// dynamic LDS of the pixel kernel: the bucket table; when the kernel builds the scan's tables itself (BUILD) the buckets'
-// running positions, the sorted ray table, the V-profiles in table order and the rays by index (16 bytes per ray each)
+// dynamic LDS of the pixel kernel.  !BUILD: the bucket table (int).  BUILD (the kernel makes the scan's tables itself): the
+// histogram / running positions of the counting sort (int: LDS atomics), the bucket table as unsigned short (a scan has at most
+// K2_LDS_RAYS rays), the sorted ray table, the V-profiles and the rays by index (16 bytes per ray each) -- 80.7 KB with the
+// kernel's static 4.3 KB at 1080 rays.
 #define K2_LDS_FIXED ((4 * K2_NBUCK + 4) * 4)
-static inline size_t k2_lds_bytes(bool build, int n_rays) { return (size_t)K2_LDS_FIXED + (build ? (size_t)4 * K2_NBUCK * 4 + (size_t)48 * (size_t)((n_rays + 3) & ~3) : 0); }
+#define K2_LDS_START16 ((4 * K2_NBUCK + 8) * 2)
+static inline size_t k2_lds_bytes(bool build, int n_rays) { return build ? (size_t)4 * K2_NBUCK * 4 + K2_LDS_START16 + (size_t)48 * (size_t)((n_rays + 3) & ~3) : (size_t)K2_LDS_FIXED; }
 
 // a T3 work item as a lane holds it between its fetch (the pixel's load is issued there) and its turn
 struct k2_t3 { int ptr, dx, dy, ray, lim2; uint16_t pix; };
@@ -583,10 +586,11 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char k2_smem[];
-    int *start = (int *)k2_smem;
+    typedef typename std::conditional<BUILD, unsigned short, int>::type start_t;
     const int n4 = (n_rays + 3) & ~3;
-    int *pos_s = (int *)(k2_smem + K2_LDS_FIXED);
-    k2_cand *cand_s = (k2_cand *)(pos_s + (BUILD ? 4 * K2_NBUCK : 0));
+    int *pos_s = (int *)k2_smem;                                   // BUILD: histogram, then the buckets' running positions
+    start_t *start = (start_t *)(k2_smem + (BUILD ? 4 * K2_NBUCK * 4 : 0));
+    k2_cand *cand_s = (k2_cand *)(k2_smem + 4 * K2_NBUCK * 4 + K2_LDS_START16);
     k2_vprof *vprof_s = (k2_vprof *)(cand_s + (BUILD ? n4 : 0));
     k2_byidx *byidx_s = (k2_byidx *)(vprof_s + (BUILD ? n4 : 0));
     __shared__ __attribute__((aligned(16))) int sval[16][64];
@@ -599,7 +603,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         float2 p_next = make_float2(0.f, 0.f);
         if (t < n_rays) p_next = sc.pts[t];                         // (a thread's next point is requested one iteration ahead)
         const float4 q = k2_pxcs(sc.d_pose, sc.h_pxcs, sc.scale);
-        for (int i = t; i < 4 * K2_NBUCK; i += 1024) start[i] = 0;  // (the histogram, then the bucket table)
+        for (int i = t; i < 4 * K2_NBUCK; i += 1024) pos_s[i] = 0;  // (the histogram, then the running positions)
         if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; }
         __syncthreads();
         int bkt[RPT];                                               // a ray's bucket (class * 1024 + slope bucket), -1: not valid
@@ -622,7 +626,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
                     vprof_s[i] = vv;
                     const float tt = r.dxc > 0 ? (float)ee.sdyc / (float)r.dxc : 0.0f;
                     bb = (r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3)) * K2_NBUCK + rs_bucket(tt);
-                    atomicAdd(&start[bb], 1);
+                    atomicAdd(&pos_s[bb], 1);
                     my_R = max(my_R, r.dxc);
                     my_total += r.dxc + 1;
                 }
@@ -639,19 +643,19 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
             int v[4], sum = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[k] = start[4 * t + k]; sum += v[k]; }
+            for (int k = 0; k < 4; k++) { v[k] = pos_s[4 * t + k]; sum += v[k]; }
             int incl = sum;
             for (int off = 1; off < 64; off <<= 1) {
                 const int o = __shfl_up(incl, off, 64);
                 if (lane_ >= off) incl += o;
             }
             if (lane_ == 63) wsum[wid] = incl;
-            __syncthreads();                                       // (every thread has read its bins: they may be overwritten)
+            __syncthreads();
             int base = incl - sum;
             for (int w = 0; w < wid; w++) base += wsum[w];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { start[4 * t + k] = base; pos_s[4 * t + k] = base; base += v[k]; }
-            if (t == 1023) start[4 * K2_NBUCK] = base;
+            for (int k = 0; k < 4; k++) { start[4 * t + k] = (start_t)base; pos_s[4 * t + k] = base; base += v[k]; }     // (each thread its own four bins)
+            if (t == 1023) start[4 * K2_NBUCK] = (start_t)base;
         }
         __syncthreads();
 #pragma unroll
@@ -676,15 +680,15 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
             }
         }
         __syncthreads();
-        n_valid = start[4 * K2_NBUCK];
+        n_valid = (int)start[4 * K2_NBUCK];
         if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;   // robot outside the map: nothing is drawn (:509-512)
     } else {
         R = counters[0]; x1 = counters[3]; y1 = counters[4];
         if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;   // robot outside the map: nothing is drawn (:509-512)
         if (threadIdx.x == 0) { s_nextA = 0; s_nextB = 0; }
-        for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = start_g[i];
+        for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = (start_t)start_g[i];
         __syncthreads();
-        n_valid = start[4 * K2_NBUCK];
+        n_valid = (int)start[4 * K2_NBUCK];
     }
     K2_STAMP(1)
     const k2_cand *cand = BUILD ? cand_s : cand_g;
@@ -899,6 +903,9 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         // one workgroup per CU measured best).
         static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
         const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        // (two workgroups per CU -- the 1080-ray tables are 80.7 KB with the 16-bit bucket table, and amdgpu_waves_per_eu(8, 8) brings
+        // the kernel under 80 SGPRs -- measured no faster: 23.5 against 23.2 us with one, and the register limit costs the
+        // one-per-CU form a microsecond: 22.2 us without it)
         const int grid = grid_env > 0 ? grid_env : build ? cus : 2 * cus;
 #define K2_PIXELS(B, T) {                                                                                                   \
             static bool attr_set = false;                                                                                   \

@@ -25,12 +25,13 @@ __device__ static inline int rs_class(bool major_x, int smaj) { return major_x ?
 // float roundings of this range and of the slopes the lines were bucketed with (each below 2e-7; a bucket is 2e-3 wide).
 // (1 / a is the hardware reciprocal, within 1 ulp: a slope error below 1e-7, inside the margin; `extra_a2` is the extra term
 // times a^2 -- 0 for K2, 1/2 for K5 -- so that the callers need no division of their own)
-__device__ static inline void rs_range(const int *start, int cls, int a, int b, float extra_a2, int &lo, int &hi)
+template <typename ST>       // (the bucket table: int, or unsigned short where LDS is tight)
+__device__ static inline void rs_range(const ST *start, int cls, int a, int b, float extra_a2, int &lo, int &hi)
 {
     const float ra = __builtin_amdgcn_rcpf((float)a), m = extra_a2 * ra * ra + 4.0e-6f;
     const int blo = rs_bucket(((float)b - 0.5f) * ra - m), bhi = rs_bucket(((float)b + 0.5f) * ra + m);
-    lo = start[cls * RS_NBUCK + blo];
-    hi = start[cls * RS_NBUCK + bhi + 1];
+    lo = (int)start[cls * RS_NBUCK + blo];
+    hi = (int)start[cls * RS_NBUCK + bhi + 1];
 }
 // classes of a cell at offset (dx, dy) from the start cell; a diagonal cell has two; the start cell itself none
 __device__ static inline int rs_classes(int dx, int dy, int cls[2], int a[2], int b[2])
