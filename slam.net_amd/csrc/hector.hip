@@ -1179,8 +1179,8 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
         const dim3 cgrid(cgrid_x);
         static const bool two_launch = getenv("SLAMHIP_K5_TWO_LAUNCHES") != nullptr;       // (tests: the large-scan path on ordinary scans)
         const bool build = n <= K5_LDS_LINES && !two_launch;
-        static bool attr_set = false;
-        if (!attr_set) { attr_set = true; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k5_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds_bytes(true, K5_LDS_LINES)); }
+        static unsigned long long attr_set = 0;                                             // one bit per device (the attribute is the device's)
+        if (!((attr_set >> (ctx->device & 63)) & 1ull)) { attr_set |= 1ull << (ctx->device & 63); (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k5_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds_bytes(true, K5_LDS_LINES)); }
         if (!build)      // all levels in every launch (MapRepMultiMap.cs:76)
             hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
                                hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);

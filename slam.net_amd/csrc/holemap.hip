@@ -908,8 +908,8 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         // one-per-CU form a microsecond: 22.2 us without it)
         const int grid = grid_env > 0 ? grid_env : build ? cus : 2 * cus;
 #define K2_PIXELS(B, T) {                                                                                                   \
-            static bool attr_set = false;                                                                                   \
-            if (!attr_set) { attr_set = true; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); } \
+            static unsigned long long attr_set = 0;              /* one bit per device (the attribute is the device's) */   \
+            if (!((attr_set >> (ctx->device & 63)) & 1ull)) { attr_set |= 1ull << (ctx->device & 63); (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); } \
             hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid + ride.ray_blocks + ride.cell_blocks), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_byidx *)cs->d_rays, \
                                (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
                                cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }

@@ -309,3 +309,17 @@ def test_hector_processor_wait_update_mode():
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_hector.py"), "-m", "gpu", "-x", "-q",
                             "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         assert r.returncode == 0, (env_extra, r.stdout.decode(errors="replace")[-3000:])
+
+
+def test_grid_update_large_scan_path():
+    """The grid update of scans with more lines than the cell kernel keeps in LDS (k5_prepare + the cell kernel reading its
+    tables from memory), forced on the ordinary test scans with SLAMHIP_K5_TWO_LAUNCHES=1: same cells.  (Natively the path
+    runs in the 3500-point case of test_grid_update_vs_oracle.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SLAMHIP_K5_TWO_LAUNCHES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_hector.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "grid_golden or grid_update_vs_oracle or map_extends or order_dependence or unordered_dense or processor_gating"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
