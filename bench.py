@@ -261,6 +261,12 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ar_us = e0.elapsed_time(e1) * 1e3 / 100
+        # the replica check: every rank built its HoleMap by the same updates -- the ranks must hold the same bits
+        replicas = None
+        try:
+            replicas = comm.replicas_equal(dev) if comm is not None else D.replicas_equal(dev.maps_checksum())
+        except Exception as e:                                     # noqa: BLE001 -- a health check must never cost the line
+            replicas = "failed: %s" % e
         if world > 1:
             t = torch.tensor([elapsed, dt_ov, ar_us if ar_us is not None else 0.0], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,7 +277,7 @@ def main():
                  "overlapped_steps": n_ov,
                  "overlapped_form": ("keys of 16 steps per ncclAllReduce on the communicator's own stream behind one event" if comm is not None
                                      else "search + all_reduce enqueued per step, nothing read back per step"),
-                 "allreduce_us": ar_us, "collective_ranks": collective_ranks}
+                 "allreduce_us": ar_us, "collective_ranks": collective_ranks, "replicas_equal": replicas}
 
     if rank == 0:
         evals = float(K_total) * a.steps

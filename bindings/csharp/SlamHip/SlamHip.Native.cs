@@ -75,6 +75,9 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_group_set_offsets(IntPtr group, Vector3* offs, int n);
         [DllImport(Lib)] internal static extern int slamhip_group_search(IntPtr group, in Vector3 searchPose, out Vector3 pose, out int dist, out int index);
         [DllImport(Lib)] internal static extern int slamhip_group_update_maps(IntPtr group, in Vector3 pose, float holeWidth, int quality, int maxObstacleHits);
+        [DllImport(Lib)] internal static extern int slamhip_group_replicas_equal(IntPtr group, out int equal);
+        [DllImport(Lib)] internal static extern int slamhip_cs_maps_checksum(IntPtr cs, ulong* holeAndObstacleWords);
+        [DllImport(Lib)] internal static extern int slamhip_hs_checksum(IntPtr hs, int level, ulong* valueAndUpdateIndexWords);
 
         internal static void Check(int status)
         {

@@ -178,6 +178,12 @@ int32_t slamhip_cs_update_obstaclemap_pxcs(slamhip_cs *cs, const float pxcs[4], 
 /* number of pixels blended by the last HoleMap update (4 algorithmic bytes each); after
  * slamhip_cs_search_and_update the figure is fetched here (this call then waits for the update) */
 int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out_pixels);
+/* Replica check (no reference counterpart; SURVEY.md sec.8e: on several GPUs the map updates run as replicas, kept
+ * bit-identical by the integer-exact kernels): 64-bit checksums of the HoleMap (out[0]; HoleMap.cs:27 Pixels as uint16) and
+ * the ObstacleMap (out[1]; ObstacleMap.cs:25 as bytes) behind everything enqueued so far:
+ *     sum over i of mix64(i << 32 | element_i) mod 2^64,  mix64 = the SplitMix64 finaliser
+ * (position-sensitive, order-independent; a host can recompute it from a download). */
+int32_t slamhip_cs_maps_checksum(slamhip_cs *cs, uint64_t out[2]);
 
 /* Diagnostics: with the environment variable SLAMHIP_K1_VERIFY=1 the distance kernel checks every end
  * point against the LDS tile box it derived by interval arithmetic and counts violations (always 0 when
@@ -248,6 +254,9 @@ int32_t slamhip_hs_bitmap_download(slamhip_hs *hs, int32_t level, uint8_t *out, 
 /* GridMap.GetMapExtends (GridMap.cs:147-207) reduced on the device: extends = {xMax, yMax, xMin, yMin} of the cells with
  * Value != 0, *found = 1; or all zeros and *found = 0 (also when a minimum never left the reference's start value 10000) */
 int32_t slamhip_hs_map_extends(slamhip_hs *hs, int32_t level, int32_t extends[4], int32_t *found);
+/* Replica check, as slamhip_cs_maps_checksum: out[0] over the level's log-odds (OccGridCell.Value, OccGridCell.cs, as its
+ * binary32 bit pattern), out[1] over its update indices (OccGridCell.UpdateIndex as uint32) */
+int32_t slamhip_hs_checksum(slamhip_hs *hs, int32_t level, uint64_t out[2]);
 /* OccGridMap.GetCachedProbability (OccGridMap.cs:97-107) for a list of cell indices */
 int32_t slamhip_hs_probability(slamhip_hs *hs, int32_t level, const int32_t *indices, int32_t n, float *out);
 
@@ -311,6 +320,8 @@ int32_t slamhip_group_search(slamhip_group *g, const float search_pose[3], float
 /* replicas apply the identical deterministic update (integer-exact kernels keep them bit-identical) */
 int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float hole_width, int32_t quality,
                                   int32_t max_obstacle_hits);
+/* *out_equal = 1 when slamhip_cs_maps_checksum agrees on every GPU of the group */
+int32_t slamhip_group_replicas_equal(slamhip_group *g, int32_t *out_equal);
 
 
 /* One process per GPU (torch.distributed.run, MPI, ...): this rank's end of an RCCL communicator.  The host framework
@@ -343,6 +354,10 @@ int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *comm, const fl
 /* Latency of the exchange step alone: `iters` 8-byte min all-reduces back to back; *out_us = device microseconds per
  * collective.  Every rank makes the same call (measurement aid for the scaling curve). */
 int32_t slamhip_comm_allreduce_probe(slamhip_comm *comm, int32_t iters, float *out_us);
+/* Replica check across the ranks: every rank checksums its maps (slamhip_cs_maps_checksum), one ncclAllReduce(min) and one
+ * ncclAllReduce(max) of the two words; *out_equal = 1 when they agree, i.e. every rank holds bit-identical maps.  Every rank
+ * makes the same call (a debug / health check: once per so many scans, not per scan). */
+int32_t slamhip_comm_replicas_equal(slamhip_cs *cs, slamhip_comm *comm, int32_t *out_equal);
 
 #ifdef __cplusplus
 }

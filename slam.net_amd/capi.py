@@ -88,6 +88,7 @@ def _declare(L):
         "slamhip_cs_update_obstaclemap": (i32, [vp, fp, i32]),
         "slamhip_cs_update_obstaclemap_pxcs": (i32, [vp, fp, i32]),
         "slamhip_cs_last_holemap_pixels": (i32, [vp, P(i64)]),
+        "slamhip_cs_maps_checksum": (i32, [vp, P(u64)]),
         "slamhip_cs_search_and_update": (i32, [vp, fp, f, i32, i32, fp, ip, ip]),
         "slamhip_cs_selfcheck_failures": (i32, [vp, P(C.c_uint32)]),
         "slamhip_csproc_create": (i32, [vp, f, i32, i32, fp, f, f, i32, i32, vpp]),
@@ -109,6 +110,7 @@ def _declare(L):
         "slamhip_hs_cells_download": (i32, [vp, i32, vp, sz]),
         "slamhip_hs_bitmap_download": (i32, [vp, i32, u8p, sz]),
         "slamhip_hs_map_extends": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "slamhip_hs_checksum": (i32, [vp, i32, P(u64)]),
         "slamhip_hs_probability": (i32, [vp, i32, ip, i32, fp]),
         "slamhip_hs_set_scan": (i32, [vp, fp, i32, fp]),
         "slamhip_hs_match": (i32, [vp, fp, fp]),
@@ -133,6 +135,7 @@ def _declare(L):
         "slamhip_group_set_offsets": (i32, [vp, fp, i32]),
         "slamhip_group_search": (i32, [vp, fp, fp, ip, ip]),
         "slamhip_group_update_maps": (i32, [vp, fp, f, i32, i32]),
+        "slamhip_group_replicas_equal": (i32, [vp, P(i32)]),
         "slamhip_comm_probe": (i32, []),
         "slamhip_comm_unique_id": (i32, [u8p]),
         "slamhip_comm_create": (i32, [vp, u8p, i32, i32, vpp]),
@@ -143,6 +146,7 @@ def _declare(L):
         "slamhip_comm_set_batch": (i32, [vp, i32]),
         "slamhip_cs_search_allreduce": (i32, [vp, vp, fp, i32, i32, u64p]),
         "slamhip_comm_allreduce_probe": (i32, [vp, i32, fp]),
+        "slamhip_comm_replicas_equal": (i32, [vp, vp, P(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

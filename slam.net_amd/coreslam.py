@@ -206,6 +206,12 @@ class CoreSlamDevice:
         capi.call("slamhip_cs_last_holemap_pixels", self._h, C.byref(v))
         return v.value
 
+    def maps_checksum(self):
+        """(HoleMap, ObstacleMap) replica-check words (slamhip_cs_maps_checksum; definition in include/slamhip.h)."""
+        out = (C.c_uint64 * 2)()
+        capi.call("slamhip_cs_maps_checksum", self._h, out)
+        return int(out[0]), int(out[1])
+
     @property
     def selfcheck_failures(self):
         v = C.c_uint32()

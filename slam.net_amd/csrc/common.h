@@ -103,3 +103,31 @@ __host__ __device__ static inline int32_t sh_abs(int32_t a) { return a < 0 ? sh_
         if (leader_ == 0) v_ = (EXPR);                                                              \
         (dst) = __builtin_amdgcn_readfirstlane(v_);                                                 \
     }
+
+// Replica check (map updates run as replicas on every GPU; integer-exact kernels keep them bit-identical --
+// this is how a host verifies it).  Position-sensitive, order-independent: sum over i of mix64(i << 32 | word_i) mod 2^64, where
+// word_i is the element zero-extended from its own width (bit pattern for floats) and mix64 the SplitMix64 finaliser
+// (Steele, Lea, Flood: "Fast splittable pseudorandom number generators").  *out must be zero before the launch.
+__host__ __device__ static inline unsigned long long sh_mix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <typename U>                  // U: uint8_t / uint16_t / uint32_t view of the array
+__global__ void __launch_bounds__(256) k_checksum(const U *__restrict__ a, size_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        acc += sh_mix64(((unsigned long long)i << 32) | (unsigned long long)a[i]);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+template <typename U>
+static inline void sh_checksum_launch(slamhip_ctx *ctx, const void *a, size_t n, unsigned long long *d_out)
+{
+    const size_t want = (n + 2047) / 2048;                          // ~8 elements per lane
+    const unsigned grid = (unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want);
+    hipLaunchKernelGGL(k_checksum<U>, dim3(grid), dim3(256), 0, ctx->stream, (const U *)a, n, d_out);
+}

@@ -886,6 +886,32 @@ extern "C" int32_t slamhip_cs_last_holemap_pixels(slamhip_cs *cs, int64_t *out)
     return SLAMHIP_OK;
 }
 
+// Replica check: checksums of the two maps as they stand behind everything enqueued so far, into words 4
+// (HoleMap) and 5 (ObstacleMap) of the result block; see sh_mix64 / k_checksum in common.h for the definition.
+int32_t cs_maps_checksum_enqueue(slamhip_cs *cs)
+{
+    slamhip_ctx *ctx = cs->ctx;
+    SH_TRY(cs_obstacle_flush(cs));                                  // (the fused call's cell pass trails one scan behind)
+    unsigned long long *d = (unsigned long long *)cs->d_key + 4;
+    SH_HIP(hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    sh_checksum_launch<uint16_t>(ctx, cs->d_hole, (size_t)cs->hs * cs->hs, d);
+    sh_checksum_launch<uint8_t>(ctx, cs->d_obst, (size_t)cs->os * cs->os, d + 1);
+    SH_HIP(hipGetLastError());
+    return SLAMHIP_OK;
+}
+extern "C" int32_t slamhip_cs_maps_checksum(slamhip_cs *cs, uint64_t out[2])
+{
+    SH_CHECK_ARG(cs && out);
+    slamhip_ctx *ctx = cs->ctx;
+    SH_HIP(hipSetDevice(ctx->device));
+    sh_mail_guard lock(ctx);
+    SH_TRY(cs_maps_checksum_enqueue(cs));
+    SH_TRY(sh_publish(ctx, cs->d_key + 4, 4));
+    SH_TRY(sh_host_wait(ctx));
+    memcpy(out, (const void *)ctx->mailbox, 2 * sizeof(uint64_t));
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
 {
     SH_CHECK_ARG(cs && out);

@@ -112,6 +112,8 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, fl
 void cs_obstacle_ride(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, int max_hits, k3_ride *out);
 void cs_obstacle_ride_commit(slamhip_cs *cs, const k3_ride *ride, int max_hits);   // after the carrying launch is in the stream
 int32_t cs_obstacle_flush(slamhip_cs *cs);                        // applies a pending cell pass (before anything reads or writes the ObstacleMap)
+// coreslam.hip: checksums of HoleMap / ObstacleMap into words 4 / 5 of the result block d_key (enqueued on the operator's stream)
+int32_t cs_maps_checksum_enqueue(slamhip_cs *cs);
 // obstacle.hip
 int32_t cs_obstacle_alloc(slamhip_cs *cs);
 void    cs_obstacle_free(slamhip_cs *cs);

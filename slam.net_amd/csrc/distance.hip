@@ -378,7 +378,6 @@ k1_search_tiled(const k1_args a)
     int zv;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));                   // opaque zero (see k1_point_lds)
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);         // wave index in the workgroup
-    const int ng = a.n_groups;
     int g, chunk, nc, nbp = 1;
     if ((int)blockIdx.x < a.n_tab_wgs) {
         // (a byte load from the kernel arguments is a VECTOR load on this target -- a full memory round trip at the head of the

@@ -197,6 +197,23 @@ extern "C" int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[
     return SLAMHIP_OK;
 }
 
+// Replica check: the replicas' maps after identical updates must be bit-identical; *out_equal = 1 when the
+// checksums of HoleMap and ObstacleMap agree on every GPU of the group.
+extern "C" int32_t slamhip_group_replicas_equal(slamhip_group *g, int32_t *out_equal)
+{
+    SH_CHECK_ARG(g && out_equal);
+    uint64_t first[2] = { 0, 0 };
+    int equal = 1;
+    for (int r = 0; r < g->n; r++) {
+        uint64_t c[2];
+        SH_TRY(slamhip_cs_maps_checksum(g->cs[r], c));
+        if (r == 0) { first[0] = c[0]; first[1] = c[1]; }
+        else if (c[0] != first[0] || c[1] != first[1]) equal = 0;
+    }
+    *out_equal = equal;
+    return SLAMHIP_OK;
+}
+
 // ---- one process per GPU: this rank's end of an RCCL communicator -------------------------------------------------
 // The host framework (torch.distributed.run, MPI, ...) only carries the 128-byte RCCL id from rank 0 to the others;
 // the per-scan exchange is issued by the library itself: K1 over this rank's block of the flat candidate list on the
@@ -426,6 +443,28 @@ extern "C" int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *c, 
     SH_TRY(sh_publish(ctx, c->d_sync_key, 2));
     SH_TRY(sh_host_wait(ctx));
     *out_key = *(volatile uint64_t *)ctx->mailbox;
+    return SLAMHIP_OK;
+}
+
+// Replica check across the ranks: every rank checksums its two maps, one min and one max all-reduce of the
+// two words; *out_equal = 1 when min == max for both, i.e. the replicas are bit-identical.  Every rank makes the same call.
+extern "C" int32_t slamhip_comm_replicas_equal(slamhip_cs *cs, slamhip_comm *c, int32_t *out_equal)
+{
+    SH_CHECK_ARG(cs && c && out_equal && cs->ctx == c->ctx);
+    slamhip_ctx *ctx = c->ctx;
+    SH_HIP(hipSetDevice(ctx->device));
+    if (c->async_dirty) SH_TRY(slamhip_comm_wait(c, nullptr));    // (collectives of one communicator are issued from one stream at a time)
+    sh_mail_guard lock(ctx);
+    SH_TRY(cs_maps_checksum_enqueue(cs));
+    uint64_t *d = cs->d_key + 4;                                   // words 4, 5: the checksums; 6, 7: their copies for the max
+    SH_HIP(hipMemcpyAsync(d + 2, d, 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    SH_NCCL(c, c->api.AllReduce(d, d, 2, ncclUint64, ncclMin, c->comm, ctx->stream));
+    SH_NCCL(c, c->api.AllReduce(d + 2, d + 2, 2, ncclUint64, ncclMax, c->comm, ctx->stream));
+    SH_TRY(sh_publish(ctx, d, 8));
+    SH_TRY(sh_host_wait(ctx));
+    uint64_t m[4];
+    memcpy(m, (const void *)ctx->mailbox, sizeof(m));
+    *out_equal = (m[0] == m[2] && m[1] == m[3]) ? 1 : 0;
     return SLAMHIP_OK;
 }
 

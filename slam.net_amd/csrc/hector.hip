@@ -941,6 +941,28 @@ extern "C" int32_t slamhip_hs_map_extends(slamhip_hs *hs, int32_t level, int32_t
     return SLAMHIP_OK;
 }
 
+// Replica check (one match is too small to shard, the grids are replicas): checksums of a level's log-odds
+// (bit patterns) and update indices behind everything enqueued so far; definition in common.h (sh_mix64 / k_checksum).
+extern "C" int32_t slamhip_hs_checksum(slamhip_hs *hs, int32_t level, uint64_t out[2])
+{
+    SH_CHECK_ARG(hs && out && level >= 0 && level < hs->n_levels);
+    hs_level &L = hs->lv[level];
+    slamhip_ctx *ctx = hs->ctx;
+    SH_HIP(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    SH_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        sh_checksum_launch<uint32_t>(ctx, L.d_value, (size_t)L.w * L.h, d);
+        sh_checksum_launch<uint32_t>(ctx, L.d_upd, (size_t)L.w * L.h, d + 1);
+        e = hipMemcpyAsync(out, d, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    SH_HIP(e);
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_hs_probability(slamhip_hs *hs, int32_t level, const int32_t *indices, int32_t n, float *out)
 {
     SH_CHECK_ARG(hs && indices && out && n > 0 && level >= 0 && level < hs->n_levels);

@@ -41,6 +41,21 @@ def allreduce_min_key(key_tensor):
     return key_tensor
 
 
+def replicas_equal(checksums):
+    """Replica check over torch.distributed (the map updates run as replicas on every rank): `checksums` =
+    this rank's words (e.g. CoreSlamDevice.maps_checksum()); True when every rank holds the same ones.  uint64 words travel
+    as two int32 halves each (gloo / RCCL reduce signed types), compared through a MIN and a MAX all-reduce."""
+    w = np.asarray(list(checksums), dtype=np.uint64)
+    halves = torch.from_numpy(w.view(np.int32).astype(np.int64))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        lo, hi = halves.to(dev), halves.to(dev).clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool((lo == hi).all().item())
+    return True
+
+
 class LibComm:
     """This rank's end of the library's own RCCL communicator (slamhip_comm_*): torch.distributed only carries the
     128-byte RCCL id from rank 0 to the others; every search step is then ONE C call that enqueues K1 on the operator's
@@ -110,6 +125,12 @@ class LibComm:
         us = C.c_float()
         capi.call("slamhip_comm_allreduce_probe", self._h, int(iters), C.byref(us))
         return float(us.value)
+
+    def replicas_equal(self, dev):
+        """slamhip_comm_replicas_equal: the ranks' HoleMap / ObstacleMap checksums agree (every rank calls it)."""
+        eq = C.c_int32()
+        capi.call("slamhip_comm_replicas_equal", dev._h, self._h, C.byref(eq))
+        return bool(eq.value)
 
     def info(self):
         r, n = C.c_int32(), C.c_int32()

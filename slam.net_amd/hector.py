@@ -62,6 +62,12 @@ class OccGridMap:
         capi.call("slamhip_hs_map_extends", self._rep._h, self.level, e, C.byref(f))
         return (bool(f.value), e[0], e[1], e[2], e[3])
 
+    def checksum(self):
+        """(log-odds, update indices) replica-check words of this level (slamhip_hs_checksum)."""
+        out = (C.c_uint64 * 2)()
+        capi.call("slamhip_hs_checksum", self._rep._h, self.level, out)
+        return int(out[0]), int(out[1])
+
     def GetCell(self, *a):
         """GridMap.GetCell(x, y) / GetCell(index) (GridMap.cs:70-96): one LogOddsCell read back from the device."""
         idx = a[1] * self.Dimensions[0] + a[0] if len(a) == 2 else int(a[0])

@@ -38,3 +38,22 @@ def npo():
 def sim():
     import slam.net_amd.sim as s
     return s
+
+
+@pytest.fixture(scope="session")
+def checksum_np():
+    """The replica-check word of include/slamhip.h (slamhip_cs_maps_checksum / slamhip_hs_checksum), restated with NumPy:
+    sum over i of mix64(i << 32 | element_i) mod 2^64, elements zero-extended from their own width."""
+    import numpy as np
+
+    def f(a):
+        a = np.ascontiguousarray(a).ravel()
+        u = a.view({1: np.uint8, 2: np.uint16, 4: np.uint32}[a.dtype.itemsize]).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            x = (np.arange(u.size, dtype=np.uint64) << np.uint64(32)) | u
+            x = x + np.uint64(0x9E3779B97F4A7C15)
+            x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            x = x ^ (x >> np.uint64(31))
+            return int(np.add.reduce(x, dtype=np.uint64))
+    return f

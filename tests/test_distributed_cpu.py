@@ -87,3 +87,35 @@ def test_key_helpers():
         assert f == tot and c == 32768
         tot += c
     assert [D.shard_range(r, 3, 10) for r in range(3)] == [(0, 3), (3, 3), (6, 4)]
+
+
+def _replica_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    import slam.net_amd.distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    same = (0xFEDCBA9876543210, 0x8000000000000001)           # (words with the top bit set: they travel as int32 halves)
+    a = D.replicas_equal(same)
+    b = D.replicas_equal((same[0], same[1] + (1 if rank == world - 1 else 0)))     # one rank's ObstacleMap word is off by one
+    c = D.replicas_equal((same[0] ^ ((1 << 63) if rank == 0 else 0), same[1]))     # rank 0 differs in the top bit only
+    out_q.put((rank, a, b, c))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_replicas_equal_gloo(world):
+    """The replica check over torch.distributed: equal words on every rank -> True on every rank, one
+    deviating rank -> False on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, a, b, c in res:
+        assert a is True and b is False and c is False, (rank, a, b, c)

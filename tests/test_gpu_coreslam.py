@@ -584,6 +584,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert j2["config"]["collective"].startswith("gloo")
     assert (j2["config"]["best_index"], j2["config"]["best_distance"]) == (j1["config"]["best_index"], j1["config"]["best_distance"])
     assert j2["roofline"]["launches"] == 50 and j2["roofline"]["avg_launch_us"] > 0 and j2["value"] > 0
+    assert j2["multi_gpu"]["replicas_equal"] is True                   # (both ranks built their HoleMap by the same updates)
     assert j1["roofline"]["launches"] == 20
 
 
@@ -625,6 +626,57 @@ def test_lib_comm_single_rank(cs_mod, ctx, sim):
     finally:
         comm.close()
         dev.close()
+
+
+def test_maps_checksum_and_replica_checks(cs_mod, ctx, det, sim, checksum_np):
+    """The replica check (map updates run as replicas on every GPU): slamhip_cs_maps_checksum equals the NumPy
+    restatement over the downloaded maps -- also right behind a fused call, whose ObstacleMap cell pass is still pending --, two
+    handles fed the same scans agree, one scan more on one of them and they do not; the one-rank communicator and the
+    one-GPU group report equal replicas."""
+    import ctypes as C
+    import slam.net_amd.capi as capi
+    import slam.net_amd.distributed as D
+    size, osize, R = 512, 100, 360
+    segs = sim.default_field()
+    a, b = make_dev(cs_mod, ctx, size, osize), make_dev(cs_mod, ctx, size, osize)
+    rng = sim.PCG32(3)
+    scans = [(p, sim.make_scan(segs, p, R, rng)[1]) for p in sim.trajectory(5)]
+    try:
+        assert a.maps_checksum() == b.maps_checksum() == (checksum_np(a.holemap_download()), checksum_np(a.obstaclemap_download()))
+        for p, xy in scans[:4]:
+            for d in (a, b):
+                d.set_scan(xy); d.update_holemap(p); d.update_obstaclemap(p)
+        ca = a.maps_checksum()
+        assert ca == b.maps_checksum() and ca == (checksum_np(a.holemap_download()), checksum_np(a.obstaclemap_download()))
+        a.set_offsets(sim.gaussian_offsets(499)); b.set_offsets(sim.gaussian_offsets(499))
+        p, xy = scans[4]
+        a.set_scan(xy); b.set_scan(xy)
+        a.search_and_update(p, 0.6, 50, 10)                         # (returns with the pose: the updates are still in the stream)
+        cf = a.maps_checksum()
+        assert cf != ca and cf != b.maps_checksum()
+        assert cf == (checksum_np(a.holemap_download()), checksum_np(a.obstaclemap_download()))
+        b.search_and_update(p, 0.6, 50, 10)
+        assert b.maps_checksum() == cf
+        comm = D.LibComm(ctx, 0, 1)
+        try:
+            assert comm.replicas_equal(a) and comm.replicas_equal(b)
+            step = comm.bind_step(a, p, 0, 500)                     # (behind asynchronous steps, too)
+            step(); step()
+            assert comm.replicas_equal(a)
+            comm.wait()
+        finally:
+            comm.close()
+    finally:
+        a.close(); b.close()
+    g = C.c_void_p()
+    dev_ids = (C.c_int32 * 1)(0)
+    capi.call("slamhip_group_create", dev_ids, 1, C.c_float(40.0), size, osize, C.byref(g))
+    try:
+        eq = C.c_int32(-1)
+        capi.call("slamhip_group_replicas_equal", g, C.byref(eq))
+        assert eq.value == 1
+    finally:
+        capi.call("slamhip_group_destroy", g)
 
 
 def test_holemap_large_scan_path():
@@ -871,6 +923,9 @@ def test_group_two_gpus(det, sim):
             dist, idx = C.c_int32(), C.c_int32()
             capi.call("slamhip_group_search", g, capi.fptr(base), capi.fptr(out_pose), C.byref(dist), C.byref(idx))
             assert idx.value == rbi and dist.value == rbd and (out_pose == rpose).all()
+        eq = C.c_int32(-1)
+        capi.call("slamhip_group_replicas_equal", g, C.byref(eq))  # the library's own replica check
+        assert eq.value == 1
         for r in range(2):                                         # the replicas hold the same, oracle-equal map
             h = C.c_void_p()
             capi.call("slamhip_group_cs", g, r, C.byref(h))
@@ -910,6 +965,7 @@ def test_bench_two_gpus_rccl():
     assert j2["config"]["collective_ranks"] == 2 and j2["multi_gpu"]["collective_ranks"] == 2
     assert (j2["config"]["best_index"], j2["config"]["best_distance"]) == (j1["config"]["best_index"], j1["config"]["best_distance"])
     assert j2["multi_gpu"]["allreduce_us"] > 0 and j2["multi_gpu"]["overlapped_evals_per_s"] > 0 and j2["value"] > 0
+    assert j2["multi_gpu"]["replicas_equal"] is True
 
 
 def test_lib_comm_blocking_step_single_rank(cs_mod, ctx, sim):

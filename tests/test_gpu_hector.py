@@ -311,6 +311,24 @@ def test_hector_processor_wait_update_mode():
         assert r.returncode == 0, (env_extra, r.stdout.decode(errors="replace")[-3000:])
 
 
+def test_grid_checksum(hs_mod, ctx, sim, checksum_np):
+    """slamhip_hs_checksum (the replica check of the grids) equals the NumPy restatement over the downloaded
+    cells on every level, and moves with an update."""
+    segs = sim.default_field()
+    rep = hs_mod.MapRepMultiMap(0.1, (400, 400), 3, ctx=ctx)
+    rng = sim.PCG32(8)
+    before = [rep.Maps[l].checksum() for l in range(3)]
+    for p in sim.trajectory(3):
+        _, xy = sim.make_scan(segs, p, 360, rng)
+        rep.UpdateByScan(hs_mod.ScanCloud(xy), p)
+    for l in range(3):
+        cells = rep.Maps[l].GetCells()
+        got = rep.Maps[l].checksum()
+        assert got == (checksum_np(cells["value"]), checksum_np(cells["update_index"])), l
+        assert got != before[l]
+    rep.close()
+
+
 def test_grid_update_large_scan_path():
     """The grid update of scans with more lines than the cell kernel keeps in LDS (k5_prepare + the cell kernel reading its
     tables from memory), forced on the ordinary test scans with SLAMHIP_K5_TWO_LAUNCHES=1: same cells.  (Natively the path
