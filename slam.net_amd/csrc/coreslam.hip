@@ -951,8 +951,8 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     if (!cs->k1_pose_written)                                    // (fallback search kernels: decode the key in a launch of its own)
         hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
                            cs->d_offs_flat, pose[0], pose[1], pose[2], cs->d_best_pose);
-    // :750-751 -- the two maps are independent: the ObstacleMap update rides on the HoleMap update's ONE launch as extra
-    // workgroups -- this scan's ray walks, and the cell pass of the previous scan (obstacle_dev.h); with per-kernel timing on,
+    // :750-751 -- the two maps are independent: the ObstacleMap update rides on the HoleMap update's ONE launch, inside its
+    // wavefronts -- this scan's ray walks, and the cell pass of the previous scan (obstacle_dev.h); with per-kernel timing on,
     // each update keeps its own launches so that the timers mean what they say
     int32_t rc_u;
     if (ctx->timing == 0) {

@@ -571,6 +571,26 @@ struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose
 // separate launch was 7.5 us plus a launch boundary.  (The order of the rays inside a bucket differs from workgroup to workgroup
 // -- LDS atomics -- so nothing that is shared out between workgroups goes by table position: T3 deals RAY INDICES.)
 // !BUILD (scans of more than K2_LDS_RAYS rays): k2_prepare's tables are read from memory.
+// the ObstacleMap update riding on the launch (see k2_pixels): a wavefront's 64 cells of the pending cell pass, whose loads it
+// requested at its start, and its ray's walk
+__device__ static __forceinline__ void k2_ride_tail(const k3_ride &ride, bool ride_cells, bool ride_ray, int ride_cell, int ride_r, int ride_nw,
+                                                    uint32_t ride_h, uint8_t ride_nh, int ride_v, float2 ride_p)
+{
+    if (ride_cells) k3_apply_loaded(ride_cell, ride_h, ride_nh, ride_v, ride.map, ride.cell_hits, ride.cell_nohit, ride.cell_max_hits);
+    for (int c = ride_cell + ride_nw * 64; c < ride.n_cells; c += ride_nw * 64)              // (ObstacleMaps of more than 512^2 cells)
+        k3_apply_cell(c, ride.map, ride.n_cells, ride.cell_hits, ride.cell_nohit, ride.cell_max_hits);
+    if (ride_ray) {                                                // (wave-uniform)
+        const float4 qo = k3_pxcs(ride.d_pose, ride.h_pxcs, ride.scale);
+        float2 pr = ride_p;
+        for (int r = ride_r; r < ride.n_points; r += ride_nw) {    // (one pass: n_points <= K2_LDS_RAYS < the launch's wavefronts)
+            if (r != ride_r) pr = ride.pts[r];
+            const k3_walk wk = k3_walk_setup(pr, qo, ride.size);
+            for (int c = 0; c < ride.chunks_per_ray && (long long)c * 64 <= wk.n; c++)
+                k3_walk_iter(wk, (long long)c * 64 + (int)(threadIdx.x & 63), ride.size, ride.hits, ride.nohit);
+        }
+    }
+}
+
 template <bool BUILD, typename T>
 __global__ void __launch_bounds__(1024)
 k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vprof_g,
@@ -578,13 +598,6 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
           const int *__restrict__ start_g, int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
           int *__restrict__ conflict_pix, int cap_conflict, int n_pix_wgs, const k3_ride ride)
 {
-    if ((int)blockIdx.x >= n_pix_wgs) {                            // riding along: the ObstacleMap update (obstacle_dev.h)
-        const int rb = (int)blockIdx.x - n_pix_wgs;
-        if (rb < ride.ray_blocks) k3_rays_unit(rb * 16 + (threadIdx.x >> 6), threadIdx.x & 63, ride.pts, ride.n_points, ride.size, ride.scale,
-                                               ride.d_pose, ride.h_pxcs, ride.hits, ride.nohit, ride.chunks_per_ray);
-        else k3_apply_cell((rb - ride.ray_blocks) * 1024 + threadIdx.x, ride.map, ride.n_cells, ride.cell_hits, ride.cell_nohit, ride.cell_max_hits);
-        return;
-    }
     extern __shared__ __attribute__((aligned(16))) char k2_smem[];
     typedef typename std::conditional<BUILD, unsigned short, int>::type start_t;
     const int n4 = (n_rays + 3) & ~3;
@@ -596,6 +609,17 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     __shared__ __attribute__((aligned(16))) int sval[16][64];
     __shared__ int s_last, s_nextA, s_nextB, s_R, s_total, wsum[16];
     K2_STAMP(0)
+    // Riding along: the ObstacleMap update (obstacle_dev.h).  Every wavefront of the launch takes 64 cells of the pending cell
+    // pass and (the rays going round the workgroups) at most one ray's walk: the loads are requested at the head, behind the scan
+    // point and the pose the tables wait for, and the work is done when the wavefront has drawn its last pixel and would wait for
+    // the rest of its workgroup -- no memory round trip and next to no time of its own.  (As extra workgroups behind the pixel
+    // ones -- the launch's LDS size lets one workgroup on a CU at a time -- the ride cost 3.2 us of the fused scan's 47.7.)
+    const int ride_w = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6), ride_nw = n_pix_wgs * 16;
+    const int ride_r = (int)(threadIdx.x >> 6) * n_pix_wgs + (int)blockIdx.x;
+    const int ride_cell = ride_w * 64 + (int)(threadIdx.x & 63);
+    const bool ride_cells = BUILD && ride.on && ride_cell < ride.n_cells, ride_ray = BUILD && ride.on && ride_r < ride.n_points;
+    uint32_t ride_h = 0; uint8_t ride_nh = 0; int ride_v = 0;
+    float2 ride_p = make_float2(0.f, 0.f);
     int R, x1, y1, n_valid;
     if (BUILD) {
         const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
@@ -603,6 +627,9 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         float2 p_next = make_float2(0.f, 0.f);
         if (t < n_rays) p_next = sc.pts[t];                         // (a thread's next point is requested one iteration ahead)
         const float4 q = k2_pxcs(sc.d_pose, sc.h_pxcs, sc.scale);
+        // (the ride's loads, behind the ones the tables wait for; consumed when the wavefront has drawn its last pixel)
+        if (ride_cells) { ride_h = ride.cell_hits[ride_cell]; ride_nh = ride.cell_nohit[ride_cell]; ride_v = ride.map[ride_cell]; }
+        if (ride_ray) ride_p = ride.pts[ride_r];
         for (int i = t; i < 4 * K2_NBUCK; i += 1024) pos_s[i] = 0;  // (the histogram, then the running positions)
         if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; }
         __syncthreads();
@@ -681,7 +708,10 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         }
         __syncthreads();
         n_valid = (int)start[4 * K2_NBUCK];
-        if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;   // robot outside the map: nothing is drawn (:509-512)
+        if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) {         // robot outside the map: nothing is drawn (:509-512)
+            if (ride.on) k2_ride_tail(ride, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p);   // (the ObstacleMap has its own test, at its own scale :557-560)
+            return;
+        }
     } else {
         R = counters[0]; x1 = counters[3]; y1 = counters[4];
         if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;   // robot outside the map: nothing is drawn (:509-512)
@@ -813,6 +843,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     // per pixel.  Queue entries are published write-through and the count is an agent-scope atomic; every wave
     // drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
     K2_STAMP(3)
+    if (BUILD && ride.on) k2_ride_tail(ride, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     K2_STAMP(4)
@@ -910,7 +941,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
 #define K2_PIXELS(B, T) {                                                                                                   \
             static unsigned long long attr_set = 0;              /* one bit per device (the attribute is the device's) */   \
             if (!((attr_set >> (ctx->device & 63)) & 1ull)) { attr_set |= 1ull << (ctx->device & 63); (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); } \
-            hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid + ride.ray_blocks + ride.cell_blocks), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_byidx *)cs->d_rays, \
+            hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_byidx *)cs->d_rays, \
                                (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
                                cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }
         if (build) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }

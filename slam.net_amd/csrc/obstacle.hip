@@ -28,8 +28,8 @@ k3_apply(int8_t *__restrict__ map, int n_cells, uint32_t *__restrict__ hits, uin
     k3_apply_cell(blockIdx.x * blockDim.x + threadIdx.x, map, n_cells, hits, nohit, max_hits);
 }
 
-// the same update as extra workgroups of the HoleMap update's launch (holemap.hip): this scan's ray walks into the current
-// scratch set, the pending cell pass out of the other one
+// the same update riding on the HoleMap update's launch (holemap.hip): this scan's ray walks into the current scratch set, the
+// pending cell pass out of the other one
 void cs_obstacle_ride(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, int max_hits, k3_ride *r)
 {
     memset(r, 0, sizeof(*r));
@@ -37,18 +37,18 @@ void cs_obstacle_ride(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, int ma
     const int b = cs->obst_buf;
     r->pts = cs->d_pts; r->n_points = cs->n_points; r->size = cs->os; r->scale = cs->oscale; r->d_pose = d_pose; r->h_pxcs = h_pxcs;
     r->hits = cs->d_o_hits[b]; r->nohit = cs->d_o_nohit[b]; r->chunks_per_ray = sh_div_up(cs->os + 1, 64);
-    r->ray_blocks = sh_div_up(r->n_points * r->chunks_per_ray, 16);
-    r->map = cs->d_obst; r->n_cells = cs->os * cs->os;
+    r->on = 1;
+    r->map = cs->d_obst;
     if (cs->obst_pending) {
         r->cell_hits = cs->d_o_hits[cs->obst_pend_buf]; r->cell_nohit = cs->d_o_nohit[cs->obst_pend_buf]; r->cell_max_hits = cs->obst_pend_max_hits;
-        r->cell_blocks = sh_div_up(r->n_cells, 1024);
+        r->n_cells = cs->os * cs->os;
     }
     (void)max_hits;
 }
 
 void cs_obstacle_ride_commit(slamhip_cs *cs, const k3_ride *r, int max_hits)
 {
-    if (r->ray_blocks <= 0) return;
+    if (!r->on) return;
     // (the pending pass, if any, went with the launch; this scan's pass is pending now)
     cs->obst_pending = true; cs->obst_pend_buf = cs->obst_buf; cs->obst_pend_max_hits = max_hits;
     cs->obst_buf ^= 1;

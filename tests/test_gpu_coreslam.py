@@ -396,6 +396,36 @@ def test_search_and_update_fused(cs_mod, ctx, det, sim):
     dev.close()
 
 
+def test_fused_robot_outside_holemap_only(cs_mod, ctx, det, sim):
+    """The fused call with the robot just left of both maps' first column: (int)(x * scale + 0.5) is -3 at the HoleMap's scale
+    -- UpdateHoleMap draws nothing (:509-512) -- but truncates to 0 at the ObstacleMap's (:553-560 test its own pixel), whose
+    update, riding on the HoleMap update's launch, must still run; and a third scan from well inside behind it."""
+    oc = det
+    size, osize, R, K = 512, 100, 360, 1024
+    segs = sim.default_field()
+    dev = cs_mod.CoreSlamDevice(ctx, 40.0, size, osize)
+    ref_h = np.full(size * size, 32750, np.uint16)
+    ref_o = np.full((osize, osize), -5, np.int8)
+    rng = sim.PCG32(23)
+    offs = np.zeros((K - 1, 3), np.float32)                              # (every candidate is the base pose: the winner is known)
+    dev.set_offsets(offs)
+    for base in (np.array([20.0, 20.0, 0.3], np.float32), np.array([-0.3, 18.07, -0.9], np.float32), np.array([-0.3, 18.07, -0.9], np.float32),
+                 np.array([21.0, 19.0, 1.0], np.float32)):
+        _, xy = sim.make_scan(segs, np.array([20.0, 20.0, float(base[2])], np.float32), R, rng)
+        dev.set_scan(xy)
+        pose, dist, idx = dev.search_and_update(base, 0.6, 50, 10)
+        rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, offs)
+        rpose[2] = oc.normalize_angle(rpose[2])
+        assert idx == rbi and dist == rbd and (pose == rpose).all()
+        before = ref_o.copy()
+        n_px = oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose)
+        if base[0] < 0:
+            assert n_px == 0 and (before != ref_o).any()                 # the case this test is about
+    assert (dev.holemap_download() == ref_h).all()
+    assert (dev.obstaclemap_download() == ref_o).all()
+    dev.close()
+
+
 def test_fused_scans_back_to_back(cs_mod, ctx, det, sim):
     """Twelve scans through set_scan + the fused call with nothing in between that waits for the device: every call
     returns with its pose while its map updates still run, the next scan's upload and search queue behind them.  Poses
