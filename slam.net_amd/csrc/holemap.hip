@@ -752,6 +752,11 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     // T3: one lane per (ray, step) beyond the zone, ray = an entry of the sorted table, steps in blocks of 64.  Software
     // pipeline: an item's pixel is requested when the item is fetched, one iteration before its turn -- the map sits in HBM /
     // Infinity Cache, a microsecond away.
+    // (Measured and rejected, round 3: sectors of equal WORK instead of equal counts -- a prefix sum over the rays' blocks of 64
+    // steps in the table phase, bounds where it passes k/8 of the total, a sector's blocks ending with its own longest ray.  On the
+    // benchmark scan the equal-count sectors hold 574 .. 1620 non-empty blocks, but their XCDs finish within 1.5 us of each other
+    // -- a block near the robot, where rays lie a pixel apart and pixels have several candidates, costs several times one far out --
+    // and the equal-work form was no better balanced and paid 3 us in the table phase.)
     // Rays are dealt BY INDEX (a scan's rays come in order of their angle: neighbours in index are neighbours in direction), and to
     // the XCDs by sector -- XCD s (workgroup b runs on XCD b % 8) draws the s-th eighth of the scan: a ray's pixels share their
     // 128-byte lines with its neighbours' (at r = 600 px adjacent rays are 3.5 px apart), and a line should meet one L2.
@@ -973,6 +978,18 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
             fprintf(stderr, "[k2 times] %d workgroups, span %.2f us; first thread of each workgroup, mean (max):", nb, (double)(t1 - t0) * 0.01);
             for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f (%.2f) |", nm[k], acc[k] / std::max(nb, 1), mx[k]);
             fprintf(stderr, " last workgroup starts at %.2f us\n", smax);
+            {   // per XCD (workgroup b runs on XCD b % 8): when its workgroups reach the end of T1, of T3 and their ticket
+                fprintf(stderr, "[k2 times] per XCD, mean (max) us from the launch's first stamp: ");
+                for (int x = 0; x < 8; x++) {
+                    double e2 = 0, e3 = 0, e5 = 0, m3 = 0, m5 = 0; int c = 0;
+                    for (int i = x; i < 512; i += 8) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8]) {
+                        const double a2 = (double)(h[i * 8 + 2] - t0) * 0.01, a3 = (double)(h[i * 8 + 3] - t0) * 0.01, a5 = (double)(h[i * 8 + 5] - t0) * 0.01;
+                        e2 += a2; e3 += a3; e5 += a5; m3 = std::max(m3, a3); m5 = std::max(m5, a5); c++;
+                    }
+                    if (c) fprintf(stderr, "[%d] T1 end %.1f, wave 0 leaves T3 %.1f (%.1f), ticket %.1f (%.1f) ", x, e2 / c, e3 / c, m3, e5 / c, m5);
+                }
+                fprintf(stderr, "\n");
+            }
             std::vector<unsigned long long> sb(512 * 16 * 8);
             (void)hipMemcpyFromSymbol(sb.data(), HIP_SYMBOL(g_k2_sub), sizeof(unsigned long long) * sb.size());
             double tt[3] = { 0, 0, 0 }, cn[3] = { 0, 0, 0 }, wmax[3] = { 0, 0, 0 };
