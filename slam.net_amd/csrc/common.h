@@ -49,19 +49,30 @@ struct sh_mail_guard {
 };
 int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words);   // enqueue; returns after the launch
 int32_t sh_publish_seq(slamhip_ctx *ctx, const void *d_src, int n_words, uint32_t seq);   // ... with a sequence number taken earlier (sh_mail_seq_next)
-// Per-scan upload as a launch: one workgroup pulls `bytes` (a multiple of 16) from a pinned staging block over PCIe and then
-// stores `seq` into the pinned word `h_flag`; sh_flag_wait(h_flag, seq) tells the host that the staging block may be refilled.
-// (A hipMemcpyAsync right after a mailbox wait takes the runtime's slow path -- it has not seen the stream finish yet -- and the
-// cross-engine dependency delays the first kernel: measured 8 us per scan; with this the per-scan path is launches only.)
-int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flag, uint32_t seq);
-// (the work of the upload's one workgroup of 1024 lanes: also rides on another launch as an extra workgroup, see k_gather_offsets)
-__device__ static inline void sh_upload16_unit(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16, uint32_t *__restrict__ flag, uint32_t seq)
+// Per-scan upload as a launch: SH_UPLOAD_PARTS workgroups pull `bytes` (a multiple of 16) from a pinned staging block over PCIe
+// and each then stores `seq` into its own pinned word h_flags[part]; sh_upload_wait(h_flags, seq) tells the host that the staging
+// block may be refilled.  (A hipMemcpyAsync right after a mailbox wait takes the runtime's slow path -- it has not seen the stream
+// finish yet -- and the cross-engine dependency delays the first kernel: measured 8 us per scan; with this the per-scan path is
+// launches only.)  Four workgroups, 16 KB per pass each: one workgroup pulls a scan's 46 KB in 5.5 us -- 2.6 us for the first
+// 16 KB, 1.4 us per further pass -- four in 3.1 us (tools/ubench_pull.hip).  The words only say "the block has been READ" (a
+// lane's stores depend on its loads, and the barrier collects the lanes): a relaxed store -- a release at system scope writes the
+// L2 back first, 3 us.
+#define SH_UPLOAD_PARTS 4
+int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flags, uint32_t seq);
+// (the work of one of the upload's workgroups of 1024 lanes: they also ride on another launch as extra workgroups, see k_gather_offsets)
+__device__ static inline void sh_upload16_part(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16, int part,
+                                               uint32_t *__restrict__ flags, uint32_t seq)
 {
-    for (int i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    for (int i = part * 1024 + (int)threadIdx.x; i < n16; i += SH_UPLOAD_PARTS * 1024) dst[i] = src[i];
     __syncthreads();                                               // every lane's loads have returned (its stores depend on them)
-    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + part, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *h_flag, uint32_t seq);
+static inline int32_t sh_upload_wait(slamhip_ctx *ctx, volatile uint32_t *h_flags, uint32_t seq)
+{
+    for (int p = 0; p < SH_UPLOAD_PARTS; p++) { const int32_t rc = sh_flag_wait(ctx, h_flags + p, seq); if (rc != SLAMHIP_OK) return rc; }
+    return SLAMHIP_OK;
+}
 int32_t sh_host_wait(slamhip_ctx *ctx);                                  // until the last sh_publish of this context has landed
 // (a kernel that is the last of its call may write the mailbox itself: words first, then sh_mail_seq_next() into word 15, released at system scope)
 static inline uint32_t sh_mail_seq_next(slamhip_ctx *ctx) { return ++ctx->mail_seq; }

@@ -117,15 +117,15 @@ int32_t sh_publish_seq(slamhip_ctx *ctx, const void *d_src, int n_words, uint32_
 }
 
 __global__ void __launch_bounds__(1024)
-k_upload16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16, uint32_t *__restrict__ flag, uint32_t seq)
+k_upload16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16, uint32_t *__restrict__ flags, uint32_t seq)
 {
-    sh_upload16_unit(src, dst, n16, flag, seq);
+    sh_upload16_part(src, dst, n16, (int)blockIdx.x, flags, seq);
 }
 
-int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flag, uint32_t seq)
+int32_t sh_upload(slamhip_ctx *ctx, const void *h_src, void *d_dst, size_t bytes, uint32_t *h_flags, uint32_t seq)
 {
-    SH_CHECK_ARG(h_src && d_dst && h_flag && bytes % 16 == 0 && bytes / 16 < (size_t)INT32_MAX);
-    hipLaunchKernelGGL(k_upload16, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)h_src, (uint4 *)d_dst, (int)(bytes / 16), h_flag, seq);
+    SH_CHECK_ARG(h_src && d_dst && h_flags && bytes % 16 == 0 && bytes / 16 < (size_t)INT32_MAX);
+    hipLaunchKernelGGL(k_upload16, dim3(SH_UPLOAD_PARTS), dim3(1024), 0, ctx->stream, (const uint4 *)h_src, (uint4 *)d_dst, (int)(bytes / 16), h_flags, seq);
     SH_HIP(hipGetLastError());
     return SLAMHIP_OK;
 }

@@ -80,8 +80,8 @@ k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_i
                  int gen_n, float gen_sxy, float gen_sth, uint64_t gen_seed, uint64_t gen_stream,
                  const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst, int up_n16, uint32_t *__restrict__ up_flag, uint32_t up_seq)
 {
-    if (up_n16 > 0 && blockIdx.x == gridDim.x - 1) {               // riding along: the scan upload (the two are independent, K1 needs both)
-        sh_upload16_unit(up_src, up_dst, up_n16, up_flag, up_seq);
+    if (up_n16 > 0 && (int)blockIdx.x >= (int)gridDim.x - SH_UPLOAD_PARTS) {   // riding along: the scan upload (the two are independent, K1 needs both)
+        sh_upload16_part(up_src, up_dst, up_n16, (int)blockIdx.x - ((int)gridDim.x - SH_UPLOAD_PARTS), up_flag, up_seq);
         return;
     }
     __shared__ float red[16][6];
@@ -341,7 +341,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     }
     if (cs->upload_pending) cs->upload_pending = false; // (the staged scan was never consumed: nothing was launched, the block is ours)
     else if (cs->scan_in_flight) {                      // the previous copy has left the staging block
-        if (!cs->ctx->mail_off) SH_TRY(sh_flag_wait(cs->ctx, (volatile uint32_t *)cs->h_key + 30, cs->upload_seq));
+        if (!cs->ctx->mail_off) SH_TRY(sh_upload_wait(cs->ctx, (volatile uint32_t *)cs->h_key + 28, cs->upload_seq));
         else SH_HIP(hipEventSynchronize(cs->ev_scan));
         cs->scan_in_flight = false;
     }
@@ -437,13 +437,13 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->h_rb_ex[(size_t)b] = (x1 - x0) * cs->hscale; cs->h_rb_ey[(size_t)b] = (y1 - y0) * cs->hscale;
         cs->h_rb_mx[(size_t)b] = 0.5f * (x0 + x1) * cs->hscale; cs->h_rb_my[(size_t)b] = 0.5f * (y0 + y1) * cs->hscale;
     }
-    cs->k1_layout_dirty = true;
+    cs->k1_scan_dirty = true;
     memcpy(h_rb, rb.data(), sizeof(int) * rb.size());
     const size_t used = (size_t)cap_ * 32 + sizeof(int) * rb.size();
     // (a blocking call that returned through the mailbox leaves a stream the runtime has not yet seen finish; the copy takes
     // its immediate path only on a stream the runtime knows to be idle: one query lets it find out)
     if (!cs->ctx->mail_off) {
-        // The upload is a launch that pulls the staging block and then tells the host (h_key word 30) that it may be refilled.
+        // The upload is a launch that pulls the staging block and then tells the host (h_key words 28 .. 31, one per workgroup of the upload) that it may be refilled.
         // It is left pending: the first launch that reads the scan issues it (cs_flush_scan) -- or the candidate gather of the
         // coming search carries it as an extra workgroup (ensure_shard): one launch and one launch boundary less per scan in the
         // processor's flow (upload -> gather -> K1 -> ...).
@@ -462,7 +462,7 @@ int32_t cs_flush_scan(slamhip_cs *cs)
 {
     if (!cs->upload_pending) return SLAMHIP_OK;
     // (the upload state is committed once the launch that carries it is in the stream: on an error the scan stays pending)
-    SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, cs->upload_bytes, (uint32_t *)cs->h_key + 30, cs->upload_seq + 1));
+    SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, cs->upload_bytes, (uint32_t *)cs->h_key + 28, cs->upload_seq + 1));
     cs->upload_pending = false;
     cs->upload_seq++;
     cs->scan_in_flight = true;
@@ -650,11 +650,11 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
     cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);
     cs->k1_layout_dirty = true;
     // a pending scan upload rides on the gather launch as one more workgroup
-    const int up_wg = cs->upload_pending ? 1 : 0;
+    const int up_wg = cs->upload_pending ? SH_UPLOAD_PARTS : 0;
     const uint4 *up_src = nullptr; uint4 *up_dst = nullptr; int up_n16 = 0; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
     if (up_wg) {                                                   // (committed below, once the gather launch is in the stream)
         up_src = (const uint4 *)cs->h_scan_blob; up_dst = (uint4 *)cs->d_scan_blob; up_n16 = (int)(cs->upload_bytes / 16);
-        up_flag = (uint32_t *)cs->h_key + 30; up_seq = cs->upload_seq + 1;
+        up_flag = (uint32_t *)cs->h_key + 28; up_seq = cs->upload_seq + 1;
     }
     if (cs->offs_on_device_sorted) {
         // flat candidates first .. first+count-1 = the un-jittered pose (flat 0) and jitters in ascending dtheta
@@ -750,6 +750,7 @@ extern "C" int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float pose[3], 
         cs->k1_done_flag = nullptr;
         SH_TRY(rc);
         if (!cs->k1_done_armed) SH_TRY(sh_publish_seq(ctx, cs->d_key, 2, seq));
+        cs_layout_idle_refresh(cs);                                // (host work under the search)
         SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));
         *out_key = *(volatile uint64_t *)ctx->mailbox;
         return SLAMHIP_OK;
@@ -961,6 +962,7 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
         rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality);
         if (rc_u == SLAMHIP_OK) rc_u = cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits);
     }
+    cs_layout_idle_refresh(cs);                                  // (host work under the search: the launch layout for the next scan)
     if (delivered) {
         SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));       // (the search's word arrives whatever became of the update launches)
         SH_TRY(rc_u);

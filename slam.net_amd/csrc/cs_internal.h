@@ -13,6 +13,9 @@
 #define K1_GROUP_SMALL 512             // 512 lanes x 1 for small ones (slamhip_cs::k1_group, ensure_shard)
 
 
+// k1_make_layout (distance.hip): a ray block's terms of the cost estimate that do not depend on the candidate group
+struct k1_block_term { double a, b, m, n, nr; };   // ex c + ey s, ex s + ey c, |mx| s + |my| c, |mx| c + |my| s, rays
+
 struct slamhip_cs {
     slamhip_ctx *ctx;
     float physical;
@@ -58,7 +61,11 @@ struct slamhip_cs {
     // (pixels) -- from the offsets (ensure_shard) -- and the chunks per group derived from them and the scan
     std::vector<float> h_grp_dth, h_grp_dxy;
     std::vector<int> k1_tab_group, k1_tab_nc, k1_tab_nbp; int k1_uni_g0, k1_uni_ng, k1_uni_nc;
+    std::vector<k1_block_term> k1_terms; std::vector<double> k1_cost, k1_lc; std::vector<int> k1_share;   // k1_make_layout's scratch (distance.hip)
     bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups; float k1_layout_theta;
+    bool k1_scan_dirty;                         // a new scan since the layout was made (set_scan): it is kept if still legal, see cs_launch_distance
+    bool k1_layout_stale;                       // ... and the one for the scan now set is made in the host's next idle wait (cs_layout_idle_refresh)
+    int k1_layout_target, k1_layout_band_parts;
     float gen_sigma_xy, gen_sigma_theta;        // offsets generated on the device: their distribution
     bool offs_theta_small;        // every |dtheta| <= 1e4: the tiled kernel's trigonometry needs no huge-angle branch
     unsigned int *d_verify;       // [8] SLAMHIP_K1_VERIFY=1: [0] tile self-check failures (must stay 0), [1..4] unit counts per kind
@@ -72,7 +79,7 @@ struct slamhip_cs {
     unsigned *k1_done_flag; unsigned k1_done_val;   // the next search launch ends with k1_done_val -> *k1_done_flag (pinned host word), if set
     bool k1_done_armed;           // ... and it will (tiled kernel)
     unsigned long long *k1_sig; unsigned long long k1_sig_val; bool k1_sig_armed;   // the same for an HSA signal (slamhip_comm: the collectives' stream waits for it)
-    uint32_t upload_seq;          // set_scan uploads issued (the launch stores it into word 30 of h_key when it has read the staging block)
+    uint32_t upload_seq;          // set_scan uploads issued (the upload's workgroups store it into words 28 .. 31 of h_key when they have read the staging block)
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------
     void *d_rays; int cap_rays;                 // rays by index (k2_byidx): clipped lengths, flags
@@ -99,6 +106,7 @@ int32_t cs_alloc_candidates(slamhip_cs *cs, int count);
 int32_t cs_flush_scan(slamhip_cs *cs);
 int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int count, bool want_dist, bool cand_sane,
                            uint64_t *key_dst);
+void cs_layout_idle_refresh(slamhip_cs *cs);   // host only: call between a search's enqueue and the wait for its result
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);
 int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all);   // the dirty rectangle := the whole map / empty (enqueued on the operator's stream)

@@ -994,12 +994,18 @@ static bool k1_chunks_legal(const slamhip_cs *cs, int nc)
     const int *rb = cs->h_rb_start.data();
     if (nc < 1 || nc > R) return false;
     int b = 0;
+    // the cuts floor(c R / nc), c = 0 .. nc, without a division per cut: quotient and remainder advance by R / nc and R % nc
+    const int dq = R / nc, dr = R % nc;
+    int rlo = 0, rem = 0;
     for (int c = 0; c < nc; c++) {
-        const int rlo = (int)(((long long)c * R) / nc), rhi = (int)(((long long)(c + 1) * R) / nc);
+        int rhi = rlo + dq;
+        rem += dr;
+        if (rem >= nc) { rem -= nc; rhi++; }
         while (b + 1 < n_rb && rb[b + 1] <= rlo) b++;                  // block of ray rlo
         int e = b;
         while (e + 1 < n_rb && rb[e + 1] < rhi) e++;                   // block of ray rhi - 1
         if (e - b + 1 > K1_MAXP || rhi - rlo > K1_MAXR) return false;
+        rlo = rhi;
     }
     return true;
 }
@@ -1015,13 +1021,18 @@ static double k1_chunks_score(const slamhip_cs *cs, int nc, double step)
     if (nc < 1 || nc > R) return -1.0;
     int b = 0;
     double worst = 0.0;
+    const int dq = R / nc, dr = R % nc;                                // (the cuts as in k1_chunks_legal)
+    int rlo = 0, rem = 0;
     for (int c = 0; c < nc; c++) {
-        const int rlo = (int)(((long long)c * R) / nc), rhi = (int)(((long long)(c + 1) * R) / nc);
+        int rhi = rlo + dq;
+        rem += dr;
+        if (rem >= nc) { rem -= nc; rhi++; }
         while (b + 1 < n_rb && rb[b + 1] <= rlo) b++;                  // block of ray rlo
         int e = b;
         while (e + 1 < n_rb && rb[e + 1] < rhi) e++;                   // block of ray rhi - 1
         if (e - b + 1 > K1_MAXP || rhi - rlo > K1_MAXR) return -1.0;
         worst = std::max(worst, (double)(rhi - rlo) + step * (double)(e - b + 1));
+        rlo = rhi;
     }
     return worst;
 }
@@ -1048,33 +1059,47 @@ static float k1_band_stage()
 // of the group (ensure_shard), the bounding box of each ray block (set_scan) and the search pose's heading.  A box
 // beyond the tile budget is staged in bands with range-tested gathers.  Only the balance of the launch depends on
 // this estimate.
-static double k1_group_cost(const slamhip_cs *cs, int g, int budget)
+// (The terms of a block that do not depend on the group are made once per layout -- k1_block_terms -- and the sum keeps the
+// order of the blocks: same doubles as the plain loop, a fifth of its time; the layout is remade for every scan, on the host's
+// critical path between two scans.)
+static void k1_block_terms(const slamhip_cs *cs, std::vector<k1_block_term> &t)
+{
+    const double c = fabs(cos((double)cs->k1_layout_theta)), s = fabs(sin((double)cs->k1_layout_theta));
+    t.resize((size_t)cs->n_rb);
+    for (int b = 0; b < cs->n_rb; b++) {
+        // the block's bounding box and centre turned into the map frame (search pose theta)
+        const double ex = cs->h_rb_ex[(size_t)b], ey = cs->h_rb_ey[(size_t)b], mx = fabs(cs->h_rb_mx[(size_t)b]), my = fabs(cs->h_rb_my[(size_t)b]);
+        k1_block_term &e = t[(size_t)b];
+        e.a = ex * c + ey * s; e.b = ex * s + ey * c; e.m = mx * s + my * c; e.n = mx * c + my * s;
+        e.nr = cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b];
+    }
+}
+static double k1_group_cost(const slamhip_cs *cs, const std::vector<k1_block_term> &t, int g, int budget)
 {
     const double dth = cs->h_grp_dth[(size_t)g], d = cs->h_grp_dxy[(size_t)g] + 4.0;
-    const double c = fabs(cos((double)cs->k1_layout_theta)), s = fabs(sin((double)cs->k1_layout_theta));
+    static const double f_band = getenv("SLAMHIP_K1_FBAND") ? atof(getenv("SLAMHIP_K1_FBAND")) : 1.9;
+    static const double f_glob = getenv("SLAMHIP_K1_FGLOBAL") ? atof(getenv("SLAMHIP_K1_FGLOBAL")) : 3.0;
+    const double stage = (double)k1_band_stage();
     double cost = 0.0;
-    for (int b = 0; b < cs->n_rb; b++) {
-        // the block's bounding box and centre turned into the map frame (search pose theta), grown by the translation
-        // spread and by the arc the centre sweeps over the group's theta range
-        const double ex = cs->h_rb_ex[(size_t)b], ey = cs->h_rb_ey[(size_t)b], mx = fabs(cs->h_rb_mx[(size_t)b]), my = fabs(cs->h_rb_my[(size_t)b]);
-        const double w = ex * c + ey * s + d + (mx * s + my * c) * dth, h = ex * s + ey * c + d + (mx * c + my * s) * dth;
+    for (size_t b = 0; b < t.size(); b++) {
+        // ... grown by the translation spread and by the arc the centre sweeps over the group's theta range
+        const k1_block_term &e = t[b];
+        const double w = e.a + d + e.m * dth, h = e.b + d + e.n * dth;
         const double bytes = 2.0 * (w + 8.0) * h;
         double f = 1.0;
         if (bytes > budget) {
             const double bands = ceil(bytes / budget);
-            static const double f_band = getenv("SLAMHIP_K1_FBAND") ? atof(getenv("SLAMHIP_K1_FBAND")) : 1.9;
-            static const double f_glob = getenv("SLAMHIP_K1_FGLOBAL") ? atof(getenv("SLAMHIP_K1_FGLOBAL")) : 3.0;
             // (cost per ray relative to a plain tile step.  The kernel takes bands where they pay against 4.5 for a global gather
             // (k1_search_tiled) -- what a gather costs the workgroup that issues it.  In the balance of the launch a global-gather
             // step weighs less: it leaves the VALU and the LDS to the workgroup it shares the compute unit with.  Measured, three
             // runs each, 4.5 -> 3.0: 16 384 candidates 27.1 -> 26.1 us per launch with events, sigma_theta 20 degrees 36.0 -> 31.9,
             // 4096^2 map with 32 768 candidates 68.2 -> 51.5, 4096 candidates 23.8 -> 22.5, the other sizes unchanged; 3.5 and 2.5
             // each have sizes that lose 4-12 us to a second round of workgroups.)
-            const double nr = cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b];
-            const bool pay = bands <= 1.0 || bands * ((double)k1_band_stage() + f_band * nr) < f_glob * nr;
-            f = bands <= K1_MAXBANDS && w <= 504.0 && pay ? f_band * bands + (bands > 1.0 ? bands * fmax((double)k1_band_stage(), 0.0) / fmax(nr, 1.0) : 0.0) : f_glob;
+            const double nr = e.nr;
+            const bool pay = bands <= 1.0 || bands * (stage + f_band * nr) < f_glob * nr;
+            f = bands <= K1_MAXBANDS && w <= 504.0 && pay ? f_band * bands + (bands > 1.0 ? bands * fmax(stage, 0.0) / fmax(nr, 1.0) : 0.0) : f_glob;
         }
-        cost += f * (cs->h_rb_start[(size_t)b + 1] - cs->h_rb_start[(size_t)b]);
+        cost += f * e.nr;
     }
     return cost;
 }
@@ -1092,10 +1117,13 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
         // more (theta tails: banded tiles) are listed with their own chunk counts.  With many groups only the outer
         // K1_TABLE_G / 2 on each side are examined.
         const int side = n_groups <= K1_TABLE_G ? n_groups : K1_TABLE_G / 2;
-        const double ref = k1_group_cost(cs, n_groups / 2, budget);
-        std::vector<double> cost((size_t)n_groups, ref);
+        std::vector<k1_block_term> &terms = cs->k1_terms;          // (kept between scans: no allocation per layout)
+        k1_block_terms(cs, terms);
+        const double ref = k1_group_cost(cs, terms, n_groups / 2, budget);
+        std::vector<double> &cost = cs->k1_cost;
+        cost.assign((size_t)n_groups, ref);
         for (int g = 0; g < n_groups; g++)
-            if (g < side || g >= n_groups - side) cost[(size_t)g] = k1_group_cost(cs, g, budget);
+            if (g < side || g >= n_groups - side) cost[(size_t)g] = k1_group_cost(cs, terms, g, budget);
         int lo = n_groups / 2, hi = n_groups / 2 + 1;
         while (lo > 0 && cost[(size_t)lo - 1] <= 1.15 * ref && (n_groups <= K1_TABLE_G || lo - 1 >= 0)) lo--;
         while (hi < n_groups && cost[(size_t)hi] <= 1.15 * ref) hi++;
@@ -1127,7 +1155,8 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
                 if (nl > 0) {
                     // what the listed groups get out of `left` workgroups: their proportional shares, none below the smallest legal
                     // count, the largest trimmed until the sum fits -- and the slowest of them
-                    std::vector<int> share; std::vector<double> lc;
+                    std::vector<int> &share = cs->k1_share; std::vector<double> &lc = cs->k1_lc;
+                    share.clear(); lc.clear();
                     long long sum = 0;
                     for (int g = 0; g < n_groups; g++) if (g < lo || g >= hi) {
                         const int v = std::max(min_legal, (int)floor(cost[(size_t)g] * (double)left / list_total + 0.5));
@@ -1211,6 +1240,28 @@ static void k1_make_layout(slamhip_cs *cs, int n_groups, int target_wgs, int bud
     }
 }
 
+// Are the layout's counts of ray ranges legal for the scan now set (k1_chunks_legal)?
+static bool k1_layout_legal(const slamhip_cs *cs)
+{
+    if (cs->k1_uni_ng > 0 && !k1_chunks_legal(cs, cs->k1_uni_nc)) return false;
+    int seen = -1;
+    for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) {
+        const int nbp = cs->k1_tab_nbp[i] > 0 ? cs->k1_tab_nbp[i] : 1, nrc = cs->k1_tab_nc[i] / nbp;
+        if (nrc * nbp != cs->k1_tab_nc[i]) return false;
+        if (nrc != seen) { if (!k1_chunks_legal(cs, nrc)) return false; seen = nrc; }
+    }
+    return true;
+}
+
+// The layout for the scan now set, made while the host has nothing else to do (it waits for a search's result): the launch that
+// just left used the previous scan's (cs_launch_distance).  Touches host state only.
+void cs_layout_idle_refresh(slamhip_cs *cs)
+{
+    if (!cs->k1_layout_stale || cs->k1_layout_dirty || cs->k1_scan_dirty || cs->n_points <= 0) return;
+    k1_make_layout(cs, cs->k1_layout_groups, cs->k1_layout_target, cs->k1_layout_budget, cs->k1_layout_spread, cs->k1_layout_band_parts);
+    cs->k1_layout_stale = false;
+}
+
 // K1 over `count` candidates in evaluation order (d_ev_idx maps to flat indices).  mode 0: d_pxcs already holds
 // (px,py,c,s); 1: d_ev_off holds jitters added to `pose`; 2: d_ev_off holds poses.  The packed arg-min key of the
 // launch is written to key_dst.  Asynchronous on the context's stream.
@@ -1261,16 +1312,30 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 
         // launch layout
         const bool have_spread = mode == 1 && !no_table && (int)cs->h_grp_dth.size() == n_groups;
-        if (cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread ||
-            (have_spread && !(fabsf(bth - cs->k1_layout_theta) < 0.1f))) {
+        // a workgroup's prologue costs as much as ~25 rays of gathers: small searches get fewer, larger chunks (a dozen
+        // rays or more each) rather than a full round of workgroups (measured at 4000 candidates x 400 rays: 21 -> 16 us)
+        int target = n_groups <= K1_TABLE_G ? target_wgs : target_wgs_uniform;
+        const long long by_work = (long long)n_groups * cs->n_points / 12;
+        if (by_work < target) target = (int)(by_work > n_groups ? by_work : n_groups);
+        bool remake = cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread ||
+                      cs->k1_layout_target != target || (have_spread && !(fabsf(bth - cs->k1_layout_theta) < 0.1f));
+        if (!remake && cs->k1_scan_dirty) {
+            // A new scan under an unchanged candidate list (the per-scan flow): the layout made for the last scan serves this one
+            // if its counts of ray ranges are legal for the new ray blocks -- only the balance of the launch depends on the layout,
+            // and consecutive scans look alike -- and the one for THIS scan is made while the host waits for the search
+            // (cs_layout_idle_refresh), for the next scan's launch: 8 us of estimate left the host's critical path between two
+            // scans (`CoreSLAMProcessor.Update` 66.6 -> 60 us; SLAMHIP_K1_LAYOUT_SYNC=1 makes every scan's layout before its launch).
+            static const int layout_sync = env_int("SLAMHIP_K1_LAYOUT_SYNC", 0);
+            if (layout_sync || !k1_layout_legal(cs)) remake = true;
+            else cs->k1_layout_stale = true;
+        }
+        cs->k1_scan_dirty = false;
+        if (remake) {
             cs->k1_layout_theta = bth;
-            // a workgroup's prologue costs as much as ~25 rays of gathers: small searches get fewer, larger chunks (a dozen
-            // rays or more each) rather than a full round of workgroups (measured at 4000 candidates x 400 rays: 21 -> 16 us)
-            int target = n_groups <= K1_TABLE_G ? target_wgs : target_wgs_uniform;
-            const long long by_work = (long long)n_groups * cs->n_points / 12;
-            if (by_work < target) target = (int)(by_work > n_groups ? by_work : n_groups);
             k1_make_layout(cs, n_groups, target, budget, have_spread, band_parts);
-            cs->k1_layout_dirty = false; cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread;
+            cs->k1_layout_dirty = false; cs->k1_layout_stale = false;
+            cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread; cs->k1_layout_target = target;
+            cs->k1_layout_band_parts = band_parts;
         }
         {   // the accumulators count up to 2^14 - 1 arrivals per candidate and sum up to 2^20 rays (pathological scans: fallback kernels)
             int nc_max = cs->k1_uni_nc;
@@ -1285,7 +1350,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                 const int g = cs->k1_tab_group[i];
                 fprintf(stderr, "   group %3d: chunks %3d, dtheta %.4f rad, spread %.1f px, cost %.0f ray units\n", g, cs->k1_tab_nc[i],
                         have_spread ? cs->h_grp_dth[(size_t)g] : 0.f, have_spread ? cs->h_grp_dxy[(size_t)g] : 0.f,
-                        have_spread ? k1_group_cost(cs, g, budget) : 0.0);
+                        have_spread ? k1_group_cost(cs, cs->k1_terms, g, budget) : 0.0);
             }
         }
         unsigned first = 0;

@@ -441,6 +441,7 @@ extern "C" int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *c, 
     else SH_HIP(hipMemsetAsync(c->d_sync_key, 0xFF, sizeof(uint64_t), ctx->stream));                     // (a rank without candidates: the neutral key)
     SH_NCCL(c, c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, ctx->stream));
     SH_TRY(sh_publish(ctx, c->d_sync_key, 2));
+    cs_layout_idle_refresh(cs);                                    // (host work under the search: cs_launch_distance)
     SH_TRY(sh_host_wait(ctx));
     *out_key = *(volatile uint64_t *)ctx->mailbox;
     return SLAMHIP_OK;

@@ -264,7 +264,7 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
             if (i < n) up_dst[i] = pre[u];
         }
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(up_flag, up_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x < SH_UPLOAD_PARTS) __hip_atomic_store(up_flag + threadIdx.x, up_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the words of sh_upload: common.h)
     } else {
 #pragma unroll
         for (int u = 0; u < HS_PRE; u++) {
@@ -1007,7 +1007,7 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
     uint32_t *up_flag = (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points);
     if (hs->upload_pending) hs->upload_pending = false; // (the staged scan was never consumed: nothing was launched, the block is ours)
     else if (hs->pts_in_flight) {                       // the previous copy has left the staging block
-        if (!hs->ctx->mail_off) SH_TRY(sh_flag_wait(hs->ctx, up_flag, hs->upload_seq));
+        if (!hs->ctx->mail_off) SH_TRY(sh_upload_wait(hs->ctx, up_flag, hs->upload_seq));
         else SH_HIP(hipEventSynchronize(hs->ev_pts));
         hs->pts_in_flight = false;
     }

@@ -186,6 +186,52 @@ def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
     dev.close()
 
 
+def test_search_changing_scans_one_candidate_list(cs_mod, ctx, det, sim):
+    """The per-scan flow: one candidate list, a new scan before every search.  The search launch keeps the layout made for the
+    previous scan while its counts of ray ranges are legal for the new scan's ray blocks, and makes the new one while the host
+    waits for the result (cs_launch_distance / cs_layout_idle_refresh).  Scans that differ wildly in size and order -- ordered,
+    shuffled (blocks of one ray), tiny, > 2000 rays -- with the tile self-check on (in the SLAMHIP_K1_VERIFY re-run below): every
+    winner equals the oracle's, through the blocking search, the fused call and the shard call alike."""
+    oc = det
+    size, K = 1024, 6000
+    segs = sim.default_field()
+    dev = make_dev(cs_mod, ctx, size, 64)
+    ref = np.full(size * size, 32750, np.uint16)
+    rng = sim.PCG32(41)
+    for p in sim.trajectory(6):
+        _, xy = sim.make_scan(segs, p, 720, rng)
+        dev.set_scan(xy); dev.update_holemap(p)
+        oc.update_holemap(ref, size, dev.hole_scale, xy, p)
+    offs = sim.gaussian_offsets(K - 1, seed=3)
+    dev.set_offsets(offs)
+    perm = np.random.default_rng(5)
+    traj = sim.trajectory(22)[6:]
+    for it, (R, shuffle) in enumerate([(720, False), (725, False), (720, True), (90, False), (2300, True), (2300, False), (1, False), (1080, False),
+                                       (1079, True), (360, False), (1080, False), (7, True), (1500, False), (1500, True), (720, False), (64, False)]):
+        p = traj[it]
+        _, xy = sim.make_scan(segs, p, R, rng)
+        if shuffle:
+            xy = xy[perm.permutation(xy.shape[0])]
+        dev.set_scan(xy)
+        base = (p + np.array([0.02, -0.01, 0.01], np.float32)).astype(np.float32)
+        rbi, rpose, rbd, _ = oc.search(ref, size, dev.hole_scale, xy, base, offs)
+        how = it % 3
+        if how == 0:
+            pose, dist, idx = dev.search(base)
+        elif how == 1:
+            pose, dist, idx = dev.pose_from_key(base, dev.search_shard(base, 0, K))
+        else:
+            pose, dist, idx = dev.search_and_update(base, 0.6, 50, 10)
+            rpose[2] = oc.normalize_angle(rpose[2])
+        assert idx == rbi and dist == rbd and (pose == rpose).all(), (it, R, shuffle)
+        if how == 2:
+            oc.update_holemap(ref, size, dev.hole_scale, xy, rpose)
+    assert (dev.holemap_download() == ref).all()
+    if os.environ.get("SLAMHIP_EXPECT_SELFCHECK"):
+        assert dev.selfcheck_failures == 0
+    dev.close()
+
+
 def test_k1_tile_boxes_selfcheck():
     """Re-run the distance tests with SLAMHIP_K1_VERIFY=1 (every end point is checked against its LDS tile
     box, every staged pixel against the map), with SLAMHIP_K1_GLOBAL=1 (global-gather fallback kernels) and
@@ -193,8 +239,9 @@ def test_k1_tile_boxes_selfcheck():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size"
+    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size or test_search_changing_scans"
     for env_extra in ({"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "1"}, {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "2"},
+                      {"SLAMHIP_K1_LAYOUT_SYNC": "1", "SLAMHIP_K1_VERIFY": "1"},   # every scan's launch layout made before its launch
                       {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "4"}, {"SLAMHIP_K1_GLOBAL": "1"},
                       {"SLAMHIP_K1_TILE_KB": "8", "SLAMHIP_K1_VERIFY": "1"},       # banded tiles and global gathers
                       {"SLAMHIP_K1_TILE_KB": "24", "SLAMHIP_K1_CPL": "1"}, {"SLAMHIP_K1_TILE_KB": "1"},
