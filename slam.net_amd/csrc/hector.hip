@@ -55,6 +55,7 @@ struct slamhip_hs {
     float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
     // K5 line tables, per level: lines by index, lines sorted by (direction class, slope bucket), bucket starts, header
     void *d_k5_byidx, *d_k5_cand; int *d_k5_start, *d_k5_hdr; int cap_lines;
+    int *d_k5_sec; int k5_sec_parity;                        // [2][HS_MAX_LEVELS][K5_SEC] sector records of the cell kernel: an update reads the set the last one wrote
 };
 
 struct hs_levels_arg { hs_level_dev lv[HS_MAX_LEVELS]; int n; };
@@ -459,12 +460,84 @@ __device__ static inline int k5_wave_min(int x)
 // the lines inside a bucket then differs from workgroup to workgroup (LDS atomics), so the work that is shared out between
 // workgroups goes by LINE INDEX (byidx), never by table position.
 #define K5_LDS_FIXED ((4 * RS_NBUCK + 4) * 4)
+#ifdef K5_TIMES
+// developer instrumentation (build with SLAMHIP_K5_TIMES=1): 100 MHz wall-clock stamps per workgroup: start, tables, zone, end
+__device__ unsigned long long g_k5_times[1024 * 4];
+#define K5_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 1024) g_k5_times[blockIdx.x * 4 + (k)] = wall_clock64(); }
+#else
+#define K5_STAMP(k) {}
+#endif
+#define K5_SEC 16                      // ints per level of the sector record: [0] the scan's line count, [1..9] the bounds of the eight sectors
+// The sector bounds for the NEXT update, by the level's first workgroup when it has drawn its last cell (its tables still stand
+// in LDS): a line's weight is its blocks of 64 steps beyond the zone (x 8) plus the fetch every line costs; an inclusive scan
+// of the weights by line index (DPP wave scans, one wavefront for the wave totals); sector k starts behind the line in which the
+// running weight passes k/8 of the total.  All 1024 threads of the workgroup call it.
+template <int RPT>
+__device__ static inline void k5_sector_bounds(const k5_line *__restrict__ byidx_s, int n_pts, int *s_wtot, int *s_wsum_all, int *s_bound,
+                                               int *__restrict__ rec_out)
+{
+    const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
+    int wgt[RPT], wincl[RPT];
+    if (t < 9) s_bound[t] = t == 0 ? 0 : n_pts;
+#pragma unroll
+    for (int it = 0; it < RPT; it++) {
+        const int i = t + it * 1024;
+        int w = 0;
+        if (i < n_pts) {
+            const k5_line ee = byidx_s[i];
+            const int bl = ((ee.flags & 1) && ee.da >= K5_ZONE) ? (ee.da - K5_ZONE) / 64 + 1 : 0;
+            w = 8 * bl + 2;
+        }
+        int incl = w;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+        wgt[it] = w; wincl[it] = incl;
+        if (lane_ == 63) s_wtot[it * 16 + wid] = incl;
+    }
+    __syncthreads();
+    if (wid == 0) {        // the (at most 48) wave totals into their exclusive prefix; the total behind them
+        constexpr int NT = RPT * 16;
+        static_assert(NT <= 63, "the wave totals and their sum fit one wavefront");
+        const int v = lane_ < NT ? s_wtot[lane_] : 0;
+        int incl = v;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+        if (lane_ < NT) s_wtot[lane_] = incl - v;
+        if (lane_ == 63) *s_wsum_all = incl;
+    }
+    __syncthreads();
+    const int run = *s_wsum_all;
+#pragma unroll
+    for (int it = 0; it < RPT; it++) {
+        const int i = t + it * 1024;
+        if (i < n_pts) {
+            const int incl = s_wtot[it * 16 + wid] + wincl[it], excl = incl - wgt[it];
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                const int ck = (k * run + 7) >> 3;
+                if (excl < ck && ck <= incl) s_bound[k] = i + 1;           // (exactly one line per threshold: the weights are positive)
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) rec_out[0] = n_pts;
+    if (t < 9) rec_out[1 + t] = s_bound[t];
+}
 static inline size_t k5_lds_bytes(bool build, int n) { return (size_t)K5_LDS_FIXED + (build ? (size_t)4 * RS_NBUCK * 4 + (size_t)32 * (size_t)((n + 3) & ~3) : 0); }
 template <bool BUILD>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox, float oy,
          const k5_line *__restrict__ byidx_all, const k5_line *__restrict__ cand_all,
-         const int *__restrict__ start_all, const int *__restrict__ hdr_all, float lo_free, float lo_occ)
+         const int *__restrict__ start_all, const int *__restrict__ hdr_all, float lo_free, float lo_occ,
+         const int *__restrict__ sec_in, int *__restrict__ sec_out)
 {
     extern __shared__ __attribute__((aligned(16))) char k5_smem[];
     int *start = (int *)k5_smem;
@@ -474,11 +547,13 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     k5_line *byidx_s = cand_s + (BUILD ? n4 : 0);
     __shared__ int wsum[16];
     __shared__ int s_R, s_nv, s_first;
+    __shared__ int s_bound[9], s_rec[10], s_wsum_all, s_wtot[((K5_LDS_LINES + 1023) / 1024) * 16];   // BUILD: the sectors of phase 2 (below)
     // workgroups are shared out over the levels (host: wg0, wgn)
     int lvl = 0;
     for (int l = 1; l < A.n; l++) if ((int)blockIdx.x >= A.lv[l].wg0) lvl = l;
     const k5_level &L = A.lv[lvl];
     int bx, by, R, nv, first_line;
+    K5_STAMP(0)
     if (BUILD) {
         const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
         constexpr int RPT = (K5_LDS_LINES + 1023) / 1024;
@@ -486,6 +561,8 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         if (t < n_pts) p_next = pts[t];
         for (int i = t; i < 4 * RS_NBUCK; i += 1024) start[i] = 0;          // (the histogram, then the bucket table)
         if (t == 0) { s_R = 0; s_nv = 0; s_first = 0x7fffffff; }
+        int rec_v = -1;                                                     // (the sectors the level's first workgroup left last time: below;
+        if (t < 10 && sec_in) rec_v = sec_in[lvl * K5_SEC + t];            //  requested here, stored behind the lines loop: no wait of its own)
         __syncthreads();
         float bxf, byf;
         sh_v2_transform(ox, oy, L.t, &bxf, &byf);                          // :126
@@ -530,7 +607,14 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             my_R = max(my_R, __shfl_down(my_R, off, 64)); my_nv += __shfl_down(my_nv, off, 64); my_first = min(my_first, __shfl_down(my_first, off, 64));
         }
         if (lane_ == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_nv, my_nv); atomicMin(&s_first, my_first); }
+        if (t < 10) s_rec[t] = rec_v;
         __syncthreads();
+        // Phase 2's sectors: the lines go to the XCDs in eight ranges of consecutive indices (locality: see phase 2) that hold EQUAL
+        // WORK, not equal counts -- with equal counts the sectors of the benchmark scan took 3.9 .. 13.6 us on level 0 (the long
+        // corridor against the near wall; SLAMHIP_K5_TIMES) and the launch waited for the slowest.  The bounds are those the level's
+        // first workgroup worked out during the LAST update (k5_sector_bounds at the end of this kernel; consecutive scans look
+        // alike, and any partition is correct -- only the balance depends on it): making them here, in every workgroup, cost the
+        // table phase 2 us (eight wavefronts per SIMD run that phase at once: an instruction more in it is 15 ns more).
         {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
             int v[4], sum = 0;
 #pragma unroll
@@ -556,7 +640,10 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         }
         R = s_R; nv = s_nv; first_line = s_first;
         __syncthreads();
-        if (nv == 0) return;
+        if (nv == 0) {
+            if (sec_out && (int)blockIdx.x == L.wg0 && t == 0) sec_out[lvl * K5_SEC] = -1;      // (no record for the next update)
+            return;
+        }
     } else {
         const int *start_g = start_all + (size_t)lvl * (4 * RS_NBUCK + 1), *hdr = hdr_all + lvl * K5_HDR;
         bx = hdr[0]; by = hdr[1]; R = hdr[2]; nv = hdr[3]; first_line = hdr[4];
@@ -564,6 +651,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         for (int i = threadIdx.x; i <= 4 * RS_NBUCK; i += 1024) start[i] = start_g[i];
         __syncthreads();
     }
+    K5_STAMP(1)
     const k5_line *cand = BUILD ? cand_s : cand_all + (size_t)lvl * cap;
     const k5_line *byidx = BUILD ? byidx_s : byidx_all + (size_t)lvl * cap;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -614,11 +702,18 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     //     line has a lane on it, and all of them see the same candidates): it applies the transitions, the others drop it.
     //     Lines are dealt by index (a scan's points come in order of their angle), to the XCDs by sector: a line's cells share
     //     their 128-byte rows with its neighbours'.
-    if (R < K5_ZONE) return;
-    const int nblk = (R - K5_ZONE) / 64 + 1;
+    K5_STAMP(2)
+    if (R < K5_ZONE) {
+        if (BUILD && sec_out && (int)blockIdx.x == L.wg0 && threadIdx.x == 0) sec_out[lvl * K5_SEC] = -1;
+        return;
+    }
     const int wg_l = (int)blockIdx.x - L.wg0;                              // workgroup within the level
     const int xcd = wg_l & 7, wgs_x = (L.wgn - xcd + 7) >> 3, wg_x = wg_l >> 3;
-    const int c0 = (int)(((long long)n_pts * xcd) >> 3), n_sec = (int)(((long long)n_pts * (xcd + 1)) >> 3) - c0;
+    // (BUILD: the sectors hold equal work, and a sector's blocks end with ITS longest line -- see the tables above)
+    const int nblk = (R - K5_ZONE) / 64 + 1;
+    const bool rec_ok = BUILD && s_rec[0] == n_pts;                        // (a record of a scan with as many lines: its bounds are a partition of this one's)
+    const int c0 = xcd == 0 ? 0 : rec_ok ? s_rec[1 + xcd] : (int)(((long long)n_pts * xcd) >> 3);
+    const int n_sec = (xcd == 7 ? n_pts : rec_ok ? s_rec[2 + xcd] : (int)(((long long)n_pts * (xcd + 1)) >> 3)) - c0;
     const int items = nblk * n_sec;
     // (software pipeline: a cell's value and update index are requested when its item is fetched, one iteration before its
     // turn -- the three arrays of a 2048^2 level are 48 MB, a microsecond away)
@@ -691,6 +786,14 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         cur = nxt;
     }
 #undef K5_FETCH
+    if (BUILD && sec_out && (int)blockIdx.x == L.wg0) {                    // (uniform: the level's first workgroup)
+        __syncthreads();
+        k5_sector_bounds<(K5_LDS_LINES + 1023) / 1024>(byidx_s, n_pts, s_wtot, &s_wsum_all, s_bound, sec_out + lvl * K5_SEC);
+    }
+#ifdef K5_TIMES
+    __syncthreads();                                                       // (the workgroup's last wavefront)
+    K5_STAMP(3)
+#endif
 }
 
 __global__ void k5_fill_cells(float *value, int32_t *upd, float *prob, size_t n)
@@ -780,6 +883,7 @@ extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
     (void)hipFree(hs->d_pts); (void)hipFree(hs->d_io);
     if (hs->h_pts) (void)hipHostFree(hs->h_pts);
     if (hs->ev_pts) (void)hipEventDestroy(hs->ev_pts);
+    (void)hipFree(hs->d_k5_sec);
     (void)hipFree(hs->d_k5_byidx); (void)hipFree(hs->d_k5_cand); (void)hipFree(hs->d_k5_start); (void)hipFree(hs->d_k5_hdr);
     if (hs->h_io) (void)hipHostFree(hs->h_io);
     free(hs);
@@ -1175,6 +1279,10 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
             SH_HIP(hipMalloc(&hs->d_k5_cand, sizeof(k5_line) * (size_t)cap * HS_MAX_LEVELS));
             SH_HIP(hipMalloc(&hs->d_k5_start, sizeof(int) * (4 * RS_NBUCK + 1) * HS_MAX_LEVELS));
             SH_HIP(hipMalloc(&hs->d_k5_hdr, sizeof(int) * K5_HDR * HS_MAX_LEVELS));
+            if (!hs->d_k5_sec) {
+                SH_HIP(hipMalloc(&hs->d_k5_sec, sizeof(int) * 2 * HS_MAX_LEVELS * K5_SEC));
+                SH_HIP(hipMemsetAsync(hs->d_k5_sec, 0xFF, sizeof(int) * 2 * HS_MAX_LEVELS * K5_SEC, ctx->stream));     // (no record: line count -1)
+            }
             hs->cap_lines = cap;
         }
         int cgrid_x = 0;
@@ -1206,16 +1314,51 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
         if (!build)      // all levels in every launch (MapRepMultiMap.cs:76)
             hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
                                hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);
-        if (build)
+        static const bool no_sectors = getenv("SLAMHIP_K5_EQUAL_SECTORS") != nullptr;       // (tuning: the sectors of phase 2 by count, as scans too large for the LDS tables have them)
+        if (build) {
+            const int *sec_in = no_sectors ? nullptr : hs->d_k5_sec + (size_t)hs->k5_sec_parity * HS_MAX_LEVELS * K5_SEC;
+            int *sec_out = no_sectors ? nullptr : hs->d_k5_sec + (size_t)(hs->k5_sec_parity ^ 1) * HS_MAX_LEVELS * K5_SEC;
             hipLaunchKernelGGL(k5_cells<true>, cgrid, dim3(1024), k5_lds_bytes(true, n), ctx->stream, A, hs->cap_lines, (const float2 *)hs->d_pts, n,
                                hs->origin[0], hs->origin[1], (const k5_line *)hs->d_k5_byidx, (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start,
-                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
-        else
+                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ, sec_in, sec_out);
+            hs->k5_sec_parity ^= 1;
+        } else
             hipLaunchKernelGGL(k5_cells<false>, cgrid, dim3(1024), k5_lds_bytes(false, n), ctx->stream, A, hs->cap_lines, (const float2 *)hs->d_pts, n,
                                hs->origin[0], hs->origin[1], (const k5_line *)hs->d_k5_byidx, (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start,
-                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ);
+                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ, (const int *)nullptr, (int *)nullptr);
     }
     SH_HIP(hipGetLastError());
+#ifdef K5_TIMES
+    {
+        static int calls = 0;
+        if (n > 0 && ++calls == 12) {
+            (void)hipStreamSynchronize(ctx->stream);
+            std::vector<unsigned long long> h(1024 * 4);
+            (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_k5_times), sizeof(unsigned long long) * h.size());
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < 1024; i++) if (h[i * 4] && h[i * 4 + 3] >= h[i * 4]) { t0 = std::min(t0, h[i * 4]); t1 = std::max(t1, h[i * 4 + 3]); }
+            fprintf(stderr, "[k5 times] span %.2f us; per level, first thread of each workgroup, mean (max) us:\n", (double)(t1 - t0) * 0.01);
+            for (int l = 0; l < hs->n_levels; l++) {
+                double acc[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 }, end = 0, endmx = 0, st = 0; int c = 0;
+                for (int i = A.lv[l].wg0; i < A.lv[l].wg0 + A.lv[l].wgn && i < 1024; i++) if (h[i * 4] && h[i * 4 + 3] >= h[i * 4]) {
+                    for (int k = 0; k < 3; k++) { const double d = (double)(h[i * 4 + k + 1] - h[i * 4 + k]) * 0.01; acc[k] += d; mx[k] = std::max(mx[k], d); }
+                    const double e = (double)(h[i * 4 + 3] - t0) * 0.01; end += e; endmx = std::max(endmx, e); st += (double)(h[i * 4] - t0) * 0.01; c++;
+                }
+                {   // per XCD sector of the level (workgroup w of the level draws sector w % 8): mean time beyond the zone
+                    fprintf(stderr, "   level %d, beyond + drain per sector:", l);
+                    for (int x = 0; x < 8; x++) {
+                        double a2 = 0; int c2 = 0;
+                        for (int i = A.lv[l].wg0 + x; i < A.lv[l].wg0 + A.lv[l].wgn && i < 1024; i += 8) if (h[i * 4] && h[i * 4 + 3] >= h[i * 4]) { a2 += (double)(h[i * 4 + 3] - h[i * 4 + 2]) * 0.01; c2++; }
+                        fprintf(stderr, " %.1f", c2 ? a2 / c2 : 0.0);
+                    }
+                    fprintf(stderr, "\n");
+                }
+                if (c) fprintf(stderr, "   level %d (%d workgroups): start +%.2f | tables %.2f (%.2f) | zone %.2f (%.2f) | beyond + drain %.2f (%.2f) | end +%.2f (%.2f)\n",
+                               l, c, st / c, acc[0] / c, mx[0], acc[1] / c, mx[1], acc[2] / c, mx[2], end / c, endmx);
+            }
+        }
+    }
+#endif
     for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144
     return SLAMHIP_OK;
 }

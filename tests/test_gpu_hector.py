@@ -329,6 +329,32 @@ def test_grid_checksum(hs_mod, ctx, sim, checksum_np):
     rep.close()
 
 
+def test_grid_update_changing_scan_sizes(hs_mod, ctx, det, sim):
+    """The cell kernel deals its lines to the XCDs by the sector bounds the PREVIOUS update left on the device (valid while the
+    scan keeps its line count, else by count): updates whose scans change size and order from one to the next -- with repeats,
+    so that a record is used, dropped and used again -- must equal the oracle cell for cell."""
+    oc = det
+    side, cell, levels = 400, 0.1, 3
+    segs = sim.default_field()
+    rep = hs_mod.MapRepMultiMap(cell, (side, side), levels, ctx=ctx)
+    ref = oc.make_pyramid(cell, side, side, levels)
+    rng = sim.PCG32(19)
+    perm = np.random.default_rng(2)
+    traj = sim.trajectory(14)
+    for it, (R, shuffle) in enumerate([(360, False), (360, False), (360, True), (361, False), (90, False), (90, False), (1500, False), (1500, True),
+                                       (1500, False), (1, False), (360, False), (360, False), (3100, False), (360, False)]):
+        p = traj[it]
+        _, xy = sim.make_scan(segs, p, R, rng)
+        if shuffle:
+            xy = xy[perm.permutation(xy.shape[0])]
+        rep.UpdateByScan(hs_mod.ScanCloud(xy), p)
+        for l in range(levels):
+            ref[l].update_by_scan(xy, p)
+    for l in range(levels):
+        assert cells_equal(rep.Maps[l].GetCells(), ref[l].cells), l
+    rep.close()
+
+
 def test_grid_update_large_scan_path():
     """The grid update of scans with more lines than the cell kernel keeps in LDS (k5_prepare + the cell kernel reading its
     tables from memory), forced on the ordinary test scans with SLAMHIP_K5_TWO_LAUNCHES=1: same cells.  (Natively the path
@@ -336,8 +362,11 @@ def test_grid_update_large_scan_path():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, SLAMHIP_K5_TWO_LAUNCHES="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_hector.py"), "-m", "gpu", "-x", "-q", "-k",
-                        "grid_golden or grid_update_vs_oracle or map_extends or order_dependence or unordered_dense or processor_gating"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    # (SLAMHIP_K5_EQUAL_SECTORS=1: the one-launch path with its lines dealt to the XCDs by count instead of by the work the
+    # last update's first workgroups measured -- the dealing must never show in the cells)
+    for extra in ({"SLAMHIP_K5_TWO_LAUNCHES": "1"}, {"SLAMHIP_K5_EQUAL_SECTORS": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_hector.py"), "-m", "gpu", "-x", "-q", "-k",
+                            "grid_golden or grid_update_vs_oracle or map_extends or order_dependence or unordered_dense or processor_gating"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, (extra, r.stdout.decode(errors="replace")[-3000:])
