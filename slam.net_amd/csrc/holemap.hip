@@ -229,9 +229,8 @@ __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
            k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof,
            int *__restrict__ start,
-           int *__restrict__ counters, int *__restrict__ total_out, int *__restrict__ dirty, const k3_ride ride)
+           int *__restrict__ counters, int *__restrict__ total_out, int *__restrict__ dirty)
 {
-    (void)ride;
     __shared__ int hist[4 * K2_NBUCK];
     __shared__ int wsum[16];
     __shared__ int s_R, s_total;
@@ -929,12 +928,9 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     sc.rb_num = rb_env; sc.rc_num = rc_env;                        // (radii, per 1080 rays, from which a wavefront takes two / four zone pixels)
     {
         sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
-        if (!build) {
-            k3_ride none;
-            memset(&none, 0, sizeof(none));
+        if (!build)
             hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                               hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty, none);
-        }
+                               hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty);
         // One round of resident workgroups, one per CU (a second round would start when the first drains; with the tables in LDS
         // one workgroup per CU measured best).
         static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
