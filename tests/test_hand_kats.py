@@ -4,7 +4,8 @@ The reference ships no tests or fixtures (SLAM.sln:6-15) and cannot be built in 
 unpinned" against the C# itself.  These cases are a third, human-checkable anchor: every expected number below was
 worked out with pencil-and-paper arithmetic from CoreSLAM/CoreSLAMProcessor.cs:320-443 (ClipRay,
 DrawLaserRayOnHoleMap), :496-534 (UpdateHoleMap), :226-259 (CalculateDistanceSISD), :456-490 / :540-593
-(DrawLaserRayOnObstacleMap, UpdateObstacleMap) and HectorSLAM/Map/OccGridMap.cs:114-239; the working is written out
+(DrawLaserRayOnObstacleMap, UpdateObstacleMap), HectorSLAM/Map/OccGridMap.cs:114-239 and HectorSLAM/Matcher/ScanMatcher.cs:135-249
+(GetCompleteHessianDerivs, InterpMapValueWithDerivatives); the working is written out
 in the comments so that a reader can follow it against the C# without running anything.  The C oracle, the NumPy
 oracle and (on the GPU box) the HIP kernels must all reproduce them.
 
@@ -300,4 +301,74 @@ def test_hand_obstaclemap_hip():
     dev.update_obstaclemap(OBST_POSE, 10)
     assert (dev.obstaclemap_download() == _obst_want()).all()
     dev.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GetCompleteHessianDerivs + InterpMapValueWithDerivatives (HectorSLAM/Matcher/ScanMatcher.cs:135-204, :206-249) by hand.
+# A 32 x 32 grid with CellLength 1 (ScaleToMap 1, Limits = Dimensions - 2 = 30: MapProperties.cs:42).  Cells hold Value 0
+# -- GetCachedProbability = exp(0) / (exp(0) + 1) = 0.5 (OccGridMap.cs:101-102) -- except three cells with Value 50:
+# exp(50) = 5.18e21, and 5.18e21 + 1 rounds to 5.18e21 in binary32, so their probability is exactly 1.0.
+# Pose (10, 20, 0) in map coordinates: transform = rotation(0) * translation(10, 20) * scale(1)  (:139-142), sinRot = 0,
+# cosRot = 1 (:145-146); a scan point (x, y) lands at map (10 + x, 20 + y).  Every number below is a dyadic fraction: the
+# sums are exact in binary32 in any order, so this known answer does not depend on how the terms are grouped.
+#
+#   p1 = (2.25, 1.5) -> map (12.25, 21.5): indMin (12, 21), factors (0.25, 0.5), xFacInv 0.75, yFacInv 0.5      (:222-242)
+#        cell (13, 21) holds 50: intensities [0.5, 1.0, 0.5, 0.5]; dx1 = -0.5, dx2 = 0, dy1 = 0, dy2 = 0.5        (:230-239)
+#        P  = ((0.5*0.75 + 1.0*0.25) * 0.5) + ((0.5*0.75 + 0.5*0.25) * 0.5) = 0.3125 + 0.25 = 0.5625             (:245-246)
+#        gx = -((-0.5*0.75) + (0*0.25)) = 0.375   -- the X-factors weight dx1, dx2 (:247) --
+#        gy = -((0*0.5) + (0.5*0.5)) = -0.25      -- and the Y-factors dy1, dy2 (:248)
+#        funVal = 1 - 0.5625 = 0.4375 (:164); rotDeriv = (-0*2.25 - 1*1.5)*0.375 + (1*2.25 - 0*1.5)*(-0.25) = -1.125 (:169-170)
+#        dTr += (0.375*0.4375, -0.25*0.4375, -1.125*0.4375) = (0.1640625, -0.109375, -0.4921875)                   (:166-172)
+#        H11 += 0.140625, H22 += 0.0625, H33 += 1.265625, H12 += -0.09375, H13 += -0.421875, H23 += 0.28125       (:174-180)
+#   p2 = (-3.5, 0.75) -> map (6.5, 20.75): indMin (6, 20), factors (0.5, 0.75); cell (6, 21) holds 50: [0.5, 0.5, 1.0, 0.5]
+#        dx1 = 0, dx2 = 0.5, dy1 = -0.5, dy2 = 0;  P = (0.5*0.25) + ((1.0*0.5 + 0.5*0.5)*0.75) = 0.125 + 0.5625 = 0.6875
+#        gx = -(0 + 0.5*0.5) = -0.25, gy = -((-0.5*0.25) + 0) = 0.125, funVal = 0.3125
+#        rotDeriv = (-0.75)*(-0.25) + (-3.5)*0.125 = 0.1875 - 0.4375 = -0.25
+#        dTr += (-0.078125, 0.0390625, -0.078125);  H11 += 0.0625, H22 += 0.015625, H33 += 0.0625, H12 += -0.03125,
+#        H13 += 0.0625, H23 += -0.03125
+#   p3 = (0.5, -2.25) -> map (10.5, 17.75): four cells with 0.5: P = 0.5, gx = gy = -0 -- contributes (signed) zeros only
+#   p4 = (20, -14.5) -> map (30.0, 5.5): X = 30 is NOT > Limits.X = 30, the point is inside (MapProperties.cs:83-87); indMin
+#        (30, 5), factors (0, 0.5); cell (31, 5) holds 50: [0.5, 1.0, 0.5, 0.5]; dx1 = -0.5, dx2 = 0, dy1 = 0, dy2 = 0.5
+#        P = ((0.5*1 + 1.0*0)*0.5) + ((0.5*1 + 0.5*0)*0.5) = 0.5;  gx = -((-0.5*1) + 0) = 0.5;  gy = -(0 + 0.5*0.5) = -0.25
+#        funVal = 0.5; rotDeriv = (14.5)*0.5 + (20)*(-0.25) = 7.25 - 5 = 2.25
+#        dTr += (0.25, -0.125, 1.125);  H11 += 0.25, H22 += 0.0625, H33 += 5.0625, H12 += -0.125, H13 += 1.125, H23 += -0.5625
+#   p5 = (20.25, -14.5) -> map (30.25, 5.5): 30.25 > 30: out of the map, Vector3.Zero (:211-214): funVal 1, all products 0
+#   totals: dTr = (0.3359375, -0.1953125, 0.5546875)
+#           H11 = 0.453125, H22 = 0.140625, H33 = 6.390625, H12 = H21 = -0.25, H13 = H31 = 0.765625, H23 = H32 = -0.3125
+HESS_XY = np.array([[2.25, 1.5], [-3.5, 0.75], [0.5, -2.25], [20.0, -14.5], [20.25, -14.5]], np.float32)
+HESS_POSE = np.array([10.0, 20.0, 0.0], np.float32)
+HESS_CELLS_50 = [21 * 32 + 13, 21 * 32 + 6, 5 * 32 + 31]
+HESS_H = np.array([[0.453125, -0.25, 0.765625], [-0.25, 0.140625, -0.3125], [0.765625, -0.3125, 6.390625]], np.float32)
+HESS_DTR = np.array([0.3359375, -0.1953125, 0.5546875], np.float32)
+
+
+def test_hand_hessian_c_oracle(oc):
+    g = oc.Grid(1.0, 32, 32)
+    cells = g.cells
+    cells["value"][HESS_CELLS_50] = 50.0
+    assert g.prob(0) == 0.5 and g.prob(HESS_CELLS_50[0]) == 1.0
+    assert (g.interp(12.25, 21.5) == np.array([0.5625, 0.375, -0.25], np.float32)).all()
+    assert (g.interp(6.5, 20.75) == np.array([0.6875, -0.25, 0.125], np.float32)).all()
+    assert (g.interp(30.0, 5.5) == np.array([0.5, 0.5, -0.25], np.float32)).all()
+    assert (g.interp(30.25, 5.5) == 0).all()
+    for threads in (1, 2, 4):                                           # (the chunks' partial sums: exact in any grouping)
+        H, d = g.hessian(HESS_XY, HESS_POSE, threads)
+        assert (H == HESS_H).all() and (d == HESS_DTR).all(), threads
+    g.close()
+
+
+@pytest.mark.gpu
+def test_hand_hessian_hip():
+    import slam.net_amd.coreslam as cs
+    import slam.net_amd.hector as hs
+    ctx = cs.Context(0)
+    rep = hs.MapRepMultiMap(1.0, (32, 32), 1, ctx=ctx)
+    cells = rep.Maps[0].GetCells().copy()
+    cells["value"][HESS_CELLS_50] = 50.0
+    rep.Maps[0].SetCells(cells)
+    rep.set_scan(hs.ScanCloud(HESS_XY))
+    H, d = rep.Maps[0].Hessian(HESS_POSE)
+    assert (H == HESS_H).all() and (d == HESS_DTR).all(), (H, d)
+    rep.close()
     ctx.close()
