@@ -5,7 +5,7 @@ unpinned" against the C# itself.  These cases are a third, human-checkable ancho
 worked out with pencil-and-paper arithmetic from CoreSLAM/CoreSLAMProcessor.cs:320-443 (ClipRay,
 DrawLaserRayOnHoleMap), :496-534 (UpdateHoleMap), :226-259 (CalculateDistanceSISD), :456-490 / :540-593
 (DrawLaserRayOnObstacleMap, UpdateObstacleMap), HectorSLAM/Map/OccGridMap.cs:114-239 and HectorSLAM/Matcher/ScanMatcher.cs:135-249
-(GetCompleteHessianDerivs, InterpMapValueWithDerivatives); the working is written out
+(GetCompleteHessianDerivs, InterpMapValueWithDerivatives) and :64-125 (MatchData, EstimateTransformationLogLh); the working is written out
 in the comments so that a reader can follow it against the C# without running anything.  The C oracle, the NumPy
 oracle and (on the GPU box) the HIP kernels must all reproduce them.
 
@@ -370,5 +370,55 @@ def test_hand_hessian_hip():
     rep.set_scan(hs.ScanCloud(HESS_XY))
     H, d = rep.Maps[0].Hessian(HESS_POSE)
     assert (H == HESS_H).all() and (d == HESS_DTR).all(), (H, d)
+    rep.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One EstimateTransformationLogLh step through MatchData(OccGridMap) (ScanMatcher.cs:64-84, :93-125) by hand, on the same kind
+# of grid (32 x 32, CellLength 1, Offset 0: mapTworld = scale(1) * translation(0, 0) is the identity, GridMap.cs:46, so world
+# and map coordinates coincide), EstimateIterations = 1, hint (10, 20, 0).  Three points chosen so that H is diagonal with
+# powers of two (Matrix4x4.Invert of a diagonal matrix: cofactor / determinant, exact here):
+#   B = (0, 3.5) -> map (10.0, 23.5): indMin (10, 23), factors (0, 0.5); cells (10, 24) and (11, 24) hold 50:
+#       intensities [0.5, 0.5, 1.0, 1.0]; dx1 = dx2 = 0 -> gx = -0; dy1 = dy2 = -0.5 -> gy = -((-0.5*0.5) + (-0.5*0.5)) = 0.5
+#       P = ((0.5*1 + 0.5*0)*0.5) + ((1.0*1 + 1.0*0)*0.5) = 0.75, funVal 0.25; rotDeriv = (-3.5)*(-0) + (0)*0.5 = 0
+#       dTr.Y += 0.5*0.25 = 0.125; H22 += 0.25
+#   C = (0, 1) -> map (10.0, 21.0): indMin (10, 21), factors (0, 0); cell (11, 21) holds 50: [0.5, 1.0, 0.5, 0.5]
+#       gx = -((0.5 - 1.0)*1 + (0)*0) = 0.5; gy = -((0.5 - 0.5)*1 + (0.5)*0) = -0; P = 0.5, funVal 0.5; rotDeriv = (-1)*0.5 = -0.5
+#       dTr.X += 0.25, dTr.Z += -0.25; H11 += 0.25, H33 += 0.25, H13 += -0.25
+#   D = (0, -1) -> map (10.0, 19.0): indMin (10, 19); cell (11, 19) holds 50: gx = 0.5, gy = -0, P = 0.5; rotDeriv = (+1)*0.5 = 0.5
+#       dTr.X += 0.25, dTr.Z += +0.25; H11 += 0.25, H33 += 0.25, H13 += +0.25
+#   H = diag(0.5, 0.25, 0.5) (M44 = 1, :202), dTr = (0.5, 0.125, 0); M11 and M22 are not zero (:97)
+#   iH = diag(2, 4, 2, 1); searchDir = Vector3.Transform(dTr, iH) = (0.5*2, 0.125*4, 0*2) = (1.0, 0.5, 0) (:105); |Z| <= 0.2
+#   estimate = (10, 20, 0) + (1.0, 0.5, 0) = (11.0, 20.5, 0) (:119); NormalizeAngle(0) = 0 (:76); world = map (:79)
+STEP_XY = np.array([[0.0, 3.5], [0.0, 1.0], [0.0, -1.0]], np.float32)
+STEP_HINT = np.array([10.0, 20.0, 0.0], np.float32)
+STEP_CELLS_50 = [24 * 32 + 10, 24 * 32 + 11, 21 * 32 + 11, 19 * 32 + 11]
+STEP_H = np.diag([0.5, 0.25, 0.5]).astype(np.float32)
+STEP_DTR = np.array([0.5, 0.125, 0.0], np.float32)
+STEP_WANT = np.array([11.0, 20.5, 0.0], np.float32)
+
+
+def test_hand_estimate_step_c_oracle(oc):
+    g = oc.Grid(1.0, 32, 32)
+    g.cells["value"][STEP_CELLS_50] = 50.0
+    H, d = g.hessian(STEP_XY, STEP_HINT, 1)
+    assert (H == STEP_H).all() and (d == STEP_DTR).all()
+    assert (g.match(STEP_XY, STEP_HINT, iterations=1) == STEP_WANT).all()
+    g.close()
+
+
+@pytest.mark.gpu
+def test_hand_estimate_step_hip():
+    import slam.net_amd.coreslam as cs
+    import slam.net_amd.hector as hs
+    ctx = cs.Context(0)
+    rep = hs.MapRepMultiMap(1.0, (32, 32), 1, ctx=ctx)
+    cells = rep.Maps[0].GetCells().copy()
+    cells["value"][STEP_CELLS_50] = 50.0
+    rep.Maps[0].SetCells(cells)
+    rep.Maps[0].EstimateIterations = 1
+    got = hs.ScanMatcher(1).MatchData(rep.Maps[0], hs.ScanCloud(STEP_XY), STEP_HINT)
+    assert (got == STEP_WANT).all(), got
     rep.close()
     ctx.close()
