@@ -715,8 +715,9 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     const int c0 = xcd == 0 ? 0 : rec_ok ? s_rec[1 + xcd] : (int)(((long long)n_pts * xcd) >> 3);
     const int n_sec = (xcd == 7 ? n_pts : rec_ok ? s_rec[2 + xcd] : (int)(((long long)n_pts * (xcd + 1)) >> 3)) - c0;
     const int items = nblk * n_sec;
-    // (software pipeline: a cell's value and update index are requested when its item is fetched, one iteration before its
-    // turn -- the three arrays of a 2048^2 level are 48 MB, a microsecond away)
+    // (software pipeline: a cell's value and update index are requested when its item is fetched, two iterations before its
+    // turn -- the three arrays of a 2048^2 level are 48 MB, a microsecond or two away; two ahead against one: 32.6 -> 32.2 us,
+    // and the kernel's 64 VGPRs leave no room for a third)
     struct k5_item { int cell, dx, dy, ray, end; float v; int u; };
 #define K5_FETCH(it, item_)                                                                         \
     {                                                                                               \
@@ -743,12 +744,13 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             }                                                                                       \
         }                                                                                           \
     }
-    k5_item cur, nxt;
-    cur.cell = -1; cur.dx = cur.dy = cur.ray = cur.end = cur.u = 0; cur.v = 0.f; nxt = cur;
+    k5_item cur, nxt, nx2;
+    cur.cell = -1; cur.dx = cur.dy = cur.ray = cur.end = cur.u = 0; cur.v = 0.f; nxt = cur; nx2 = cur;
     int item = wg_x * 16 + wv;
     K5_FETCH(cur, item)
+    K5_FETCH(nxt, item + wgs_x * 16)
     for (; item < items; item += wgs_x * 16) {
-        K5_FETCH(nxt, item + wgs_x * 16)
+        K5_FETCH(nx2, item + 2 * wgs_x * 16)
         if (cur.cell >= 0) {
             const int dx = cur.dx, dy = cur.dy;
             const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
@@ -783,7 +785,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
                 L.prob[cur.cell] = hs_prob_v(v);
             }
         }
-        cur = nxt;
+        cur = nxt; nxt = nx2;
     }
 #undef K5_FETCH
     if (BUILD && sec_out && (int)blockIdx.x == L.wg0) {                    // (uniform: the level's first workgroup)
