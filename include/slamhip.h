@@ -240,7 +240,7 @@ int32_t slamhip_csproc_cs(slamhip_csproc *p, slamhip_cs **out_cs);
 int32_t slamhip_hs_create(slamhip_ctx *ctx, float cell_length, int32_t width, int32_t height, int32_t levels,
                           slamhip_hs **out);
 int32_t slamhip_hs_destroy(slamhip_hs *hs);
-int32_t slamhip_hs_reset(slamhip_hs *hs);                                   /* MapRepMultiMap.Reset :63-66 */
+int32_t slamhip_hs_reset(slamhip_hs *hs);                                   /* MapRepMultiMap.Reset :63-66; also resets the probabilities (deviation D5, slamhip_hs_probability) */
 int32_t slamhip_hs_level_info(slamhip_hs *hs, int32_t level, int32_t *width, int32_t *height, float *cell_length);
 /* SetUpdateFactorFree / SetUpdateFactorOccupied (:83-95; OccGridMap.cs:58-79) */
 int32_t slamhip_hs_set_factors(slamhip_hs *hs, float update_free_factor, float update_occupied_factor);
@@ -257,7 +257,11 @@ int32_t slamhip_hs_map_extends(slamhip_hs *hs, int32_t level, int32_t extends[4]
 /* Replica check, as slamhip_cs_maps_checksum: out[0] over the level's log-odds (OccGridCell.Value, OccGridCell.cs, as its
  * binary32 bit pattern), out[1] over its update indices (OccGridCell.UpdateIndex as uint32) */
 int32_t slamhip_hs_checksum(slamhip_hs *hs, int32_t level, uint64_t out[2]);
-/* OccGridMap.GetCachedProbability (OccGridMap.cs:97-107) for a list of cell indices */
+/* OccGridMap.GetCachedProbability (OccGridMap.cs:97-107) for a list of cell indices: exp(v)/(exp(v)+1) of each cell's
+ * CURRENT value.  Deviation D5: the reference's cache is not invalidated by Reset (OccGridMap.cs:244-252 resets
+ * currCacheIndex but not cacheArray[i].Index, which only the constructor sets to -1, :38-42), so a cell cached in epoch e
+ * before a Reset is served its pre-reset probability in epoch e after it; here -- and in the matcher, which reads the same
+ * grid -- a probability never outlives the value it was computed from. */
 int32_t slamhip_hs_probability(slamhip_hs *hs, int32_t level, const int32_t *indices, int32_t n, float *out);
 
 /* The ScanCloud handed to MatchData / UpdateByScan: points + scan.Pose.xy (ScanCloud.cs:15-20) */

@@ -129,6 +129,9 @@ struct oracle_grid {
     m3x2 map_t_world, world_t_map;            /* GridMap.cs:14-15 */
     int curr_update_index, curr_mark_occ, curr_mark_free;   /* OccGridMap.cs:20-22 */
     float odds_occ, odds_free, lo_occ, lo_free;             /* OccGridMap.cs:24-27 */
+    /* the literal cache of OccGridMap.cs:16-19,38-42,97-107 -- kept ONLY for oracle_grid_prob_literal (deviation D5, below);
+     * nothing else in the oracle reads it */
+    float *cache_val; int *cache_idx; int curr_cache_index;
 };
 
 static float scale_to_map(const oracle_grid *g) { return 1.0f / g->cell_len; } /* MapProperties.cs:32 */
@@ -142,15 +145,19 @@ oracle_grid *oracle_grid_create(float cell_len, int w, int h, float off_x, float
     oracle_grid *g = (oracle_grid *)calloc(1, sizeof(*g));
     g->w = w; g->h = h; g->cell_len = cell_len; g->off_x = off_x; g->off_y = off_y;
     g->cells = (oracle_cell *)malloc(sizeof(oracle_cell) * (size_t)w * h);
+    g->cache_val = (float *)calloc((size_t)w * h, sizeof(float));
+    g->cache_idx = (int *)malloc(sizeof(int) * (size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; i++) g->cache_idx[i] = -1;   /* OccGridMap.cs:38-42: the ONLY place Index is set to -1 */
+    g->curr_cache_index = 0;                                            /* :19 */
     g->map_t_world = m3x2_mul(m3x2_scale(scale_to_map(g)), m3x2_translation(off_x, off_y)); /* GridMap.cs:46 */
-    if (!m3x2_invert(g->map_t_world, &g->world_t_map)) { free(g->cells); free(g); return NULL; } /* :47-50 */
+    if (!m3x2_invert(g->map_t_world, &g->world_t_map)) { free(g->cells); free(g->cache_val); free(g->cache_idx); free(g); return NULL; } /* :47-50 */
     g->odds_occ = 0.9f; g->odds_free = 0.4f;                 /* OccGridMap.cs:24-25 */
     g->lo_free = prob_to_logodds(g->odds_free);              /* :46 */
     g->lo_occ = prob_to_logodds(g->odds_occ);                /* :47 */
     oracle_grid_reset(g);
     return g;
 }
-void oracle_grid_destroy(oracle_grid *g) { if (g) { free(g->cells); free(g); } }
+void oracle_grid_destroy(oracle_grid *g) { if (g) { free(g->cells); free(g->cache_val); free(g->cache_idx); free(g); } }
 
 /* GridMap.cs:56-62 + LogOddsCell.cs:38-42 + OccGridMap.cs:244-252 */
 void oracle_grid_reset(oracle_grid *g)
@@ -158,6 +165,7 @@ void oracle_grid_reset(oracle_grid *g)
     size_t n = (size_t)g->w * g->h;
     for (size_t i = 0; i < n; i++) { g->cells[i].value = 0.0f; g->cells[i].update_index = -1; }
     g->curr_update_index = 0; g->curr_mark_occ = -1; g->curr_mark_free = -1;
+    g->curr_cache_index = 0;      /* :248 -- and cacheArray[i].Index is NOT touched (deviation D5) */
 }
 void oracle_grid_set_factors(oracle_grid *g, float free_f, float occ_f)   /* OccGridMap.cs:58-79 */
 {
@@ -169,12 +177,32 @@ oracle_cell *oracle_grid_cells(oracle_grid *g) { return g->cells; }
 int oracle_grid_w(const oracle_grid *g) { return g->w; }
 int oracle_grid_h(const oracle_grid *g) { return g->h; }
 
-/* OccGridMap.cs:97-107 GetCachedProbability (the cache is value-transparent: it is invalidated
- * on every UpdateByScan, :147, so the cached value always equals this expression) */
+/* OccGridMap.cs:97-107 GetCachedProbability, as a function of the cell's CURRENT value.
+ *
+ * DEVIATION D5 (documented; oracle, library and tests agree on it).  The reference caches this expression per cell and
+ * cache epoch: `currCacheIndex` is incremented by every UpdateByScan (:147), so between two Resets the cached value always
+ * equals the expression (the cache is value-transparent).  It is NOT transparent across `Reset()`: :244-252 sets
+ * currCacheIndex back to 0 but leaves every cacheArray[i].Index as it was (only the constructor writes -1, :38-42), so a
+ * cell that was cached in epoch e before the Reset is served its PRE-RESET probability when it is queried in epoch e after
+ * the Reset -- until the epochs differ again.  That is a reference bug (a matcher reading probabilities of a map that no
+ * longer exists), it depends on which cells an earlier match happened to touch, and it is not reproduced: this function,
+ * the device's probability grids (hector.hip: refreshed by every writer of the log-odds grid, reset included) and
+ * slamhip_hs_cell_prob return the current value's probability.  oracle_grid_prob_literal below restates the C# cache
+ * literally so that tests/test_oracle_kat.py can SHOW the reference's behaviour next to the chosen one. */
 float oracle_grid_prob(oracle_grid *g, int index)
 {
     float odds = expf(g->cells[index].value);               /* :101 */
     return odds / (odds + 1.0f);                            /* :102 */
+}
+/* OccGridMap.cs:97-107 literally, cache and all (D5: used by no product path and no other oracle function) */
+float oracle_grid_prob_literal(oracle_grid *g, int index)
+{
+    if (g->cache_idx[index] != g->curr_cache_index) {       /* :99 */
+        float odds = expf(g->cells[index].value);           /* :101 */
+        g->cache_val[index] = odds / (odds + 1.0f);         /* :102 */
+        g->cache_idx[index] = g->curr_cache_index;          /* :103 */
+    }
+    return g->cache_val[index];                             /* :106 */
 }
 
 /* GridMap.cs:133-137 */
@@ -252,6 +280,7 @@ void oracle_grid_update_by_scan(oracle_grid *g, const float *xy, int n_points,
         if (bx != ex || by != ey) update_line(g, bx, by, ex, ey);           /* :137-140 */
     }
     g->curr_update_index += 3;                                              /* :144 */
+    g->curr_cache_index++;                                                  /* :147 */
 }
 
 /* GridMap.cs:104-115 */

@@ -130,7 +130,8 @@ void   oracle_grid_get_logodds(const oracle_grid *g, float *lo_free, float *lo_o
 oracle_cell *oracle_grid_cells(oracle_grid *g);
 int    oracle_grid_w(const oracle_grid *g);
 int    oracle_grid_h(const oracle_grid *g);
-float  oracle_grid_prob(oracle_grid *g, int index);             /* OccGridMap.cs:97-107 */
+float  oracle_grid_prob(oracle_grid *g, int index);             /* OccGridMap.cs:97-107 as a function of the current value (deviation D5) */
+float  oracle_grid_prob_literal(oracle_grid *g, int index);     /* OccGridMap.cs:97-107 with the literal cache: stale across Reset (D5) */
 void   oracle_grid_map_pose(const oracle_grid *g, const float world[3], float out[3]);   /* GridMap.cs:133-137 */
 void   oracle_grid_world_pose(const oracle_grid *g, const float map[3], float out[3]);   /* GridMap.cs:122-126 */
 /* OccGridMap.cs:114-148 (+:155-239) */

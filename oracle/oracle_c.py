@@ -95,6 +95,7 @@ def _declare(L):
     L.oracle_grid_w.argtypes = [vp]; L.oracle_grid_w.restype = C.c_int
     L.oracle_grid_h.argtypes = [vp]; L.oracle_grid_h.restype = C.c_int
     L.oracle_grid_prob.argtypes = [vp, C.c_int]; L.oracle_grid_prob.restype = f
+    L.oracle_grid_prob_literal.argtypes = [vp, C.c_int]; L.oracle_grid_prob_literal.restype = f
     L.oracle_grid_map_pose.argtypes = [vp, fp, fp]
     L.oracle_grid_world_pose.argtypes = [vp, fp, fp]
     L.oracle_grid_update_by_scan.argtypes = [vp, fp, C.c_int, fp, fp]
@@ -332,6 +333,10 @@ class Grid:
 
     def prob(self, index):
         return lib().oracle_grid_prob(self._h, int(index))
+
+    def prob_literal(self, index):
+        """OccGridMap.cs:97-107 with the C# cache restated literally (deviation D5: stale across Reset)"""
+        return lib().oracle_grid_prob_literal(self._h, int(index))
 
     def map_pose(self, world):
         w = _f32(world); o = np.empty(3, np.float32)

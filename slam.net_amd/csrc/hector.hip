@@ -5,16 +5,21 @@
 // iterations of one match run in ONE persistent workgroup (the reference fans out to ParallelWorker
 // threads once per iteration, :154); the nine sums are accumulated per lane in fp32, reduced across the
 // workgroup in fp64 and the 3x3 system is solved on the device with the BCL's cofactor formulas.
-// Occupancy probabilities are computed on the fly as exp(v)/(exp(v)+1) (OccGridMap.cs:97-107) instead of
-// through the reference's lazily filled cache.  Float parity target: pose within 1e-4 m / 1e-4 rad (H6).
+// Occupancy probabilities exp(v)/(exp(v)+1) (OccGridMap.GetCachedProbability, OccGridMap.cs:97-107) are READ from a dense
+// per-level grid `prob` that every writer of the log-odds grid keeps current (K5 for the cells it touches, upload and
+// reset for all of them) -- the device's form of the reference's per-cell cache, without its epochs: the value always is
+// the current cell's probability, also across Reset, where the reference's cache can serve pre-reset values (deviation
+// D5: oracle/hector_oracle.c, DESIGN.md sec.3, tests/test_oracle_kat.py::test_hector_reset_cache_aliasing_d5).
+// Float parity target: pose within 1e-4 m / 1e-4 rad (H6).
 //
 // K5 replaces OccGridMap.UpdateByScan and friends (HectorSLAM/Map/OccGridMap.cs:114-239) for every level of
-// the pyramid (MapRepMultiMap.cs:73-77).  The once-per-scan guards make a cell's new value depend only on
+// the pyramid (MapRepMultiMap.cs:73-77) in one launch.  The once-per-scan guards make a cell's new value depend only on
 // (a) whether it is touched as free, (b) whether it is an end point, and (c) whether the first free touch
-// precedes the first end-point touch in ray order.  Every cell of every line is an
-// independent fragment (closed-form Bresenham position): pass 0 records atomicMin(2*ray + isOcc) plus an
-// end-point flag per cell; pass 1 elects one fragment per cell and replays the at most two state
-// transitions literally -- bit-exact fp32 cell values.
+// precedes the first end-point touch in ray order.  No atomics and no per-cell scratch: lines are sorted
+// by direction class and slope (raster.h, shared with the HoleMap update); a cell has ONE writer -- the wavefront of a
+// cell near the begin cell, or beyond that the lane of the lowest line index among the lines that touch it (one lane
+// per (line, step), closed-form Bresenham position) -- which finds the first "free" line and the first line that ends
+// in the cell and replays the at most two state transitions literally: bit-exact fp32 cell values and update indices.
 #include "common.h"
 #include "m3x2.h"
 #include "raster.h"

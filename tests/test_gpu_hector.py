@@ -370,3 +370,52 @@ def test_grid_update_large_scan_path():
                             "grid_golden or grid_update_vs_oracle or map_extends or order_dependence or unordered_dense or processor_gating"],
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         assert r.returncode == 0, (extra, r.stdout.decode(errors="replace")[-3000:])
+
+
+def test_reset_probabilities_are_current_d5(hs_mod, ctx, det, sim):
+    """Deviation D5 (OccGridMap.cs:97-107,147,244-252; tests/test_oracle_kat.py shows the C# behaviour): after Reset the
+    reference can serve pre-reset probabilities out of its cache.  The library's probability grids follow the cells: the
+    hand case (0.9 before the Reset, 0.4 after Reset + a scan that crosses the cell as free), and a match after
+    Reset + remapping equals the oracle's match on a freshly built map."""
+    rep = hs_mod.MapRepMultiMap(1.0, (32, 32), 1, ctx=ctx)
+    cell = 10 * 32 + 15
+    pose = np.array([10.0, 10.0, 0.0], np.float32)
+    rep.UpdateByScan(hs_mod.ScanCloud(np.array([[5.0, 0.0]], np.float32)), pose)
+    assert abs(float(rep.Maps[0].GetCachedProbability(cell)[0]) - 0.9) < 1e-6
+    rep.Reset()
+    assert float(rep.Maps[0].GetCachedProbability(cell)[0]) == 0.5
+    rep.UpdateByScan(hs_mod.ScanCloud(np.array([[8.0, 0.0]], np.float32)), pose)
+    assert abs(float(rep.Maps[0].GetCachedProbability(cell)[0]) - 0.4) < 1e-6       # the C# cache would say 0.9 here (same epoch 1)
+    g = det.Grid(1.0, 32, 32)
+    g.update_by_scan(np.array([[8.0, 0.0]], np.float32), pose)
+    assert float(rep.Maps[0].GetCachedProbability(cell)[0]) == np.float32(g.prob(cell))
+    rep.close()
+
+    # a pyramid that is mapped, matched (the match touches -- in the C# -- the cache), reset and mapped elsewhere: the match on the
+    # new map equals the oracle's match on a map that never saw the first one
+    segs = sim.default_field()
+    rng = sim.PCG32(11)
+    side, cellm, R = 400, 0.1, 360
+    rep = hs_mod.MapRepMultiMap(cellm, (side, side), 2, ctx=ctx)
+    m = hs_mod.ScanMatcher(1)
+    first = [np.array([12.0 + 0.05 * i, 14.0, 0.02 * i], np.float32) for i in range(4)]
+    for p in first:
+        rep.UpdateByScan(hs_mod.ScanCloud(sim.make_scan(segs, p, R, rng)[1]), p)
+    m.MatchData(rep, hs_mod.ScanCloud(sim.make_scan(segs, first[-1], R, rng)[1]), first[-1])
+    rep.Reset()
+    levels = det.make_pyramid(cellm, side, side, 2)
+    second = [np.array([20.0 + 0.05 * i, 20.0 + 0.02 * i, 0.01 * i], np.float32) for i in range(4)]
+    for p in second:
+        xy = sim.make_scan(segs, p, R, rng)[1]
+        rep.UpdateByScan(hs_mod.ScanCloud(xy), p)
+        for g in levels:
+            g.update_by_scan(xy, p)
+    for l, g in enumerate(levels):
+        assert cells_equal(rep.Maps[l].GetCells(), g.cells)
+    xy = sim.make_scan(segs, second[-1], R, rng)[1]
+    hint = second[-1] + np.array([0.05, -0.04, 0.01], np.float32)
+    got = m.MatchData(rep, hs_mod.ScanCloud(xy), hint)
+    ref = det.match_pyramid(levels, xy, hint, [3, 3])
+    assert abs(got[0] - ref[0]) < POS_TOL and abs(got[1] - ref[1]) < POS_TOL and abs(got[2] - ref[2]) < ANG_TOL
+    m.Dispose()
+    rep.close()

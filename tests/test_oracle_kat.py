@@ -258,6 +258,56 @@ def test_hector_logodds_and_prob(oc, npo):
     assert (g.cells["update_index"] == -1).all() and (g.cells["value"] == 0).all()   # LogOddsCell.cs:38-42
 
 
+def test_hector_reset_cache_aliasing_d5(oc):
+    """Deviation D5 (OccGridMap.cs:16-19,38-42,97-107,147,244-252), worked by hand from the C# text.
+
+    Epoch bookkeeping of the reference: cacheArray[i].Index = -1 only in the constructor (:38-42); currCacheIndex starts at 0
+    (:19), UpdateByScan ends with currCacheIndex++ (:147), Reset sets currCacheIndex = 0 (:248) and leaves cacheArray alone.
+
+      scan A (ray to +5 cells): cell (15,10) occupied -> Value = logOddsOccupied = 2.1972244; currCacheIndex 0 -> 1
+      GetCachedProbability(cell): Index -1 != 1 -> odds = e^2.1972244 = 9, 9/10 = 0.9 cached with Index 1            (:99-104)
+      Reset(): Value 0, currCacheIndex = 0; the cache entry keeps (0.9, Index 1)
+      GetCachedProbability(cell) now: Index 1 != 0 -> recomputed, e^0 / (e^0 + 1) = 0.5, cached with Index 0          (fresh)
+      scan B (ray to +8 cells): cell (15,10) is crossed as FREE -> Value = logOddsFree = -0.40546516; currCacheIndex 0 -> 1
+      ... the first query after the Reset was in epoch 0, so the entry holds Index 0 != 1: fresh again (0.4).
+    The aliasing needs the SAME epoch number on both sides of the Reset with no query in between:
+      new map, scan A (epoch 1), query (cached 0.9 @ Index 1), Reset (epoch 0), scan B (epoch 1), query:
+      Index 1 == currCacheIndex 1 -> the reference returns the PRE-RESET 0.9 for a cell whose value says 0.4.
+    The oracle's literal restatement shows exactly that; oracle_grid_prob -- what the library implements -- returns 0.4."""
+    cell = 10 * 32 + 15
+    scan_a = np.array([[5.0, 0.0]], np.float32)
+    scan_b = np.array([[8.0, 0.0]], np.float32)
+    pose = [10.0, 10.0, 0.0]
+    p_occ, p_free = np.float32(0.9), np.float32(0.4)
+
+    g = oc.Grid(1.0, 32, 32)
+    g.update_by_scan(scan_a, pose)
+    assert abs(np.float32(g.prob_literal(cell)) - p_occ) < 1e-6 and g.prob_literal(cell) == g.prob(cell)
+    g.reset()
+    g.update_by_scan(scan_b, pose)
+    assert g.cells["value"][cell] == np.float32(g.logodds[0])                   # the map says "free"
+    assert abs(np.float32(g.prob(cell)) - p_free) < 1e-6                        # chosen behaviour: the current value's probability
+    assert abs(np.float32(g.prob_literal(cell)) - p_occ) < 1e-6                 # the C# cache: the map that was reset away
+    # one more scan moves the epoch on and the literal cache recovers (B again: Value < 0 so a second "free" is added)
+    g.update_by_scan(scan_b, pose)
+    assert g.prob_literal(cell) == g.prob(cell)
+
+    # a query between Reset and the next scan re-tags the entry with epoch 0: no aliasing (the working above)
+    g = oc.Grid(1.0, 32, 32)
+    g.update_by_scan(scan_a, pose)
+    g.prob_literal(cell)
+    g.reset()
+    assert g.prob_literal(cell) == 0.5
+    g.update_by_scan(scan_b, pose)
+    assert g.prob_literal(cell) == g.prob(cell)
+    # without a Reset the cache is value-transparent: every cell, after every scan
+    g = oc.Grid(1.0, 32, 32)
+    for s in (scan_a, scan_b, scan_a):
+        g.update_by_scan(s, pose)
+        for c in range(10 * 32 + 8, 10 * 32 + 20):
+            assert g.prob_literal(c) == g.prob(c)
+
+
 def test_hector_update_semantics(oc):
     """Quirks 21,22 (OccGridMap.cs:137,158-161,192-239)."""
     g = oc.Grid(1.0, 32, 32)
