@@ -1,0 +1,224 @@
+/*
+ * abi_harness.c -- a NON-Python caller of the C-ABI (TEST INFRASTRUCTURE; built and run by tests/test_abi_harness.py).
+ *
+ * What P/Invoke does, in C: dlopen("libslamhip.so"), resolve the entry points by NAME (the strings below are the
+ * EntryPoint values of bindings/csharp/SlamHip/Native.cs), call them through plain function pointers with
+ * caller-owned malloc'ed buffers, and compare with the golden vectors of tests/golden/ (written out as raw
+ * little-endian arrays by the test: C has no .npz reader).  No header of the library is included on purpose --
+ * the prototypes are restated here the way a foreign binding restates them, so a change of the ABI that the
+ * header and the Python wrapper follow together still breaks THIS file.
+ *
+ *   abi_harness <libslamhip.so> <dir>
+ *     <dir>/k1.meta  "size physical R K"             k1_pixels.u16 k1_xy.f32 k1_pxcs.f32 k1_base.f32 k1_offs.f32 k1_dist.i32
+ *     <dir>/k2.meta  "size physical R scans hw q"     k2_xy.f32 k2_pxcs.f32 k2_after1.u16 k2_after_all.u16 k2_counts.i64
+ *     <dir>/k5.meta  "side cell_bits R scans"         k5_xy.f32 k5_poses.f32 k5_value.f32 k5_upd.i32
+ *   exit code 0 = every comparison bit-exact; otherwise the first failure is printed.
+ *
+ * Replaces nothing in the reference: it stands where Simulation/MainWindow.xaml.cs:69-72,145-146 would stand if it were a C
+ * program ("all three callers go through the same extern "C" symbols").
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct slamhip_ctx slamhip_ctx;
+typedef struct slamhip_cs slamhip_cs;
+typedef struct slamhip_hs slamhip_hs;
+typedef struct { int32_t update_index; float value; } cell_t;          /* LogOddsCell.cs:16,21 sequential layout */
+
+static const char *(*p_last_error)(void);
+static int32_t (*p_ctx_create)(int32_t, slamhip_ctx **);
+static int32_t (*p_ctx_destroy)(slamhip_ctx *);
+static int32_t (*p_cs_create)(slamhip_ctx *, float, int32_t, int32_t, slamhip_cs **);
+static int32_t (*p_cs_destroy)(slamhip_cs *);
+static int32_t (*p_cs_info)(slamhip_cs *, int32_t *, float *, int32_t *, float *);
+static int32_t (*p_cs_holemap_upload)(slamhip_cs *, const uint16_t *, size_t);
+static int32_t (*p_cs_holemap_download)(slamhip_cs *, uint16_t *, size_t);
+static int32_t (*p_cs_set_scan)(slamhip_cs *, const float *, int32_t);
+static int32_t (*p_cs_distance_pxcs)(slamhip_cs *, const float *, int32_t, int32_t *, int32_t *, int32_t *);
+static int32_t (*p_cs_set_offsets)(slamhip_cs *, const float *, int32_t);
+static int32_t (*p_cs_search)(slamhip_cs *, const float *, float *, int32_t *, int32_t *);
+static int32_t (*p_cs_update_holemap_pxcs)(slamhip_cs *, const float *, float, int32_t);
+static int32_t (*p_cs_last_holemap_pixels)(slamhip_cs *, int64_t *);
+static int32_t (*p_hs_create)(slamhip_ctx *, float, int32_t, int32_t, int32_t, slamhip_hs **);
+static int32_t (*p_hs_destroy)(slamhip_hs *);
+static int32_t (*p_hs_set_scan)(slamhip_hs *, const float *, int32_t, const float *);
+static int32_t (*p_hs_update_by_scan)(slamhip_hs *, const float *);
+static int32_t (*p_hs_cells_download)(slamhip_hs *, int32_t, cell_t *, size_t);
+
+#define RESOLVE(var, name) do { *(void **)(&var) = dlsym(h, name); if (!var) { fprintf(stderr, "abi_harness: missing symbol %s\n", name); return 2; } } while (0)
+#define CALL(expr) do { int32_t rc_ = (expr); if (rc_ != 0) { fprintf(stderr, "abi_harness: %s -> %d (%s)\n", #expr, (int)rc_, p_last_error()); return 3; } } while (0)
+#define FAIL(...) do { fprintf(stderr, "abi_harness: " __VA_ARGS__); fprintf(stderr, "\n"); return 4; } while (0)
+
+static void *slurp(const char *dir, const char *name, size_t want_bytes)
+{
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s", dir, name);
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "abi_harness: cannot open %s\n", path); exit(5); }
+    void *buf = malloc(want_bytes ? want_bytes : 1);
+    size_t got = fread(buf, 1, want_bytes, f);
+    int extra = fgetc(f);
+    fclose(f);
+    if (got != want_bytes || extra != EOF) { fprintf(stderr, "abi_harness: %s has the wrong size (want %zu bytes)\n", path, want_bytes); exit(5); }
+    return buf;
+}
+static int read_meta(const char *dir, const char *name, double *v, int n)
+{
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s", dir, name);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    int k = 0;
+    while (k < n && fscanf(f, "%lf", &v[k]) == 1) k++;
+    fclose(f);
+    return k == n;
+}
+
+/* K1: CalculateDistance over a candidate list given as (px,py,c,s) + the search over the jitter list (CoreSLAMProcessor.cs:226-259,:624-710) */
+static int replay_k1(slamhip_ctx *ctx, const char *dir)
+{
+    double m[4];
+    if (!read_meta(dir, "k1.meta", m, 4)) FAIL("k1.meta missing");
+    const int size = (int)m[0], R = (int)m[2], K = (int)m[3];
+    const float physical = (float)m[1];
+    uint16_t *pixels = slurp(dir, "k1_pixels.u16", sizeof(uint16_t) * (size_t)size * size);
+    float *xy = slurp(dir, "k1_xy.f32", sizeof(float) * 2 * (size_t)R);
+    float *pxcs = slurp(dir, "k1_pxcs.f32", sizeof(float) * 4 * (size_t)K);
+    float *base = slurp(dir, "k1_base.f32", sizeof(float) * 3);
+    float *offs = slurp(dir, "k1_offs.f32", sizeof(float) * 3 * (size_t)(K - 1));
+    int32_t *want = slurp(dir, "k1_dist.i32", sizeof(int32_t) * (size_t)K);
+    slamhip_cs *cs = NULL;
+    CALL(p_cs_create(ctx, physical, size, size / 4 > 0 ? size / 4 : 1, &cs));
+    CALL(p_cs_holemap_upload(cs, pixels, (size_t)size * size));
+    CALL(p_cs_set_scan(cs, xy, R));
+    int32_t *dist = malloc(sizeof(int32_t) * (size_t)K), bi = -1, bd = -1;
+    memset(dist, 0xAB, sizeof(int32_t) * (size_t)K);
+    CALL(p_cs_distance_pxcs(cs, pxcs, K, dist, &bi, &bd));
+    int wbi = 0;
+    for (int k = 0; k < K; k++) {
+        if (dist[k] != want[k]) FAIL("k1: distance %d is %d, golden %d", k, (int)dist[k], (int)want[k]);
+        if (want[k] < want[wbi]) wbi = k;                        /* first strictly smaller wins (:644,:700) */
+    }
+    if (bi != wbi || bd != want[wbi]) FAIL("k1: arg-min (%d, %d), golden (%d, %d)", (int)bi, (int)bd, wbi, (int)want[wbi]);
+    float pose[3] = { 0, 0, 0 };
+    int32_t sd = -1, si = -1;
+    CALL(p_cs_set_offsets(cs, offs, K - 1));
+    CALL(p_cs_search(cs, base, pose, &sd, &si));
+    if (si != wbi || sd != want[wbi]) FAIL("k1: search winner (%d, %d), golden (%d, %d)", (int)si, (int)sd, wbi, (int)want[wbi]);
+    /* the winner's pose is search_pose + offs[index - 1] in binary32 (:635-637) */
+    for (int c = 0; c < 3; c++) {
+        const float w = wbi == 0 ? base[c] : base[c] + offs[3 * (wbi - 1) + c];
+        if (memcmp(&w, &pose[c], 4) != 0) FAIL("k1: winner pose component %d is %.9g, expected %.9g", c, pose[c], w);
+    }
+    CALL(p_cs_destroy(cs));
+    free(pixels); free(xy); free(pxcs); free(base); free(offs); free(want); free(dist);
+    printf("k1 ok: %d candidates x %d rays on %d^2, winner %d distance %d\n", K, R, size, (int)si, (int)sd);
+    return 0;
+}
+
+/* K2: UpdateHoleMap, ten scans in sequence (CoreSLAMProcessor.cs:496-534,:359-443) */
+static int replay_k2(slamhip_ctx *ctx, const char *dir)
+{
+    double m[6];
+    if (!read_meta(dir, "k2.meta", m, 6)) FAIL("k2.meta missing");
+    const int size = (int)m[0], R = (int)m[2], scans = (int)m[3], q = (int)m[5];
+    const float physical = (float)m[1], hw = (float)m[4];
+    const size_t n = (size_t)size * size;
+    float *xy = slurp(dir, "k2_xy.f32", sizeof(float) * 2 * (size_t)R * scans);
+    float *pxcs = slurp(dir, "k2_pxcs.f32", sizeof(float) * 4 * (size_t)scans);
+    uint16_t *after1 = slurp(dir, "k2_after1.u16", sizeof(uint16_t) * n);
+    uint16_t *after_all = slurp(dir, "k2_after_all.u16", sizeof(uint16_t) * n);
+    int64_t *counts = slurp(dir, "k2_counts.i64", sizeof(int64_t) * (size_t)scans);
+    slamhip_cs *cs = NULL;
+    CALL(p_cs_create(ctx, physical, size, size / 4 > 0 ? size / 4 : 1, &cs));
+    uint16_t *got = malloc(sizeof(uint16_t) * n);
+    for (int i = 0; i < scans; i++) {
+        CALL(p_cs_set_scan(cs, xy + 2 * (size_t)R * i, R));
+        CALL(p_cs_update_holemap_pxcs(cs, pxcs + 4 * i, hw, q));
+        int64_t px = -1;
+        CALL(p_cs_last_holemap_pixels(cs, &px));
+        if (px != counts[i]) FAIL("k2: scan %d blended %lld pixels, golden %lld", i, (long long)px, (long long)counts[i]);
+        if (i == 0) {
+            CALL(p_cs_holemap_download(cs, got, n));
+            if (memcmp(got, after1, sizeof(uint16_t) * n) != 0) FAIL("k2: HoleMap after the first scan differs from the golden image");
+        }
+    }
+    CALL(p_cs_holemap_download(cs, got, n));
+    for (size_t i = 0; i < n; i++)
+        if (got[i] != after_all[i]) FAIL("k2: pixel %zu is %u, golden %u", i, (unsigned)got[i], (unsigned)after_all[i]);
+    CALL(p_cs_destroy(cs));
+    free(xy); free(pxcs); free(after1); free(after_all); free(counts); free(got);
+    printf("k2 ok: %d scans x %d rays on %d^2\n", scans, R, size);
+    return 0;
+}
+
+/* K5: OccGridMap.UpdateByScan, six scans (HectorSLAM/Map/OccGridMap.cs:114-239) */
+static int replay_k5(slamhip_ctx *ctx, const char *dir)
+{
+    double m[4];
+    if (!read_meta(dir, "k5.meta", m, 4)) FAIL("k5.meta missing");
+    const int side = (int)m[0], R = (int)m[2], scans = (int)m[3];
+    const uint32_t cell_bits = (uint32_t)m[1];
+    float cell;
+    memcpy(&cell, &cell_bits, 4);
+    const size_t n = (size_t)side * side;
+    float *xy = slurp(dir, "k5_xy.f32", sizeof(float) * 2 * (size_t)R * scans);
+    float *poses = slurp(dir, "k5_poses.f32", sizeof(float) * 3 * (size_t)scans);
+    float *value = slurp(dir, "k5_value.f32", sizeof(float) * n);
+    int32_t *upd = slurp(dir, "k5_upd.i32", sizeof(int32_t) * n);
+    slamhip_hs *hs = NULL;
+    CALL(p_hs_create(ctx, cell, side, side, 1, &hs));
+    const float origin[2] = { 0.0f, 0.0f };
+    for (int i = 0; i < scans; i++) {
+        CALL(p_hs_set_scan(hs, xy + 2 * (size_t)R * i, R, origin));
+        CALL(p_hs_update_by_scan(hs, poses + 3 * i));
+    }
+    cell_t *cells = malloc(sizeof(cell_t) * n);
+    CALL(p_hs_cells_download(hs, 0, cells, n));
+    for (size_t i = 0; i < n; i++) {
+        if (cells[i].update_index != upd[i]) FAIL("k5: cell %zu update index %d, golden %d", i, (int)cells[i].update_index, (int)upd[i]);
+        if (memcmp(&cells[i].value, &value[i], 4) != 0) FAIL("k5: cell %zu value %.9g, golden %.9g", i, cells[i].value, value[i]);
+    }
+    CALL(p_hs_destroy(hs));
+    free(xy); free(poses); free(value); free(upd); free(cells);
+    printf("k5 ok: %d scans x %d rays on %d^2\n", scans, R, side);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) { fprintf(stderr, "usage: abi_harness <libslamhip.so> <fixture dir>\n"); return 1; }
+    void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "abi_harness: dlopen failed: %s\n", dlerror()); return 2; }
+    RESOLVE(p_last_error, "slamhip_last_error");
+    RESOLVE(p_ctx_create, "slamhip_ctx_create");
+    RESOLVE(p_ctx_destroy, "slamhip_ctx_destroy");
+    RESOLVE(p_cs_create, "slamhip_cs_create");
+    RESOLVE(p_cs_destroy, "slamhip_cs_destroy");
+    RESOLVE(p_cs_info, "slamhip_cs_info");
+    RESOLVE(p_cs_holemap_upload, "slamhip_cs_holemap_upload");
+    RESOLVE(p_cs_holemap_download, "slamhip_cs_holemap_download");
+    RESOLVE(p_cs_set_scan, "slamhip_cs_set_scan");
+    RESOLVE(p_cs_distance_pxcs, "slamhip_cs_distance_pxcs");
+    RESOLVE(p_cs_set_offsets, "slamhip_cs_set_offsets");
+    RESOLVE(p_cs_search, "slamhip_cs_search");
+    RESOLVE(p_cs_update_holemap_pxcs, "slamhip_cs_update_holemap_pxcs");
+    RESOLVE(p_cs_last_holemap_pixels, "slamhip_cs_last_holemap_pixels");
+    RESOLVE(p_hs_create, "slamhip_hs_create");
+    RESOLVE(p_hs_destroy, "slamhip_hs_destroy");
+    RESOLVE(p_hs_set_scan, "slamhip_hs_set_scan");
+    RESOLVE(p_hs_update_by_scan, "slamhip_hs_update_by_scan");
+    RESOLVE(p_hs_cells_download, "slamhip_hs_cells_download");
+    if (strcmp(argv[2], "--symbols-only") == 0) { printf("symbols ok\n"); return 0; }   /* (the CPU suite: no GPU, no compute) */
+    slamhip_ctx *ctx = NULL;
+    CALL(p_ctx_create(0, &ctx));
+    int rc = replay_k1(ctx, argv[2]);
+    if (rc == 0) rc = replay_k2(ctx, argv[2]);
+    if (rc == 0) rc = replay_k5(ctx, argv[2]);
+    CALL(p_ctx_destroy(ctx));
+    if (rc == 0) printf("abi_harness: all golden replays bit-exact\n");
+    return rc;
+}
