@@ -5,7 +5,8 @@ Workload (BASELINE.json `metric` / north_star): CoreSLAM Monte-Carlo search on a
 1080-ray scan, --cands candidate poses per GPU per step (default 16384 = BASELINE.json configs[1]/[2]).
 One "step" = one full search over this rank's shard of the flat candidate list = ONE launch of K1
 (k1_search_tiled: candidate transform pose + jitter -> px,py,c,s with device trig, batched distance over
-all rays from LDS-staged HoleMap tiles, per-candidate accumulation and arg-min); with N > 1 GPUs the
+all rays from LDS-staged HoleMap tiles, per-candidate accumulation and arg-min; at N = 1 the packed key of a step lands in a
+result word owned by the handle, slamhip_cs_search_shard_enqueue); with N > 1 GPUs the
 per-rank packed (distance << 32 | index) keys are min-all-reduced over RCCL (one 8-byte all-reduce per step).  All inputs (map, scan, jitter list) are resident in HBM
 before the timed region.  Weak scaling: per-GPU candidates are fixed as N grows.
 
@@ -114,6 +115,15 @@ def main():
     search_args = (dev._h, capi.fptr(base), int(first), int(count), C.c_void_p(key.data_ptr()))
     assert key.dtype == torch.int64 and key.numel() == 1           # packed (distance << 32 | index): MIN on int64 is exact
 
+    # N = 1: the enqueue-only search whose result word the handle owns (slamhip_cs_search_shard_enqueue: no caller memory, so the
+    # kernel needs no final arriver -- the end of the launch is the completion); the last step's word is read after the region
+    ring_fn = capi.lib().slamhip_cs_search_shard_enqueue
+    ring_slot = C.c_void_p()
+    ring_args = (dev._h, capi.fptr(base), int(first), int(count), C.byref(ring_slot))
+
+    def step_ring():
+        capi.check(ring_fn(*ring_args))
+
     def step_torch():
         capi.check(search_fn(*search_args))
         if world > 1:
@@ -162,7 +172,7 @@ def main():
         collective = "%s all_reduce(min, 8 B) per scan via torch.distributed, reduced key read by the host before the next step" % ("rccl" if backend == "nccl" else backend)
         collective_ranks = dist.get_world_size()
     else:
-        step = step_torch
+        step = step_ring if os.environ.get("SLAMHIP_BENCH_N1_STEP", "ring") == "ring" else step_torch
         step_overlapped = None
 
     def sync_all():
@@ -204,7 +214,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     if comm is None:
-        final_key = int(key.item())
+        final_key = dev.key_read(ring_slot.value) if step is step_ring else int(key.item())
     k1_ms, k1_n = (0.0, 0)
     k1_how = "two HIP events on the operator's stream around the timed region"
     if two_events:
@@ -347,13 +357,12 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
     import torch
 
     def time_search(d, pose, count, steps):
-        key = torch.full((1,), -1, dtype=torch.int64, device="cuda")
         for _ in range(6):
-            d.search_shard_async(pose, 0, count, key.data_ptr())
+            d.search_shard_enqueue(pose, 0, count)
         ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            d.search_shard_async(pose, 0, count, key.data_ptr())
+            d.search_shard_enqueue(pose, 0, count)
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / steps
         return {"us_per_step": dt * 1e6, "evals_per_s": count / dt,

@@ -164,6 +164,15 @@ int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float search_pose[3], int3
  * (8 bytes, e.g. a torch tensor fed to an RCCL all-reduce on the same stream). */
 int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float search_pose[3], int32_t first,
                                       int32_t count, uint64_t *d_out_key);
+/* Enqueue-only form with a result word owned by the handle: *d_key receives the DEVICE address of the word that holds the packed
+ * key once the stream reaches that point -- one of a ring of 4 words, valid until three further calls of this function on the
+ * handle have been enqueued.  No caller memory is involved, so the kernel needs no final arriver: the workgroups that complete
+ * candidates min their keys straight into the word (the previous call's launch left it all ones), and the end of the launch is
+ * the completion (the cross-thread arg-min of :695-705 as fire-and-forget atomics).  slamhip_cs_key_read waits for the handle's
+ * stream and copies one such word to the host. */
+int32_t slamhip_cs_search_shard_enqueue(slamhip_cs *cs, const float search_pose[3], int32_t first, int32_t count,
+                                        const uint64_t **d_key);
+int32_t slamhip_cs_key_read(slamhip_cs *cs, const uint64_t *d_key, uint64_t *out_key);
 /* Recompute the winner's pose from a (possibly all-reduced) key: search_pose + offs[index-1]. */
 int32_t slamhip_cs_pose_from_key(slamhip_cs *cs, const float search_pose[3], uint64_t key,
                                  float out_pose[3], int32_t *out_dist, int32_t *out_index);

@@ -82,6 +82,8 @@ def _declare(L):
         "slamhip_cs_search": (i32, [vp, fp, fp, ip, ip]),
         "slamhip_cs_search_shard": (i32, [vp, fp, i32, i32, u64p]),
         "slamhip_cs_search_shard_async": (i32, [vp, fp, i32, i32, vp]),
+        "slamhip_cs_search_shard_enqueue": (i32, [vp, fp, i32, i32, C.POINTER(C.c_void_p)]),
+        "slamhip_cs_key_read": (i32, [vp, vp, u64p]),
         "slamhip_cs_pose_from_key": (i32, [vp, fp, u64, fp, ip, ip]),
         "slamhip_cs_update_holemap": (i32, [vp, fp, f, i32]),
         "slamhip_cs_update_holemap_pxcs": (i32, [vp, fp, f, i32]),

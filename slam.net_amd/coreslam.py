@@ -177,6 +177,18 @@ class CoreSlamDevice:
         sp = capi.f32(search_pose)
         capi.call("slamhip_cs_search_shard_async", self._h, capi.fptr(sp), int(first), int(count), C.c_void_p(device_ptr))
 
+    def search_shard_enqueue(self, search_pose, first, count):
+        """Enqueue-only search into the handle's result ring; returns the device address of the key (slamhip_cs_search_shard_enqueue)."""
+        sp = capi.f32(search_pose)
+        d = C.c_void_p()
+        capi.call("slamhip_cs_search_shard_enqueue", self._h, capi.fptr(sp), int(first), int(count), C.byref(d))
+        return d.value
+
+    def key_read(self, device_ptr):
+        k = C.c_uint64()
+        capi.call("slamhip_cs_key_read", self._h, C.c_void_p(device_ptr), C.byref(k))
+        return k.value
+
     def pose_from_key(self, search_pose, key):
         sp = capi.f32(search_pose)
         pose = np.empty(3, np.float32); d, i = C.c_int32(), C.c_int32()

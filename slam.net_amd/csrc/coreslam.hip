@@ -141,7 +141,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
     (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_verify);
-    (void)hipFree(cs->d_k1_gmin); (void)hipFree(cs->d_k1_acc);
+    (void)hipFree(cs->d_k1_gmin); (void)hipFree(cs->d_k1_acc); (void)hipFree(cs->d_k1_ring);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
     if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
     cs_holemap_free(cs);
@@ -733,6 +733,31 @@ extern "C" int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float pos
 {
     SH_CHECK_ARG(cs && d_out_key);
     return search_enqueue(cs, pose, first, count, d_out_key);     // prep arms the key, K1/K1r min into it
+}
+
+// Enqueue-only form whose result word the handle owns (a ring of K1_RING_SLOTS words): K1 needs no last finisher for it -- the
+// finishing workgroups min straight into the word, which the previous ring launch left all ones (distance.hip, ring mode).
+extern "C" int32_t slamhip_cs_search_shard_enqueue(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count,
+                                                   const uint64_t **d_key)
+{
+    SH_CHECK_ARG(cs && d_key);
+    cs->k1_ring_request = true;
+    const int32_t rc = search_enqueue(cs, pose, first, count, nullptr);
+    cs->k1_ring_request = false;
+    SH_TRY(rc);
+    *d_key = cs->k1_ring_last;
+    return SLAMHIP_OK;
+}
+
+// Waits for the handle's stream and reads one result word of the ring (or any 8-byte device word of this context).
+extern "C" int32_t slamhip_cs_key_read(slamhip_cs *cs, const uint64_t *d_key, uint64_t *out_key)
+{
+    SH_CHECK_ARG(cs && d_key && out_key);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    SH_HIP(hipMemcpyAsync(cs->h_key + 8, d_key, sizeof(uint64_t), hipMemcpyDeviceToHost, cs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    *out_key = cs->h_key[8];
+    return SLAMHIP_OK;
 }
 
 extern "C" int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float pose[3], int32_t first, int32_t count, uint64_t *out_key)

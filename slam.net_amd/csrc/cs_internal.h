@@ -10,6 +10,7 @@
 #define CS_RB_EXTENT_PX 128.0f         // upper limit; set_scan lowers it at fine map scales (coreslam.hip)
 #define K1_GROUP 1024                  // theta-consecutive candidates per K1 workgroup ("group"): 512 lanes x 2 ...
 #define K1_GROUP_BIG 2048              // ... or 512 lanes x 4 for large searches,
+#define K1_RING_SLOTS 4                // result words of the enqueue-only search (valid until K1_RING_SLOTS - 1 further ring launches)
 #define K1_GROUP_SMALL 512             // 512 lanes x 1 for small ones (slamhip_cs::k1_group, ensure_shard)
 
 
@@ -79,6 +80,11 @@ struct slamhip_cs {
     unsigned *k1_done_flag; unsigned k1_done_val;   // the next search launch ends with k1_done_val -> *k1_done_flag (pinned host word), if set
     bool k1_done_armed;           // ... and it will (tiled kernel)
     unsigned long long *k1_sig; unsigned long long k1_sig_val; bool k1_sig_armed;   // the same for an HSA signal (slamhip_comm: the collectives' stream waits for it)
+    // enqueue-only searches (slamhip_cs_search_shard_enqueue): a ring of result words, all ones at rest; a ring launch mins into
+    // slot k1_ring_pos and leaves slot k1_ring_pos + 1 all ones for the next ring launch (distance.hip)
+    uint64_t *d_k1_ring; unsigned k1_ring_pos;
+    bool k1_ring_request;         // the next search launch is a ring launch ...
+    uint64_t *k1_ring_last;       // ... and this is the slot it used
     uint32_t upload_seq;          // set_scan uploads issued (the upload's workgroups store it into words 28 .. 31 of h_key when they have read the staging block)
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------

@@ -228,6 +228,10 @@ struct k1_args {
     unsigned long long *sig; unsigned long long sig_val;   // sharded search: sig_val -> *sig (an HSA signal another stream waits for) once the key is out, or null
     unsigned *done_flag; unsigned done_val;     // blocking search: word 15 of the context's mailbox (pinned host memory, common.h) -- the launch's last act is the key into
                                                 // words 0-1 and done_val into word 15 -- or null
+    // Enqueue-only search (slamhip_cs_search_shard_enqueue): the result word is a slot of the handle's ring, all ones when the launch
+    // starts -- the workgroups that finish candidates min their keys straight into it (no return, no count, no last finisher: the
+    // END OF THE LAUNCH is the completion) -- and this launch leaves the NEXT slot all ones for the next one.  Null: key_out + the chain.
+    unsigned long long *ring_slot, *ring_reset;
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
@@ -398,6 +402,8 @@ k1_search_tiled(const k1_args a)
         chunk = b / (unsigned)a.uni_ng;
         g = a.uni_g0 + (b - chunk * a.uni_ng);
     }
+    if (a.ring_reset && blockIdx.x == 0 && t == 0)                 // (the slot of the NEXT ring launch; launches are ordered by the stream)
+        __hip_atomic_store(a.ring_reset, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     K1_STAMP(0)
 #ifdef K1_TIMES
     if (t == 0 && blockIdx.x < 4096) { for (int k = 0; k < 8; k++) g_k1_sub[blockIdx.x * 8 + k] = 0; }
@@ -911,6 +917,15 @@ k1_search_tiled(const k1_args a)
             nfin += (unsigned)__shfl_down((int)nfin, off, 64);
         }
     }
+    if (a.ring_slot) {
+        // ring mode: a wavefront that finished candidates contributes its minimum itself -- one atomic without return per such
+        // wavefront (the finishing workgroup of a group: up to eight on one address, ~12 ns each at the memory side), no LDS round,
+        // no barrier, nothing waits for anything: the launch's end is the completion.  Three dependent round trips shorter than
+        // the chain below, which the slowest workgroup of the launch used to run after its last gather.
+        if (lane == 0 && nfin != 0) (void)__hip_atomic_fetch_min(a.ring_slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        K1_STAMP(9)
+        return;
+    }
     if (lane == 0) { wkey[wv] = key; wfin[wv] = nfin; }
     __syncthreads();
     if (t != 0) return;
@@ -1284,6 +1299,20 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     const int n_rb = cs->n_rb;
     int32_t *dist = want_dist ? cs->d_dist : nullptr;
     unsigned long long *key = (unsigned long long *)key_dst;
+    // a ring launch: the result word is the ring's current slot (all ones now), and the launch rests the next one
+    unsigned long long *ring_slot = nullptr, *ring_reset = nullptr;
+    const bool ring = cs->k1_ring_request;
+    cs->k1_ring_request = false;
+    if (ring) {
+        if (!cs->d_k1_ring) {
+            SH_HIP(hipMalloc(&cs->d_k1_ring, sizeof(uint64_t) * K1_RING_SLOTS));
+            SH_HIP(hipMemsetAsync(cs->d_k1_ring, 0xFF, sizeof(uint64_t) * K1_RING_SLOTS, ctx->stream));
+            cs->k1_ring_pos = 0;
+        }
+        ring_slot = (unsigned long long *)cs->d_k1_ring + cs->k1_ring_pos % K1_RING_SLOTS;
+        ring_reset = (unsigned long long *)cs->d_k1_ring + (cs->k1_ring_pos + 1) % K1_RING_SLOTS;
+        key = ring_slot;
+    }
     const float bx = pose ? pose[0] : 0.f, by = pose ? pose[1] : 0.f, bth = pose ? pose[2] : 0.f;
 
     if (tiled) {
@@ -1309,6 +1338,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         cs->k1_done_armed = a.done_flag != nullptr;
         a.sig = cs->k1_sig; a.sig_val = cs->k1_sig_val;
         cs->k1_sig_armed = a.sig != nullptr;
+        a.ring_slot = ring_slot; a.ring_reset = ring_reset;
+        if (ring && (a.best_pose || a.done_flag || a.sig)) SH_FAIL(SLAMHIP_ERR_STATE, "a ring search delivers nothing but its key");
 
         // launch layout
         const bool have_spread = mode == 1 && !no_table && (int)cs->h_grp_dth.size() == n_groups;
@@ -1396,6 +1427,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 #undef K1_LAUNCH
         }
         SH_HIP(hipGetLastError());
+        if (ring) { cs->k1_ring_last = (uint64_t *)ring_slot; cs->k1_ring_pos++; }
 #ifdef K1_TIMES
         {
             static int calls = 0;
@@ -1534,5 +1566,9 @@ fallback:
                            count, cs->n_points, cs->d_ev_idx, dist, key);
     }
     SH_HIP(hipGetLastError());
+    if (ring) {                                                    // (the fallback's first kernel arms its own key; the next slot is rested by a fill)
+        SH_HIP(hipMemsetAsync(ring_reset, 0xFF, sizeof(uint64_t), ctx->stream));
+        cs->k1_ring_last = (uint64_t *)ring_slot; cs->k1_ring_pos++;
+    }
     return SLAMHIP_OK;
 }

@@ -232,6 +232,55 @@ def test_search_changing_scans_one_candidate_list(cs_mod, ctx, det, sim):
     dev.close()
 
 
+def test_search_enqueue_ring(cs_mod, ctx, det, sim):
+    """slamhip_cs_search_shard_enqueue (the ring of result words: finishing workgroups min straight into the word, no final
+    arriver): every key equals the blocking search's and the oracle's -- back to back launches from different poses (each launch
+    must find its word all ones: the previous one rests it), interleaved with blocking searches, shards, and a changed list."""
+    oc = det
+    size, R, K = 1024, 720, 6000
+    dev = make_dev(cs_mod, ctx, size)
+    segs = sim.default_field()
+    rng = sim.PCG32(77)
+    ref = np.full(size * size, 32750, np.uint16)
+    for p in sim.trajectory(6):
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy); dev.update_holemap(p)
+        oc.update_holemap(ref, size, dev.hole_scale, xy, p)
+    true_pose = sim.trajectory(7)[-1]
+    _, xy = sim.make_scan(segs, true_pose, R, rng)
+    offs = sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=5)
+    dev.set_scan(xy); dev.set_offsets(offs)
+    poses = [(true_pose + np.array([0.01 * i, -0.02 * i, 0.004 * i], np.float32)).astype(np.float32) for i in range(9)]
+    want = []
+    for p in poses:
+        bi, _, bd, _ = oc.search(ref, size, dev.hole_scale, xy, p, offs)
+        want.append((int(bd) << 32) | int(bi))
+    # nine launches back to back, results read afterwards: slots are reused after four launches, so read the last three late
+    slots = [dev.search_shard_enqueue(p, 0, K) for p in poses]
+    assert len(set(slots)) == 4
+    for i in (6, 7, 8):
+        assert dev.key_read(slots[i]) == want[i], i
+    # one at a time, interleaved with the blocking form (which does not touch the ring) and with shards of the list
+    for i, p in enumerate(poses):
+        s = dev.search_shard_enqueue(p, 0, K)
+        assert dev.search_shard(p, 0, K) == want[i]
+        assert dev.key_read(s) == want[i], i
+    cuts = [0, 1, 700, 2048, 4097, K]
+    keys = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        keys.append(dev.key_read(dev.search_shard_enqueue(poses[3], a, b - a)))
+        assert keys[-1] == dev.search_shard(poses[3], a, b - a)
+    assert min(keys) == want[3]
+    # another list (another group size: 512 lanes x 1), same ring
+    offs2 = sim.gaussian_offsets(2999, 0.05, math.radians(3.0), seed=6)
+    dev.set_offsets(offs2)
+    bi, _, bd, _ = oc.search(ref, size, dev.hole_scale, xy, poses[1], offs2)
+    assert dev.key_read(dev.search_shard_enqueue(poses[1], 0, 3000)) == (int(bd) << 32) | int(bi)
+    if os.environ.get("SLAMHIP_EXPECT_SELFCHECK"):
+        assert dev.selfcheck_failures == 0
+    dev.close()
+
+
 def test_k1_tile_boxes_selfcheck():
     """Re-run the distance tests with SLAMHIP_K1_VERIFY=1 (every end point is checked against its LDS tile
     box, every staged pixel against the map), with SLAMHIP_K1_GLOBAL=1 (global-gather fallback kernels) and
@@ -239,7 +288,7 @@ def test_k1_tile_boxes_selfcheck():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size or test_search_changing_scans"
+    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size or test_search_changing_scans or test_search_enqueue_ring"
     for env_extra in ({"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "1"}, {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "2"},
                       {"SLAMHIP_K1_LAYOUT_SYNC": "1", "SLAMHIP_K1_VERIFY": "1"},   # every scan's launch layout made before its launch
                       {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "4"}, {"SLAMHIP_K1_GLOBAL": "1"},
