@@ -272,9 +272,20 @@ def main():
             torch.cuda.synchronize()
             ar_us = e0.elapsed_time(e1) * 1e3 / 100
         # the replica check: every rank built its HoleMap by the same updates -- the ranks must hold the same bits
+        # (every rank joins the check's collectives whatever happened to it locally: the library's call contributes words that
+        # cannot match and reports afterwards, the torch.distributed form is handed None -- a rank that skipped them would leave
+        # the others waiting)
         replicas = None
         try:
-            replicas = comm.replicas_equal(dev) if comm is not None else D.replicas_equal(dev.maps_checksum())
+            if comm is not None:
+                replicas = comm.replicas_equal(dev)
+            else:
+                words = None
+                try:
+                    words = dev.maps_checksum()
+                except Exception as e:                             # noqa: BLE001
+                    print("bench.py: maps_checksum failed on rank %d: %s" % (rank, e), file=sys.stderr)
+                replicas = D.replicas_equal(words)
         except Exception as e:                                     # noqa: BLE001 -- a health check must never cost the line
             replicas = "failed: %s" % e
         if world > 1:
@@ -335,6 +346,27 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs, final_key, checks)
             if "other_workloads" in out and "error" not in out["other_workloads"]:
                 out["other_workloads"]["winners_match_oracle"] = out["cpu_baseline"].pop("other_workloads_match", None)
+        if world > 1:
+            # N > 1: the reduced key of the last step against ONE oracle search over the whole flat list of K_total candidates
+            # (rank 0's host, ~0.3 s at 131 072 candidates), so that a scaling line never carries a winner nobody verified; and
+            # the CPU baseline on a short budget (the other ranks wait in the process group's teardown)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle_c as oc
+                oc.set_trig_mode(oc.TRIG_DET)
+                obi, _, obd, _ = oc.search(dev.holemap_download(), dev.hole_size, dev.hole_scale, xy, base, offs)
+                out["config"]["winner_matches_oracle"] = bool(((int(obd) << 32) | int(obi)) == int(final_key))
+            except Exception as e:                                 # noqa: BLE001
+                out["config"]["winner_matches_oracle"] = "check failed: %r" % (e,)
+            if not a.no_cpu_baseline:
+                try:
+                    a.cpu_seconds = min(a.cpu_seconds, 6.0)
+                    a.cpu_short = True
+                    n1 = a.cands - 1                               # (the per-GPU workload: rank 0's block of the list)
+                    out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs[:n1], None, ())
+                    out["cpu_baseline"]["sample"] += " (N > 1: short budget, one GPU's share of the candidates)"
+                except Exception as e:                             # noqa: BLE001
+                    out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
     if comm is not None:
@@ -566,12 +598,13 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=()):
     rate = evals / secs
     scans = max(int(a.cpu_seconds * rate / evals) - 1, 1)
     secs2, evals2, bi, bd, per = oc.cpu_baseline_search_timed(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, scans)
-    if secs2 < 10.0:           # (the first scans run cold: the calibration above undershoots) -- aim for ~15 s of measured work
+    short = bool(getattr(a, "cpu_short", False))                   # (N > 1: the headline sample only, a few seconds)
+    if secs2 < 10.0 and not short:           # (the first scans run cold: the calibration above undershoots) -- aim for ~15 s of measured work
         scans = max(int(scans * 15.0 / max(secs2, 1e-3)), scans)
         secs2, evals2, bi, bd, per = oc.cpu_baseline_search_timed(pix, dev.hole_size, dev.hole_scale, xy, base, offs, T, iters, scans)
     # parity spot-check on the full candidate list of the GPU step (single oracle pass, ~0.1 s)
     rbi, _, rbd, _ = oc.search(pix, dev.hole_size, dev.hole_scale, xy, base, offs)
-    same = bool(((rbd << 32) | rbi) == gpu_key)
+    same = bool(((rbd << 32) | rbi) == gpu_key) if gpu_key is not None else None
 
     def short_run(pix_, size_, scale_, xy_, base_, offs_, T_, iters_, seconds):
         s_, e_, _, _ = oc.cpu_baseline_search(pix_, size_, scale_, xy_, base_, offs_, T_, iters_, 3)        # warm-up: 3 scans
@@ -582,11 +615,13 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=()):
 
     sweep = {}
     for Ts in (1, 4):
-        if Ts < T:
+        if Ts < T and not short:
             sweep["T%d" % Ts] = short_run(pix, dev.hole_size, dev.hole_scale, xy, base, offs, Ts, max(n // Ts // 16, 1), 2.5)
     # config C1: the reference's own CPU-runnable case -- map built by 30 oracle mapping updates (the GPU plays no part)
     c1 = {}
     try:
+        if short:
+            raise StopIteration
         size1, R1, it1 = 400, 360, 1000
         scale1 = size1 / 40.0
         pix1 = np.full(size1 * size1, 32750, np.uint16)
@@ -601,6 +636,8 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=()):
         for Ts in sorted(set([1, 4, T])):
             offs1 = sim.gaussian_offsets(Ts * it1, 0.1, math.radians(10.0), seed=42)
             c1["T%d" % Ts] = short_run(pix1, size1, scale1, xy1, base1, offs1, Ts, it1, 2.5)
+    except StopIteration:
+        c1 = {"skipped": "N > 1 run: short CPU budget"}
     except Exception as e:                                         # noqa: BLE001
         c1 = {"error": repr(e)}
     # the other configurations' winners (bench.other_workloads collected the inputs and the GPU's answers)

@@ -364,6 +364,15 @@ int32_t slamhip_comm_set_batch(slamhip_comm *comm, int32_t steps);
  * event).  *out_key = min over all ranks of (distance << 32 | flat index).  Every rank makes the same call. */
 int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *comm, const float search_pose[3], int32_t first,
                                     int32_t count, uint64_t *out_key);
+/* One scan of the SLAM loop on every rank -- search (CoreSLAMProcessor.cs:732), exchange (:695-705 as ncclAllReduce(min, uint64, 1)),
+ * both map updates from the winner's pose (:750-751) -- with NO host hop between the exchange and the updates: a one-thread launch
+ * decodes the reduced key into the pose on the device (every rank holds the whole jitter list), the replicas' map updates are
+ * enqueued behind it, and the call returns when key and pose have reached the host; the updates run on, and everything that touches
+ * the maps afterwards is ordered behind them (as slamhip_cs_search_and_update).  out_pose: theta normalised (:746).  Every rank
+ * makes the same call; a rank whose own part fails still joins the collective (with the neutral key) and reports afterwards. */
+int32_t slamhip_cs_search_allreduce_and_update(slamhip_cs *cs, slamhip_comm *comm, const float search_pose[3], int32_t first,
+                                               int32_t count, float hole_width, int32_t quality, int32_t max_obstacle_hits,
+                                               float out_pose[3], int32_t *out_dist, int32_t *out_index);
 /* Latency of the exchange step alone: `iters` 8-byte min all-reduces back to back; *out_us = device microseconds per
  * collective.  Every rank makes the same call (measurement aid for the scaling curve). */
 int32_t slamhip_comm_allreduce_probe(slamhip_comm *comm, int32_t iters, float *out_us);

@@ -147,6 +147,7 @@ def _declare(L):
         "slamhip_comm_wait": (i32, [vp, C.POINTER(C.c_uint64)]),
         "slamhip_comm_set_batch": (i32, [vp, i32]),
         "slamhip_cs_search_allreduce": (i32, [vp, vp, fp, i32, i32, u64p]),
+        "slamhip_cs_search_allreduce_and_update": (i32, [vp, vp, fp, i32, i32, f, i32, i32, fp, ip, ip]),
         "slamhip_comm_allreduce_probe": (i32, [vp, i32, fp]),
         "slamhip_comm_replicas_equal": (i32, [vp, vp, P(i32)]),
     }

@@ -438,6 +438,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->h_rb_mx[(size_t)b] = 0.5f * (x0 + x1) * cs->hscale; cs->h_rb_my[(size_t)b] = 0.5f * (y0 + y1) * cs->hscale;
     }
     cs->k1_scan_dirty = true;
+    cs->scan_gen++;
     memcpy(h_rb, rb.data(), sizeof(int) * rb.size());
     const size_t used = (size_t)cap_ * 32 + sizeof(int) * rb.size();
     // (a blocking call that returned through the mailbox leaves a stream the runtime has not yet seen finish; the copy takes
@@ -575,7 +576,7 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
     return SLAMHIP_OK;
 }
 
-static int32_t flush_generate(slamhip_cs *cs)
+int32_t cs_flush_generate(slamhip_cs *cs)
 {
     if (!cs->gen_pending) return SLAMHIP_OK;
     cs->gen_pending = false;
@@ -589,7 +590,7 @@ extern "C" int32_t slamhip_cs_offsets_download(slamhip_cs *cs, float *offs, int3
 {
     SH_CHECK_ARG(cs && offs && n == cs->n_offs);
     SH_HIP(hipSetDevice(cs->ctx->device));
-    SH_TRY(flush_generate(cs));
+    SH_TRY(cs_flush_generate(cs));
     if (n > 0) {
         SH_HIP(hipMemcpyAsync(offs, cs->d_offs_flat, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, cs->ctx->stream));
         SH_HIP(hipStreamSynchronize(cs->ctx->stream));
@@ -601,7 +602,7 @@ static int32_t host_offsets(slamhip_cs *cs)
 {
     if (cs->h_offs.size() == (size_t)cs->n_offs * 3) return SLAMHIP_OK;
     cs->h_offs.resize((size_t)cs->n_offs * 3);
-    SH_TRY(flush_generate(cs));
+    SH_TRY(cs_flush_generate(cs));
     if (cs->n_offs > 0) {
         SH_HIP(hipMemcpyAsync(cs->h_offs.data(), cs->d_offs_flat, sizeof(float) * 3 * (size_t)cs->n_offs,
                               hipMemcpyDeviceToHost, cs->ctx->stream));
@@ -648,6 +649,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
     cs->k1_group = grp;
     const int ng = sh_div_up(count, grp);
     cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);
+    cs->h_grp_lohi.assign((size_t)ng * 6, 0.0f);                   // per group: min / max of dx, dy, dtheta (host lists: exact; generated lists: from the quantiles)
     cs->k1_layout_dirty = true;
     // a pending scan upload rides on the gather launch as one more workgroup
     const int up_wg = cs->upload_pending ? SH_UPLOAD_PARTS : 0;
@@ -666,7 +668,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
                                n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream, up_src, up_dst, up_n16, up_flag, up_seq);
         } else {
-            SH_TRY(flush_generate(cs));
+            SH_TRY(cs_flush_generate(cs));
             hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
                                0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq);
@@ -678,6 +680,9 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             const double q1 = fmin(fmax((k1 + 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
             cs->h_grp_dth[(size_t)g] = (float)(fabs(cs->gen_sigma_theta) * (host_normcdfinv(q1) - host_normcdfinv(q0)));
             cs->h_grp_dxy[(size_t)g] = 7.0f * fabsf(cs->gen_sigma_xy) * cs->hscale;
+            float *lh = &cs->h_grp_lohi[(size_t)g * 6];
+            lh[0] = lh[2] = -3.5f * fabsf(cs->gen_sigma_xy); lh[1] = lh[3] = 3.5f * fabsf(cs->gen_sigma_xy);
+            lh[4] = (float)(fabs(cs->gen_sigma_theta) * host_normcdfinv(q0)); lh[5] = (float)(fabs(cs->gen_sigma_theta) * host_normcdfinv(q1));
         }
     } else {
         // theta = search_pose.Z + dtheta and float addition is monotone, so sorting by dtheta sorts by theta
@@ -698,6 +703,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
                 }
             }
             cs->h_grp_dth[(size_t)g] = hi[2] - lo[2];
+            for (int k = 0; k < 3; k++) { cs->h_grp_lohi[(size_t)g * 6 + 2 * k] = lo[k]; cs->h_grp_lohi[(size_t)g * 6 + 2 * k + 1] = hi[k]; }
             cs->h_grp_dxy[(size_t)g] = fmaxf(hi[0] - lo[0], hi[1] - lo[1]) * cs->hscale;
         }
         SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <vector>
+#include <utility>
 
 // Rays are grouped into blocks of at most CS_RB_MAX spatially close points (Z-order sorted, extent
 // limited to CS_RB_EXTENT_PX map pixels); a workgroup of the distance kernel handles
@@ -61,8 +62,18 @@ struct slamhip_cs {
     // K1 launch layout: per group of 1024 evaluation-order candidates the theta range (rad) and translation spread
     // (pixels) -- from the offsets (ensure_shard) -- and the chunks per group derived from them and the scan
     std::vector<float> h_grp_dth, h_grp_dxy;
+    std::vector<float> h_grp_lohi;              // per group: min, max of dx | dy | dtheta over its candidates' jitters (layout estimates only)
     std::vector<int> k1_tab_group, k1_tab_nc, k1_tab_nbp; int k1_uni_g0, k1_uni_ng, k1_uni_nc;
     std::vector<k1_block_term> k1_terms; std::vector<double> k1_cost, k1_lc; std::vector<int> k1_share;   // k1_make_layout's scratch (distance.hip)
+    // ray ranges of the uniform part cut by COST (rays + a weight per ray block touched) instead of by count (k1_balanced_cuts):
+    // cuts by count of ranges (cuts[0 .. n], n <= the count asked for; empty: none), for scan generation k1_cut_gen at weight k1_cut_w
+    std::vector<std::pair<int, std::vector<int>>> k1_cut_cache; uint32_t k1_cut_gen, k1_cut_layout_gen;
+    uint32_t k1_layout_gen;                     // layouts made so far (k1_make_layout)
+    std::vector<int> k1_cut_parts;              // per ray block: parts it is cut into (its whole tile would not fit the budget for the widest uniform group)
+    std::vector<char> k1_cut_cand;              // per ray block: its tile may exceed the budget (worth the exact box test)
+    std::vector<double> k1_cut_wsc;             // (scratch)
+    std::vector<double> k1_cut_wb;              // per ray block: the weight of one more tile step, in ray units (k1_cut_weights)
+    uint32_t scan_gen;                          // scans set so far (slamhip_cs_set_scan)
     bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups; float k1_layout_theta;
     bool k1_scan_dirty;                         // a new scan since the layout was made (set_scan): it is kept if still legal, see cs_launch_distance
     bool k1_layout_stale;                       // ... and the one for the scan now set is made in the host's next idle wait (cs_layout_idle_refresh)
@@ -113,6 +124,8 @@ int32_t cs_flush_scan(slamhip_cs *cs);
 int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int count, bool want_dist, bool cand_sane,
                            uint64_t *key_dst);
 void cs_layout_idle_refresh(slamhip_cs *cs);   // host only: call between a search's enqueue and the wait for its result
+// coreslam.hip: produces a device-generated jitter list that is still pending (slamhip_cs_generate_offsets)
+int32_t cs_flush_generate(slamhip_cs *cs);
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);
 int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all);   // the dirty rectangle := the whole map / empty (enqueued on the operator's stream)

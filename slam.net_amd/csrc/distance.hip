@@ -196,6 +196,7 @@ k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_poin
 static_assert(K1_MAXBANDS == 4, "the step threads split t into (piece, band) with shifts");
 #define K1_TABLE_G 64                  // groups with their own chunk count (the rest: one uniform count)
 #define K1_TABLE_WGS 2048
+#define K1_MAXCUT 640                  // entries of the cut table in the kernel arguments (ray ranges cut by cost: k1_balanced_cuts)
 #define K1_ACC_INMAP 36                // accumulator fields: pixel sum below (R < 2^20 rays x 65535), workgroups with an in-map end point,
 #define K1_ACC_ARRIVED 50              // workgroups arrived (chunks per group < 2^14)
 #define K1_ZERO_OFS 0                  // dynamic LDS: a zero word (16 bytes), then the tile
@@ -236,6 +237,10 @@ struct k1_args {
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
     int n_tab_wgs, uni_g0, uni_ng, uni_nc;
+    // ray ranges cut by cost (k1_balanced_cuts) instead of the equal-count formula: uni_cut -- range c of the uniform part is rays
+    // [cut[c], cut[c + 1]); tab_cut > 0 -- listed workgroup w's range starts at cut[tab_cut + w] and ends where the workgroup of
+    // the next range of its group starts (w + nbp), or with the scan
+    int uni_cut, tab_cut;
     const float *grp_bounds;            // mode 1: per group {min dx, max dx, min dy, max dy, min dtheta, max dtheta, -, -} of the jitters, or null
     // One 8-byte record per dispatch position, every member at a multiple of its size.  (Separate byte / short / word
     // arrays indexed by the same position let the compiler form the scalar base "kernarg + p" for the byte loads and
@@ -246,6 +251,7 @@ struct k1_args {
         unsigned short first, nc;      // first workgroup of the position, workgroups
     } tab[K1_TABLE_G];
     alignas(4) unsigned char wg_pos[K1_TABLE_WGS];   // workgroup -> dispatch position (read a word at a time)
+    alignas(4) unsigned short cut[K1_MAXCUT];       // (read a word at a time)
 };
 static_assert(sizeof(k1_args) <= 4096, "kernel arguments are limited to 4 KB");
 static_assert(sizeof(k1_args::tab_rec) == 8 && offsetof(k1_args, tab) % 8 == 0, "table records are 8-byte aligned");
@@ -422,6 +428,15 @@ k1_search_tiled(const k1_args a)
     // run time is the number of tile steps, which more ray ranges would not reduce)
     const int rc = chunk / nbp, bp = chunk - rc * nbp, nrc = nc / nbp;
     int rlo, rhi;
+#define K1_CUT(i) ((int)((((const unsigned *)a.cut)[(i) >> 1] >> (((i) & 1) * 16)) & 0xffffu))
+    if (a.uni_cut && (int)blockIdx.x >= a.n_tab_wgs) {             // (uniform part: nbp = 1, rc = chunk)
+        rlo = K1_CUT(chunk); rhi = K1_CUT(chunk + 1);
+    } else if (a.tab_cut && (int)blockIdx.x < a.n_tab_wgs) {
+        const int i0 = a.tab_cut + (int)blockIdx.x;
+        rlo = K1_CUT(i0);
+        rhi = rc + 1 < nrc ? K1_CUT(i0 + nbp) : a.n_rays;
+    } else
+#undef K1_CUT
     if (a.n_rays <= 46340) {                                       // (rc < nrc <= n_rays: the products fit 32 bits; the 64-bit division is a hundred scalar instructions)
         rlo = (int)(((unsigned)rc * (unsigned)a.n_rays) / (unsigned)nrc); rhi = (int)(((unsigned)(rc + 1) * (unsigned)a.n_rays) / (unsigned)nrc);
     } else { rlo = (int)(((long long)rc * a.n_rays) / nrc); rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc); }
@@ -1062,6 +1077,182 @@ static int k1_legal_chunks(const slamhip_cs *cs, int nc)
     return nc;
 }
 
+// Ray ranges cut by cost.  A workgroup's compute phase is its rays PLUS its tile steps -- one per ray block it touches -- and a
+// step costs as much as a dozen or two rays of gathers (barrier, tile write, barrier, the next tile's loads; SLAMHIP_K1_TIMES at
+// the headline size: 43-ray ranges of 2 steps take 8 us, of 5 steps 13 us, and the launch waits for the slowest).  Equal COUNTS
+// of rays per range leave that to where the cuts happen to fall on the block boundaries; here the cuts minimise the largest
+// rays + sum of the weights wb[] of the blocks touched, over at most nc ranges: binary search on the bound, greedy fill (a range
+// takes whole blocks while they fit, then a fragment of the next one -- but no fragment shorter than half its block's weight: a
+// step that short is all overhead).  A block's weight grows with its tile (k1_cut_weights).
+// Every range holds <= K1_MAXR rays of <= K1_MAXP blocks.  Returns the number of ranges (<= nc; 0: no such cut), cuts[0 .. n].
+static int k1_balanced_cuts(const slamhip_cs *cs, int nc, const std::vector<double> &wb, const std::vector<int> &parts, std::vector<int> &cuts)
+{
+    const int R = cs->n_points, n_rb = cs->n_rb;
+    const int *rb = cs->h_rb_start.data();
+    if (nc < 1 || R < 1 || n_rb < 1 || (int)wb.size() != n_rb || (int)parts.size() != n_rb) return 0;
+    double wsum = 0.0, wmax = 0.0;
+    for (int b = 0; b < n_rb; b++) { wsum += wb[(size_t)b]; wmax = std::max(wmax, wb[(size_t)b]); }
+    auto fill = [&](double T, std::vector<int> *out) -> int {
+        int r = 0, b = 0, n = 0;
+        if (out) { out->clear(); out->push_back(0); }
+        while (r < R) {
+            while (b + 1 < n_rb && rb[b + 1] <= r) b++;                // block of ray r
+            int e = r, bb = b, pieces = 0;
+            double wacc = 0.0;
+            while (e < R && pieces < K1_MAXP) {
+                const int bend = rb[bb + 1];
+                const double w = wb[(size_t)bb];
+                const int min_frag = (int)(w * 0.5) > 1 ? (int)(w * 0.5) : 1;
+                const double room = T - ((double)(e - r) + wacc + w);
+                int take = bend - e;
+                if (take > K1_MAXR - (e - r)) take = K1_MAXR - (e - r);
+                // a block whose whole tile would not fit the budget (parts > 1: it would be staged in bands, at twice the cost per
+                // ray and more) is never one piece of a range: ranges end at its inner marks
+                bool at_mark = false;
+                if (parts[(size_t)bb] > 1) {
+                    const int b0 = rb[bb], len = bend - b0, k = parts[(size_t)bb];
+                    const int j = (int)(((long long)(e - b0) * k) / len) + 1;          // the next mark: b0 + ceil(j * len / k)
+                    const int mark = b0 + (int)(((long long)j * len + k - 1) / k);
+                    if (mark < bend && mark - e <= take) { take = mark - e; at_mark = true; }
+                    if (at_mark && (double)take <= room) { e += take; pieces++; break; }   // (the range ends at the mark)
+                    at_mark = false;
+                }
+                const bool whole = take == bend - e && (double)take <= room;
+                if (!whole) {
+                    int part = room < (double)take ? (int)room : take;
+                    if (part < 0) part = 0;
+                    // a fragment: only if it is worth a step, and never one that leaves a shorter-than-worthwhile rest
+                    if (pieces > 0 && (part < min_frag || (bend - e) - part < min_frag)) part = 0;
+                    if (pieces == 0 && part < 1) return 1 << 30;       // the bound does not even admit one ray: infeasible
+                    e += part;
+                    if (part > 0) pieces++;
+                    break;
+                }
+                e = bend; pieces++; bb++; wacc += w;
+            }
+            if (e == r) return 1 << 30;
+            if (out) out->push_back(e);
+            r = e; n++;
+            if (n > nc) return n;
+        }
+        return n;
+    };
+    // (the bound lies between the mean cost of a range and the whole scan's: start near the mean, widen until a bound fits)
+    double lo = ((double)R + wsum) / (double)nc - 1.0, hi = lo * 1.25 + wmax + 2.0;
+    const double top = (double)R + wsum + 1.0;
+    if (lo < 1.0) lo = 1.0;
+    for (int it = 0; it < 12 && hi < top && fill(hi, nullptr) > nc; it++) { lo = hi; hi = hi * 1.5; }
+    if (hi > top) hi = top;
+    if (fill(hi, nullptr) > nc) return 0;
+    for (int it = 0; it < 24 && hi - lo > 0.75; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (fill(mid, nullptr) <= nc) hi = mid; else lo = mid;
+    }
+    const int n = fill(hi, &cuts);
+    if (n < 1 || n > nc || cuts.back() != R) return 0;
+    return n;
+}
+
+// The weight of a ray block in k1_balanced_cuts, in ray units: what one more tile step costs a workgroup.  Barriers, the tile's
+// LDS writes and the issue of its loads all grow with the tile, so: w_fix + w_kb * (the tile's size in KB for the middle candidate
+// group -- the block's bounding box turned into the map frame, grown by the group's translation spread and theta arc: the terms
+// of k1_group_cost).  Without the groups' spreads (explicit pose lists): the box grown by a nominal 48 pixels.
+static void k1_cut_weights(const slamhip_cs *cs, int n_groups, bool have_spread, double w_fix, double w_kb, int budget, const float pose[3],
+                           std::vector<double> &wb, std::vector<int> &parts)
+{
+    const int n_rb = cs->n_rb;
+    std::vector<char> &cand = const_cast<slamhip_cs *>(cs)->k1_cut_cand;
+    cand.assign((size_t)n_rb, 0);
+    wb.assign((size_t)n_rb, w_fix);
+    parts.assign((size_t)n_rb, 1);
+    // the widest uniform group (the uniform part's outer groups): a block whose tile for THAT group exceeds the budget is cut
+    double dth_w = 0.0, d_w = 48.0;
+    if (have_spread && cs->k1_uni_ng > 0) {
+        for (int g = cs->k1_uni_g0; g < cs->k1_uni_g0 + cs->k1_uni_ng && (size_t)g < cs->h_grp_dth.size(); g++) dth_w = std::max(dth_w, (double)cs->h_grp_dth[(size_t)g]);
+        d_w = 4.0;
+        for (int g = cs->k1_uni_g0; g < cs->k1_uni_g0 + cs->k1_uni_ng && (size_t)g < cs->h_grp_dxy.size(); g++) d_w = std::max(d_w, (double)cs->h_grp_dxy[(size_t)g] + 4.0);
+    }
+    const double th = have_spread ? (double)cs->k1_layout_theta : 0.0;
+    const double c = fabs(cos(th)), s = fabs(sin(th));
+    const int gm = n_groups / 2;
+    const double dth = have_spread && (size_t)gm < cs->h_grp_dth.size() ? (double)cs->h_grp_dth[(size_t)gm] : 0.0;
+    const double d = have_spread && (size_t)gm < cs->h_grp_dxy.size() ? (double)cs->h_grp_dxy[(size_t)gm] + 4.0 : 48.0;
+    for (int b = 0; b < n_rb; b++) {
+        const double ex = cs->h_rb_ex[(size_t)b], ey = cs->h_rb_ey[(size_t)b], mx = fabs(cs->h_rb_mx[(size_t)b]), my = fabs(cs->h_rb_my[(size_t)b]);
+        const double w = ex * c + ey * s + d + (mx * s + my * c) * dth, h = ex * s + ey * c + d + (mx * c + my * s) * dth;
+        wb[(size_t)b] = w_fix + w_kb * (2.0 * (w + 8.0) * h / 1024.0);
+        // (a first, generous estimate for the widest uniform group picks the blocks worth the exact box below)
+        const double ww = ex * c + ey * s + d_w + (mx * s + my * c) * dth_w, hw = ex * s + ey * c + d_w + (mx * c + my * s) * dth_w;
+        cand[(size_t)b] = 2.0 * (ww + 8.0) * hw > 0.5 * (double)budget || ww > 300.0;
+    }
+    (void)pose; (void)budget;
+}
+
+// Would rays [r0, r1) of the sorted scan, as ONE piece, be staged in bands (or gathered from memory) for candidate group g?
+// The kernel's own decision on the host: the box of the end points by k1_ray_box's interval arithmetic from the group's jitter
+// bounds (k1_search_tiled's prologue), against the tile budget and the staging pass.
+struct k1_host_bounds { float pxl, pxh, pyl, pyh, cmin, cmax, smin, smax; };
+static k1_host_bounds k1_group_bounds_host(const slamhip_cs *cs, int g, const float pose[3])
+{
+    const float *lh = &cs->h_grp_lohi[(size_t)g * 6];
+    const float scale = cs->hscale;
+    k1_host_bounds b;
+    b.pxl = (pose[0] + lh[0]) * scale + 0.5f; b.pxh = (pose[0] + lh[1]) * scale + 0.5f;
+    b.pyl = (pose[1] + lh[2]) * scale + 0.5f; b.pyh = (pose[1] + lh[3]) * scale + 0.5f;
+    const double tl = (double)pose[2] + lh[4], thh = (double)pose[2] + lh[5];
+    double cl = std::min(cos(tl), cos(thh)), ch = std::max(cos(tl), cos(thh)), sl = std::min(sin(tl), sin(thh)), sh = std::max(sin(tl), sin(thh));
+    for (int k = (int)ceil(tl / 1.5707963267948966); (double)k * 1.5707963267948966 <= thh; k++) {
+        switch (((k % 4) + 4) % 4) { case 0: ch = 1.0; break; case 1: sh = 1.0; break; case 2: cl = -1.0; break; default: sl = -1.0; break; }
+    }
+    const float pad = scale * 1.0e-4f;
+    b.cmin = (float)cl * scale - pad; b.cmax = (float)ch * scale + pad; b.smin = (float)sl * scale - pad; b.smax = (float)sh * scale + pad;
+    return b;
+}
+static bool k1_piece_banded(const slamhip_cs *cs, const k1_host_bounds &b, int r0, int r1, int budget)
+{
+    const float *pts = (const float *)((const char *)cs->h_scan_blob + (size_t)cs->cap_points * 24);     // the sorted rays (set_scan's staging block)
+    const int S = cs->hs;
+    float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
+    for (int r = r0; r < r1; r++) {
+        const float X = pts[2 * (size_t)r], Y = pts[2 * (size_t)r + 1];
+        const float cx0 = b.cmin * X, cx1 = b.cmax * X, sy0 = b.smin * Y, sy1 = b.smax * Y, sx0 = b.smin * X, sx1 = b.smax * X, cy0 = b.cmin * Y, cy1 = b.cmax * Y;
+        x0 = fminf(x0, b.pxl + fminf(cx0, cx1) - fmaxf(sy0, sy1)); x1 = fmaxf(x1, b.pxh + fmaxf(cx0, cx1) - fminf(sy0, sy1));
+        y0 = fminf(y0, b.pyl + fminf(sx0, sx1) + fminf(cy0, cy1)); y1 = fmaxf(y1, b.pyh + fmaxf(sx0, sx1) + fmaxf(cy0, cy1));
+    }
+    const int ix0 = std::max((int)x0, 0), iy0 = std::max((int)y0, 0), ix1 = std::min((int)x1, S - 1), iy1 = std::min((int)y1, S - 1);
+    if (ix1 < ix0 || iy1 < iy0) return false;
+    const int xa = ix0 & ~7, ww = ((ix1 - xa + 1) + 7) & ~7, vpr = ww >> 3;
+    int shf = 0; while ((1 << shf) < vpr) shf++;
+    const int hmax = std::min(budget / (ww * 2), 4096 >> shf), H = iy1 - iy0 + 1;
+    return vpr > 64 || hmax < 1 || H > hmax;
+}
+// Do the cuts put a piece on a banded tile, for one of the two outer groups of the uniform part, that the equal-count ranges would
+// not?  (A block's fragment can span as much of the map as the whole block -- the rays of a block are in Z order, not along the
+// wall -- so this is asked of the pieces as cut, not estimated per block.)  Counts the rays on banded pieces.
+static int k1_cuts_banded_rays(const slamhip_cs *cs, const std::vector<int> &cuts, const float pose[3], int budget, const std::vector<char> &cand)
+{
+    if (cs->k1_uni_ng <= 0 || cs->h_grp_lohi.size() < (size_t)(cs->k1_uni_g0 + cs->k1_uni_ng) * 6 || !cs->h_scan_blob) return 0;
+    const int n_rb = cs->n_rb;
+    const int *rb = cs->h_rb_start.data();
+    int banded = 0;
+    for (int e = 0; e < 2; e++) {
+        const int g = e == 0 ? cs->k1_uni_g0 : cs->k1_uni_g0 + cs->k1_uni_ng - 1;
+        if (e == 1 && g == cs->k1_uni_g0) break;
+        const k1_host_bounds b = k1_group_bounds_host(cs, g, pose);
+        int blk = 0;
+        for (size_t c = 0; c + 1 < cuts.size(); c++) {
+            const int lo = cuts[c], hi = cuts[c + 1];
+            while (blk + 1 < n_rb && rb[blk + 1] <= lo) blk++;
+            for (int bb = blk; bb < n_rb && rb[bb] < hi; bb++) {
+                if (!cand[(size_t)bb]) continue;
+                const int r0 = std::max(lo, rb[bb]), r1 = std::min(hi, rb[bb + 1]);
+                if (r1 > r0 && k1_piece_banded(cs, b, r0, r1, budget)) banded += r1 - r0;
+            }
+        }
+    }
+    return banded;
+}
+
 // Cost of staging one band of a banded tile, in ray units (measured best on MI355X: 5; a huge value: multi-band tiles
 // never, global gathers instead; a hugely negative one: bands whenever they fit)
 static float k1_band_stage()
@@ -1274,7 +1465,7 @@ void cs_layout_idle_refresh(slamhip_cs *cs)
 {
     if (!cs->k1_layout_stale || cs->k1_layout_dirty || cs->k1_scan_dirty || cs->n_points <= 0) return;
     k1_make_layout(cs, cs->k1_layout_groups, cs->k1_layout_target, cs->k1_layout_budget, cs->k1_layout_spread, cs->k1_layout_band_parts);
-    cs->k1_layout_stale = false;
+    cs->k1_layout_stale = false; cs->k1_layout_gen++;
 }
 
 // K1 over `count` candidates in evaluation order (d_ev_idx maps to flat indices).  mode 0: d_pxcs already holds
@@ -1364,7 +1555,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         if (remake) {
             cs->k1_layout_theta = bth;
             k1_make_layout(cs, n_groups, target, budget, have_spread, band_parts);
-            cs->k1_layout_dirty = false; cs->k1_layout_stale = false;
+            cs->k1_layout_dirty = false; cs->k1_layout_stale = false; cs->k1_layout_gen++;
             cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread; cs->k1_layout_target = target;
             cs->k1_layout_band_parts = band_parts;
         }
@@ -1384,20 +1575,103 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                         have_spread ? k1_group_cost(cs, cs->k1_terms, g, budget) : 0.0);
             }
         }
-        unsigned first = 0;
+        // Ray ranges cut by cost (k1_balanced_cuts), remade when the scan, a count of ranges or the weight changed: the uniform
+        // part's and every listed group's (groups with the same count of ranges share the cut).  A cut may come out with fewer
+        // ranges than asked for: the group then runs with that many workgroups.
+        // The weight of a tile step in ray units: 20 where it was calibrated (2048^2 map = 51.2 pixels per metre, two candidates per
+        // lane), less on coarser maps (smaller tiles, and the 64-ray cap makes blocks long in rays: 1024^2 wants about half, 256^2
+        // none) and in proportion to what a ray costs the workgroup (four candidates per lane: a ray takes twice as long, the step
+        // does not).  SLAMHIP_K1_CUT_WFIX = 0 and SLAMHIP_K1_CUT_WKB = 0: the equal-count formula everywhere.
+        static const double cut_w20 = getenv("SLAMHIP_K1_CUT_WFIX") ? atof(getenv("SLAMHIP_K1_CUT_WFIX")) : 20.0;
+        static const double cut_wkb = getenv("SLAMHIP_K1_CUT_WKB") ? atof(getenv("SLAMHIP_K1_CUT_WKB")) : 0.0;
+        const int cpl_group = group == K1_GROUP_BIG ? 4 : group == K1_GROUP_SMALL ? 1 : 2;
+        const double cut_wfix = cut_w20 * std::min(1.0, (double)cs->hscale / 51.2) * 2.0 / (double)cpl_group;
+        static const int cut_keep = env_int("SLAMHIP_K1_CUT_KEEP", 90);   // per cent of the asked-for ranges a cut must keep
+        static const int cut_tab = env_int("SLAMHIP_K1_CUT_TAB", 0);      // (the listed groups too: measured slower)
         const int n_tab = (int)cs->k1_tab_group.size();
+        const float pose3[3] = { bx, by, bth };
+        const bool cuts_on = (cut_wfix > 0.0 || cut_wkb > 0.0) && cs->n_points < 65536;
+        if (cuts_on && (cs->k1_cut_gen != cs->scan_gen || cs->k1_cut_layout_gen != cs->k1_layout_gen)) {
+            cs->k1_cut_cache.clear();
+            cs->k1_cut_gen = cs->scan_gen; cs->k1_cut_layout_gen = cs->k1_layout_gen;
+            k1_cut_weights(cs, n_groups, have_spread, cut_wfix, cut_wkb, budget, pose3, cs->k1_cut_wb, cs->k1_cut_parts);
+        }
+        cs->k1_cut_cache.reserve(K1_TABLE_G + 8);                      // (the entries' addresses are held below: no reallocation)
+        auto cuts_for = [&](int nrc) -> const std::vector<int> * {       // nullptr: no cut for this count (the formula stays)
+            if (!cuts_on || nrc < 2) return nullptr;
+            for (auto &e : cs->k1_cut_cache) if (e.first == nrc) return e.second.empty() ? nullptr : &e.second;
+            cs->k1_cut_cache.emplace_back(nrc, std::vector<int>());
+            std::vector<int> &c = cs->k1_cut_cache.back().second;
+            // The cut must keep (nearly) the asked-for count of ranges: where blocks are long in rays (coarse maps: a 64-ray block is
+            // one tile) heavy weights end in one block per range -- 17 ranges for 25 at 1024^2 -- and the workgroups that are not
+            // launched cost more than the steps that are saved (measured: 24 -> 33 us).  The weights are scaled down until it does.
+            std::vector<double> &wsc = cs->k1_cut_wsc;
+            double scale = 1.0;
+            for (int tries = 0; tries < 6; tries++, scale *= 0.6) {
+                wsc.resize(cs->k1_cut_wb.size());
+                for (size_t i = 0; i < wsc.size(); i++) wsc[i] = cs->k1_cut_wb[i] * scale;
+                const int n = k1_balanced_cuts(cs, nrc, wsc, cs->k1_cut_parts, c);
+                if (n < 1) { c.clear(); break; }
+                if (n * 100 >= nrc * cut_keep) break;
+                c.clear();
+            }
+            if (!c.empty() && nrc == cs->k1_uni_nc && have_spread) {
+                // a cut that puts more rays on banded tiles (for the uniform part's outer groups) than the equal-count ranges do is
+                // dropped: a banded piece costs its workgroup more than twice a plain one, the launch waits for it (1024^2 map:
+                // four workgroups at 19 us in a 21 us launch)
+                std::vector<int> eq((size_t)nrc + 1);
+                for (int k = 0; k <= nrc; k++) eq[(size_t)k] = (int)(((long long)k * cs->n_points) / nrc);
+                if (k1_cuts_banded_rays(cs, c, pose3, budget, cs->k1_cut_cand) > k1_cuts_banded_rays(cs, eq, pose3, budget, cs->k1_cut_cand)) c.clear();
+            }
+            return c.empty() ? nullptr : &c;
+        };
+        a.uni_cut = 0; a.tab_cut = 0;
+        int n_cut = 0;                                                 // entries of a.cut in use
+        a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
+        if (cs->k1_uni_ng > 0) {
+            const std::vector<int> *c = cuts_for(cs->k1_uni_nc);
+            if (c && (int)c->size() <= K1_MAXCUT) {
+                for (size_t i = 0; i < c->size(); i++) a.cut[i] = (unsigned short)(*c)[i];
+                n_cut = (int)c->size();
+                a.uni_cut = 1; a.uni_nc = (int)c->size() - 1;
+            }
+        }
+        // the listed groups: all of them from the table, or none
+        std::vector<const std::vector<int> *> tcut((size_t)n_tab, nullptr);
+        bool tab_ok = cut_tab && n_tab > 0;
+        long long tab_wgs = 0;
+        for (int p = 0; p < n_tab && tab_ok; p++) {
+            const int nbp = cs->k1_tab_nbp[(size_t)p] > 0 ? cs->k1_tab_nbp[(size_t)p] : 1;
+            tcut[(size_t)p] = cuts_for(cs->k1_tab_nc[(size_t)p] / nbp);
+            if (!tcut[(size_t)p]) tab_ok = false; else tab_wgs += (long long)(tcut[(size_t)p]->size() - 1) * nbp;
+        }
+        if (tab_ok && n_cut + tab_wgs > K1_MAXCUT) tab_ok = false;
+        unsigned first = 0;
         for (int p = 0; p < n_tab; p++) {
             k1_args::tab_rec &rec = a.tab[p];
+            const int nbp = cs->k1_tab_nbp[(size_t)p] > 0 ? cs->k1_tab_nbp[(size_t)p] : 1;
+            const int nc_p = tab_ok ? (int)(tcut[(size_t)p]->size() - 1) * nbp : cs->k1_tab_nc[(size_t)p];
             rec.group = (unsigned short)cs->k1_tab_group[(size_t)p];
             rec.nbp = (unsigned short)cs->k1_tab_nbp[(size_t)p];
-            rec.first = (unsigned short)first; rec.nc = (unsigned short)cs->k1_tab_nc[(size_t)p];
-            first += (unsigned)cs->k1_tab_nc[(size_t)p];
+            rec.first = (unsigned short)first; rec.nc = (unsigned short)nc_p;
+            if (tab_ok)
+                for (int w = 0; w < nc_p; w++) a.cut[n_cut + (int)first + w] = (unsigned short)(*tcut[(size_t)p])[(size_t)(w / nbp)];
+            first += (unsigned)nc_p;
+        }
+        if (tab_ok) a.tab_cut = n_cut;
+        if (dump && a.uni_cut) {
+            fprintf(stderr, "   uniform ranges cut by cost (%d of %d asked for; ray blocks start at", a.uni_nc, cs->k1_uni_nc);
+            for (int b = 0; b <= cs->n_rb; b++) fprintf(stderr, " %d", cs->h_rb_start[(size_t)b]);
+            fprintf(stderr, "; blocks in parts:");
+            for (int b = 0; b < cs->n_rb && (size_t)b < cs->k1_cut_parts.size(); b++) if (cs->k1_cut_parts[(size_t)b] > 1) fprintf(stderr, " %d:%d", b, cs->k1_cut_parts[(size_t)b]);
+            fprintf(stderr, "):");
+            for (int c = 0; c <= a.uni_nc; c++) fprintf(stderr, " %d", (int)a.cut[c]);
+            fprintf(stderr, "\n");
         }
         for (int p = 0; p < n_tab; p++)
             for (unsigned w = a.tab[p].first; w < (unsigned)a.tab[p].first + a.tab[p].nc; w++) a.wg_pos[w] = (unsigned char)p;
         a.n_tab_wgs = (int)first;
-        a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
-        const int n_wgs = (int)first + cs->k1_uni_nc * cs->k1_uni_ng;
+        const int n_wgs = (int)first + a.uni_nc * cs->k1_uni_ng;
         // candidates per lane: 2 (512 lanes, 8 waves) measured best or equal from 16k to 256k candidates on MI355X;
         // 1 (16 waves: slow start) and 4 (4 waves: the VALU starves at 2 waves / SIMD) stay selectable for experiments
         const int cpl = cpl_env == 1 || cpl_env == 4 ? cpl_env : 2;

@@ -9,10 +9,15 @@
 // RCCL is resolved with dlopen at group creation so that single-GPU users of libslamhip never load it
 // (and a host process that already loaded its own librccl, e.g. PyTorch, shares that copy).
 #include "cs_internal.h"
+#include "det_trig.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <vector>
 #include <string>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 
 struct rccl_api {
     void *lib;
@@ -68,6 +73,65 @@ static int32_t load_rccl(rccl_api *api)
 #define SH_NCCL(g, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
         slamhip_set_error("%s failed: %s", #expr, (g)->api.GetErrorString(r_)); return SLAMHIP_ERR_RCCL; } } while (0)
 
+// One worker thread per GPU of a group: a job (the enqueue of a rank's search + its end of the collective + the wait for its
+// stream; a rank's map update) runs on every rank AT THE SAME TIME instead of one rank after the other from the caller's thread --
+// a launch costs the host ~5 us, the serial loop made an eight-GPU search step 8 x (enqueue + synchronise) long.  The workers
+// bind their device once (the HIP device is per thread).  One-GPU groups run their jobs inline (SLAMHIP_GROUP_THREADS=1 forces
+// the worker: the tests do, so that the machinery is exercised on a one-GPU box).
+struct sh_group_workers {
+    int n = 0;
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0;                       // job generation: a worker runs the job once per increment
+    int pending = 0;
+    bool quit = false;
+    std::function<int32_t(int)> job;
+    std::vector<int32_t> rc;
+    std::vector<std::string> err;
+    void start(int n_, const std::vector<int> &devices)
+    {
+        n = n_; rc.assign((size_t)n, SLAMHIP_OK); err.assign((size_t)n, std::string());
+        for (int r = 0; r < n; r++)
+            th.emplace_back([this, r, devices]() {
+                (void)hipSetDevice(devices[(size_t)r]);
+                uint64_t seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv_go.wait(lk, [&] { return quit || gen != seen; });
+                    if (quit) return;
+                    seen = gen;
+                    lk.unlock();
+                    const int32_t v = job(r);
+                    std::string e = v != SLAMHIP_OK ? std::string(slamhip_last_error()) : std::string();
+                    lk.lock();
+                    rc[(size_t)r] = v; err[(size_t)r] = e;
+                    if (--pending == 0) cv_done.notify_all();
+                }
+            });
+    }
+    // runs fn(rank) on every rank's worker, returns the first failure (its message becomes the caller's last error)
+    int32_t run(const std::function<int32_t(int)> &fn)
+    {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            job = fn; pending = n; gen++;
+            cv_go.notify_all();
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+        for (int r = 0; r < n; r++)
+            if (rc[(size_t)r] != SLAMHIP_OK) { slamhip_set_error("rank %d: %s", r, err[(size_t)r].c_str()); return rc[(size_t)r]; }
+        return SLAMHIP_OK;
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
+        th.clear();
+    }
+};
+
 struct slamhip_group {
     int n;
     rccl_api api;
@@ -76,11 +140,22 @@ struct slamhip_group {
     std::vector<ncclComm_t> comm;
     std::vector<uint64_t *> d_key;
     int n_offs;
+    sh_group_workers *workers;              // null: jobs run inline on the caller's thread (one-GPU groups)
+    uint64_t h_key;
 };
+
+// fn(rank) on every rank: in parallel on the workers, or inline
+static int32_t group_run(slamhip_group *g, const std::function<int32_t(int)> &fn)
+{
+    if (g->workers) return g->workers->run(fn);
+    for (int r = 0; r < g->n; r++) { SH_HIP(hipSetDevice(g->ctx[r]->device)); SH_TRY(fn(r)); }
+    return SLAMHIP_OK;
+}
 
 extern "C" int32_t slamhip_group_destroy(slamhip_group *g)
 {
     if (!g) return SLAMHIP_OK;
+    if (g->workers) { g->workers->stop(); delete g->workers; g->workers = nullptr; }
     for (int r = 0; r < (int)g->comm.size(); r++) if (g->comm[r]) g->api.CommDestroy(g->comm[r]);
     for (int r = 0; r < (int)g->cs.size(); r++) {
         if (g->d_key.size() > (size_t)r && g->d_key[r]) { (void)hipSetDevice(g->ctx[r]->device); (void)hipFree(g->d_key[r]); }
@@ -97,7 +172,7 @@ extern "C" int32_t slamhip_group_create(const int32_t *devices, int32_t n, float
 {
     SH_CHECK_ARG(devices && n >= 1 && n <= 64 && out);
     slamhip_group *g = new slamhip_group();
-    g->n = n; g->n_offs = 0;
+    g->n = n; g->n_offs = 0; g->workers = nullptr; g->h_key = 0;
     int32_t rc = load_rccl(&g->api);
     for (int r = 0; r < n && rc == SLAMHIP_OK; r++) {
         slamhip_ctx *c = nullptr; slamhip_cs *cs = nullptr; uint64_t *dk = nullptr;
@@ -111,6 +186,10 @@ extern "C" int32_t slamhip_group_create(const int32_t *devices, int32_t n, float
         std::vector<int> devs(devices, devices + n);
         ncclResult_t r_ = g->api.CommInitAll(g->comm.data(), n, devs.data());
         if (r_ != ncclSuccess) { slamhip_set_error("ncclCommInitAll failed: %s", g->api.GetErrorString(r_)); rc = SLAMHIP_ERR_RCCL; }
+    }
+    if (rc == SLAMHIP_OK && (n > 1 || getenv("SLAMHIP_GROUP_THREADS"))) {
+        g->workers = new sh_group_workers();
+        g->workers->start(n, std::vector<int>(devices, devices + n));
     }
     if (rc != SLAMHIP_OK) { slamhip_group_destroy(g); return rc; }
     *out = g;
@@ -141,15 +220,13 @@ extern "C" int32_t slamhip_group_reset(slamhip_group *g, int32_t unmapped)
 extern "C" int32_t slamhip_group_holemap_upload(slamhip_group *g, const uint16_t *pix, size_t n)
 {
     SH_CHECK_ARG(g);
-    for (int r = 0; r < g->n; r++) SH_TRY(slamhip_cs_holemap_upload(g->cs[r], pix, n));
-    return SLAMHIP_OK;
+    return group_run(g, [g, pix, n](int r) -> int32_t { return slamhip_cs_holemap_upload(g->cs[r], pix, n); });
 }
 
 extern "C" int32_t slamhip_group_set_scan(slamhip_group *g, const float *xy, int32_t n)
 {
     SH_CHECK_ARG(g);
-    for (int r = 0; r < g->n; r++) SH_TRY(slamhip_cs_set_scan(g->cs[r], xy, n));
-    return SLAMHIP_OK;
+    return group_run(g, [g, xy, n](int r) -> int32_t { return slamhip_cs_set_scan(g->cs[r], xy, n); });   // (per scan: every rank sorts and stages at the same time)
 }
 
 extern "C" int32_t slamhip_group_set_offsets(slamhip_group *g, const float *offs, int32_t n)
@@ -164,37 +241,44 @@ extern "C" int32_t slamhip_group_search(slamhip_group *g, const float pose[3], f
 {
     SH_CHECK_ARG(g && pose);
     const int K = g->n_offs + 1;                 // flat candidates, 0 = un-jittered pose
+    const float p3[3] = { pose[0], pose[1], pose[2] };
     // contiguous blocks keep the flat (thread-major) indices, so the packed-key min reproduces the
-    // reference tie-break across GPUs exactly as across threads (:695-705)
-    for (int r = 0; r < g->n; r++) {
+    // reference tie-break across GPUs exactly as across threads (:695-705).
+    // Every rank, on its own worker thread and its own communicator: the search over its block, its end of
+    // ncclAllReduce(min, uint64, 1) behind it on the same stream, the wait for the stream.  A rank whose search cannot be
+    // enqueued still joins the collective -- with the neutral key -- and reports afterwards: the others must not hang in it.
+    const int32_t rc = group_run(g, [g, K, p3](int r) -> int32_t {
         const int first = (int)((long long)K * r / g->n), last = (int)((long long)K * (r + 1) / g->n);
-        SH_HIP(hipSetDevice(g->ctx[r]->device));
+        hipStream_t st = g->ctx[r]->stream;
+        int32_t rc_local = SLAMHIP_OK;
+        std::string err;
         if (last > first) {
-            SH_TRY(slamhip_cs_search_shard_async(g->cs[r], pose, first, last - first, g->d_key[r]));
-        } else {
-            SH_HIP(hipMemsetAsync(g->d_key[r], 0xFF, sizeof(uint64_t), g->ctx[r]->stream));
+            rc_local = slamhip_cs_search_shard_async(g->cs[r], p3, first, last - first, g->d_key[r]);
+            if (rc_local != SLAMHIP_OK) err = slamhip_last_error();
         }
-    }
-    SH_NCCL(g, g->api.GroupStart());
-    for (int r = 0; r < g->n; r++) {
-        ncclResult_t r_ = g->api.AllReduce(g->d_key[r], g->d_key[r], 1, ncclUint64, ncclMin, g->comm[r], g->ctx[r]->stream);
-        if (r_ != ncclSuccess) { g->api.GroupEnd(); slamhip_set_error("ncclAllReduce failed: %s", g->api.GetErrorString(r_)); return SLAMHIP_ERR_RCCL; }
-    }
-    SH_NCCL(g, g->api.GroupEnd());
-    uint64_t key = 0;
+        if (last <= first || rc_local != SLAMHIP_OK) (void)hipMemsetAsync(g->d_key[r], 0xFF, sizeof(uint64_t), st);
+        const ncclResult_t r_ = g->api.AllReduce(g->d_key[r], g->d_key[r], 1, ncclUint64, ncclMin, g->comm[r], st);
+        if (r == 0) (void)hipMemcpyAsync(&g->h_key, g->d_key[0], sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        const hipError_t e = hipStreamSynchronize(st);
+        if (rc_local != SLAMHIP_OK) { slamhip_set_error("%s", err.c_str()); return rc_local; }
+        if (r_ != ncclSuccess) { slamhip_set_error("ncclAllReduce failed: %s", g->api.GetErrorString(r_)); return SLAMHIP_ERR_RCCL; }
+        SH_HIP(e);
+        return SLAMHIP_OK;
+    });
+    SH_TRY(rc);
     SH_HIP(hipSetDevice(g->ctx[0]->device));
-    SH_HIP(hipMemcpyAsync(&key, g->d_key[0], sizeof(uint64_t), hipMemcpyDeviceToHost, g->ctx[0]->stream));
-    for (int r = 0; r < g->n; r++) { SH_HIP(hipSetDevice(g->ctx[r]->device)); SH_HIP(hipStreamSynchronize(g->ctx[r]->stream)); }
-    return slamhip_cs_pose_from_key(g->cs[0], pose, key, out_pose, out_dist, out_index);
+    return slamhip_cs_pose_from_key(g->cs[0], pose, g->h_key, out_pose, out_dist, out_index);
 }
 
 extern "C" int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float hole_width, int32_t quality, int32_t max_hits)
 {
     SH_CHECK_ARG(g && pose);
-    // the replicas update concurrently: enqueue on every GPU's stream, then wait for all of them
-    for (int r = 0; r < g->n; r++) SH_TRY(cs_update_maps_enqueue(g->cs[r], pose, hole_width, quality, max_hits));
-    for (int r = 0; r < g->n; r++) SH_TRY(cs_update_maps_finish(g->cs[r]));
-    return SLAMHIP_OK;
+    const float p3[3] = { pose[0], pose[1], pose[2] };
+    // the replicas update concurrently: every rank's worker enqueues on its GPU's stream and waits for it
+    return group_run(g, [g, p3, hole_width, quality, max_hits](int r) -> int32_t {
+        SH_TRY(cs_update_maps_enqueue(g->cs[r], p3, hole_width, quality, max_hits));
+        return cs_update_maps_finish(g->cs[r]);
+    });
 }
 
 // Replica check: the replicas' maps after identical updates must be bit-identical; *out_equal = 1 when the
@@ -437,13 +521,93 @@ extern "C" int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *c, 
     SH_HIP(hipSetDevice(ctx->device));
     if (c->async_dirty) SH_TRY(slamhip_comm_wait(c, nullptr));    // (collectives of one communicator are issued from one stream at a time)
     sh_mail_guard lock(ctx);
-    if (count > 0) SH_TRY(slamhip_cs_search_shard_async(cs, pose, first, count, c->d_sync_key));
-    else SH_HIP(hipMemsetAsync(c->d_sync_key, 0xFF, sizeof(uint64_t), ctx->stream));                     // (a rank without candidates: the neutral key)
+    // A rank whose search cannot be enqueued still joins the collective -- with the neutral key -- and reports afterwards: the
+    // other ranks are in it and would wait for this one for good.
+    int32_t rc_local = SLAMHIP_OK;
+    std::string err;
+    if (count > 0) {
+        rc_local = slamhip_cs_search_shard_async(cs, pose, first, count, c->d_sync_key);
+        if (rc_local != SLAMHIP_OK) err = slamhip_last_error();
+    }
+    if (count <= 0 || rc_local != SLAMHIP_OK) (void)hipMemsetAsync(c->d_sync_key, 0xFF, sizeof(uint64_t), ctx->stream);       // (the neutral key)
     SH_NCCL(c, c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, ctx->stream));
     SH_TRY(sh_publish(ctx, c->d_sync_key, 2));
     cs_layout_idle_refresh(cs);                                    // (host work under the search: cs_launch_distance)
     SH_TRY(sh_host_wait(ctx));
     *out_key = *(volatile uint64_t *)ctx->mailbox;
+    if (rc_local != SLAMHIP_OK) { slamhip_set_error("%s", err.c_str()); return rc_local; }
+    return SLAMHIP_OK;
+}
+
+// The reduced key decoded on the device: the winner's pose (search_pose + offs[index - 1], :635-637; theta normalised, :746) into
+// the handle's result block for the map updates queued behind, key and pose into the mailbox for the host.
+__global__ void k_winner_from_key(const unsigned long long *__restrict__ key, const float *__restrict__ offs_flat, int n_offs,
+                                  float bx, float by, float bth, unsigned long long *__restrict__ result, uint32_t *__restrict__ mailbox, uint32_t seq)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long k = *key;
+    const uint32_t flat = (uint32_t)k;
+    float x = bx, y = by, th = bth;
+    if (flat > 0 && flat <= (uint32_t)n_offs) { x = bx + offs_flat[3 * (size_t)(flat - 1)]; y = by + offs_flat[3 * (size_t)(flat - 1) + 1]; th = bth + offs_flat[3 * (size_t)(flat - 1) + 2]; }
+    const float thn = sh_normalize_angle(th);
+    float *pose = (float *)(result + 1);                           // (the result block: key | pose x, y, theta normalised, theta | ...)
+    result[0] = k;
+    pose[0] = x; pose[1] = y; pose[2] = thn; pose[3] = th;
+    if (mailbox) {
+        *(unsigned long long *)mailbox = k;
+        float *mp = (float *)(mailbox + 2);
+        mp[0] = x; mp[1] = y; mp[2] = thn;
+        __hip_atomic_store(mailbox + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// One scan of the SLAM loop on every rank (CoreSLAMProcessor.cs:732 -> :750-751), no host hop between the exchange and the map
+// updates: K1 over this rank's block, ncclAllReduce(min, uint64, 1), a one-thread launch that decodes the reduced key into the
+// winner's pose ON THE DEVICE (every rank holds the whole jitter list) and hands key + pose to the host, and behind it the
+// replicas' map updates from that device-resident pose -- all on the operator's stream.  Returns when the pose is known; the
+// updates run on (everything that touches the maps afterwards is ordered behind them).  Every rank makes the same call.
+extern "C" int32_t slamhip_cs_search_allreduce_and_update(slamhip_cs *cs, slamhip_comm *c, const float pose[3], int32_t first, int32_t count,
+                                                          float hole_width, int32_t quality, int32_t max_hits,
+                                                          float out_pose[3], int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(cs && c && pose && cs->ctx == c->ctx && count >= 0);
+    SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
+    slamhip_ctx *ctx = c->ctx;
+    SH_HIP(hipSetDevice(ctx->device));
+    if (c->async_dirty) SH_TRY(slamhip_comm_wait(c, nullptr));
+    sh_mail_guard lock(ctx);
+    int32_t rc_local = SLAMHIP_OK;
+    std::string err;
+    if (count > 0) {
+        rc_local = slamhip_cs_search_shard_async(cs, pose, first, count, c->d_sync_key);
+        if (rc_local != SLAMHIP_OK) err = slamhip_last_error();
+    } else rc_local = cs_flush_generate(cs);                      // (a rank without candidates still decodes the winner from the list)
+    if (count <= 0 || rc_local != SLAMHIP_OK) (void)hipMemsetAsync(c->d_sync_key, 0xFF, sizeof(uint64_t), ctx->stream);
+    SH_NCCL(c, c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, ctx->stream));
+    const uint32_t seq = sh_mail_seq_next(ctx);
+    hipLaunchKernelGGL(k_winner_from_key, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *)c->d_sync_key, (const float *)cs->d_offs_flat,
+                       cs->n_offs, pose[0], pose[1], pose[2], (unsigned long long *)cs->d_key, ctx->mail_off ? (uint32_t *)nullptr : ctx->mailbox, seq);
+    int32_t rc_u = hipGetLastError() == hipSuccess ? SLAMHIP_OK : SLAMHIP_ERR_HIP;
+    if (rc_u == SLAMHIP_OK && rc_local == SLAMHIP_OK && cs->n_points > 0) {
+        if (ctx->timing == 0) rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality, true, max_hits);
+        else {
+            rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality);
+            if (rc_u == SLAMHIP_OK) rc_u = cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits);
+        }
+    }
+    cs_layout_idle_refresh(cs);
+    if (ctx->mail_off) {
+        SH_HIP(hipMemcpyAsync(ctx->mailbox, cs->d_key, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SH_HIP(hipStreamSynchronize(ctx->stream));
+    } else SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));
+    cs->hole_pixels_pending = rc_u == SLAMHIP_OK && rc_local == SLAMHIP_OK && cs->n_points > 0;
+    const uint64_t key = *(const volatile uint64_t *)ctx->mailbox;
+    const float *hp = (const float *)(ctx->mailbox + 2);
+    if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
+    if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);
+    if (out_index) *out_index = (int32_t)(uint32_t)key;
+    if (rc_local != SLAMHIP_OK) { slamhip_set_error("%s", err.c_str()); return rc_local; }
+    SH_TRY(rc_u);
     return SLAMHIP_OK;
 }
 
@@ -456,7 +620,9 @@ extern "C" int32_t slamhip_comm_replicas_equal(slamhip_cs *cs, slamhip_comm *c, 
     SH_HIP(hipSetDevice(ctx->device));
     if (c->async_dirty) SH_TRY(slamhip_comm_wait(c, nullptr));    // (collectives of one communicator are issued from one stream at a time)
     sh_mail_guard lock(ctx);
-    SH_TRY(cs_maps_checksum_enqueue(cs));
+    // (a rank whose checksums cannot be enqueued still joins the two collectives -- the others are in them -- and reports afterwards)
+    const int32_t rc_local = cs_maps_checksum_enqueue(cs);
+    const std::string err = rc_local != SLAMHIP_OK ? std::string(slamhip_last_error()) : std::string();
     uint64_t *d = cs->d_key + 4;                                   // words 4, 5: the checksums; 6, 7: their copies for the max
     SH_HIP(hipMemcpyAsync(d + 2, d, 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     SH_NCCL(c, c->api.AllReduce(d, d, 2, ncclUint64, ncclMin, c->comm, ctx->stream));
@@ -466,6 +632,7 @@ extern "C" int32_t slamhip_comm_replicas_equal(slamhip_cs *cs, slamhip_comm *c, 
     uint64_t m[4];
     memcpy(m, (const void *)ctx->mailbox, sizeof(m));
     *out_equal = (m[0] == m[2] && m[1] == m[3]) ? 1 : 0;
+    if (rc_local != SLAMHIP_OK) { *out_equal = 0; slamhip_set_error("%s", err.c_str()); return rc_local; }
     return SLAMHIP_OK;
 }
 

@@ -9,7 +9,7 @@
 // per-level grid `prob` that every writer of the log-odds grid keeps current (K5 for the cells it touches, upload and
 // reset for all of them) -- the device's form of the reference's per-cell cache, without its epochs: the value always is
 // the current cell's probability, also across Reset, where the reference's cache can serve pre-reset values (deviation
-// D5: oracle/hector_oracle.c, DESIGN.md sec.3, tests/test_oracle_kat.py::test_hector_reset_cache_aliasing_d5).
+// D5: DESIGN.md sec.3 and include/slamhip.h, slamhip_hs_probability).
 // Float parity target: pose within 1e-4 m / 1e-4 rad (H6).
 //
 // K5 replaces OccGridMap.UpdateByScan and friends (HectorSLAM/Map/OccGridMap.cs:114-239) for every level of

@@ -44,16 +44,21 @@ def allreduce_min_key(key_tensor):
 def replicas_equal(checksums):
     """Replica check over torch.distributed (the map updates run as replicas on every rank): `checksums` =
     this rank's words (e.g. CoreSlamDevice.maps_checksum()); True when every rank holds the same ones.  uint64 words travel
-    as two int32 halves each (gloo / RCCL reduce signed types), compared through a MIN and a MAX all-reduce."""
-    w = np.asarray(list(checksums), dtype=np.uint64)
+    as two int32 halves each (gloo / RCCL reduce signed types), compared through a MIN and a MAX all-reduce.
+    A rank that could not produce its words passes None: it still joins both collectives (the others are in them) with words
+    that cannot match, and every rank gets False."""
+    failed = checksums is None
+    w = np.asarray([0, 2 ** 64 - 1] if failed else list(checksums), dtype=np.uint64)
     halves = torch.from_numpy(w.view(np.int32).astype(np.int64))
+    if failed:
+        halves = torch.tensor([-2 ** 31, 2 ** 31 - 1, -2 ** 31, 2 ** 31 - 1], dtype=torch.int64)[:halves.numel()] if halves.numel() <= 4 else halves
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         lo, hi = halves.to(dev), halves.to(dev).clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        return bool((lo == hi).all().item())
-    return True
+        return bool((lo == hi).all().item()) and not failed
+    return not failed
 
 
 class LibComm:
@@ -116,6 +121,14 @@ class LibComm:
             capi.check(fn(*args))
             return int(k.value)
         return step
+
+    def search_allreduce_and_update(self, dev, pose, first, count, hole_width=0.6, quality=50, max_hits=10):
+        """One scan on every rank: sharded search, RCCL min, winner decoded on the device, both map updates queued behind it
+        (slamhip_cs_search_allreduce_and_update); returns (pose with theta normalised, distance, flat index)."""
+        out = np.empty(3, np.float32); d, i = C.c_int32(), C.c_int32()
+        capi.call("slamhip_cs_search_allreduce_and_update", dev._h, self._h, capi.fptr(np.ascontiguousarray(pose, np.float32)), int(first), int(count),
+                  C.c_float(hole_width), int(quality), int(max_hits), capi.fptr(out), C.byref(d), C.byref(i))
+        return out, int(d.value), int(i.value)
 
     def set_batch(self, steps):
         capi.call("slamhip_comm_set_batch", self._h, int(steps))

@@ -1130,3 +1130,67 @@ def test_lib_comm_blocking_step_single_rank(cs_mod, ctx, sim):
     finally:
         comm.close()
         dev.close()
+
+
+def test_lib_comm_fused_scan_single_rank(cs_mod, ctx, det, sim):
+    """slamhip_cs_search_allreduce_and_update on a one-rank communicator: search over the rank's block, the collective, the winner
+    decoded ON THE DEVICE from the reduced key, both map updates queued behind it -- winner, pose and both maps equal the oracle's
+    scan by scan (as slamhip_cs_search_and_update does without a communicator), also with a sub-block of the list (the winner of
+    the block) and for a rank without candidates (the neutral key: search pose, maps updated from it)."""
+    import slam.net_amd.distributed as D
+    oc = det
+    size, osize, R, K = 512, 128, 540, 3000
+    dev = make_dev(cs_mod, ctx, size, osize)
+    segs = sim.default_field()
+    rng = sim.PCG32(21)
+    ref_h = np.full(size * size, 32750, np.uint16)
+    ref_o = np.full(osize * osize, -5, np.int8)
+    traj = sim.trajectory(12)
+    for p in traj[:4]:
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy); dev.update_holemap(p); dev.update_obstaclemap(p)
+        oc.update_holemap(ref_h, size, dev.hole_scale, xy, p)
+        oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, p)
+    offs = sim.gaussian_offsets(K - 1, 0.05, math.radians(4.0), seed=9)
+    dev.set_offsets(offs)
+    comm = D.LibComm(ctx, 0, 1)
+    try:
+        for i, p in enumerate(traj[4:]):
+            _, xy = sim.make_scan(segs, p, R, rng)
+            base = (p + np.array([0.02, -0.01, 0.005], np.float32)).astype(np.float32)
+            dev.set_scan(xy)
+            first, count = ((0, K), (K // 4, K // 2), (0, K), (5, 0))[i % 4]
+            pose, dist, idx = comm.search_allreduce_and_update(dev, base, first, count, 0.6, 50, 10)
+            if count > 0:
+                sub = offs[first - 1:first - 1 + count] if first > 0 else offs[:count - 1]
+                rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, sub) if first == 0 else (None, None, None, None)
+                if first > 0:                                      # a block that does not hold candidate 0: every candidate is base + offs
+                    d_all = [oc.distance(ref_h, size, dev.hole_scale, xy, (base + o).astype(np.float32)) for o in sub]
+                    j = int(np.argmin(np.asarray(d_all, np.int64)))
+                    rbi, rbd, rpose = first + j, int(d_all[j]), (base + sub[j]).astype(np.float32)
+                assert (idx, dist) == (int(rbi), int(rbd)), (i, idx, dist, rbi, rbd)
+            else:
+                assert (dist << 32 | (idx & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF == 2 ** 64 - 1
+                rpose = base.copy()
+            rp = np.asarray(rpose, np.float32).copy()
+            rp[2] = oc.normalize_angle(rp[2])
+            assert (pose == rp).all(), (i, pose, rp)
+            oc.update_holemap(ref_h, size, dev.hole_scale, xy, rp)
+            oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rp)
+            assert (dev.holemap_download() == ref_h).all(), i
+            assert (dev.obstaclemap_download().reshape(-1) == ref_o).all(), i
+    finally:
+        comm.close()
+        dev.close()
+
+
+def test_group_worker_threads():
+    """The group's per-GPU worker threads (slamhip_group_search / _update_maps / _set_scan run every rank's part on its own
+    thread): forced on for the one-GPU group of test_group_single_gpu with SLAMHIP_GROUP_THREADS=1."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ); env["SLAMHIP_GROUP_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "test_group_single_gpu or test_maps_checksum_and_replica_checks"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
