@@ -68,6 +68,7 @@ struct slamhip_cs {
     // ray ranges of the uniform part cut by COST (rays + a weight per ray block touched) instead of by count (k1_balanced_cuts):
     // cuts by count of ranges (cuts[0 .. n], n <= the count asked for; empty: none), for scan generation k1_cut_gen at weight k1_cut_w
     std::vector<std::pair<int, std::vector<int>>> k1_cut_cache; uint32_t k1_cut_gen, k1_cut_layout_gen;
+    uint32_t k1_cut_seen_scan, k1_cut_seen_layout;   // the (scan, layout) of the last tiled launch: cuts are made from the second launch of a pair on
     uint32_t k1_layout_gen;                     // layouts made so far (k1_make_layout)
     std::vector<int> k1_cut_parts;              // per ray block: parts it is cut into (its whole tile would not fit the budget for the widest uniform group)
     std::vector<char> k1_cut_cand;              // per ray block: its tile may exceed the budget (worth the exact box test)

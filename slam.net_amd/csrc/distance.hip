@@ -1077,6 +1077,8 @@ static int k1_legal_chunks(const slamhip_cs *cs, int nc)
     return nc;
 }
 
+static double g_cut_t[4] = { 0, 0, 0, 0 };   // developer aid (SLAMHIP_K1_CUT_TIMES): host microseconds in weights / balanced cuts / banded check
+static inline double k1_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec * 1e6 + (double)t.tv_nsec * 1e-3; }
 // Ray ranges cut by cost.  A workgroup's compute phase is its rays PLUS its tile steps -- one per ray block it touches -- and a
 // step costs as much as a dozen or two rays of gathers (barrier, tile write, barrier, the next tile's loads; SLAMHIP_K1_TIMES at
 // the headline size: 43-ray ranges of 2 steps take 8 us, of 5 steps 13 us, and the launch waits for the slowest).  Equal COUNTS
@@ -1138,13 +1140,14 @@ static int k1_balanced_cuts(const slamhip_cs *cs, int nc, const std::vector<doub
         return n;
     };
     // (the bound lies between the mean cost of a range and the whole scan's: start near the mean, widen until a bound fits)
-    double lo = ((double)R + wsum) / (double)nc - 1.0, hi = lo * 1.25 + wmax + 2.0;
+    // (this runs once per scan on the host's critical path in the per-scan flow: a handful of fills of ~0.3 us each)
+    double lo = ((double)R + wsum) / (double)nc - 1.0, hi = lo + wmax + 3.0;
     const double top = (double)R + wsum + 1.0;
     if (lo < 1.0) lo = 1.0;
-    for (int it = 0; it < 12 && hi < top && fill(hi, nullptr) > nc; it++) { lo = hi; hi = hi * 1.5; }
+    for (int it = 0; it < 12 && hi < top && fill(hi, nullptr) > nc; it++) { lo = hi; hi = hi * 1.3 + 2.0; }
     if (hi > top) hi = top;
-    if (fill(hi, nullptr) > nc) return 0;
-    for (int it = 0; it < 24 && hi - lo > 0.75; it++) {
+    if (hi >= top && fill(hi, nullptr) > nc) return 0;
+    for (int it = 0; it < 24 && hi - lo > 1.5; it++) {
         const double mid = 0.5 * (lo + hi);
         if (fill(mid, nullptr) <= nc) hi = mid; else lo = mid;
     }
@@ -1183,7 +1186,8 @@ static void k1_cut_weights(const slamhip_cs *cs, int n_groups, bool have_spread,
         wb[(size_t)b] = w_fix + w_kb * (2.0 * (w + 8.0) * h / 1024.0);
         // (a first, generous estimate for the widest uniform group picks the blocks worth the exact box below)
         const double ww = ex * c + ey * s + d_w + (mx * s + my * c) * dth_w, hw = ex * s + ey * c + d_w + (mx * c + my * s) * dth_w;
-        cand[(size_t)b] = 2.0 * (ww + 8.0) * hw > 0.5 * (double)budget || ww > 300.0;
+        static const double cand_f = getenv("SLAMHIP_K1_CUT_CAND") ? atof(getenv("SLAMHIP_K1_CUT_CAND")) : 0.9;
+        cand[(size_t)b] = 2.0 * (ww + 8.0) * hw > cand_f * (double)budget || ww > 440.0;
     }
     (void)pose; (void)budget;
 }
@@ -1578,11 +1582,11 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         // Ray ranges cut by cost (k1_balanced_cuts), remade when the scan, a count of ranges or the weight changed: the uniform
         // part's and every listed group's (groups with the same count of ranges share the cut).  A cut may come out with fewer
         // ranges than asked for: the group then runs with that many workgroups.
-        // The weight of a tile step in ray units: 20 where it was calibrated (2048^2 map = 51.2 pixels per metre, two candidates per
+        // The weight of a tile step in ray units: 26 where it was calibrated (2048^2 map = 51.2 pixels per metre, two candidates per
         // lane), less on coarser maps (smaller tiles, and the 64-ray cap makes blocks long in rays: 1024^2 wants about half, 256^2
         // none) and in proportion to what a ray costs the workgroup (four candidates per lane: a ray takes twice as long, the step
         // does not).  SLAMHIP_K1_CUT_WFIX = 0 and SLAMHIP_K1_CUT_WKB = 0: the equal-count formula everywhere.
-        static const double cut_w20 = getenv("SLAMHIP_K1_CUT_WFIX") ? atof(getenv("SLAMHIP_K1_CUT_WFIX")) : 20.0;
+        static const double cut_w20 = getenv("SLAMHIP_K1_CUT_WFIX") ? atof(getenv("SLAMHIP_K1_CUT_WFIX")) : 26.0;
         static const double cut_wkb = getenv("SLAMHIP_K1_CUT_WKB") ? atof(getenv("SLAMHIP_K1_CUT_WKB")) : 0.0;
         const int cpl_group = group == K1_GROUP_BIG ? 4 : group == K1_GROUP_SMALL ? 1 : 2;
         const double cut_wfix = cut_w20 * std::min(1.0, (double)cs->hscale / 51.2) * 2.0 / (double)cpl_group;
@@ -1590,11 +1594,20 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         static const int cut_tab = env_int("SLAMHIP_K1_CUT_TAB", 0);      // (the listed groups too: measured slower)
         const int n_tab = (int)cs->k1_tab_group.size();
         const float pose3[3] = { bx, by, bth };
-        const bool cuts_on = (cut_wfix > 0.0 || cut_wkb > 0.0) && cs->n_points < 65536;
+        // The cuts cost the host ~7 us (mostly the exact box test of the pieces, k1_cuts_banded_rays) and buy a launch ~1 us: they are
+        // made when a scan is searched for the SECOND time under one layout -- a list searched from many poses, a benchmark loop --
+        // and never in the per-scan flow, where every launch sees a new scan and the host's time between two scans is what counts
+        // (measured there: CoreSLAMProcessor.Update 66 -> 77 us per scan with the cuts made for every scan).  SLAMHIP_K1_CUT_ALWAYS=1: always.
+        static const int cut_always = env_int("SLAMHIP_K1_CUT_ALWAYS", 0);
+        const bool cut_repeat = cut_always || (cs->k1_cut_seen_scan == cs->scan_gen && cs->k1_cut_seen_layout == cs->k1_layout_gen);
+        cs->k1_cut_seen_scan = cs->scan_gen; cs->k1_cut_seen_layout = cs->k1_layout_gen;
+        const bool cuts_on = cut_repeat && (cut_wfix > 0.0 || cut_wkb > 0.0) && cs->n_points < 65536;
         if (cuts_on && (cs->k1_cut_gen != cs->scan_gen || cs->k1_cut_layout_gen != cs->k1_layout_gen)) {
             cs->k1_cut_cache.clear();
             cs->k1_cut_gen = cs->scan_gen; cs->k1_cut_layout_gen = cs->k1_layout_gen;
+            const double tw0 = k1_now_us();
             k1_cut_weights(cs, n_groups, have_spread, cut_wfix, cut_wkb, budget, pose3, cs->k1_cut_wb, cs->k1_cut_parts);
+            g_cut_t[0] += k1_now_us() - tw0;
         }
         cs->k1_cut_cache.reserve(K1_TABLE_G + 8);                      // (the entries' addresses are held below: no reallocation)
         auto cuts_for = [&](int nrc) -> const std::vector<int> * {       // nullptr: no cut for this count (the formula stays)
@@ -1610,7 +1623,9 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             for (int tries = 0; tries < 6; tries++, scale *= 0.6) {
                 wsc.resize(cs->k1_cut_wb.size());
                 for (size_t i = 0; i < wsc.size(); i++) wsc[i] = cs->k1_cut_wb[i] * scale;
+                const double tb0 = k1_now_us();
                 const int n = k1_balanced_cuts(cs, nrc, wsc, cs->k1_cut_parts, c);
+                g_cut_t[1] += k1_now_us() - tb0;
                 if (n < 1) { c.clear(); break; }
                 if (n * 100 >= nrc * cut_keep) break;
                 c.clear();
@@ -1619,12 +1634,19 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                 // a cut that puts more rays on banded tiles (for the uniform part's outer groups) than the equal-count ranges do is
                 // dropped: a banded piece costs its workgroup more than twice a plain one, the launch waits for it (1024^2 map:
                 // four workgroups at 19 us in a 21 us launch)
-                std::vector<int> eq((size_t)nrc + 1);
-                for (int k = 0; k <= nrc; k++) eq[(size_t)k] = (int)(((long long)k * cs->n_points) / nrc);
-                if (k1_cuts_banded_rays(cs, c, pose3, budget, cs->k1_cut_cand) > k1_cuts_banded_rays(cs, eq, pose3, budget, cs->k1_cut_cand)) c.clear();
+                const double tc0 = k1_now_us();
+                const int banded = k1_cuts_banded_rays(cs, c, pose3, budget, cs->k1_cut_cand);
+                g_cut_t[2] += k1_now_us() - tc0;
+                if (banded > 0) {                                  // (seldom: the equal-count ranges are only looked at then)
+                    std::vector<int> eq((size_t)nrc + 1);
+                    for (int k = 0; k <= nrc; k++) eq[(size_t)k] = (int)(((long long)k * cs->n_points) / nrc);
+                    if (banded > k1_cuts_banded_rays(cs, eq, pose3, budget, cs->k1_cut_cand)) c.clear();
+                }
             }
             return c.empty() ? nullptr : &c;
         };
+        static const int cut_times = env_int("SLAMHIP_K1_CUT_TIMES", 0);     // developer aid: host time of the cuts, printed every 64 makes
+        timespec ct0; if (cut_times) clock_gettime(CLOCK_MONOTONIC, &ct0);
         a.uni_cut = 0; a.tab_cut = 0;
         int n_cut = 0;                                                 // entries of a.cut in use
         a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
@@ -1634,6 +1656,16 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                 for (size_t i = 0; i < c->size(); i++) a.cut[i] = (unsigned short)(*c)[i];
                 n_cut = (int)c->size();
                 a.uni_cut = 1; a.uni_nc = (int)c->size() - 1;
+            }
+        }
+        if (cut_times) {
+            static double acc = 0.0; static int nacc = 0;
+            timespec ct1; clock_gettime(CLOCK_MONOTONIC, &ct1);
+            acc += (double)(ct1.tv_sec - ct0.tv_sec) * 1e6 + (double)(ct1.tv_nsec - ct0.tv_nsec) * 1e-3;
+            if (++nacc == 64) {
+                fprintf(stderr, "[slamhip] K1 cuts: %.2f us of host time per launch (uniform part): weights %.2f | balanced cuts %.2f | banded check %.2f\n", acc / nacc,
+                        g_cut_t[0] / nacc, g_cut_t[1] / nacc, g_cut_t[2] / nacc);
+                acc = 0.0; nacc = 0; g_cut_t[0] = g_cut_t[1] = g_cut_t[2] = 0.0;
             }
         }
         // the listed groups: all of them from the table, or none

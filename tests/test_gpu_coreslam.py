@@ -301,6 +301,10 @@ def test_k1_tile_boxes_selfcheck():
                       {"SLAMHIP_K1_GROUP": "512", "SLAMHIP_K1_VERIFY": "1"},       # groups of 512 candidates (512 lanes x 1), as small searches use
                       {"SLAMHIP_K1_GROUP": "512"}, {"SLAMHIP_K1_GROUP": "1024"},
                       {"SLAMHIP_K1_NOBOUNDS": "1", "SLAMHIP_K1_VERIFY": "1"},      # search-mode bounds from the in-kernel reduction
+                      {"SLAMHIP_K1_CUT_ALWAYS": "1", "SLAMHIP_K1_VERIFY": "1"},    # ray ranges cut by cost from the first launch of a scan on
+                      {"SLAMHIP_K1_CUT_ALWAYS": "1", "SLAMHIP_K1_CUT_TAB": "1", "SLAMHIP_K1_CUT_WFIX": "40"},   # ... the listed groups' too, heavy weights
+                      {"SLAMHIP_K1_CUT_ALWAYS": "1", "SLAMHIP_K1_CUT_WFIX": "3", "SLAMHIP_K1_CUT_WKB": "1.5", "SLAMHIP_K1_CUT_KEEP": "100"},
+                      {"SLAMHIP_K1_CUT_WFIX": "0"},                                # the equal-count formula everywhere
                       {"SLAMHIP_K1_TARGET_WGS": "64", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "64"},
                       {"SLAMHIP_K1_TARGET_WGS": "100000", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "100000", "SLAMHIP_K1_CPL": "1"}):
         env = dict(os.environ); env.update(env_extra); env["SLAMHIP_EXPECT_SELFCHECK"] = "1"
