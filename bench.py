@@ -513,8 +513,30 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
         proc.Update([cs.ScanSegment(pscans[10 + i % 60], zero)])
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / 200
-    out["coreslam_processor_update_2048_map_1080_rays_16384_candidates"] = {"us_per_scan": dt * 1e6, "scans_per_s": 1.0 / dt}
+    out["coreslam_processor_update_2048_map_1080_rays_16384_candidates"] = {"us_per_scan": dt * 1e6, "scans_per_s": 1.0 / dt,
+                                                                            "caller": "Python mirror of the C# class over ctypes (the interpreter's part of a scan is ~8 us)"}
     proc.Dispose()
+    # ... and from a NATIVE caller of the C-ABI (tests/abi_harness.c --bench-proc: gcc, dlopen, slamhip_csproc_update in a C loop):
+    # what a P/Invoke caller pays per scan.  A process of its own, while this one is idle.
+    try:
+        import shutil
+        import subprocess
+        import tempfile
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if cc:
+            with tempfile.TemporaryDirectory() as td:
+                exe = os.path.join(td, "abi_harness")
+                subprocess.check_call([cc, "-O1", "-o", exe, os.path.join(ROOT, "tests", "abi_harness.c"), "-ldl", "-lm"])
+                r = subprocess.run([exe, capi.SO_PATH, "--bench-proc", "2048", "1080", "16385", "300"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+                txt = r.stdout.decode(errors="replace")
+                if r.returncode == 0 and "proc_us_per_scan" in txt:
+                    us = float(txt.split("proc_us_per_scan")[1].split()[0])
+                    out["coreslam_processor_update_native_caller_2048_map_1080_rays_16385_candidates"] = {
+                        "us_per_scan": us, "scans_per_s": 1e6 / us, "caller": "tests/abi_harness.c --bench-proc (C, dlopen): a rectangular room, 300 scans"}
+                else:
+                    out["coreslam_processor_update_native_caller_2048_map_1080_rays_16385_candidates"] = {"error": txt[-400:]}
+    except Exception as e:                                         # noqa: BLE001
+        out["coreslam_processor_update_native_caller_2048_map_1080_rays_16385_candidates"] = {"error": repr(e)}
     # C4: Hector Gauss-Newton match, 3-level 2048^2 pyramid, 1080 rays
     rep = hs.MapRepMultiMap(40.0 / 2048, (2048, 2048), 3, ctx=ctx)
     rng = sim.PCG32(3)

@@ -354,33 +354,53 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     // K1 sums integers, so it may visit the rays in any order: sort them along a Z-order curve at
     // 64-pixel granularity so that a ray block's end points stay close together in the map (the rigid
     // candidate transform preserves distances), then cut the sorted list into blocks of <= CS_RB_MAX.
+    // (This function is the host's critical path between two scans: 12 us at 1080 points before round 4, of which two thirds
+    // were libm calls -- fminf / fmaxf are not inlined without fast-math -- and a loop the compiler could not vectorise; now ~4.)
+#define SH_MINF(a, b) ((a) < (b) ? (a) : (b))
+#define SH_MAXF(a, b) ((a) > (b) ? (a) : (b))
     bool sane = true;
     std::vector<uint64_t> &keys = cs->h_sort_keys;                 // (kept between scans: no allocation per scan)
     keys.resize((size_t)n);
-    const float cell = 64.0f / cs->hscale;          // metres per 64 px
-    // (one pass over the points makes the keys and the histograms of all three 11-bit digits: a digit whose histogram has a single
-    // occupied bin -- a scan spans few 64-pixel cells, the high digits are equal -- needs no pass of its own)
-    static thread_local unsigned cnt3[3][2048];
-    memset(cnt3, 0, sizeof(cnt3));
-    for (int i = 0; i < n; i++) {
-        const float X = xy[2 * i], Y = xy[2 * i + 1];
-        if (!(fabsf(X) < 1.0e9f) || !(fabsf(Y) < 1.0e9f)) sane = false;
-        float gx = X / cell + 32768.0f, gy = Y / cell + 32768.0f;
-        uint32_t ux = gx > 0.0f ? (gx < 65535.0f ? (uint32_t)gx : 65535u) : 0u;
-        uint32_t uy = gy > 0.0f ? (gy < 65535.0f ? (uint32_t)gy : 65535u) : 0u;
-        const uint32_t code = part1by1(ux) | (part1by1(uy) << 1);
-        keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
-        cnt3[0][code & 2047u]++; cnt3[1][(code >> 11) & 2047u]++; cnt3[2][code >> 22]++;
+    const float icell = cs->hscale / 64.0f;         // 64-pixel cells per metre (ordering only: any monotone map of the coordinates does)
+    // cell coordinates of every point (a branch-free loop over the 2 n floats: vectorised), their minima, and the sanity flag
+    std::vector<int> &cellxy = cs->h_cell_xy;
+    cellxy.resize((size_t)n * 2);
+    {
+        int bad = 0;
+        int *cu = cellxy.data();
+        for (int i = 0; i < 2 * n; i++) {
+            const float v = xy[i];
+            bad |= !(fabsf(v) < 1.0e9f);
+            float g = v * icell + 32768.0f;
+            g = g > 0.0f ? g : 0.0f;                 // (NaN -> 0)
+            g = g < 65535.0f ? g : 65535.0f;
+            cu[i] = (int)g;
+        }
+        sane = !bad;
     }
-    {   // LSD radix sort on the 32-bit Morton code (up to 3 stable passes of 11 bits; ties keep ray order): std::sort was
-        // most of this function's time at ~1000 rays
+    int umin = 65535, vmin = 65535;
+    for (int i = 0; i < n; i++) { umin = cellxy[2 * (size_t)i] < umin ? cellxy[2 * (size_t)i] : umin; vmin = cellxy[2 * (size_t)i + 1] < vmin ? cellxy[2 * (size_t)i + 1] : vmin; }
+    // Morton codes of the cell coordinates RELATIVE to the scan's first cell: a scan spans a few dozen cells, so the codes are small
+    // and the radix sort below needs one pass (around 32768 the absolute coordinates differ in their top bits: three passes)
+    static thread_local unsigned cnt3[3][2048];
+    uint32_t c_or = 0, c_and = ~0u;
+    for (int i = 0; i < n; i++) {
+        const uint32_t code = part1by1((uint32_t)(cellxy[2 * (size_t)i] - umin)) | (part1by1((uint32_t)(cellxy[2 * (size_t)i + 1] - vmin)) << 1);
+        keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
+        c_or |= code; c_and &= code;
+    }
+    {   // LSD radix sort on the 32-bit Morton code (up to 3 stable passes of 11 bits; ties keep ray order), a pass only for a digit
+        // in which the codes differ
         std::vector<uint64_t> &tmp = cs->h_sort_tmp;
         tmp.resize((size_t)n);
         uint64_t *src = keys.data(), *dst = tmp.data();
+        const uint32_t vary = c_or ^ c_and;
         for (int pass = 0; pass < 3; pass++) {
             const int shift = 32 + 11 * pass;
+            if (((vary >> (11 * pass)) & 2047u) == 0) continue;   // every key has the same digit
             unsigned *cnt = cnt3[pass];
-            if (cnt[(src[0] >> shift) & 2047u] == (unsigned)n) continue;      // every key in one bin
+            memset(cnt, 0, sizeof(unsigned) * 2048);
+            for (int i = 0; i < n; i++) cnt[(src[i] >> shift) & 2047u]++;
             unsigned sum = 0;
             for (int k = 0; k < 2048; k++) { const unsigned c = cnt[k]; cnt[k] = sum; sum += c; }
             for (int i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
@@ -411,7 +431,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         const float X = xy[2 * i], Y = xy[2 * i + 1];
         sorted[2 * j] = X; sorted[2 * j + 1] = Y;
         if (cur > 0) {
-            const float nx0 = fminf(bx0, X), nx1 = fmaxf(bx1, X), ny0 = fminf(by0, Y), ny1 = fmaxf(by1, Y);
+            const float nx0 = SH_MINF(bx0, X), nx1 = SH_MAXF(bx1, X), ny0 = SH_MINF(by0, Y), ny1 = SH_MAXF(by1, Y);
             if (cur == CS_RB_MAX || !(nx1 - nx0 <= ext) || !(ny1 - ny0 <= ext)) { rb.push_back(j); cur = 0; }
             else { bx0 = nx0; bx1 = nx1; by0 = ny0; by1 = ny1; }
         }
@@ -431,12 +451,14 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         float x0 = sorted[2 * (size_t)r0], x1 = x0, y0 = sorted[2 * (size_t)r0 + 1], y1 = y0;
         for (int r = r0; r < r1; r++) {
             const float X = sorted[2 * (size_t)r], Y = sorted[2 * (size_t)r + 1];
-            x0 = fminf(x0, X); x1 = fmaxf(x1, X); y0 = fminf(y0, Y); y1 = fmaxf(y1, Y);
-            rayblk[4 * (size_t)r] = r0; rayblk[4 * (size_t)r + 1] = r1; rayblk[4 * (size_t)r + 2] = b; rayblk[4 * (size_t)r + 3] = 0;
+            x0 = SH_MINF(x0, X); x1 = SH_MAXF(x1, X); y0 = SH_MINF(y0, Y); y1 = SH_MAXF(y1, Y);
+            ((int4 *)rayblk)[r] = make_int4(r0, r1, b, 0);
         }
         cs->h_rb_ex[(size_t)b] = (x1 - x0) * cs->hscale; cs->h_rb_ey[(size_t)b] = (y1 - y0) * cs->hscale;
         cs->h_rb_mx[(size_t)b] = 0.5f * (x0 + x1) * cs->hscale; cs->h_rb_my[(size_t)b] = 0.5f * (y0 + y1) * cs->hscale;
     }
+#undef SH_MINF
+#undef SH_MAXF
     cs->k1_scan_dirty = true;
     cs->scan_gen++;
     memcpy(h_rb, rb.data(), sizeof(int) * rb.size());

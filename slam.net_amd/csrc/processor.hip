@@ -38,6 +38,9 @@ struct slamhip_csproc {
     uint64_t seed, scan_no;
     bool pinned;
     std::vector<float> cloud;
+    // ScanSegmentsToCloud: a lidar's ray angles repeat from scan to scan, so the deterministic sine / cosine of ray r is kept with
+    // the angle it was made for and reused while the angle is bit-identical (the same floats by construction; 6 -> 1.5 us per scan)
+    std::vector<float> trig_angle, trig_s, trig_c;
 };
 
 extern "C" int32_t slamhip_csproc_destroy(slamhip_csproc *p)
@@ -131,13 +134,20 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
     // ScanSegmentsToCloud (:187-207): polar -> cartesian in the robot frame, on the host
     g_pt.start();
     p->cloud.resize((size_t)n * 2);
+    if (p->trig_angle.size() < (size_t)n) {
+        const size_t old = p->trig_angle.size();
+        p->trig_angle.resize((size_t)n); p->trig_s.resize((size_t)n); p->trig_c.resize((size_t)n);
+        for (size_t k = old; k < (size_t)n; k++) { p->trig_angle[k] = NAN; p->trig_s[k] = 0.f; p->trig_c[k] = 0.f; }   // (NaN never compares equal: recomputed)
+    }
     for (int sgm = 0; sgm < n_seg; sgm++) {                               // :191
         const float px = seg_poses[3 * sgm] - odo[0];                     // :194
         const float py = seg_poses[3 * sgm + 1] - odo[1];
         const float pz = seg_poses[3 * sgm + 2] - odo[2];
         for (int r = seg_start[sgm]; r < seg_start[sgm + 1]; r++) {       // :196
             float s, c;
-            sh_det_sincosf(rays[2 * r] + pz, &s, &c);
+            const float ang = rays[2 * r] + pz;                           // :200-201 angle + pose.Z
+            if (ang == p->trig_angle[(size_t)r]) { s = p->trig_s[(size_t)r]; c = p->trig_c[(size_t)r]; }
+            else { sh_det_sincosf(ang, &s, &c); p->trig_angle[(size_t)r] = ang; p->trig_s[(size_t)r] = s; p->trig_c[(size_t)r] = c; }
             p->cloud[2 * (size_t)r] = px + rays[2 * r + 1] * c;           // :200
             p->cloud[2 * (size_t)r + 1] = py + rays[2 * r + 1] * s;       // :201
         }

@@ -14,6 +14,12 @@
  *     <dir>/k5.meta  "side cell_bits R scans"         k5_xy.f32 k5_poses.f32 k5_value.f32 k5_upd.i32
  *   exit code 0 = every comparison bit-exact; otherwise the first failure is printed.
  *
+ *   abi_harness <libslamhip.so> --bench-proc <hole_size> <rays> <candidates> <scans>
+ *     times slamhip_csproc_update (CoreSLAMProcessor.Update, CoreSLAMProcessor.cs:717-752) from a native caller: what a P/Invoke
+ *     caller pays per scan, without an interpreter in the loop (bench.py's own figure goes through Python / ctypes).  The scans are
+ *     a rectangular room seen from a slowly moving robot (ranges by ray / wall intersection, made here); prints one line
+ *     "proc_us_per_scan <x>".  Timing only: parity of this path is tests/test_gpu_coreslam.py's business.
+ *
  * Replaces nothing in the reference: it stands where Simulation/MainWindow.xaml.cs:69-72,145-146 would stand if it were a C
  * program ("all three callers go through the same extern "C" symbols").
  */
@@ -22,6 +28,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
+#include <time.h>
 
 typedef struct slamhip_ctx slamhip_ctx;
 typedef struct slamhip_cs slamhip_cs;
@@ -188,8 +196,78 @@ static int replay_k5(slamhip_ctx *ctx, const char *dir)
     return 0;
 }
 
+typedef struct slamhip_csproc slamhip_csproc;
+static int32_t (*p_csproc_create)(slamhip_ctx *, float, int32_t, int32_t, const float *, float, float, int32_t, int32_t, slamhip_csproc **);
+static int32_t (*p_csproc_destroy)(slamhip_csproc *);
+static int32_t (*p_csproc_update)(slamhip_csproc *, const float *, const int32_t *, int32_t, const float *);
+static int32_t (*p_csproc_get_pose)(slamhip_csproc *, float *);
+static int32_t (*p_ctx_synchronize)(slamhip_ctx *);
+
+/* range from (x, y) along angle a to the walls of the room [5,35] x [8,32] (metres; the robot stays inside) */
+static float room_range(double x, double y, double a)
+{
+    const double c = cos(a), s = sin(a);
+    double t = 1e9;
+    if (c > 1e-12) t = fmin(t, (35.0 - x) / c); else if (c < -1e-12) t = fmin(t, (5.0 - x) / c);
+    if (s > 1e-12) t = fmin(t, (32.0 - y) / s); else if (s < -1e-12) t = fmin(t, (8.0 - y) / s);
+    return (float)t;
+}
+
+static int bench_proc(void *h, int size, int R, int K, int scans)
+{
+    RESOLVE(p_csproc_create, "slamhip_csproc_create");
+    RESOLVE(p_csproc_destroy, "slamhip_csproc_destroy");
+    RESOLVE(p_csproc_update, "slamhip_csproc_update");
+    RESOLVE(p_csproc_get_pose, "slamhip_csproc_get_pose");
+    RESOLVE(p_ctx_synchronize, "slamhip_ctx_synchronize");
+    slamhip_ctx *ctx = NULL;
+    CALL(p_ctx_create(0, &ctx));
+    const float start[3] = { 20.0f, 20.0f, 0.0f };
+    slamhip_csproc *p = NULL;
+    const int threads = 64, iters = (K - 1) / threads;          /* (K - 1) jitters + the base pose, as the C# constructor's T x iterations */
+    CALL(p_csproc_create(ctx, 40.0f, size, size / 4, start, 0.1f, 0.17453292f, iters, threads, &p));
+    const int n_distinct = 64, warm = 12;
+    float *rays = malloc(sizeof(float) * 2 * (size_t)R * n_distinct), *poses = malloc(sizeof(float) * 3 * n_distinct);
+    for (int k = 0; k < n_distinct; k++) {
+        const double x = 20.0 + 0.04 * k, y = 20.0 + 0.015 * k, th = 0.004 * k;
+        poses[3 * k] = (float)x; poses[3 * k + 1] = (float)y; poses[3 * k + 2] = (float)th;
+        for (int i = 0; i < R; i++) {
+            const double a = (double)i * 6.283185307179586 / R;
+            rays[2 * ((size_t)k * R + i)] = (float)a;
+            rays[2 * ((size_t)k * R + i) + 1] = room_range(x, y, a + th) + 0.002f * (float)((i * 7 + k * 3) % 11 - 5);
+        }
+    }
+    const int32_t seg_start[2] = { 0, R };
+    for (int k = 0; k < warm; k++) CALL(p_csproc_update(p, poses + 3 * k, seg_start, 1, rays + 2 * (size_t)k * R));
+    CALL(p_ctx_synchronize(ctx));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int k = 0; k < scans; k++) {
+        const int j = warm + k % (n_distinct - warm);
+        CALL(p_csproc_update(p, poses + 3 * j, seg_start, 1, rays + 2 * (size_t)j * R));
+    }
+    CALL(p_ctx_synchronize(ctx));                                /* (Update returns with the pose; the last scan's map updates belong to the figure) */
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    float pose[3];
+    CALL(p_csproc_get_pose(p, pose));
+    printf("proc_us_per_scan %.3f  (%d scans, %d^2 map, %d rays, %d candidates; last pose %.3f %.3f %.4f)\n",
+           ((double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3) / scans, scans, size, R, threads * iters + 1, pose[0], pose[1], pose[2]);
+    CALL(p_csproc_destroy(p));
+    CALL(p_ctx_destroy(ctx));
+    free(rays); free(poses);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 7 && strcmp(argv[2], "--bench-proc") == 0) {
+        void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "abi_harness: dlopen failed: %s\n", dlerror()); return 2; }
+        RESOLVE(p_last_error, "slamhip_last_error");
+        RESOLVE(p_ctx_create, "slamhip_ctx_create");
+        RESOLVE(p_ctx_destroy, "slamhip_ctx_destroy");
+        return bench_proc(h, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+    }
     if (argc != 3) { fprintf(stderr, "usage: abi_harness <libslamhip.so> <fixture dir>\n"); return 1; }
     void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "abi_harness: dlopen failed: %s\n", dlerror()); return 2; }

@@ -20,7 +20,7 @@ def build_harness(tmp):
     if cc is None:
         pytest.skip("no C compiler")
     exe = os.path.join(tmp, "abi_harness")
-    subprocess.check_call([cc, "-O1", "-Wall", "-Werror", "-o", exe, SRC, "-ldl"])
+    subprocess.check_call([cc, "-O1", "-Wall", "-Werror", "-o", exe, SRC, "-ldl", "-lm"])
     return exe
 
 
@@ -81,3 +81,14 @@ def test_native_caller_replays_golden_fixtures(tmp_path):
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out
     assert "k1 ok" in out and "k2 ok" in out and "k5 ok" in out and "all golden replays bit-exact" in out
+
+
+@pytest.mark.gpu
+def test_native_caller_times_processor_update(tmp_path):
+    """--bench-proc: CoreSLAMProcessor.Update from the native caller (a short run: the mode works and tracks the room)."""
+    exe = build_harness(str(tmp_path))
+    r = subprocess.run([exe, lib_path(), "--bench-proc", "512", "360", "2049", "40"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "proc_us_per_scan" in out, out
+    us = float(out.split("proc_us_per_scan")[1].split()[0])
+    assert 1.0 < us < 5000.0, out
