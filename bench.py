@@ -491,7 +491,40 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
     ctx.synchronize()
     dt_f = (time.perf_counter() - t0) / 20
     mirror_ok = bool((mirror == d3.holemap_download()).all())
+    # ... and the asynchronous, span-exact mirror (slamhip_cs_holemap_mirror_async): after every scan ONE request -- the spans the
+    # scan's rays crossed are snapshotted on the device and pushed into the host array from a copy stream while the next scan
+    # runs; the array is waited for (slamhip_cs_holemap_mirror_wait, the C# `Pixels` getter) once per scan, just before the next
+    # request, as a caller that looks at the map after every scan would.  us_to_pose: the fused call on an idle device with a push
+    # of the previous scan still in flight -- what the mirror costs the scan itself.
+    amirror = np.zeros(2048 * 2048, np.uint16)
+    d3.holemap_mirror_async(amirror)
+    d3.holemap_mirror_wait()
+    for _ in range(5):
+        d3.search_and_update(b3)
+        d3.holemap_mirror_async(amirror)
+    d3.holemap_mirror_wait()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        d3.search_and_update(b3)
+        d3.holemap_mirror_async(amirror)           # (waits for the previous push first: one in flight)
+    _, pushed_px = d3.holemap_mirror_wait()
+    ctx.synchronize()
+    dt_a = (time.perf_counter() - t0) / 100
+    amirror_ok = bool((amirror == d3.holemap_download()).all())
+    lat_a = []
+    for _ in range(30):
+        ctx.synchronize()
+        d3.holemap_mirror_async(amirror)
+        t1 = time.perf_counter()
+        d3.search_and_update(b3)
+        lat_a.append(time.perf_counter() - t1)
+        d3.holemap_mirror_wait()
+    d3.holemap_mirror_release()
     out["c3_fused_search_and_map_updates_2048"] = {"us_per_scan": dt * 1e6, "scans_per_s": 1.0 / dt,
+                                                    "us_per_scan_with_async_mirror": dt_a * 1e6, "async_mirror_pixels_per_scan": int(pushed_px),
+                                                    "async_mirror_equals_full_download": amirror_ok,
+                                                    "us_to_pose_with_async_push_in_flight_median": float(np.median(lat_a)) * 1e6,
                                                     "search_evals_per_s": 16384 / dt,
                                                     "us_to_pose_idle_device_median": float(np.median(lat)) * 1e6,
                                                     "us_per_scan_with_mirror": dt_m * 1e6, "us_per_scan_with_full_downloads": dt_f * 1e6,
@@ -515,6 +548,26 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
     dt = (time.perf_counter() - t0) / 200
     out["coreslam_processor_update_2048_map_1080_rays_16384_candidates"] = {"us_per_scan": dt * 1e6, "scans_per_s": 1.0 / dt,
                                                                             "caller": "Python mirror of the C# class over ctypes (the interpreter's part of a scan is ~8 us)"}
+    # the same loop with the host mirror of the HoleMap kept up to date: one asynchronous request per scan behind the Update
+    # (what the C# shim's default MirrorMaps does) -- a MOVING robot, so what changes per scan is what a real run changes
+    pm = np.zeros(2048 * 2048, np.uint16)
+    proc.device.holemap_mirror_async(pm)
+    proc.device.holemap_mirror_wait()
+    px_acc = 0
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(200):
+        proc.Update([cs.ScanSegment(pscans[10 + i % 60], zero)])
+        proc.device.holemap_mirror_async(pm)       # (waits for the previous push first)
+        if i % 20 == 19:
+            px_acc += proc.device.holemap_mirror_wait()[1]
+    proc.device.holemap_mirror_wait()
+    ctx.synchronize()
+    dt_pm = (time.perf_counter() - t0) / 200
+    pm_ok = bool((pm == proc.device.holemap_download()).all())
+    proc.device.holemap_mirror_release()
+    out["coreslam_processor_update_2048_map_1080_rays_16384_candidates"].update({
+        "us_per_scan_with_async_mirror": dt_pm * 1e6, "async_mirror_pixels_per_scan_sampled": px_acc // 10, "async_mirror_equals_full_download": pm_ok})
     proc.Dispose()
     # ... and from a NATIVE caller of the C-ABI (tests/abi_harness.c --bench-proc: gcc, dlopen, slamhip_csproc_update in a C loop):
     # what a P/Invoke caller pays per scan.  A process of its own, while this one is idle.

@@ -55,10 +55,11 @@ namespace CoreSLAM
 
         /// <summary>Seed of the candidate generator (new: the reference seeds from entropy).</summary>
         public ulong Seed { get; set; } = 0x5EED5EEDUL;
-        /// <summary>Refresh the managed map mirrors after every Update (source compatibility).  The HoleMap mirror copies only the
-        /// bounding rectangle of the scan just drawn (slamhip_cs_holemap_mirror), the ObstacleMap is small and comes whole; the
-        /// copies wait for the map updates that Update would otherwise leave running while the host prepares its next scan
-        /// (bench.py, other_workloads: us_per_scan_with_mirror against us_per_scan).</summary>
+        /// <summary>Refresh the managed map mirrors after every Update (source compatibility).  The HoleMap mirror is asynchronous
+        /// (slamhip_cs_holemap_mirror_async: the 16-byte units that changed, pushed from a copy stream while the next scan runs;
+        /// HoleMap.Pixels waits for the push in flight), the ObstacleMap is small and comes whole -- its download waits for the
+        /// map updates that Update would otherwise leave running while the host prepares its next scan
+        /// (bench.py, other_workloads: us_per_scan_with_async_mirror against us_per_scan).</summary>
         public bool MirrorMaps { get; set; } = true;
 
         public CoreSLAMProcessor(float physicalMapSize, int holeMapSize, int obstacleMapSize, Vector3 startPose,
@@ -95,7 +96,7 @@ namespace CoreSLAM
             Pose = startPose;
             lastOdometryPose = Vector3.Zero;
             scanCount = 0;
-            if (MirrorMaps) { HoleMap.Mirror(); ObstacleMap.Download(); }
+            if (MirrorMaps) { HoleMap.MirrorAsync(); ObstacleMap.Download(); }
         }
 
         /// <summary>Use this jitter list (n x (dx, dy, dtheta), flat thread-major order) instead of generated ones.</summary>
@@ -153,7 +154,7 @@ namespace CoreSLAM
                     Native.Check(Native.slamhip_cs_update_obstaclemap(cs.Ptr, Pose, MaxObstacleHits));         // :751
                 }
             }
-            if (MirrorMaps) { HoleMap.Mirror(); ObstacleMap.Download(); }
+            if (MirrorMaps) { HoleMap.MirrorAsync(); ObstacleMap.Download(); }
         }
 
         // ScanSegmentsToCloud (:187-207): every segment's rays in the frame of the last odometry pose.

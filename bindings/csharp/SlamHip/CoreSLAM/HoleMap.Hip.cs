@@ -1,8 +1,10 @@
 // CoreSLAM.HoleMap on the GPU: the public surface of the reference class (CoreSLAM/HoleMap.cs:10-56) with the pixels
 // living in device memory.  `Pixels` stays a managed ushort[] because callers read it directly
-// (Simulation/MainWindow.xaml.cs:229): it is a MIRROR, refreshed by Download() (everything) or Mirror() (the rectangle
-// the scans since the last refresh touched) -- CoreSLAMProcessor.Update calls Mirror() after every scan when MirrorMaps is
-// set (the default, for source compatibility).
+// (Simulation/MainWindow.xaml.cs:229): it is a MIRROR, refreshed by Download() (everything), Mirror() (blocking: the rectangle
+// the scans since the last refresh touched) or MirrorAsync() (the 16-byte units that changed, pushed from a copy stream while
+// the next scan runs) -- CoreSLAMProcessor.Update calls MirrorAsync() after every scan when MirrorMaps is set (the default, for
+// source compatibility), and the `Pixels` getter waits for the push that is in flight: a reader never sees a half-written map,
+// and a caller that does not look at the map pays nothing for it.
 using System;
 using SlamHip;
 
@@ -12,8 +14,15 @@ namespace CoreSLAM
     {
         private readonly Handle cs;                                     // slamhip_cs of the owning processor
 
-        /// <summary>Host mirror of the device pixels, row-major [y * Size + x] (HoleMap.cs:27).</summary>
-        public readonly ushort[] Pixels;
+        private readonly ushort[] pixels;
+        private bool pushInFlight;
+
+        /// <summary>Host mirror of the device pixels, row-major [y * Size + x] (HoleMap.cs:27).  Reading it waits for an
+        /// asynchronous refresh that is still in flight (slamhip_cs_holemap_mirror_wait).</summary>
+        public ushort[] Pixels
+        {
+            get { WaitMirror(); return pixels; }
+        }
 
         /// <summary>Side length in pixels (HoleMap.cs:32).</summary>
         public int Size { get; }
@@ -28,14 +37,15 @@ namespace CoreSLAM
             Scale = scale;
             // (on the pinned object heap: the address never changes, so the library page-locks the array once for its partial
             // mirror copies -- slamhip_cs_holemap_mirror)
-            Pixels = GC.AllocateArray<ushort>(sizePixels * sizePixels, pinned: true);
+            pixels = GC.AllocateArray<ushort>(sizePixels * sizePixels, pinned: true);
         }
 
         /// <summary>Refresh Pixels from the device (2 bytes per pixel over PCIe: 8 MiB at 2048 x 2048).</summary>
         public unsafe void Download()
         {
-            fixed (ushort* p = Pixels)
-                Native.Check(Native.slamhip_cs_holemap_download(cs.Ptr, p, (nuint)Pixels.Length));
+            WaitMirror();
+            fixed (ushort* p = pixels)
+                Native.Check(Native.slamhip_cs_holemap_download(cs.Ptr, p, (nuint)pixels.Length));
         }
 
         /// <summary>Bring Pixels up to date by copying only what the updates since the last Mirror()/Download() call can have
@@ -44,22 +54,43 @@ namespace CoreSLAM
         public unsafe void Mirror()
         {
             int* rect = stackalloc int[4];
-            fixed (ushort* p = Pixels)
-                Native.Check(Native.slamhip_cs_holemap_mirror(cs.Ptr, p, (nuint)Pixels.Length, rect));
+            WaitMirror();
+            fixed (ushort* p = pixels)
+                Native.Check(Native.slamhip_cs_holemap_mirror(cs.Ptr, p, (nuint)pixels.Length, rect));
+        }
+
+        /// <summary>Asynchronous refresh: enqueues the snapshot of what changed since the last refresh behind the map updates in
+        /// flight and returns at once; the data arrive from a copy stream while the next scan runs.  (The pinned array is
+        /// page-locked and mapped into the device's address space by the library on the first call.)</summary>
+        public unsafe void MirrorAsync()
+        {
+            fixed (ushort* p = pixels)
+                Native.Check(Native.slamhip_cs_holemap_mirror_async(cs.Ptr, p, (nuint)pixels.Length));
+            pushInFlight = true;
+        }
+
+        /// <summary>Waits for the refresh in flight, if any (the `Pixels` getter calls it).</summary>
+        public unsafe void WaitMirror()
+        {
+            if (!pushInFlight) return;
+            long px;
+            Native.Check(Native.slamhip_cs_holemap_mirror_wait(cs.Ptr, null, &px));
+            pushInFlight = false;
         }
 
         /// <summary>Replace the device pixels with Pixels (restoring a saved map).</summary>
         public unsafe void Upload()
         {
-            fixed (ushort* p = Pixels)
-                Native.Check(Native.slamhip_cs_holemap_upload(cs.Ptr, p, (nuint)Pixels.Length));
+            WaitMirror();
+            fixed (ushort* p = pixels)
+                Native.Check(Native.slamhip_cs_holemap_upload(cs.Ptr, p, (nuint)pixels.Length));
         }
 
         /// <summary>Two pixels per byte, the 4 most significant bits of each (HoleMap.cs:44-55) -- packed on the device, so only
         /// a quarter of the map crosses PCIe.</summary>
         public unsafe byte[] GetPackedPixels()
         {
-            byte[] packed = new byte[Pixels.Length / 2];
+            byte[] packed = new byte[pixels.Length / 2];
             fixed (byte* p = packed)
                 Native.Check(Native.slamhip_cs_holemap_download_packed(cs.Ptr, p, (nuint)packed.Length));
             return packed;

@@ -33,6 +33,9 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_cs_holemap_download(IntPtr cs, ushort* pixels, nuint n);
         [DllImport(Lib)] internal static extern int slamhip_cs_holemap_download_packed(IntPtr cs, byte* packed, nuint nBytes);
         [DllImport(Lib)] internal static extern int slamhip_cs_holemap_mirror(IntPtr cs, ushort* pixels, nuint n, int* rectX0Y0X1Y1);
+        [DllImport(Lib)] internal static extern int slamhip_cs_holemap_mirror_async(IntPtr cs, ushort* pixels, nuint n);
+        [DllImport(Lib)] internal static extern int slamhip_cs_holemap_mirror_wait(IntPtr cs, int* rectX0Y0X1Y1, long* pixelsPushed);
+        [DllImport(Lib)] internal static extern int slamhip_cs_holemap_mirror_release(IntPtr cs);
         [DllImport(Lib)] internal static extern int slamhip_cs_obstaclemap_upload(IntPtr cs, sbyte* pixels, nuint n);
         [DllImport(Lib)] internal static extern int slamhip_cs_obstaclemap_download(IntPtr cs, sbyte* pixels, nuint n);
         [DllImport(Lib)] internal static extern int slamhip_cs_set_scan(IntPtr cs, Vector2* points, int nPoints);

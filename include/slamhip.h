@@ -117,6 +117,21 @@ int32_t slamhip_cs_holemap_download(slamhip_cs *cs, uint16_t *pixels, size_t n_p
  * (everything on the first call and after reset / upload).  out_rect (optional) = {x0, y0, x1, y1} inclusive, or {0, 0, -1, -1}
  * when nothing changed.  `pixels` must be the array the previous mirror call filled. */
 int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pixels, size_t n_pixels, int32_t out_rect[4]);
+/* The same without stalling the scan (the reference's callers read HoleMap.Pixels live: HoleMap.cs:27,
+ * Simulation/MainWindow.xaml.cs:227-249).  From the first call on the HoleMap updates keep, per map row, the span of columns their
+ * rays crossed.  _async enqueues behind everything queued so far ONE launch that copies those spans into a shadow map on the
+ * device and rests them, and -- on a copy stream, behind an event -- a launch that stores the shadow's spans straight into
+ * `pixels`; it returns at once, and the next search starts as soon as the snapshot is taken.  _wait blocks until the last push
+ * has landed; out_rect = the bounding rectangle x0, y0, x1, y1 of what it refreshed (x1 < x0: nothing), *out_pixels = the pixels
+ * of its spans.  After _wait, `pixels` equals a full download taken at the moment of the _async call.
+ * Contract: `pixels` is PAGE-LOCKED and mapped into the device's address space on its first use (hipHostRegister: 8 MiB at 2048^2,
+ * 512 MiB at 16384^2) and stays so until slamhip_cs_holemap_mirror_release, slamhip_cs_destroy, or a call with another array --
+ * the caller must keep it alive (and, in managed code, at a fixed address: pinned object heap / GCHandle) until then and must
+ * not read it between _async and _wait.  One push is in flight at a time: _async waits for the previous one first.  The
+ * blocking slamhip_cs_holemap_mirror page-locks its array the same way. */
+int32_t slamhip_cs_holemap_mirror_async(slamhip_cs *cs, uint16_t *pixels, size_t n_pixels);
+int32_t slamhip_cs_holemap_mirror_wait(slamhip_cs *cs, int32_t out_rect[4], int64_t *out_pixels);
+int32_t slamhip_cs_holemap_mirror_release(slamhip_cs *cs);   /* waits, then unregisters the array (either mirror form) */
 /* HoleMap.GetPackedPixels (HoleMap.cs:44-55): 4-bit packing done on the device; n_bytes = Size*Size/2 */
 int32_t slamhip_cs_holemap_download_packed(slamhip_cs *cs, uint8_t *packed, size_t n_bytes);
 /* ObstacleMap.Pixels (ObstacleMap.cs:31): sbyte[Size,Size], [y,x] row-major */

@@ -71,6 +71,9 @@ def _declare(L):
         "slamhip_cs_holemap_download": (i32, [vp, u16p, sz]),
         "slamhip_cs_holemap_download_packed": (i32, [vp, u8p, sz]),
         "slamhip_cs_holemap_mirror": (i32, [vp, u16p, sz, ip]),
+        "slamhip_cs_holemap_mirror_async": (i32, [vp, u16p, sz]),
+        "slamhip_cs_holemap_mirror_wait": (i32, [vp, ip, P(i64)]),
+        "slamhip_cs_holemap_mirror_release": (i32, [vp]),
         "slamhip_cs_obstaclemap_upload": (i32, [vp, i8p, sz]),
         "slamhip_cs_obstaclemap_download": (i32, [vp, i8p, sz]),
         "slamhip_cs_set_scan": (i32, [vp, fp, i32]),

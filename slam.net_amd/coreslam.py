@@ -119,6 +119,24 @@ class CoreSlamDevice:
         capi.call("slamhip_cs_holemap_mirror", self._h, pixels.ctypes.data_as(C.POINTER(C.c_uint16)), pixels.size, capi.iptr(rect))
         return tuple(int(v) for v in rect)
 
+    def holemap_mirror_async(self, pixels):
+        """Asynchronous, span-exact refresh of the host mirror `pixels` (slamhip_cs_holemap_mirror_async): returns at once; the
+        array is page-locked on first use, must stay alive until holemap_mirror_release / close, and must not be read before
+        holemap_mirror_wait."""
+        assert pixels.dtype == np.uint16 and pixels.size == self.hole_size * self.hole_size and pixels.flags.c_contiguous
+        self._mirror_keepalive = pixels
+        capi.call("slamhip_cs_holemap_mirror_async", self._h, pixels.ctypes.data_as(C.POINTER(C.c_uint16)), pixels.size)
+
+    def holemap_mirror_wait(self):
+        """Waits for the last asynchronous mirror push; returns ((x0, y0, x1, y1), pixels pushed)."""
+        rect = np.zeros(4, np.int32); px = C.c_int64()
+        capi.call("slamhip_cs_holemap_mirror_wait", self._h, capi.iptr(rect), C.byref(px))
+        return tuple(int(v) for v in rect), int(px.value)
+
+    def holemap_mirror_release(self):
+        capi.call("slamhip_cs_holemap_mirror_release", self._h)
+        self._mirror_keepalive = None
+
     def obstaclemap_upload(self, pixels):
         p = np.ascontiguousarray(pixels, np.int8).reshape(-1)
         capi.call("slamhip_cs_obstaclemap_upload", self._h, p.ctypes.data_as(C.POINTER(C.c_int8)), p.size)

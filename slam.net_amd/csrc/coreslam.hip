@@ -143,6 +143,11 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_verify);
     (void)hipFree(cs->d_k1_gmin); (void)hipFree(cs->d_k1_acc); (void)hipFree(cs->d_k1_ring);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
+    if (cs->mirror_stream) { (void)hipStreamSynchronize(cs->mirror_stream); (void)hipStreamDestroy(cs->mirror_stream); }
+    if (cs->ev_snap) (void)hipEventDestroy(cs->ev_snap);
+    if (cs->ev_push) (void)hipEventDestroy(cs->ev_push);
+    (void)hipFree(cs->d_hole_span); (void)hipFree(cs->d_hole_span_snap); (void)hipFree(cs->d_hole_shadow); (void)hipFree(cs->d_mirror_sum); (void)hipFree(cs->d_mirror_mask);
+    if (cs->h_mirror_sum) (void)hipHostFree(cs->h_mirror_sum);
     if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
     cs_holemap_free(cs);
     cs_obstacle_free(cs);
@@ -204,6 +209,7 @@ extern "C" int32_t slamhip_cs_reset(slamhip_cs *cs, int32_t unmapped)
     SH_TRY(cs_obstacle_flush(cs));
     SH_HIP(hipMemsetAsync(cs->d_obst, (int)(uint8_t)(int8_t)unmapped, (size_t)cs->os * cs->os, cs->ctx->stream)); // :170
     SH_TRY(cs_holemap_dirty_set(cs, true));
+    SH_TRY(cs_holemap_span_set(cs, true));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     return SLAMHIP_OK;
 }
@@ -215,6 +221,7 @@ extern "C" int32_t slamhip_cs_holemap_upload(slamhip_cs *cs, const uint16_t *pix
     SH_HIP(hipSetDevice(cs->ctx->device));
     SH_HIP(hipMemcpyAsync(cs->d_hole, pix, n * sizeof(uint16_t), hipMemcpyHostToDevice, cs->ctx->stream));
     SH_TRY(cs_holemap_dirty_set(cs, true));
+    SH_TRY(cs_holemap_span_set(cs, true));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     return SLAMHIP_OK;
 }
@@ -249,7 +256,12 @@ extern "C" int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pix, size
         // A managed caller keeps the array at a fixed address (pinned object heap / GCHandle), as the C# shim's HoleMap does.
         static const bool no_reg = getenv("SLAMHIP_MIRROR_NOREG") != nullptr;
         if (!no_reg && (cs->mirror_reg != (void *)pix || cs->mirror_reg_bytes != n * sizeof(uint16_t))) {
-            if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
+            if (cs->mirror_stream) { (void)hipStreamSynchronize(cs->mirror_stream); (void)hipStreamDestroy(cs->mirror_stream); }
+    if (cs->ev_snap) (void)hipEventDestroy(cs->ev_snap);
+    if (cs->ev_push) (void)hipEventDestroy(cs->ev_push);
+    (void)hipFree(cs->d_hole_span); (void)hipFree(cs->d_hole_span_snap); (void)hipFree(cs->d_hole_shadow); (void)hipFree(cs->d_mirror_sum); (void)hipFree(cs->d_mirror_mask);
+    if (cs->h_mirror_sum) (void)hipHostFree(cs->h_mirror_sum);
+    if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
             cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0;
             if (hipHostRegister(pix, n * sizeof(uint16_t), hipHostRegisterDefault) == hipSuccess) { cs->mirror_reg = pix; cs->mirror_reg_bytes = n * sizeof(uint16_t); }
             else (void)hipGetLastError();                          // (not registrable: the copy below still works, slowly)
@@ -267,6 +279,178 @@ extern "C" int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pix, size
         SH_HIP(hipStreamSynchronize(ctx->stream));
     } else { r[0] = r[1] = 0; r[2] = r[3] = -1; }
     if (out_rect) memcpy(out_rect, r, sizeof(r));
+    return SLAMHIP_OK;
+}
+
+
+// ---- asynchronous, span-exact host mirror -----------------------------------------------------------------------------------
+// `HoleMap.Pixels` is read live by the reference's callers (HoleMap.cs:27; Simulation/MainWindow.xaml.cs:227-249), so a
+// source-compatible shim keeps a host mirror.  The blocking form above stalls every scan for the bounding rectangle of the scan
+// (7 of 8 MiB at 2048^2: 258 us per scan against 44 without).  This form moves what was DRAWN and does not stall the scan:
+//   K2 keeps, per map row, the column span its rays crossed since the last snapshot (k2_row_spans, holemap.hip);
+//   slamhip_cs_holemap_mirror_async enqueues, behind the updates on the operator's stream, ONE launch that copies those spans into a
+//   shadow map (device to device: microseconds), takes the spans with it and rests them; on a copy stream, behind an event, a
+//   second launch pushes the shadow's spans straight into the caller's array -- page-locked and mapped into the device's address
+//   space on first use, so the stores travel over PCIe from the lanes, span by span, with no staging and no compaction -- and a
+//   16-byte summary follows; the next search starts as soon as the snapshot is taken;
+//   slamhip_cs_holemap_mirror_wait (the C# `Pixels` getter) waits for the push.
+__global__ void __launch_bounds__(256) k_span_fill(int2 *__restrict__ span, int size, int full)
+{
+    const int y = blockIdx.x * 256 + threadIdx.x;
+    if (y < size) span[y] = full ? make_int2(0, size - 1) : make_int2(size, -1);
+}
+// One wavefront per row: the row's span in 8-pixel (16-byte) units, map against shadow -- a unit that DIFFERS is copied into the
+// shadow and marked in the row's bit mask (a span covers what the rays crossed; what they changed is less: a pixel that is blended
+// towards the value it already has -- free space in a mapped area -- keeps it, and only what changed needs to travel).  The span
+// moves to the snapshot table and is rested; the summary (bounding rectangle of the changed units, their pixels, rows) through
+// wave-level atomics.  `all`: the shadow holds nothing yet (first request, another array): every unit of the span is news.
+__global__ void __launch_bounds__(256) k_mirror_snapshot(const uint16_t *__restrict__ map, uint16_t *__restrict__ shadow, int2 *__restrict__ span,
+                                                         int2 *__restrict__ snap, unsigned long long *__restrict__ mask, int chunks, int size, int all,
+                                                         int *__restrict__ sum)
+{
+    const int lane = threadIdx.x & 63, y = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (y >= size) return;
+    const int2 sp = span[y];
+    if (lane == 0) { snap[y] = sp; span[y] = make_int2(size, -1); }
+    if (sp.y < sp.x) return;
+    const size_t row = (size_t)y * size;
+    const int upr = (size + 7) >> 3;                               // units per row (the last may be short: rows that are not whole units go pixel by pixel)
+    const bool vec = size % 8 == 0;
+    int n_changed = 0, ulo = upr, uhi = -1;
+    for (int c = (sp.x >> 3) >> 6; c <= (sp.y >> 3) >> 6; c++) {
+        const int u = c * 64 + lane;
+        bool ch = false;
+        if (u >= (sp.x >> 3) && u <= (sp.y >> 3) && u < upr) {
+            if (vec) {
+                const uint4 a = ((const uint4 *)(map + row))[u], b = ((const uint4 *)(shadow + row))[u];
+                ch = all || a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+                if (ch) ((uint4 *)(shadow + row))[u] = a;
+            } else {
+                for (int x = u * 8; x < u * 8 + 8 && x < size; x++) {
+                    const uint16_t a = map[row + x];
+                    if (all || a != shadow[row + x]) { ch = true; shadow[row + x] = a; }
+                }
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ch);
+        if (lane == 0) mask[(size_t)y * chunks + c] = m;
+        if (m) {
+            n_changed += __builtin_popcountll(m);
+            ulo = min(ulo, c * 64 + (int)__builtin_ctzll(m)); uhi = max(uhi, c * 64 + 63 - (int)__builtin_clzll(m));
+        }
+    }
+    if (lane == 0 && n_changed > 0) {
+        atomicMin(&sum[0], ulo * 8); atomicMin(&sum[1], y); atomicMax(&sum[2], min(uhi * 8 + 7, size - 1)); atomicMax(&sum[3], y);
+        atomicAdd((unsigned long long *)&sum[4], (unsigned long long)n_changed * 8ull);
+        atomicAdd(&sum[6], 1);
+    }
+}
+// the shadow's marked units into the caller's array (host memory mapped into the device's address space), a wavefront per row at a time
+__global__ void __launch_bounds__(256) k_mirror_push(const uint16_t *__restrict__ shadow, const int2 *__restrict__ snap, const unsigned long long *__restrict__ mask,
+                                                     int chunks, uint16_t *__restrict__ host, int size)
+{
+    const int lane = threadIdx.x & 63, wpb = 4;
+    const int upr = (size + 7) >> 3;
+    const bool vec = size % 8 == 0 && ((size_t)host & 15) == 0;
+    for (int y = (int)blockIdx.x * wpb + (int)(threadIdx.x >> 6); y < size; y += (int)gridDim.x * wpb) {
+        const int2 sp = snap[y];
+        if (sp.y < sp.x) continue;
+        const size_t row = (size_t)y * size;
+        for (int c = (sp.x >> 3) >> 6; c <= (sp.y >> 3) >> 6; c++) {
+            const unsigned long long m = mask[(size_t)y * chunks + c];
+            const int u = c * 64 + lane;
+            if (!((m >> lane) & 1ull) || u >= upr) continue;
+            if (vec) ((uint4 *)(host + row))[u] = ((const uint4 *)(shadow + row))[u];
+            else for (int x = u * 8; x < u * 8 + 8 && x < size; x++) host[row + x] = shadow[row + x];
+        }
+    }
+}
+
+__global__ void k_mirror_sum_rest(int *__restrict__ sum)
+{
+    if (threadIdx.x < 8) sum[threadIdx.x] = threadIdx.x < 2 ? 0x7fffffff : threadIdx.x < 4 ? -1 : 0;
+}
+
+static int32_t mirror_resources(slamhip_cs *cs)
+{
+    if (cs->d_hole_span) return SLAMHIP_OK;
+    const size_t npix = (size_t)cs->hs * cs->hs;
+    SH_HIP(hipMalloc(&cs->d_hole_span, sizeof(int2) * (size_t)cs->hs));
+    SH_HIP(hipMalloc(&cs->d_hole_span_snap, sizeof(int2) * (size_t)cs->hs));
+    SH_HIP(hipMalloc(&cs->d_hole_shadow, sizeof(uint16_t) * npix));
+    cs->mirror_chunks = (((cs->hs + 7) >> 3) + 63) >> 6;           // 64-unit chunks per row: one mask word each
+    SH_HIP(hipMalloc(&cs->d_mirror_mask, sizeof(unsigned long long) * (size_t)cs->hs * cs->mirror_chunks));
+    SH_HIP(hipMalloc(&cs->d_mirror_sum, sizeof(int) * 8));
+    SH_HIP(hipHostMalloc(&cs->h_mirror_sum, sizeof(int) * 8));
+    SH_HIP(hipStreamCreateWithFlags(&cs->mirror_stream, hipStreamNonBlocking));
+    SH_HIP(hipEventCreateWithFlags(&cs->ev_snap, hipEventDisableTiming));
+    SH_HIP(hipEventCreateWithFlags(&cs->ev_push, hipEventDisableTiming));
+    return SLAMHIP_OK;
+}
+
+// every row's span := the whole row / empty (enqueued on the operator's stream); a no-op while no mirror is kept
+int32_t cs_holemap_span_set(slamhip_cs *cs, bool all)
+{
+    if (!cs->mirror_on) return SLAMHIP_OK;
+    hipLaunchKernelGGL(k_span_fill, dim3(sh_div_up(cs->hs, 256)), dim3(256), 0, cs->ctx->stream, cs->d_hole_span, cs->hs, all ? 1 : 0);
+    SH_HIP(hipGetLastError());
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_holemap_mirror_release(slamhip_cs *cs)
+{
+    SH_CHECK_ARG(cs);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (cs->mirror_stream) SH_HIP(hipStreamSynchronize(cs->mirror_stream));
+    SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+    cs->mirror_pending = false;
+    if (cs->mirror_reg) { (void)hipHostUnregister(cs->mirror_reg); cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0; cs->mirror_dev_ptr = nullptr; }
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_holemap_mirror_wait(slamhip_cs *cs, int32_t out_rect[4], int64_t *out_pixels)
+{
+    SH_CHECK_ARG(cs);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (cs->mirror_pending) { SH_HIP(hipEventSynchronize(cs->ev_push)); cs->mirror_pending = false; }
+    const int *h = cs->h_mirror_sum;
+    const bool any = h && h[6] > 0;
+    if (out_rect) { out_rect[0] = any ? h[0] : 0; out_rect[1] = any ? h[1] : 0; out_rect[2] = any ? h[2] : -1; out_rect[3] = any ? h[3] : -1; }
+    if (out_pixels) *out_pixels = any ? (int64_t)(((uint64_t)(uint32_t)h[5] << 32) | (uint32_t)h[4]) : 0;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_holemap_mirror_async(slamhip_cs *cs, uint16_t *pix, size_t n)
+{
+    SH_CHECK_ARG(cs && pix && n == (size_t)cs->hs * cs->hs);
+    slamhip_ctx *ctx = cs->ctx;
+    SH_HIP(hipSetDevice(ctx->device));
+    SH_TRY(mirror_resources(cs));
+    if (cs->mirror_pending) SH_TRY(slamhip_cs_holemap_mirror_wait(cs, nullptr, nullptr));    // (one push in flight: the shadow and its spans are single)
+    bool fresh = !cs->mirror_on;                                   // the first call: everything the device holds is news to this array
+    if (cs->mirror_reg != (void *)pix || cs->mirror_reg_bytes != n * sizeof(uint16_t) || !cs->mirror_dev_ptr) {
+        if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
+        cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0; cs->mirror_dev_ptr = nullptr;
+        SH_HIP(hipHostRegister(pix, n * sizeof(uint16_t), hipHostRegisterMapped));
+        cs->mirror_reg = pix; cs->mirror_reg_bytes = n * sizeof(uint16_t);
+        SH_HIP(hipHostGetDevicePointer(&cs->mirror_dev_ptr, pix, 0));
+        fresh = true;                                              // (another array: it holds nothing yet)
+    }
+    cs->mirror_on = true;
+    if (fresh) SH_TRY(cs_holemap_span_set(cs, true));
+    hipLaunchKernelGGL(k_mirror_sum_rest, dim3(1), dim3(64), 0, ctx->stream, cs->d_mirror_sum);
+    hipLaunchKernelGGL(k_mirror_snapshot, dim3(sh_div_up(cs->hs, 4)), dim3(256), 0, ctx->stream, (const uint16_t *)cs->d_hole, cs->d_hole_shadow,
+                       cs->d_hole_span, cs->d_hole_span_snap, cs->d_mirror_mask, cs->mirror_chunks, cs->hs, fresh ? 1 : 0, cs->d_mirror_sum);
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipEventRecord(cs->ev_snap, ctx->stream));
+    SH_HIP(hipStreamWaitEvent(cs->mirror_stream, cs->ev_snap, 0));
+    static const int push_wgs = getenv("SLAMHIP_MIRROR_WGS") ? atoi(getenv("SLAMHIP_MIRROR_WGS")) : 32;
+    hipLaunchKernelGGL(k_mirror_push, dim3(push_wgs > 0 ? push_wgs : 32), dim3(256), 0, cs->mirror_stream, (const uint16_t *)cs->d_hole_shadow,
+                       (const int2 *)cs->d_hole_span_snap, (const unsigned long long *)cs->d_mirror_mask, cs->mirror_chunks, (uint16_t *)cs->mirror_dev_ptr, cs->hs);
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipMemcpyAsync(cs->h_mirror_sum, cs->d_mirror_sum, sizeof(int) * 8, hipMemcpyDeviceToHost, cs->mirror_stream));
+    SH_HIP(hipEventRecord(cs->ev_push, cs->mirror_stream));
+    cs->mirror_pending = true;
     return SLAMHIP_OK;
 }
 

@@ -108,6 +108,16 @@ struct slamhip_cs {
     int *d_k2_counters;           // [0] longest ray, [1] conflict pixels, [2] blended pixels, [3] x1, [4] y1
     int *d_conflict_pix; int cap_conflict;
     void *mirror_reg; size_t mirror_reg_bytes;   // the caller's mirror array, page-locked on first use (slamhip_cs_holemap_mirror)
+    // asynchronous host mirror (slamhip_cs_holemap_mirror_async): per-row column spans of what the updates since the last snapshot
+    // may have changed (K2 keeps them while mirror_on), a shadow map the snapshot launch copies the spans into, the spans as
+    // snapshotted, a copy stream on which a launch pushes the shadow's spans into the caller's (page-locked, device-mapped) array
+    bool mirror_on, mirror_pending;
+    int2 *d_hole_span, *d_hole_span_snap;       // [hs] (first column, last column); empty: (hs, -1)
+    uint16_t *d_hole_shadow;                    // [hs * hs]
+    unsigned long long *d_mirror_mask; int mirror_chunks;   // [hs][mirror_chunks]: per row and 64 units (of 8 pixels) the units the last snapshot found changed
+    int *d_mirror_sum; int *h_mirror_sum;       // [8] x0, y0, x1, y1, pixels (low, high), rows, -: what the last snapshot holds (device; pinned host copy)
+    hipStream_t mirror_stream; hipEvent_t ev_snap, ev_push;
+    void *mirror_dev_ptr;                       // the device address of the registered host array
     int *d_hole_dirty;            // [4] x0, y0, x1, y1 (inclusive): pixels the HoleMap updates may have changed since the last slamhip_cs_holemap_mirror
     int64_t last_hole_pixels;
     bool hole_pixels_pending;     // ... still on the device (d_key word 6): slamhip_cs_search_and_update returned with the pose, the updates run on
@@ -130,7 +140,8 @@ void cs_layout_idle_refresh(slamhip_cs *cs);   // host only: call between a sear
 int32_t cs_flush_generate(slamhip_cs *cs);
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);
-int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all);   // the dirty rectangle := the whole map / empty (enqueued on the operator's stream)
+int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all);
+int32_t cs_holemap_span_set(slamhip_cs *cs, bool all);    // coreslam.hip: the asynchronous mirror's row spans := whole rows / empty (no-op while no mirror is kept)   // the dirty rectangle := the whole map / empty (enqueued on the operator's stream)
 void    cs_holemap_free(slamhip_cs *cs);
 int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality, int32_t max_hits);
 int32_t cs_update_maps_finish(slamhip_cs *cs);

@@ -562,7 +562,7 @@ static inline size_t k2_lds_bytes(bool build, int n_rays) { return build ? (size
 struct k2_t3 { int ptr, dx, dy, ray, lim2; uint16_t pix; };
 
 // what the kernel needs of the scan when it makes the tables itself
-struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, rc_num; };
+struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, rc_num; int2 *span; };
 
 // BUILD: ONE launch per HoleMap update.  Every workgroup makes the scan's ray tables itself, in LDS -- per ray the literal
 // arithmetic of :519-530 / :361-399 (k2_make_ray), a counting sort into 4 direction classes x 1024 slope buckets -- instead of
@@ -587,6 +587,81 @@ __device__ static __forceinline__ void k2_ride_tail(const k3_ride &ride, bool ri
             for (int c = 0; c < ride.chunks_per_ray && (long long)c * 64 <= wk.n; c++)
                 k3_walk_iter(wk, (long long)c * 64 + (int)(threadIdx.x & 63), ride.size, ride.hits, ride.nohit);
         }
+    }
+}
+
+// Row spans for the asynchronous host mirror (slamhip_cs_holemap_mirror_async): per map row the interval of columns that the
+// updates since the last snapshot may have changed.  Workgroup w owns the rows [w * rpw, (w + 1) * rpw) and is their only writer;
+// it walks the scan's rays (the by-index table: clipped lengths, direction flags) and, for every row of its band a ray crosses,
+// the columns the ray's steps fall into there -- from the closed form of the step positions (m(k) of the table comment above):
+// one column for a y-major ray, the run of an x-major one, a pixel of margin either side (the spans must COVER what was drawn,
+// no more is asked of them).  Division-free for maps up to 16384 (the float reciprocal, settled exactly, as in the step lanes).
+template <typename T>
+__device__ static inline T k2_floor_div(T N, T D)                   // N >= 0, D > 0
+{
+    if (sizeof(T) == 4) {
+        T q = (T)((float)N * __builtin_amdgcn_rcpf((float)D));
+        T r = N - q * D;
+        if (r < 0) { q--; r += D; } else if (r >= D) { q++; r -= D; }
+        if (r < 0) q--; else if (r >= D) q++;
+        return q;
+    }
+    return N / D;
+}
+template <typename T>
+__device__ static __noinline__ void k2_row_spans(const k2_byidx *byidx, int n_rays, int x1, int y1, int size, int n_pix_wgs, int2 *__restrict__ span)
+{
+    __shared__ int s_lo[128], s_hi[128];
+    const int t = threadIdx.x;
+    const int rpw = (size + n_pix_wgs - 1) / n_pix_wgs;
+    const int band0 = (int)blockIdx.x * rpw, band1 = min(band0 + rpw, size);
+    for (int row0 = band0; row0 < band1; row0 += 128) {
+        const int nrow = min(128, band1 - row0);
+        if (t < 128) { s_lo[t] = size; s_hi[t] = -1; }
+        __syncthreads();
+        for (int i = t; i < n_rays; i += 1024) {
+            const k2_byidx e = byidx[i];
+            if (!(e.flags & 1)) continue;
+            const int smaj = ((e.flags >> 2) & 3) - 1, major_x = (e.flags >> 1) & 1;
+            const int dxc = e.dxc, sd = e.sdyc, dyc = sd < 0 ? -sd : sd, sgn = sd < 0 ? -1 : 1;
+            const int mcap = dyc < dxc ? dyc : dxc;                // (the minor offset never exceeds the major one: m(k) <= k)
+            const int ye = major_x ? y1 + sgn * mcap : y1 + smaj * dxc;
+            const int ya = max(min(y1, ye), row0), yb = min(max(y1, ye), row0 + nrow - 1);
+            const bool odd = dyc > dxc;                            // (a ray whose clip wrapped: covered generously)
+            for (int y = ya; y <= yb; y++) {
+                int xa, xb;
+                if (odd) {
+                    const int xe = major_x ? x1 + smaj * dxc : x1 + sgn * mcap;
+                    xa = min(x1, xe); xb = max(x1, xe);
+                } else if (!major_x) {                             // y-major: one pixel in the row
+                    const int k = (y - y1) * smaj;
+                    const T N = (T)2 * dyc * k - dxc, D = (T)2 * dxc;
+                    int m = 0;
+                    if (N > 0) { const T q = k2_floor_div<T>(N + D - 1, D); m = q < (T)k ? (int)q : k; }
+                    xa = xb = x1 + sgn * m;
+                } else {                                           // x-major: the steps k with m(k) = j
+                    const int j = (y - y1) * sgn;
+                    int klo = 0, khi = dxc;
+                    if (dyc > 0) {
+                        if (j > 0) klo = (int)k2_floor_div<T>((T)dxc * (2 * j - 1), (T)2 * dyc);
+                        khi = (int)k2_floor_div<T>((T)dxc * (2 * j + 1), (T)2 * dyc) + 1;
+                        if (khi > dxc) khi = dxc;
+                        if (klo > dxc) klo = dxc;
+                    }
+                    const int p = x1 + smaj * klo, q = x1 + smaj * khi;
+                    xa = min(p, q); xb = max(p, q);
+                }
+                xa = max(xa - 1, 0); xb = min(xb + 1, size - 1);
+                atomicMin(&s_lo[y - row0], xa); atomicMax(&s_hi[y - row0], xb);
+            }
+        }
+        __syncthreads();
+        if (t < nrow && s_hi[t] >= s_lo[t]) {
+            int2 g = span[row0 + t];
+            g.x = min(g.x, s_lo[t]); g.y = max(g.y, s_hi[t]);
+            span[row0 + t] = g;
+        }
+        __syncthreads();
     }
 }
 
@@ -848,6 +923,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     // drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
     K2_STAMP(3)
     if (BUILD && ride.on) k2_ride_tail(ride, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p);
+    if (sc.span) k2_row_spans<T>(byidx, n_rays, x1, y1, size, n_pix_wgs, sc.span);    // (only while a host mirror is being kept: slamhip_cs_holemap_mirror_async)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     K2_STAMP(4)
@@ -924,6 +1000,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     k2_scan sc;
     sc.pts = cs->d_pts; sc.scale = cs->hscale; sc.hole_width = hole_width; sc.d_pose = d_pose; sc.h_pxcs = h_pxcs;
     sc.total_out = (int *)cs->d_key + 6; sc.dirty = cs->d_hole_dirty;
+    sc.span = cs->mirror_on ? cs->d_hole_span : nullptr;
     static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, rc_env = getenv("SLAMHIP_K2_RC") ? atoi(getenv("SLAMHIP_K2_RC")) : 28;
     sc.rb_num = rb_env; sc.rc_num = rc_env;                        // (radii, per 1080 rays, from which a wavefront takes two / four zone pixels)
     {

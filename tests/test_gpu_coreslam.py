@@ -966,6 +966,55 @@ def test_holemap_partial_mirror(cs_mod, ctx, sim):
     dev.close()
 
 
+@pytest.mark.parametrize("size,R", [(1024, 720), (2048, 1080), (300, 360), (512, 2600)])   # (300: rows that are not whole 16-byte units; 2600 rays: the large-scan tables)
+def test_holemap_async_mirror(cs_mod, ctx, sim, size, R):
+    """slamhip_cs_holemap_mirror_async / _wait (live HoleMap.Pixels without stalling the scan): twelve fused
+    scans back to back, a mirror request after each -- after _wait the mirror equals a full download taken at the same point,
+    every scan; what is pushed is a fraction of the map; several updates between two requests come together; a request without
+    an update pushes nothing; reset, upload and another array make everything news again."""
+    segs = sim.default_field()
+    dev = make_dev(cs_mod, ctx, size, 64)
+    rng = sim.PCG32(8)
+    mirror = np.zeros(size * size, np.uint16)
+    dev.holemap_mirror_async(mirror)
+    rect, px = dev.holemap_mirror_wait()
+    assert rect == (0, 0, size - 1, size - 1) and px >= size * size and (mirror == 32750).all()     # the first request: everything (in 8-pixel units)
+    dev.holemap_mirror_async(mirror)
+    assert dev.holemap_mirror_wait() == ((0, 0, -1, -1), 0)
+    dev.set_offsets(sim.gaussian_offsets(1500, 0.05, 0.05, seed=3))
+    fractions = []
+    for k, p in enumerate(sim.trajectory(12, step=(0.35, 0.2, 0.05))):
+        pose = (p + np.array([-6.0 + k, 4.0 - k, 0.0], np.float32)).astype(np.float32)     # wander, also towards the map's edge
+        _, xy = sim.make_scan(segs, pose, R, rng)
+        dev.set_scan(xy * (0.35 if k % 3 == 0 else 1.0))
+        if k % 4 == 3:
+            dev.update_holemap(pose, 2.0, 50)                                              # (a plain update with wide holes in between)
+        dev.search_and_update(pose, 0.6, 50, 10)                                           # returns with the pose: the updates run on
+        dev.holemap_mirror_async(mirror)
+        want = dev.holemap_download()                                                      # (ordered behind the updates, like the snapshot)
+        rect, px = dev.holemap_mirror_wait()
+        assert (mirror == want).all(), (k, int((mirror != want).sum()))
+        assert 0 < px <= size * (size + 7) and 0 <= rect[0] <= rect[2] < size and 0 <= rect[1] <= rect[3] < size
+        fractions.append(px / float(size * size))
+    assert min(fractions) < 0.6, fractions
+    # two handles on one context do not disturb each other's mirrors; another array starts from everything
+    other = np.zeros(size * size, np.uint16)
+    dev.holemap_mirror_async(other)
+    rect, px = dev.holemap_mirror_wait()
+    assert px >= size * size and (other == dev.holemap_download()).all()
+    dev.reset()
+    dev.holemap_mirror_async(other)
+    dev.holemap_mirror_wait()
+    assert (other == 32750).all()                          # (only the units that differ from the last snapshot travel)
+    up = np.arange(size * size, dtype=np.uint32).astype(np.uint16)
+    dev.holemap_upload(up)
+    dev.holemap_mirror_async(other)
+    dev.holemap_mirror_wait()
+    assert (other == up).all()
+    dev.holemap_mirror_release()
+    dev.close()
+
+
 def test_two_handles_one_context_two_threads(cs_mod, ctx, det, sim):
     """Handles that share a context may be driven from different threads (slamhip.h): their blocking calls deliver results
     through the context's one mailbox, under its lock.  Two operator objects with different maps / scans / lists are hammered
