@@ -562,32 +562,36 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         }
         sane = !bad;
     }
-    int umin = 65535, vmin = 65535;
-    for (int i = 0; i < n; i++) { umin = cellxy[2 * (size_t)i] < umin ? cellxy[2 * (size_t)i] : umin; vmin = cellxy[2 * (size_t)i + 1] < vmin ? cellxy[2 * (size_t)i + 1] : vmin; }
-    // Morton codes of the cell coordinates RELATIVE to the scan's first cell: a scan spans a few dozen cells, so the codes are small
-    // and the radix sort below needs one pass (around 32768 the absolute coordinates differ in their top bits: three passes)
-    static thread_local unsigned cnt3[3][2048];
-    uint32_t c_or = 0, c_and = ~0u;
+    // Morton codes of the cell coordinates.  The order is that of the ABSOLUTE codes -- the scan frame's origin, the robot, is the
+    // curve's major boundary: the scan splits into its four quadrants first, then recursively; measured at the headline size against
+    // codes relative to the scan's first cell: 18.9 against 24.7 us per search, the blocks' shapes decide what fits a tile -- but
+    // the codes are COMPRESSED: with every cell within 2^m of 32768 in both directions, bits m .. 15 of a coordinate all follow
+    // bit 15, so subtracting 32768 - 2^m keeps every comparison and leaves 2 (m + 1) bits: two 8-bit passes for scans up to
+    // 128 cells (160 m at 2048^2 / 40 m) instead of three 11-bit ones with their 2048-bin prefix sums.
+    int dmax = 0;
+    for (int i = 0; i < 2 * n; i++) { const int d = cellxy[(size_t)i] >= 32768 ? cellxy[(size_t)i] - 32768 : 32767 - cellxy[(size_t)i]; dmax = d > dmax ? d : dmax; }
+    int mbits = 0;
+    while ((1 << mbits) <= dmax) mbits++;                         // every cell in [32768 - 2^m, 32768 + 2^m)
+    const bool compressed = mbits <= 10;
+    const int shift_c = compressed ? 32768 - (1 << mbits) : 0;
+    const int code_bits = compressed ? 2 * (mbits + 1) : 32;
     for (int i = 0; i < n; i++) {
-        const uint32_t code = part1by1((uint32_t)(cellxy[2 * (size_t)i] - umin)) | (part1by1((uint32_t)(cellxy[2 * (size_t)i + 1] - vmin)) << 1);
+        const uint32_t code = part1by1((uint32_t)(cellxy[2 * (size_t)i] - shift_c)) | (part1by1((uint32_t)(cellxy[2 * (size_t)i + 1] - shift_c)) << 1);
         keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
-        c_or |= code; c_and &= code;
     }
-    {   // LSD radix sort on the 32-bit Morton code (up to 3 stable passes of 11 bits; ties keep ray order), a pass only for a digit
-        // in which the codes differ
+    {   // LSD radix sort on the code (stable 8-bit passes over the bits in use; ties keep ray order)
         std::vector<uint64_t> &tmp = cs->h_sort_tmp;
         tmp.resize((size_t)n);
         uint64_t *src = keys.data(), *dst = tmp.data();
-        const uint32_t vary = c_or ^ c_and;
-        for (int pass = 0; pass < 3; pass++) {
-            const int shift = 32 + 11 * pass;
-            if (((vary >> (11 * pass)) & 2047u) == 0) continue;   // every key has the same digit
-            unsigned *cnt = cnt3[pass];
-            memset(cnt, 0, sizeof(unsigned) * 2048);
-            for (int i = 0; i < n; i++) cnt[(src[i] >> shift) & 2047u]++;
+        unsigned cnt[256];
+        for (int lo = 0; lo < code_bits; lo += 8) {
+            const int shift = 32 + lo;
+            memset(cnt, 0, sizeof(cnt));
+            for (int i = 0; i < n; i++) cnt[(src[i] >> shift) & 255u]++;
+            if (cnt[(src[0] >> shift) & 255u] == (unsigned)n) continue;      // every key has the same digit
             unsigned sum = 0;
-            for (int k = 0; k < 2048; k++) { const unsigned c = cnt[k]; cnt[k] = sum; sum += c; }
-            for (int i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
+            for (int k = 0; k < 256; k++) { const unsigned c = cnt[k]; cnt[k] = sum; sum += c; }
+            for (int i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 255u]++] = src[i];
             uint64_t *t = src; src = dst; dst = t;
         }
         if (src != keys.data()) memcpy(keys.data(), src, sizeof(uint64_t) * (size_t)n);
@@ -610,16 +614,31 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     if (cs->n_offs + 1 >= 131072) ext_px = CS_RB_EXTENT_PX;   // (very many candidates: two bands of a big block beat more, smaller blocks -- measured)
     if (ext_env > 0) ext_px = (float)ext_env;
     const float ext = ext_px / cs->hscale;                     // block extent limit in metres
+    // A block's tile is the box of its end points in the MAP frame, grown by the candidates' translation spread and the arc their
+    // theta range sweeps: a block that is large in both directions there -- a corner of the room -- overflows the tile budget even
+    // within the extent limit and is staged in bands at more than twice the cost, for every candidate group (seen at the headline
+    // size: one such block kept twelve workgroups 17 us in a 19 us launch).  So the limits are tested on the points turned by the
+    // last search heading (the layout's; 0 before the first search), and the box area, margins included, CAN be limited too
+    // (SLAMHIP_RB_AREA = fraction of the tile budget).  Measured at the headline size, us per search: no area limit 18.9, 0.8 of
+    // the budget 20.2 (more, smaller blocks: more tile steps) -- off by default; the ranges' cuts avoid banded pieces instead
+    // (k1_cuts_banded_rays, distance.hip).
+    static const float area_f = getenv("SLAMHIP_RB_AREA") ? (float)atof(getenv("SLAMHIP_RB_AREA")) : 0.0f;    // of the tile budget; <= 0: no area limit (the default: see below)
+    const float rth = cs->k1_layout_theta;
+    const float rc = cosf(rth), rs = sinf(rth);
+    const float marg = (spread_px + 40.0f) / cs->hscale;       // metres: translation spread + a nominal arc
+    const float amax = area_f > 0.0f ? area_f * (60.0f * 1024.0f / 2.0f) / (cs->hscale * cs->hscale) : 3.0e38f;   // square metres
     for (int j = 0; j < n; j++) {
         const int i = (int)(uint32_t)keys[j];
         const float X = xy[2 * i], Y = xy[2 * i + 1];
         sorted[2 * j] = X; sorted[2 * j + 1] = Y;
+        const float Xr = rc * X - rs * Y, Yr = rs * X + rc * Y;
         if (cur > 0) {
-            const float nx0 = SH_MINF(bx0, X), nx1 = SH_MAXF(bx1, X), ny0 = SH_MINF(by0, Y), ny1 = SH_MAXF(by1, Y);
-            if (cur == CS_RB_MAX || !(nx1 - nx0 <= ext) || !(ny1 - ny0 <= ext)) { rb.push_back(j); cur = 0; }
+            const float nx0 = SH_MINF(bx0, Xr), nx1 = SH_MAXF(bx1, Xr), ny0 = SH_MINF(by0, Yr), ny1 = SH_MAXF(by1, Yr);
+            const float ex = nx1 - nx0, ey = ny1 - ny0;
+            if (cur == CS_RB_MAX || !(ex <= ext) || !(ey <= ext) || !((ex + marg) * (ey + marg) <= amax)) { rb.push_back(j); cur = 0; }
             else { bx0 = nx0; bx1 = nx1; by0 = ny0; by1 = ny1; }
         }
-        if (cur == 0) { bx0 = bx1 = X; by0 = by1 = Y; }
+        if (cur == 0) { bx0 = bx1 = Xr; by0 = by1 = Yr; }
         cur++;
     }
     rb.push_back(n);
