@@ -18,16 +18,19 @@
  *     library copies in/out and never retains them.  Device memory lives behind opaque handles.
  *   - a handle is single-caller (like the reference objects: ParallelWorker.Work is "blocking,
  *     non-reentrant", BaseSLAM/ParallelWorker.cs:95); different handles may be used from different
- *     threads, also handles that share one slamhip_ctx: the context's completion mailbox is guarded
- *     by a lock, so the blocking calls of such handles take turns (they share one HIP stream
- *     anyway); give each thread its own context if they should overlap.
+ *     threads, also handles that share one slamhip_ctx -- with per-kernel timing off
+ *     (slamhip_ctx_timing_enable(ctx, 0), the default: the timers' event pool is not locked): the
+ *     context's completion mailbox is guarded by a lock, so the blocking calls of such handles take
+ *     turns (they share one HIP stream anyway); give each thread its own context if they should
+ *     overlap or be timed.
  *   - calls block until their RESULT is on the host unless the name ends in _async.  Two calls
  *     return as soon as the result the caller reads is there while work that returns nothing is
  *     still running on the device: slamhip_cs_search_and_update / slamhip_csproc_update (back with
  *     the pose; the two map updates run on) and slamhip_hsproc_update (the grid update runs on).
  *     Every later call on the same context is ordered behind that work, so the caller sees the
  *     reference's sequential semantics.  A blocking wait polls a pinned word for up to ~300 us and
- *     then sleeps in hipStreamSynchronize.
+ *     then goes on polling it between 20 us sleeps, asking the stream for faults (it never waits for
+ *     the stream itself: work queued behind the result is not waited for).
  *   - float poses are (x [m], y [m], theta [rad]) = System.Numerics.Vector3; points are
  *     System.Numerics.Vector2 (8 B); LogOddsCell is {int32 UpdateIndex; float Value} (8 B).
  *   - there is no CPU fallback: every compute entry point launches HIP kernels on gfx950.

@@ -151,9 +151,21 @@ int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val)
         }
         __builtin_ia32_pause();
     }
-    SH_HIP(hipStreamSynchronize(ctx->stream));                     // (reports a device fault)
-    if (sh_flag_reached(flag, val)) return SLAMHIP_OK;
-    SH_FAIL(SLAMHIP_ERR_HIP, "the stream is idle but the completion word never arrived");
+    // Past the spin budget (a long search: very many candidates, a 4096^2 map): keep waiting for the WORD, not for the stream --
+    // a call that returns with the pose while the map updates run on must not sit through those updates as well.  The stream is
+    // only ASKED (hipStreamQuery: a fault is reported, an idle stream without the word is an error), between short sleeps.
+    for (;;) {
+        for (int k = 0; k < 64; k++) { if (sh_flag_reached(flag, val)) return SLAMHIP_OK; __builtin_ia32_pause(); }
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (sh_flag_reached(flag, val)) return SLAMHIP_OK;
+        if (q == hipSuccess) {                                     // idle: the word must be there (a store to pinned host memory, released at system scope)
+            for (int k = 0; k < 1000; k++) { if (sh_flag_reached(flag, val)) return SLAMHIP_OK; __builtin_ia32_pause(); }
+            SH_FAIL(SLAMHIP_ERR_HIP, "the stream is idle but the completion word never arrived");
+        }
+        if (q != hipErrorNotReady) SH_HIP(q);                      // a device fault
+        timespec ts = { 0, 20000 };                                // 20 us
+        nanosleep(&ts, nullptr);
+    }
 }
 
 int32_t sh_host_wait(slamhip_ctx *ctx)

@@ -24,6 +24,7 @@
 #include "m3x2.h"
 #include "raster.h"
 #include <vector>
+#include <atomic>
 #include <chrono>
 #include <stdlib.h>
 
@@ -157,6 +158,10 @@ __device__ unsigned long long g_k4_times[16];
 
 // GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) broadcast in sums[].
 // order: dTr.x, dTr.y, dTr.z, H11, H22, H33, H12, H13, H23
+// (Round 4, measured and rejected: a 4 x 4 window of probabilities per point kept in registers across a level's iterations, so
+// that iterations 2 .. n read no memory -- 34.0 -> 37.1 us per match: the first iteration's 64 bytes per point in four unaligned
+// 16-byte loads cost more than the later iterations' taps, which hit the L2 anyway; and the compiler folds a select between
+// struct members into one indexed load, i.e. puts the window into scratch memory, unless the values pass through an opaque asm.)
 // PRE: the thread's (at most HS_PRE) points are already in registers (pre[]): the scan does not change between the
 // iterations of a match, and the point load heads a chain of two dependent memory round trips (point -> four taps).
 #define HS_PRE 2
@@ -1298,7 +1303,10 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
             // scan touches, which halve from level to level (the zone around the begin cell is the same on every level: a floor
             // of 1/16 each).  (Round 2 shared them out by cell count with a floor of 1/8: 551 workgroups, i.e. a second round that
             // started when the first drained -- half of the kernel's 35 us.)
-            static const int wgs_env = getenv("SLAMHIP_K5_WGS") ? atoi(getenv("SLAMHIP_K5_WGS")) : 512;
+            // (every level needs a workgroup on each of the eight XCD sectors its lines are dealt to: below 8 workgroups per level
+            // -- 8 levels x 16 as the floor is a sixteenth -- lines of the missing sectors would not be drawn; the override is clamped)
+            static const int wgs_raw = getenv("SLAMHIP_K5_WGS") ? atoi(getenv("SLAMHIP_K5_WGS")) : 512;
+            static const int wgs_env = wgs_raw < 128 ? 128 : wgs_raw;
             double tot = 0.0;
             for (int l = 0; l < hs->n_levels; l++) tot += (double)hs->lv[l].w + (double)hs->lv[l].h;
             int first = 0, left = wgs_env;
@@ -1308,6 +1316,7 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
                 if (k < floor_k) k = floor_k;
                 const int must_leave = (hs->n_levels - 1 - l) * floor_k;   // (the levels still to come keep their floor)
                 if (k > left - must_leave) k = left - must_leave > 1 ? left - must_leave : 1;
+                if (k < 8) k = 8;                                  // (one workgroup per XCD sector at least, whatever the shares)
                 A.lv[l].wg0 = first; A.lv[l].wgn = k;
                 first += k; left -= k;
             }
@@ -1316,8 +1325,8 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
         const dim3 cgrid(cgrid_x);
         static const bool two_launch = getenv("SLAMHIP_K5_TWO_LAUNCHES") != nullptr;       // (tests: the large-scan path on ordinary scans)
         const bool build = n <= K5_LDS_LINES && !two_launch;
-        static unsigned long long attr_set = 0;                                             // one bit per device (the attribute is the device's)
-        if (!((attr_set >> (ctx->device & 63)) & 1ull)) { attr_set |= 1ull << (ctx->device & 63); (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k5_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds_bytes(true, K5_LDS_LINES)); }
+        static std::atomic<unsigned long long> attr_set{0};                                             // one bit per device (the attribute is the device's)
+        if (!((attr_set.load(std::memory_order_acquire) >> (ctx->device & 63)) & 1ull)) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k5_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds_bytes(true, K5_LDS_LINES)); attr_set.fetch_or(1ull << (ctx->device & 63), std::memory_order_release); }
         if (!build)      // all levels in every launch (MapRepMultiMap.cs:76)
             hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
                                hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);

@@ -29,6 +29,7 @@
 #include "raster.h"
 #include "obstacle_dev.h"
 #include <vector>
+#include <atomic>
 #include <algorithm>
 #include <stdlib.h>
 
@@ -1015,10 +1016,12 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         // (two workgroups per CU -- the 1080-ray tables are 80.7 KB with the 16-bit bucket table, and amdgpu_waves_per_eu(8, 8) brings
         // the kernel under 80 SGPRs -- measured no faster: 23.5 against 23.2 us with one, and the register limit costs the
         // one-per-CU form a microsecond: 22.2 us without it)
-        const int grid = grid_env > 0 ? grid_env : build ? cus : 2 * cus;
+        // (the rays beyond the zone are dealt to eight XCD sectors, sector s to the workgroups b with b % 8 == s: fewer than eight
+        // workgroups would leave sectors undrawn -- the developer override is clamped)
+        const int grid = grid_env > 0 ? (grid_env < 8 ? 8 : grid_env) : build ? cus : 2 * cus;
 #define K2_PIXELS(B, T) {                                                                                                   \
-            static unsigned long long attr_set = 0;              /* one bit per device (the attribute is the device's) */   \
-            if (!((attr_set >> (ctx->device & 63)) & 1ull)) { attr_set |= 1ull << (ctx->device & 63); (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); } \
+            static std::atomic<unsigned long long> attr_set{0};              /* one bit per device (the attribute is the device's) */   \
+            if (!((attr_set.load(std::memory_order_acquire) >> (ctx->device & 63)) & 1ull)) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); attr_set.fetch_or(1ull << (ctx->device & 63), std::memory_order_release); } \
             hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_byidx *)cs->d_rays, \
                                (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
                                cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }
