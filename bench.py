@@ -310,12 +310,13 @@ def main():
             achieved = a.cands * bytes_per_eval / avg_s / 1e9
             traffic, traffic_src = pmc_traffic(a)
             peak_m, peak_src = measured_peak()
+            valu = valu_ceiling(a, a.cands * bytes_per_eval)
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "peak_measured": peak_m, "peak_measured_source": peak_src,
                     "kernel": "k1_search_tiled", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
                     "bytes_per_launch": a.cands * bytes_per_eval,
-                    "timing": k1_how}
+                    "timing": k1_how, "valu": valu}
         out = {
             "metric": "candidate-pose distance evals/sec on 2048^2 map, 1080-ray scan, 1/2/4/8 GPU",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -640,6 +641,31 @@ def pmc_traffic(a):
         except Exception:
             pass
     return None, None
+
+
+def valu_ceiling(a, bytes_per_launch):
+    """What actually binds the dominant kernel at this size: its VALU work.  Replayed from the committed SQ-counter profile of this
+    command (profiles/rNN_k1_sq.json, newest round first; PMC counters cannot be read inside the timed run): busy_us = the time the
+    VALU pipes of a SIMD are busy per launch (SQ_ACTIVE_INST_VALU quad-cycles x 4 / 1024 SIMDs at 2.1 GHz), launch_us = the launch's
+    duration in the same profile, frac_of_hbm_roofline_if_valu_bound = the HBM-roofline fraction the launch would reach if it took
+    only busy_us -- the ceiling of this kernel at this candidate count, whatever its latencies.  None without a matching profile."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k1_sq.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            h = t["headline_16384_candidates"]
+            if a.cands != 16384 or a.size != 2048 or a.rays != 1080:
+                return None
+            busy = float(h["derived"]["valu_busy_us_per_simd_if_evenly_spread"])
+            launch = float(h["avg_launch_ns_rocprof_stats"]) * 1e-3
+            return {"busy_us": round(busy, 2), "launch_us": round(launch, 2), "busy_frac_of_launch": round(busy / launch, 3),
+                    "frac_of_hbm_roofline_if_valu_bound": round(bytes_per_launch / (busy * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
+                    "wave_cycles_waiting_frac": round(float(h["derived"].get("fraction_of_wave_cycles_waiting_waitcnt_or_barrier", 0.0)), 3),
+                    "source": "replayed from %s (separate rocprofv3 --pmc passes of this command, not this run)" % os.path.relpath(path, ROOT)}
+        except Exception:
+            pass
+    return None
 
 
 def measured_peak():

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) k_span_fill(int2 *__restrict__ span, int 
 // wave-level atomics.  `all`: the shadow holds nothing yet (first request, another array): every unit of the span is news.
 __global__ void __launch_bounds__(256) k_mirror_snapshot(const uint16_t *__restrict__ map, uint16_t *__restrict__ shadow, int2 *__restrict__ span,
                                                          int2 *__restrict__ snap, unsigned long long *__restrict__ mask, int chunks, int size, int all,
-                                                         int *__restrict__ sum)
+                                                         int lines, int *__restrict__ sum)
 {
     const int lane = threadIdx.x & 63, y = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (y >= size) return;
@@ -332,7 +332,14 @@ __global__ void __launch_bounds__(256) k_mirror_snapshot(const uint16_t *__restr
                 }
             }
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(ch);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(ch);
+        if (lines && m) {
+            // whole 64-byte lines travel: a lone 16-byte store to host memory is a partial-line write over PCIe (a transaction of
+            // its own, a read-modify-write at the host's memory controller) -- the four units of a line that holds a changed one
+            // are pushed together (the other three equal the shadow already: nothing to copy here)
+            unsigned long long g = (m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x1111111111111111ull;
+            m = g | (g << 1) | (g << 2) | (g << 3);
+        }
         if (lane == 0) mask[(size_t)y * chunks + c] = m;
         if (m) {
             n_changed += __builtin_popcountll(m);
@@ -347,9 +354,10 @@ __global__ void __launch_bounds__(256) k_mirror_snapshot(const uint16_t *__restr
 }
 // the shadow's marked units into the caller's array (host memory mapped into the device's address space), a wavefront per row at a time
 __global__ void __launch_bounds__(256) k_mirror_push(const uint16_t *__restrict__ shadow, const int2 *__restrict__ snap, const unsigned long long *__restrict__ mask,
-                                                     int chunks, uint16_t *__restrict__ host, int size)
+                                                     int chunks, uint16_t *__restrict__ host, int size, const int *__restrict__ sum, int *__restrict__ host_sum)
 {
     const int lane = threadIdx.x & 63, wpb = 4;
+    if (blockIdx.x == 0 && threadIdx.x < 8) host_sum[threadIdx.x] = sum[threadIdx.x];     // (the snapshot's summary: pinned host words, no copy of its own)
     const int upr = (size + 7) >> 3;
     const bool vec = size % 8 == 0 && ((size_t)host & 15) == 0;
     for (int y = (int)blockIdx.x * wpb + (int)(threadIdx.x >> 6); y < size; y += (int)gridDim.x * wpb) {
@@ -438,17 +446,19 @@ extern "C" int32_t slamhip_cs_holemap_mirror_async(slamhip_cs *cs, uint16_t *pix
     }
     cs->mirror_on = true;
     if (fresh) SH_TRY(cs_holemap_span_set(cs, true));
+    static const int mirror_lines = getenv("SLAMHIP_MIRROR_LINES") ? atoi(getenv("SLAMHIP_MIRROR_LINES")) : 1;
     hipLaunchKernelGGL(k_mirror_sum_rest, dim3(1), dim3(64), 0, ctx->stream, cs->d_mirror_sum);
     hipLaunchKernelGGL(k_mirror_snapshot, dim3(sh_div_up(cs->hs, 4)), dim3(256), 0, ctx->stream, (const uint16_t *)cs->d_hole, cs->d_hole_shadow,
-                       cs->d_hole_span, cs->d_hole_span_snap, cs->d_mirror_mask, cs->mirror_chunks, cs->hs, fresh ? 1 : 0, cs->d_mirror_sum);
+                       cs->d_hole_span, cs->d_hole_span_snap, cs->d_mirror_mask, cs->mirror_chunks, cs->hs, fresh ? 1 : 0,
+                       (mirror_lines && cs->hs % 32 == 0) ? 1 : 0, cs->d_mirror_sum);
     SH_HIP(hipGetLastError());
     SH_HIP(hipEventRecord(cs->ev_snap, ctx->stream));
     SH_HIP(hipStreamWaitEvent(cs->mirror_stream, cs->ev_snap, 0));
     static const int push_wgs = getenv("SLAMHIP_MIRROR_WGS") ? atoi(getenv("SLAMHIP_MIRROR_WGS")) : 32;
     hipLaunchKernelGGL(k_mirror_push, dim3(push_wgs > 0 ? push_wgs : 32), dim3(256), 0, cs->mirror_stream, (const uint16_t *)cs->d_hole_shadow,
-                       (const int2 *)cs->d_hole_span_snap, (const unsigned long long *)cs->d_mirror_mask, cs->mirror_chunks, (uint16_t *)cs->mirror_dev_ptr, cs->hs);
+                       (const int2 *)cs->d_hole_span_snap, (const unsigned long long *)cs->d_mirror_mask, cs->mirror_chunks, (uint16_t *)cs->mirror_dev_ptr, cs->hs,
+                       (const int *)cs->d_mirror_sum, cs->h_mirror_sum);
     SH_HIP(hipGetLastError());
-    SH_HIP(hipMemcpyAsync(cs->h_mirror_sum, cs->d_mirror_sum, sizeof(int) * 8, hipMemcpyDeviceToHost, cs->mirror_stream));
     SH_HIP(hipEventRecord(cs->ev_push, cs->mirror_stream));
     cs->mirror_pending = true;
     return SLAMHIP_OK;

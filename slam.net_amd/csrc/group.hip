@@ -525,13 +525,17 @@ extern "C" int32_t slamhip_cs_search_allreduce(slamhip_cs *cs, slamhip_comm *c, 
     // other ranks are in it and would wait for this one for good.
     int32_t rc_local = SLAMHIP_OK;
     std::string err;
+    // (the search delivers into a word of the handle's result ring -- no final arriver in the kernel, slamhip_cs_search_shard_enqueue --
+    // and the collective reduces that word in place: the ring rests a slot only three launches later)
+    uint64_t *d_key = c->d_sync_key;
     if (count > 0) {
-        rc_local = slamhip_cs_search_shard_async(cs, pose, first, count, c->d_sync_key);
-        if (rc_local != SLAMHIP_OK) err = slamhip_last_error();
+        const uint64_t *slot = nullptr;
+        rc_local = slamhip_cs_search_shard_enqueue(cs, pose, first, count, &slot);
+        if (rc_local != SLAMHIP_OK) err = slamhip_last_error(); else d_key = (uint64_t *)slot;
     }
-    if (count <= 0 || rc_local != SLAMHIP_OK) (void)hipMemsetAsync(c->d_sync_key, 0xFF, sizeof(uint64_t), ctx->stream);       // (the neutral key)
-    SH_NCCL(c, c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, ctx->stream));
-    SH_TRY(sh_publish(ctx, c->d_sync_key, 2));
+    if (count <= 0 || rc_local != SLAMHIP_OK) (void)hipMemsetAsync(d_key, 0xFF, sizeof(uint64_t), ctx->stream);       // (the neutral key)
+    SH_NCCL(c, c->api.AllReduce(d_key, d_key, 1, ncclUint64, ncclMin, c->comm, ctx->stream));
+    SH_TRY(sh_publish(ctx, d_key, 2));
     cs_layout_idle_refresh(cs);                                    // (host work under the search: cs_launch_distance)
     SH_TRY(sh_host_wait(ctx));
     *out_key = *(volatile uint64_t *)ctx->mailbox;
