@@ -288,6 +288,25 @@ def main():
                 replicas = D.replicas_equal(words)
         except Exception as e:                                     # noqa: BLE001 -- a health check must never cost the line
             replicas = "failed: %s" % e
+        # the fused per-scan form on every rank (slamhip_cs_search_allreduce_and_update: search, exchange, winner decoded on the device,
+        # the replicas' map updates behind it -- no host hop): three scans, then the replica check again.  The first scan sees the
+        # map of the timed region, so its key must be the timed region's; the maps move on from there (saved first for the oracle).
+        pix_saved = dev.holemap_download() if rank == 0 else None
+        fused = None
+        if comm is not None:
+            try:
+                f_first = None
+                tf0 = time.perf_counter()
+                for k in range(3):
+                    f_pose, f_dist, f_idx = comm.search_allreduce_and_update(dev, base, first, count, 0.6, 50, 10)
+                    if k == 0:
+                        f_first = ((int(f_dist) & 0xFFFFFFFF) << 32) | (int(f_idx) & 0xFFFFFFFF)
+                ctx.synchronize()
+                tf = (time.perf_counter() - tf0) / 3
+                fused = {"first_scan_key_equals_search_key": bool(f_first == int(final_key)), "us_per_scan": tf * 1e6,
+                         "replicas_equal_after": comm.replicas_equal(dev)}
+            except Exception as e:                                 # noqa: BLE001
+                fused = {"error": repr(e)}
         if world > 1:
             t = torch.tensor([elapsed, dt_ov, ar_us if ar_us is not None else 0.0], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -298,7 +317,8 @@ def main():
                  "overlapped_steps": n_ov,
                  "overlapped_form": ("keys of 16 steps per ncclAllReduce on the communicator's own stream behind one event" if comm is not None
                                      else "search + all_reduce enqueued per step, nothing read back per step"),
-                 "allreduce_us": ar_us, "collective_ranks": collective_ranks, "replicas_equal": replicas}
+                 "allreduce_us": ar_us, "collective_ranks": collective_ranks, "replicas_equal": replicas,
+                 "fused_scan_allreduce_and_update": fused}
 
     if rank == 0:
         evals = float(K_total) * a.steps
@@ -355,7 +375,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "oracle"))
                 import oracle_c as oc
                 oc.set_trig_mode(oc.TRIG_DET)
-                obi, _, obd, _ = oc.search(dev.holemap_download(), dev.hole_size, dev.hole_scale, xy, base, offs)
+                obi, _, obd, _ = oc.search(pix_saved if pix_saved is not None else dev.holemap_download(), dev.hole_size, dev.hole_scale, xy, base, offs)
                 out["config"]["winner_matches_oracle"] = bool(((int(obd) << 32) | int(obi)) == int(final_key))
             except Exception as e:                                 # noqa: BLE001
                 out["config"]["winner_matches_oracle"] = "check failed: %r" % (e,)
@@ -364,7 +384,7 @@ def main():
                     a.cpu_seconds = min(a.cpu_seconds, 6.0)
                     a.cpu_short = True
                     n1 = a.cands - 1                               # (the per-GPU workload: rank 0's block of the list)
-                    out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs[:n1], None, ())
+                    out["cpu_baseline"] = cpu_baseline(a, dev, xy, base, offs[:n1], None, (), pix=pix_saved)
                     out["cpu_baseline"]["sample"] += " (N > 1: short budget, one GPU's share of the candidates)"
                 except Exception as e:                             # noqa: BLE001
                     out["cpu_baseline"] = {"error": repr(e)}
@@ -678,7 +698,7 @@ def measured_peak():
         return None, None
 
 
-def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=()):
+def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=(), pix=None):
     """The reference's ParallelWorker-structured CPU search (oracle/cpu_baseline.c, kind = "port": the C#
     reference cannot run here) on the SAME map / scan / candidates, bounded to ~a.cpu_seconds of CPU work at
     T = min(nproc, 64) threads, plus short runs at T = 1 and T = 4 and BASELINE.json's config C1 (400^2 map,
@@ -690,7 +710,8 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=()):
     import oracle_c as oc
     import slam.net_amd.sim as sim
     oc.set_trig_mode(oc.TRIG_DET)
-    pix = dev.holemap_download()
+    if pix is None:
+        pix = dev.holemap_download()
     # WaitHandle.WaitAll caps the reference's ParallelWorker at 64 threads (BaseSLAM/ParallelWorker.cs:115)
     T = min(os.cpu_count() or 1, 64)
     n = offs.shape[0]

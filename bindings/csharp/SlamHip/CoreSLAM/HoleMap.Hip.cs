@@ -35,8 +35,10 @@ namespace CoreSLAM
             this.cs = cs;
             Size = sizePixels;
             Scale = scale;
-            // (on the pinned object heap: the address never changes, so the library page-locks the array once for its partial
-            // mirror copies -- slamhip_cs_holemap_mirror)
+            // (on the pinned object heap: the address never changes while a refresh is in flight.  A managed array does not own its
+            // pages, so the library serves it through its pinned staging buffer and copies the changed row ranges in
+            // slamhip_cs_holemap_mirror_wait; a host that wants the device to write the mirror directly hands the library
+            // page-aligned native memory -- NativeMemory.AlignedAlloc(bytes, 4096) -- and wraps it in a Span)
             pixels = GC.AllocateArray<ushort>(sizePixels * sizePixels, pinned: true);
         }
 

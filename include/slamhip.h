@@ -127,11 +127,16 @@ int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pixels, size_t n_pix
  * `pixels`; it returns at once, and the next search starts as soon as the snapshot is taken.  _wait blocks until the last push
  * has landed; out_rect = the bounding rectangle x0, y0, x1, y1 of what it refreshed (x1 < x0: nothing), *out_pixels = the pixels
  * of its spans.  After _wait, `pixels` equals a full download taken at the moment of the _async call.
- * Contract: `pixels` is PAGE-LOCKED and mapped into the device's address space on its first use (hipHostRegister: 8 MiB at 2048^2,
- * 512 MiB at 16384^2) and stays so until slamhip_cs_holemap_mirror_release, slamhip_cs_destroy, or a call with another array --
- * the caller must keep it alive (and, in managed code, at a fixed address: pinned object heap / GCHandle) until then and must
- * not read it between _async and _wait.  One push is in flight at a time: _async waits for the previous one first.  The
- * blocking slamhip_cs_holemap_mirror page-locks its array the same way. */
+ * Contract: `pixels` must stay alive, and must not be read, between _async and _wait (the caller passes it once; _wait uses it).
+ * WHERE THE DEVICE WRITES depends on the array: one that OWNS its pages -- it starts on a 4096-byte boundary and is a whole number
+ * of pages long (posix_memalign, NativeMemory.AlignedAlloc, mmap; 8 MiB at 2048^2) -- is page-locked and mapped into the device's
+ * address space on its first use (hipHostRegister) and written by the device directly; it stays registered until
+ * slamhip_cs_holemap_mirror_release, slamhip_cs_destroy, or a call with another array.  Any other array (a managed array on the
+ * pinned object heap, a NumPy array: they share their first and last page with other objects, which the runtime pins for its own
+ * copies -- registering such pages ended in device write faults in the randomised soak) is served through a pinned staging buffer
+ * of the library's, and _wait copies the changed row ranges into it on the HOST (a pass over what changed; measured at 2048^2 with
+ * a moving robot: 225 us per scan against 164 with a request per scan).  One push is in flight at a time: _async waits for the
+ * previous one first.  The blocking slamhip_cs_holemap_mirror follows the same rule for its copies. */
 int32_t slamhip_cs_holemap_mirror_async(slamhip_cs *cs, uint16_t *pixels, size_t n_pixels);
 int32_t slamhip_cs_holemap_mirror_wait(slamhip_cs *cs, int32_t out_rect[4], int64_t *out_pixels);
 int32_t slamhip_cs_holemap_mirror_release(slamhip_cs *cs);   /* waits, then unregisters the array (either mirror form) */

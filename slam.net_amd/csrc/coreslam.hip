@@ -148,6 +148,9 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     if (cs->ev_push) (void)hipEventDestroy(cs->ev_push);
     (void)hipFree(cs->d_hole_span); (void)hipFree(cs->d_hole_span_snap); (void)hipFree(cs->d_hole_shadow); (void)hipFree(cs->d_mirror_sum); (void)hipFree(cs->d_mirror_mask);
     if (cs->h_mirror_sum) (void)hipHostFree(cs->h_mirror_sum);
+    (void)hipFree(cs->d_mirror_rows);
+    if (cs->h_mirror_rows) (void)hipHostFree(cs->h_mirror_rows);
+    if (cs->h_mirror_stage) (void)hipHostFree(cs->h_mirror_stage);
     if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
     cs_holemap_free(cs);
     cs_obstacle_free(cs);
@@ -237,11 +240,54 @@ extern "C" int32_t slamhip_cs_holemap_download(slamhip_cs *cs, uint16_t *pix, si
 // HoleMap update leaves the bounding square of its scan in a device-side dirty rectangle; this call fetches the rectangle, copies
 // only those rows and columns into the caller's full-size array and rests the rectangle.  `pix` must be the array the previous
 // mirror call (or a full download) filled; the first call after create / reset / upload copies the whole map.
+extern "C" int32_t slamhip_cs_holemap_mirror_wait(slamhip_cs *cs, int32_t out_rect[4], int64_t *out_pixels);
+
+// Where may the device write?  Page-locking a caller's array (hipHostRegister) is only safe when the array OWNS its pages: an
+// array in the middle of a heap shares its first and last page with other objects, and the runtime pins those for its own
+// pageable copies -- read-only for a copy source.  Seen in the randomised soak (tests/fuzz_parity.py, small NumPy arrays): after a
+// few hundred register / unregister cycles a later device write into such a page died with "write access to a read-only page".
+// So: an array that starts on a page boundary and is a whole number of pages long (an aligned allocation: posix_memalign,
+// NativeMemory.AlignedAlloc, mmap) is registered and written by the device directly; any other array is served through a pinned
+// staging buffer of the library's own and copied by the HOST in the waiting call, row range by row range.
+static bool mirror_owns_pages(const void *p, size_t bytes)
+{
+    static const bool never = getenv("SLAMHIP_MIRROR_NOREG") != nullptr;
+    return !never && ((uintptr_t)p & 4095u) == 0 && (bytes & 4095u) == 0 && bytes >= 4096;
+}
+static int32_t mirror_stage(slamhip_cs *cs)
+{
+    if (cs->h_mirror_stage) return SLAMHIP_OK;
+    SH_HIP(hipHostMalloc(&cs->h_mirror_stage, sizeof(uint16_t) * (size_t)cs->hs * cs->hs));
+    return SLAMHIP_OK;
+}
+// the array the device may write for this caller array: the array itself (registered, `flags`) or the staging buffer
+static int32_t mirror_target(slamhip_cs *cs, uint16_t *pix, size_t n, unsigned flags, uint16_t **out_dev, bool *out_direct)
+{
+    const size_t bytes = n * sizeof(uint16_t);
+    if (mirror_owns_pages(pix, bytes)) {
+        if (cs->mirror_reg != (void *)pix || cs->mirror_reg_bytes != bytes || cs->mirror_reg_flags != flags) {
+            if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
+            cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0; cs->mirror_dev_ptr = nullptr;
+            SH_HIP(hipHostRegister(pix, bytes, flags));
+            cs->mirror_reg = pix; cs->mirror_reg_bytes = bytes; cs->mirror_reg_flags = flags;
+            if (flags & hipHostRegisterMapped) SH_HIP(hipHostGetDevicePointer(&cs->mirror_dev_ptr, pix, 0));
+        }
+        *out_dev = (flags & hipHostRegisterMapped) ? (uint16_t *)cs->mirror_dev_ptr : pix;
+        *out_direct = true;
+        return SLAMHIP_OK;
+    }
+    SH_TRY(mirror_stage(cs));
+    *out_dev = cs->h_mirror_stage;
+    *out_direct = false;
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pix, size_t n, int32_t out_rect[4])
 {
     SH_CHECK_ARG(cs && pix && n == (size_t)cs->hs * cs->hs);
     slamhip_ctx *ctx = cs->ctx;
     SH_HIP(hipSetDevice(ctx->device));
+    if (cs->mirror_pending) SH_TRY(slamhip_cs_holemap_mirror_wait(cs, nullptr, nullptr));
     int r[4];
     {
         sh_mail_guard lock(ctx);
@@ -251,37 +297,31 @@ extern "C" int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pix, size
         memcpy(r, (const void *)ctx->mailbox, sizeof(r));
     }
     if (r[2] >= r[0] && r[3] >= r[1]) {
-        // The mirror array is page-locked on its first use (a strided copy into pageable memory goes row by row through the
-        // runtime's staging buffer: 2.1 ms for a 1713 x 1713 rectangle, against 0.23 ms for the whole 2048^2 map in one piece).
-        // A managed caller keeps the array at a fixed address (pinned object heap / GCHandle), as the C# shim's HoleMap does.
-        static const bool no_reg = getenv("SLAMHIP_MIRROR_NOREG") != nullptr;
-        if (!no_reg && (cs->mirror_reg != (void *)pix || cs->mirror_reg_bytes != n * sizeof(uint16_t))) {
-            if (cs->mirror_stream) { (void)hipStreamSynchronize(cs->mirror_stream); (void)hipStreamDestroy(cs->mirror_stream); }
-    if (cs->ev_snap) (void)hipEventDestroy(cs->ev_snap);
-    if (cs->ev_push) (void)hipEventDestroy(cs->ev_push);
-    (void)hipFree(cs->d_hole_span); (void)hipFree(cs->d_hole_span_snap); (void)hipFree(cs->d_hole_shadow); (void)hipFree(cs->d_mirror_sum); (void)hipFree(cs->d_mirror_mask);
-    if (cs->h_mirror_sum) (void)hipHostFree(cs->h_mirror_sum);
-    if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
-            cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0;
-            if (hipHostRegister(pix, n * sizeof(uint16_t), hipHostRegisterDefault) == hipSuccess) { cs->mirror_reg = pix; cs->mirror_reg_bytes = n * sizeof(uint16_t); }
-            else (void)hipGetLastError();                          // (not registrable: the copy below still works, slowly)
-        }
+        // (a strided copy into pageable memory goes row by row through the runtime's staging buffer: 2.1 ms for a 1713 x 1713
+        // rectangle, against 0.23 ms for the whole 2048^2 map in one piece -- so the copy lands in page-locked memory: the caller's
+        // array when it owns its pages, else the library's staging buffer, from which the host copies the rows on)
+        uint16_t *dst = nullptr; bool direct = false;
+        SH_TRY(mirror_target(cs, pix, n, hipHostRegisterDefault, &dst, &direct));
         const size_t pitch = (size_t)cs->hs * sizeof(uint16_t);
         const size_t rows = (size_t)(r[3] - r[1] + 1), cols = (size_t)(r[2] - r[0] + 1);
         if (cols * 4 >= (size_t)cs->hs * 3) {                      // nearly full rows: whole rows in one linear copy
             const size_t ofs = (size_t)r[1] * cs->hs;
-            SH_HIP(hipMemcpyAsync(pix + ofs, cs->d_hole + ofs, rows * pitch, hipMemcpyDeviceToHost, ctx->stream));
+            SH_HIP(hipMemcpyAsync(dst + ofs, cs->d_hole + ofs, rows * pitch, hipMemcpyDeviceToHost, ctx->stream));
             r[0] = 0; r[2] = cs->hs - 1;
         } else {
             const size_t ofs = (size_t)r[1] * cs->hs + (size_t)r[0];
-            SH_HIP(hipMemcpy2DAsync(pix + ofs, pitch, cs->d_hole + ofs, pitch, cols * sizeof(uint16_t), rows, hipMemcpyDeviceToHost, ctx->stream));
+            SH_HIP(hipMemcpy2DAsync(dst + ofs, pitch, cs->d_hole + ofs, pitch, cols * sizeof(uint16_t), rows, hipMemcpyDeviceToHost, ctx->stream));
         }
         SH_HIP(hipStreamSynchronize(ctx->stream));
+        if (!direct) {
+            const size_t c2 = (size_t)(r[2] - r[0] + 1) * sizeof(uint16_t);
+            for (int y = r[1]; y <= r[3]; y++) memcpy(pix + (size_t)y * cs->hs + r[0], dst + (size_t)y * cs->hs + r[0], c2);
+            cs->mirror_user = nullptr;         // (the staging buffer no longer equals the asynchronous form's shadow: its next request starts from everything)
+        }
     } else { r[0] = r[1] = 0; r[2] = r[3] = -1; }
     if (out_rect) memcpy(out_rect, r, sizeof(r));
     return SLAMHIP_OK;
 }
-
 
 // ---- asynchronous, span-exact host mirror -----------------------------------------------------------------------------------
 // `HoleMap.Pixels` is read live by the reference's callers (HoleMap.cs:27; Simulation/MainWindow.xaml.cs:227-249), so a
@@ -306,12 +346,12 @@ __global__ void __launch_bounds__(256) k_span_fill(int2 *__restrict__ span, int 
 // wave-level atomics.  `all`: the shadow holds nothing yet (first request, another array): every unit of the span is news.
 __global__ void __launch_bounds__(256) k_mirror_snapshot(const uint16_t *__restrict__ map, uint16_t *__restrict__ shadow, int2 *__restrict__ span,
                                                          int2 *__restrict__ snap, unsigned long long *__restrict__ mask, int chunks, int size, int all,
-                                                         int lines, int *__restrict__ sum)
+                                                         int lines, int *__restrict__ sum, int2 *__restrict__ rows)
 {
     const int lane = threadIdx.x & 63, y = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (y >= size) return;
     const int2 sp = span[y];
-    if (lane == 0) { snap[y] = sp; span[y] = make_int2(size, -1); }
+    if (lane == 0) { snap[y] = sp; span[y] = make_int2(size, -1); rows[y] = make_int2(size, -1); }
     if (sp.y < sp.x) return;
     const size_t row = (size_t)y * size;
     const int upr = (size + 7) >> 3;                               // units per row (the last may be short: rows that are not whole units go pixel by pixel)
@@ -347,6 +387,7 @@ __global__ void __launch_bounds__(256) k_mirror_snapshot(const uint16_t *__restr
         }
     }
     if (lane == 0 && n_changed > 0) {
+        rows[y] = make_int2(ulo, uhi);                             // the units of this row that travel (first, last): the host's copy in _wait goes by them
         atomicMin(&sum[0], ulo * 8); atomicMin(&sum[1], y); atomicMax(&sum[2], min(uhi * 8 + 7, size - 1)); atomicMax(&sum[3], y);
         atomicAdd((unsigned long long *)&sum[4], (unsigned long long)n_changed * 8ull);
         atomicAdd(&sum[6], 1);
@@ -354,10 +395,13 @@ __global__ void __launch_bounds__(256) k_mirror_snapshot(const uint16_t *__restr
 }
 // the shadow's marked units into the caller's array (host memory mapped into the device's address space), a wavefront per row at a time
 __global__ void __launch_bounds__(256) k_mirror_push(const uint16_t *__restrict__ shadow, const int2 *__restrict__ snap, const unsigned long long *__restrict__ mask,
-                                                     int chunks, uint16_t *__restrict__ host, int size, const int *__restrict__ sum, int *__restrict__ host_sum)
+                                                     int chunks, uint16_t *__restrict__ host, int size, const int *__restrict__ sum, int *__restrict__ host_sum,
+                                                     const int2 *__restrict__ rows, int2 *__restrict__ host_rows)
 {
     const int lane = threadIdx.x & 63, wpb = 4;
     if (blockIdx.x == 0 && threadIdx.x < 8) host_sum[threadIdx.x] = sum[threadIdx.x];     // (the snapshot's summary: pinned host words, no copy of its own)
+    if (host_rows)                                                 // (staged mirror: the rows' changed ranges for the host's copy)
+        for (int y = (int)blockIdx.x * 256 + (int)threadIdx.x; y < size; y += (int)gridDim.x * 256) host_rows[y] = rows[y];
     const int upr = (size + 7) >> 3;
     const bool vec = size % 8 == 0 && ((size_t)host & 15) == 0;
     for (int y = (int)blockIdx.x * wpb + (int)(threadIdx.x >> 6); y < size; y += (int)gridDim.x * wpb) {
@@ -389,6 +433,8 @@ static int32_t mirror_resources(slamhip_cs *cs)
     cs->mirror_chunks = (((cs->hs + 7) >> 3) + 63) >> 6;           // 64-unit chunks per row: one mask word each
     SH_HIP(hipMalloc(&cs->d_mirror_mask, sizeof(unsigned long long) * (size_t)cs->hs * cs->mirror_chunks));
     SH_HIP(hipMalloc(&cs->d_mirror_sum, sizeof(int) * 8));
+    SH_HIP(hipMalloc(&cs->d_mirror_rows, sizeof(int2) * (size_t)cs->hs));
+    SH_HIP(hipHostMalloc(&cs->h_mirror_rows, sizeof(int2) * (size_t)cs->hs));
     SH_HIP(hipHostMalloc(&cs->h_mirror_sum, sizeof(int) * 8));
     SH_HIP(hipStreamCreateWithFlags(&cs->mirror_stream, hipStreamNonBlocking));
     SH_HIP(hipEventCreateWithFlags(&cs->ev_snap, hipEventDisableTiming));
@@ -411,8 +457,9 @@ extern "C" int32_t slamhip_cs_holemap_mirror_release(slamhip_cs *cs)
     SH_HIP(hipSetDevice(cs->ctx->device));
     if (cs->mirror_stream) SH_HIP(hipStreamSynchronize(cs->mirror_stream));
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
-    cs->mirror_pending = false;
+    if (cs->mirror_pending) SH_TRY(slamhip_cs_holemap_mirror_wait(cs, nullptr, nullptr));
     if (cs->mirror_reg) { (void)hipHostUnregister(cs->mirror_reg); cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0; cs->mirror_dev_ptr = nullptr; }
+    cs->mirror_user = nullptr;                                     // (the next request, whatever its array, starts from everything)
     return SLAMHIP_OK;
 }
 
@@ -420,8 +467,22 @@ extern "C" int32_t slamhip_cs_holemap_mirror_wait(slamhip_cs *cs, int32_t out_re
 {
     SH_CHECK_ARG(cs);
     SH_HIP(hipSetDevice(cs->ctx->device));
-    if (cs->mirror_pending) { SH_HIP(hipEventSynchronize(cs->ev_push)); cs->mirror_pending = false; }
     const int *h = cs->h_mirror_sum;
+    if (cs->mirror_pending) {
+        SH_HIP(hipEventSynchronize(cs->ev_push));
+        cs->mirror_pending = false;
+        if (!cs->mirror_direct && cs->mirror_user && h[6] > 0) {
+            // staged: the changed units of every row, from the library's pinned buffer into the caller's array
+            uint16_t *pix = cs->mirror_user;
+            const int S = cs->hs;
+            for (int y = h[1]; y <= h[3]; y++) {
+                const int2 ru = cs->h_mirror_rows[y];
+                if (ru.y < ru.x) continue;
+                const size_t x0 = (size_t)ru.x * 8, x1 = std::min((size_t)ru.y * 8 + 8, (size_t)S);
+                memcpy(pix + (size_t)y * S + x0, cs->h_mirror_stage + (size_t)y * S + x0, (x1 - x0) * sizeof(uint16_t));
+            }
+        }
+    }
     const bool any = h && h[6] > 0;
     if (out_rect) { out_rect[0] = any ? h[0] : 0; out_rect[1] = any ? h[1] : 0; out_rect[2] = any ? h[2] : -1; out_rect[3] = any ? h[3] : -1; }
     if (out_pixels) *out_pixels = any ? (int64_t)(((uint64_t)(uint32_t)h[5] << 32) | (uint32_t)h[4]) : 0;
@@ -435,29 +496,25 @@ extern "C" int32_t slamhip_cs_holemap_mirror_async(slamhip_cs *cs, uint16_t *pix
     SH_HIP(hipSetDevice(ctx->device));
     SH_TRY(mirror_resources(cs));
     if (cs->mirror_pending) SH_TRY(slamhip_cs_holemap_mirror_wait(cs, nullptr, nullptr));    // (one push in flight: the shadow and its spans are single)
-    bool fresh = !cs->mirror_on;                                   // the first call: everything the device holds is news to this array
-    if (cs->mirror_reg != (void *)pix || cs->mirror_reg_bytes != n * sizeof(uint16_t) || !cs->mirror_dev_ptr) {
-        if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
-        cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0; cs->mirror_dev_ptr = nullptr;
-        SH_HIP(hipHostRegister(pix, n * sizeof(uint16_t), hipHostRegisterMapped));
-        cs->mirror_reg = pix; cs->mirror_reg_bytes = n * sizeof(uint16_t);
-        SH_HIP(hipHostGetDevicePointer(&cs->mirror_dev_ptr, pix, 0));
-        fresh = true;                                              // (another array: it holds nothing yet)
-    }
+    // the first call, or another array than the last request's: everything the device holds is news to it
+    bool fresh = !cs->mirror_on || cs->mirror_user != pix;
+    uint16_t *dst = nullptr; bool direct = false;
+    SH_TRY(mirror_target(cs, pix, n, hipHostRegisterMapped, &dst, &direct));
+    cs->mirror_user = pix; cs->mirror_direct = direct;
     cs->mirror_on = true;
     if (fresh) SH_TRY(cs_holemap_span_set(cs, true));
     static const int mirror_lines = getenv("SLAMHIP_MIRROR_LINES") ? atoi(getenv("SLAMHIP_MIRROR_LINES")) : 1;
     hipLaunchKernelGGL(k_mirror_sum_rest, dim3(1), dim3(64), 0, ctx->stream, cs->d_mirror_sum);
     hipLaunchKernelGGL(k_mirror_snapshot, dim3(sh_div_up(cs->hs, 4)), dim3(256), 0, ctx->stream, (const uint16_t *)cs->d_hole, cs->d_hole_shadow,
                        cs->d_hole_span, cs->d_hole_span_snap, cs->d_mirror_mask, cs->mirror_chunks, cs->hs, fresh ? 1 : 0,
-                       (mirror_lines && cs->hs % 32 == 0) ? 1 : 0, cs->d_mirror_sum);
+                       (mirror_lines && cs->hs % 32 == 0) ? 1 : 0, cs->d_mirror_sum, cs->d_mirror_rows);
     SH_HIP(hipGetLastError());
     SH_HIP(hipEventRecord(cs->ev_snap, ctx->stream));
     SH_HIP(hipStreamWaitEvent(cs->mirror_stream, cs->ev_snap, 0));
     static const int push_wgs = getenv("SLAMHIP_MIRROR_WGS") ? atoi(getenv("SLAMHIP_MIRROR_WGS")) : 32;
     hipLaunchKernelGGL(k_mirror_push, dim3(push_wgs > 0 ? push_wgs : 32), dim3(256), 0, cs->mirror_stream, (const uint16_t *)cs->d_hole_shadow,
-                       (const int2 *)cs->d_hole_span_snap, (const unsigned long long *)cs->d_mirror_mask, cs->mirror_chunks, (uint16_t *)cs->mirror_dev_ptr, cs->hs,
-                       (const int *)cs->d_mirror_sum, cs->h_mirror_sum);
+                       (const int2 *)cs->d_hole_span_snap, (const unsigned long long *)cs->d_mirror_mask, cs->mirror_chunks, dst, cs->hs,
+                       (const int *)cs->d_mirror_sum, cs->h_mirror_sum, (const int2 *)cs->d_mirror_rows, direct ? (int2 *)nullptr : cs->h_mirror_rows);
     SH_HIP(hipGetLastError());
     SH_HIP(hipEventRecord(cs->ev_push, cs->mirror_stream));
     cs->mirror_pending = true;

@@ -118,6 +118,10 @@ struct slamhip_cs {
     int *d_mirror_sum; int *h_mirror_sum;       // [8] x0, y0, x1, y1, pixels (low, high), rows, -: what the last snapshot holds (device; pinned host copy)
     hipStream_t mirror_stream; hipEvent_t ev_snap, ev_push;
     void *mirror_dev_ptr;                       // the device address of the registered host array
+    unsigned mirror_reg_flags;                  // ... and the flags it was registered with
+    uint16_t *mirror_user; bool mirror_direct;  // the caller's array of the last request; whether the device writes it directly (it owns its pages) or the staging buffer
+    uint16_t *h_mirror_stage;                   // [hs * hs] pinned: what the device writes for arrays that do not own their pages
+    int2 *d_mirror_rows, *h_mirror_rows;        // [hs] per row the first / last changed 8-pixel unit of the last snapshot (device; pinned host copy for the staged form)
     int *d_hole_dirty;            // [4] x0, y0, x1, y1 (inclusive): pixels the HoleMap updates may have changed since the last slamhip_cs_holemap_mirror
     int64_t last_hole_pixels;
     bool hole_pixels_pending;     // ... still on the device (d_key word 6): slamhip_cs_search_and_update returned with the pose, the updates run on

@@ -44,6 +44,7 @@ def main():
             size = int(rng.choice([64, 256, 400, 1024])); osize = int(rng.choice([16, 64, 100]))
             start = np.array([rng.uniform(12, 28), rng.uniform(12, 28), rng.uniform(-3, 3)], np.float32)
             K = int(rng.choice([1, 200, 1500])); thr = int(rng.choice([1, 4]))
+            if os.environ.get("FUZZ_TRACE"): print("case %d kind 3: processor size %d/%d K %dx%d" % (n_cases, size, osize, K, thr), flush=True)
             proc = cs.CoreSLAMProcessor(40.0, size, osize, start, 0.1, 0.17, K, thr, ctx=ctx)
             ref = oc.CSProc(40.0, size, osize, start)
             hw = float(rng.choice([0.6, 2.0])); q = int(rng.choice([50, 200])); sb = int(rng.choice([0, 2, 5])); mh = int(rng.choice([10, 3]))
@@ -79,6 +80,8 @@ def main():
             q = int(rng.choice([1, 50, 128, 255]))
             mh = int(rng.choice([10, 1, 127, -3]))
             phys = float(rng.choice([40.0, 40.0, 25.0, 100.0]))                 # pixels per metre = size / phys
+            if os.environ.get("FUZZ_TRACE"):
+                print("case %d kind %d: size %d/%d R %d hw %.1f q %d mh %d phys %.0f" % (n_cases, kind, size, osize, R, hw, q, mh, phys), flush=True)
             dev = cs.CoreSlamDevice(ctx, phys, size, osize)
             ref = np.full(size * size, 32750, np.uint16)
             oref = np.full(osize * osize, -5, np.int8)
@@ -113,6 +116,21 @@ def main():
                 oc.update_obstaclemap(oref, osize, dev.obst_scale, xy, p, mh)
                 if dev.last_holemap_pixels != n:
                     ok = False; why.append("pixel count %d vs %d at update %d" % (dev.last_holemap_pixels, n, it))
+            if rng.random() < 0.25 and ok and not os.environ.get("FUZZ_NO_MIRROR"):
+                # round 4: the asynchronous mirror -- requested now (everything is news to a fresh array), then once more after
+                # another update of the last scan: both times the array equals a full download
+                if os.environ.get("FUZZ_TRACE"): print("   mirror", flush=True)
+                mir = np.zeros(size * size, np.uint16)
+                dev.holemap_mirror_async(mir); dev.holemap_mirror_wait()
+                okm = bool((mir == dev.holemap_download()).all())
+                if trace:
+                    dev.update_holemap(trace[-1][1], hw, q)
+                    oc.update_holemap(ref, size, dev.hole_scale, trace[-1][0], trace[-1][1], hw, q)
+                    dev.holemap_mirror_async(mir); dev.holemap_mirror_wait()
+                    okm = okm and bool((mir == dev.holemap_download()).all())
+                dev.holemap_mirror_release()
+                if not okm:
+                    ok = False; why.append("asynchronous mirror differs from a full download")
             got = dev.holemap_download()
             gob = dev.obstaclemap_download().ravel()
             if not (got == ref).all():
@@ -138,6 +156,14 @@ def main():
                     offs = dev.offsets_download()
                 rbi, rpose, rbd, rall = oc.search(got, size, dev.hole_scale, xy, base, offs)
                 ok = gi == rbi and gd == rbd and bool((np.asarray(gp)[:2] == rpose[:2]).all())
+                if ok and not fused and rng.random() < 0.5:
+                    # round 4: the enqueue-only search into the handle's result ring, three times in a row -- the second launch
+                    # under one layout makes the ray ranges' cost cuts, every launch must find its result word rested
+                    if os.environ.get("FUZZ_TRACE"): print("   ring K %d" % K, flush=True)
+                    slots = [dev.search_shard_enqueue(base, 0, K) for _ in range(3)]
+                    keys = [dev.key_read(sl) for sl in slots]
+                    ok = all(k == ((int(rbd) << 32) | int(rbi)) for k in keys)
+                    if not ok: why.append("ring search: keys %s, oracle idx %d dist %d" % (keys, rbi, rbd))
                 if not ok:
                     why.append("search: got idx %d dist %d pose %s, oracle idx %d dist %d pose %s" % (gi, gd, gp, rbi, rbd, rpose))
                     if a.dump:
@@ -180,6 +206,7 @@ def main():
             cell = 40.0 / side
             R = int(rng.choice([8, 180, 1080, 3000]))
             side_h = side if rng.random() < 0.7 else int(rng.choice([side // 2 + 3, side + 37]))      # rectangular maps too
+            if os.environ.get("FUZZ_TRACE"): print("case %d kind 2: hector %dx%d levels %d R %d" % (n_cases, side, side_h, levels, R), flush=True)
             rep = hs.MapRepMultiMap(cell, (side, side_h), levels, ctx=ctx)
             ref = oc.make_pyramid(cell, side, side_h, levels)
             ff, fo = 0.4, 0.9

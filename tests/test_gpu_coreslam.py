@@ -715,6 +715,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert (j2["config"]["best_index"], j2["config"]["best_distance"]) == (j1["config"]["best_index"], j1["config"]["best_distance"])
     assert j2["roofline"]["launches"] == 50 and j2["roofline"]["avg_launch_us"] > 0 and j2["value"] > 0
     assert j2["multi_gpu"]["replicas_equal"] is True                   # (both ranks built their HoleMap by the same updates)
+    assert j2["config"]["winner_matches_oracle"] is True               # (N > 1: rank 0 checks the reduced key against one oracle search over the whole list)
     assert j1["roofline"]["launches"] == 20
 
 
@@ -975,7 +976,15 @@ def test_holemap_async_mirror(cs_mod, ctx, sim, size, R):
     segs = sim.default_field()
     dev = make_dev(cs_mod, ctx, size, 64)
     rng = sim.PCG32(8)
-    mirror = np.zeros(size * size, np.uint16)
+    if size == 2048:
+        # an array that OWNS its pages (starts on a page boundary, whole pages long): the device writes it directly; the other
+        # sizes run the staged form (an ordinary NumPy array shares its first and last page with the heap: slamhip.h)
+        raw = np.zeros(size * size + 4096, np.uint16)
+        ofs = (-raw.ctypes.data % 4096) // 2
+        mirror = raw[ofs:ofs + size * size]
+        assert mirror.ctypes.data % 4096 == 0
+    else:
+        mirror = np.zeros(size * size, np.uint16)
     dev.holemap_mirror_async(mirror)
     rect, px = dev.holemap_mirror_wait()
     assert rect == (0, 0, size - 1, size - 1) and px >= size * size and (mirror == 32750).all()     # the first request: everything (in 8-pixel units)
@@ -1011,6 +1020,16 @@ def test_holemap_async_mirror(cs_mod, ctx, sim, size, R):
     dev.holemap_mirror_async(other)
     dev.holemap_mirror_wait()
     assert (other == up).all()
+    # the blocking rectangle mirror and the asynchronous one on the same array, in turns
+    for k in range(4):
+        p = np.array([18.0 + k, 21.0, 0.3 * k], np.float32)
+        _, xy = sim.make_scan(segs, p, min(R, 1080), rng)
+        dev.set_scan(xy); dev.update_holemap(p, 0.6, 50)
+        if k % 2:
+            dev.holemap_mirror(other)
+        else:
+            dev.holemap_mirror_async(other); dev.holemap_mirror_wait()
+        assert (other == dev.holemap_download()).all(), k
     dev.holemap_mirror_release()
     dev.close()
 
@@ -1247,3 +1266,24 @@ def test_group_worker_threads():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q", "-k",
                         "test_group_single_gpu or test_maps_checksum_and_replica_checks"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+
+
+def test_bench_library_collective_one_rank():
+    """bench.py with SLAMHIP_BENCH_COLLECTIVE=lib1: the N > 1 section of the benchmark -- the library's own RCCL communicator, the
+    blocking per-scan step, the overlapped form, the collective's probe, the replica check and the fused per-scan form
+    (slamhip_cs_search_allreduce_and_update) with its self-checks -- on ONE rank, which is all a one-GPU box can run; the driver's
+    multi-GPU run goes through the same code with N ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SLAMHIP_BENCH_COLLECTIVE="lib1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3", "--size", "1024", "--map-updates", "8",
+                        "--cands", "4096", "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert "libslamhip" in j["config"]["collective"] and j["config"]["collective_ranks"] == 1
+    m = j["multi_gpu"]
+    assert m["replicas_equal"] is True and m["allreduce_us"] > 0
+    f = m["fused_scan_allreduce_and_update"]
+    assert f["first_scan_key_equals_search_key"] is True and f["replicas_equal_after"] is True and f["us_per_scan"] > 0, f
