@@ -71,7 +71,6 @@ struct slamhip_cs {
     std::vector<std::pair<int, std::vector<int>>> k1_cut_cache; uint32_t k1_cut_gen, k1_cut_layout_gen;
     uint32_t k1_cut_seen_scan, k1_cut_seen_layout;   // the (scan, layout) of the last tiled launch: cuts are made from the second launch of a pair on
     uint32_t k1_layout_gen;                     // layouts made so far (k1_make_layout)
-    std::vector<int> k1_cut_parts;              // per ray block: parts it is cut into (its whole tile would not fit the budget for the widest uniform group)
     std::vector<char> k1_cut_cand;              // per ray block: its tile may exceed the budget (worth the exact box test)
     std::vector<double> k1_cut_wsc;             // (scratch)
     std::vector<double> k1_cut_wb;              // per ray block: the weight of one more tile step, in ray units (k1_cut_weights)

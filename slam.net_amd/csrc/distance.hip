@@ -1087,11 +1087,11 @@ static inline double k1_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 // takes whole blocks while they fit, then a fragment of the next one -- but no fragment shorter than half its block's weight: a
 // step that short is all overhead).  A block's weight grows with its tile (k1_cut_weights).
 // Every range holds <= K1_MAXR rays of <= K1_MAXP blocks.  Returns the number of ranges (<= nc; 0: no such cut), cuts[0 .. n].
-static int k1_balanced_cuts(const slamhip_cs *cs, int nc, const std::vector<double> &wb, const std::vector<int> &parts, std::vector<int> &cuts)
+static int k1_balanced_cuts(const slamhip_cs *cs, int nc, const std::vector<double> &wb, std::vector<int> &cuts)
 {
     const int R = cs->n_points, n_rb = cs->n_rb;
     const int *rb = cs->h_rb_start.data();
-    if (nc < 1 || R < 1 || n_rb < 1 || (int)wb.size() != n_rb || (int)parts.size() != n_rb) return 0;
+    if (nc < 1 || R < 1 || n_rb < 1 || (int)wb.size() != n_rb) return 0;
     double wsum = 0.0, wmax = 0.0;
     for (int b = 0; b < n_rb; b++) { wsum += wb[(size_t)b]; wmax = std::max(wmax, wb[(size_t)b]); }
     auto fill = [&](double T, std::vector<int> *out) -> int {
@@ -1108,17 +1108,6 @@ static int k1_balanced_cuts(const slamhip_cs *cs, int nc, const std::vector<doub
                 const double room = T - ((double)(e - r) + wacc + w);
                 int take = bend - e;
                 if (take > K1_MAXR - (e - r)) take = K1_MAXR - (e - r);
-                // a block whose whole tile would not fit the budget (parts > 1: it would be staged in bands, at twice the cost per
-                // ray and more) is never one piece of a range: ranges end at its inner marks
-                bool at_mark = false;
-                if (parts[(size_t)bb] > 1) {
-                    const int b0 = rb[bb], len = bend - b0, k = parts[(size_t)bb];
-                    const int j = (int)(((long long)(e - b0) * k) / len) + 1;          // the next mark: b0 + ceil(j * len / k)
-                    const int mark = b0 + (int)(((long long)j * len + k - 1) / k);
-                    if (mark < bend && mark - e <= take) { take = mark - e; at_mark = true; }
-                    if (at_mark && (double)take <= room) { e += take; pieces++; break; }   // (the range ends at the mark)
-                    at_mark = false;
-                }
                 const bool whole = take == bend - e && (double)take <= room;
                 if (!whole) {
                     int part = room < (double)take ? (int)room : take;
@@ -1160,15 +1149,14 @@ static int k1_balanced_cuts(const slamhip_cs *cs, int nc, const std::vector<doub
 // LDS writes and the issue of its loads all grow with the tile, so: w_fix + w_kb * (the tile's size in KB for the middle candidate
 // group -- the block's bounding box turned into the map frame, grown by the group's translation spread and theta arc: the terms
 // of k1_group_cost).  Without the groups' spreads (explicit pose lists): the box grown by a nominal 48 pixels.
-static void k1_cut_weights(const slamhip_cs *cs, int n_groups, bool have_spread, double w_fix, double w_kb, int budget, const float pose[3],
-                           std::vector<double> &wb, std::vector<int> &parts)
+static void k1_cut_weights(const slamhip_cs *cs, int n_groups, bool have_spread, double w_fix, double w_kb, int budget, std::vector<double> &wb)
 {
     const int n_rb = cs->n_rb;
     std::vector<char> &cand = const_cast<slamhip_cs *>(cs)->k1_cut_cand;
     cand.assign((size_t)n_rb, 0);
     wb.assign((size_t)n_rb, w_fix);
-    parts.assign((size_t)n_rb, 1);
-    // the widest uniform group (the uniform part's outer groups): a block whose tile for THAT group exceeds the budget is cut
+    // the widest uniform group (the uniform part's outer groups): a block whose tile for THAT group may exceed the budget is marked
+    // for the exact box test of the pieces (k1_cuts_banded_rays)
     double dth_w = 0.0, d_w = 48.0;
     if (have_spread && cs->k1_uni_ng > 0) {
         for (int g = cs->k1_uni_g0; g < cs->k1_uni_g0 + cs->k1_uni_ng && (size_t)g < cs->h_grp_dth.size(); g++) dth_w = std::max(dth_w, (double)cs->h_grp_dth[(size_t)g]);
@@ -1189,7 +1177,6 @@ static void k1_cut_weights(const slamhip_cs *cs, int n_groups, bool have_spread,
         static const double cand_f = getenv("SLAMHIP_K1_CUT_CAND") ? atof(getenv("SLAMHIP_K1_CUT_CAND")) : 0.9;
         cand[(size_t)b] = 2.0 * (ww + 8.0) * hw > cand_f * (double)budget || ww > 440.0;
     }
-    (void)pose; (void)budget;
 }
 
 // Would rays [r0, r1) of the sorted scan, as ONE piece, be staged in bands (or gathered from memory) for candidate group g?
@@ -1606,7 +1593,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             cs->k1_cut_cache.clear();
             cs->k1_cut_gen = cs->scan_gen; cs->k1_cut_layout_gen = cs->k1_layout_gen;
             const double tw0 = k1_now_us();
-            k1_cut_weights(cs, n_groups, have_spread, cut_wfix, cut_wkb, budget, pose3, cs->k1_cut_wb, cs->k1_cut_parts);
+            k1_cut_weights(cs, n_groups, have_spread, cut_wfix, cut_wkb, budget, cs->k1_cut_wb);
             g_cut_t[0] += k1_now_us() - tw0;
         }
         cs->k1_cut_cache.reserve(K1_TABLE_G + 8);                      // (the entries' addresses are held below: no reallocation)
@@ -1624,7 +1611,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                 wsc.resize(cs->k1_cut_wb.size());
                 for (size_t i = 0; i < wsc.size(); i++) wsc[i] = cs->k1_cut_wb[i] * scale;
                 const double tb0 = k1_now_us();
-                const int n = k1_balanced_cuts(cs, nrc, wsc, cs->k1_cut_parts, c);
+                const int n = k1_balanced_cuts(cs, nrc, wsc, c);
                 g_cut_t[1] += k1_now_us() - tb0;
                 if (n < 1) { c.clear(); break; }
                 if (n * 100 >= nrc * cut_keep) break;
@@ -1694,8 +1681,6 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         if (dump && a.uni_cut) {
             fprintf(stderr, "   uniform ranges cut by cost (%d of %d asked for; ray blocks start at", a.uni_nc, cs->k1_uni_nc);
             for (int b = 0; b <= cs->n_rb; b++) fprintf(stderr, " %d", cs->h_rb_start[(size_t)b]);
-            fprintf(stderr, "; blocks in parts:");
-            for (int b = 0; b < cs->n_rb && (size_t)b < cs->k1_cut_parts.size(); b++) if (cs->k1_cut_parts[(size_t)b] > 1) fprintf(stderr, " %d:%d", b, cs->k1_cut_parts[(size_t)b]);
             fprintf(stderr, "):");
             for (int c = 0; c <= a.uni_nc; c++) fprintf(stderr, " %d", (int)a.cut[c]);
             fprintf(stderr, "\n");
