@@ -98,7 +98,10 @@ def _replica_worker(rank, world, port, out_q):
     a = D.replicas_equal(same)
     b = D.replicas_equal((same[0], same[1] + (1 if rank == world - 1 else 0)))     # one rank's ObstacleMap word is off by one
     c = D.replicas_equal((same[0] ^ ((1 << 63) if rank == 0 else 0), same[1]))     # rank 0 differs in the top bit only
-    out_q.put((rank, a, b, c))
+    # a rank that could not make its words (None) still joins both collectives -- the others are in them -- and every rank gets False
+    d = D.replicas_equal(None if rank == world - 1 else same)
+    e = D.replicas_equal(same)                                                       # (and the next check is not disturbed)
+    out_q.put((rank, a, b, c, d, e))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -117,5 +120,5 @@ def test_replicas_equal_gloo(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, a, b, c in res:
-        assert a is True and b is False and c is False, (rank, a, b, c)
+    for rank, a, b, c, d, e in res:
+        assert a is True and b is False and c is False and d is False and e is True, (rank, a, b, c, d, e)
