@@ -354,6 +354,11 @@ int32_t slamhip_group_set_offsets(slamhip_group *g, const float *offs, int32_t n
 int32_t slamhip_group_search(slamhip_group *g, const float search_pose[3], float out_pose[3],
                              int32_t *out_dist, int32_t *out_index);
 /* replicas apply the identical deterministic update (integer-exact kernels keep them bit-identical) */
+/* One scan on every GPU of the group in one call (CoreSLAMProcessor.cs:732, :695-705, :750-751): search over the GPU's block,
+ * ncclAllReduce(min), the winner decoded on each device, each replica's map updates queued behind -- as
+ * slamhip_cs_search_allreduce_and_update, every rank on its own worker thread; returns with key and pose (theta normalised). */
+int32_t slamhip_group_search_and_update(slamhip_group *g, const float search_pose[3], float hole_width, int32_t quality,
+                                        int32_t max_obstacle_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index);
 int32_t slamhip_group_update_maps(slamhip_group *g, const float pose[3], float hole_width, int32_t quality,
                                   int32_t max_obstacle_hits);
 /* *out_equal = 1 when slamhip_cs_maps_checksum agrees on every GPU of the group */

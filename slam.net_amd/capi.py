@@ -140,6 +140,7 @@ def _declare(L):
         "slamhip_group_set_offsets": (i32, [vp, fp, i32]),
         "slamhip_group_search": (i32, [vp, fp, fp, ip, ip]),
         "slamhip_group_update_maps": (i32, [vp, fp, f, i32, i32]),
+        "slamhip_group_search_and_update": (i32, [vp, fp, f, i32, i32, fp, ip, ip]),
         "slamhip_group_replicas_equal": (i32, [vp, P(i32)]),
         "slamhip_comm_probe": (i32, []),
         "slamhip_comm_unique_id": (i32, [u8p]),

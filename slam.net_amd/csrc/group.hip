@@ -570,26 +570,28 @@ __global__ void k_winner_from_key(const unsigned long long *__restrict__ key, co
 // winner's pose ON THE DEVICE (every rank holds the whole jitter list) and hands key + pose to the host, and behind it the
 // replicas' map updates from that device-resident pose -- all on the operator's stream.  Returns when the pose is known; the
 // updates run on (everything that touches the maps afterwards is ordered behind them).  Every rank makes the same call.
-extern "C" int32_t slamhip_cs_search_allreduce_and_update(slamhip_cs *cs, slamhip_comm *c, const float pose[3], int32_t first, int32_t count,
-                                                          float hole_width, int32_t quality, int32_t max_hits,
-                                                          float out_pose[3], int32_t *out_dist, int32_t *out_index)
+// (the body shared by the one-process-per-GPU form and the single-process group: `comm` is this rank's communicator, d_neutral a
+// device word of the caller's for a rank without candidates)
+static int32_t fused_allreduce_scan(slamhip_cs *cs, rccl_api &api, ncclComm_t comm, uint64_t *d_neutral, const float pose[3], int32_t first, int32_t count,
+                                    float hole_width, int32_t quality, int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index)
 {
-    SH_CHECK_ARG(cs && c && pose && cs->ctx == c->ctx && count >= 0);
-    SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
-    slamhip_ctx *ctx = c->ctx;
-    SH_HIP(hipSetDevice(ctx->device));
-    if (c->async_dirty) SH_TRY(slamhip_comm_wait(c, nullptr));
+    slamhip_ctx *ctx = cs->ctx;
     sh_mail_guard lock(ctx);
     int32_t rc_local = SLAMHIP_OK;
     std::string err;
+    uint64_t *d_key = d_neutral;
     if (count > 0) {
-        rc_local = slamhip_cs_search_shard_async(cs, pose, first, count, c->d_sync_key);
-        if (rc_local != SLAMHIP_OK) err = slamhip_last_error();
+        const uint64_t *slot = nullptr;
+        rc_local = slamhip_cs_search_shard_enqueue(cs, pose, first, count, &slot);        // (into the handle's result ring: no final arriver in the kernel)
+        if (rc_local != SLAMHIP_OK) err = slamhip_last_error(); else d_key = (uint64_t *)slot;
     } else rc_local = cs_flush_generate(cs);                      // (a rank without candidates still decodes the winner from the list)
-    if (count <= 0 || rc_local != SLAMHIP_OK) (void)hipMemsetAsync(c->d_sync_key, 0xFF, sizeof(uint64_t), ctx->stream);
-    SH_NCCL(c, c->api.AllReduce(c->d_sync_key, c->d_sync_key, 1, ncclUint64, ncclMin, c->comm, ctx->stream));
+    if (count <= 0 || rc_local != SLAMHIP_OK) (void)hipMemsetAsync(d_key, 0xFF, sizeof(uint64_t), ctx->stream);
+    {
+        const ncclResult_t r_ = api.AllReduce(d_key, d_key, 1, ncclUint64, ncclMin, comm, ctx->stream);
+        if (r_ != ncclSuccess) { slamhip_set_error("ncclAllReduce failed: %s", api.GetErrorString(r_)); return SLAMHIP_ERR_RCCL; }
+    }
     const uint32_t seq = sh_mail_seq_next(ctx);
-    hipLaunchKernelGGL(k_winner_from_key, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *)c->d_sync_key, (const float *)cs->d_offs_flat,
+    hipLaunchKernelGGL(k_winner_from_key, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *)d_key, (const float *)cs->d_offs_flat,
                        cs->n_offs, pose[0], pose[1], pose[2], (unsigned long long *)cs->d_key, ctx->mail_off ? (uint32_t *)nullptr : ctx->mailbox, seq);
     int32_t rc_u = hipGetLastError() == hipSuccess ? SLAMHIP_OK : SLAMHIP_ERR_HIP;
     if (rc_u == SLAMHIP_OK && rc_local == SLAMHIP_OK && cs->n_points > 0) {
@@ -612,6 +614,43 @@ extern "C" int32_t slamhip_cs_search_allreduce_and_update(slamhip_cs *cs, slamhi
     if (out_index) *out_index = (int32_t)(uint32_t)key;
     if (rc_local != SLAMHIP_OK) { slamhip_set_error("%s", err.c_str()); return rc_local; }
     SH_TRY(rc_u);
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_search_allreduce_and_update(slamhip_cs *cs, slamhip_comm *c, const float pose[3], int32_t first, int32_t count,
+                                                          float hole_width, int32_t quality, int32_t max_hits,
+                                                          float out_pose[3], int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(cs && c && pose && cs->ctx == c->ctx && count >= 0);
+    SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
+    SH_HIP(hipSetDevice(c->ctx->device));
+    if (c->async_dirty) SH_TRY(slamhip_comm_wait(c, nullptr));
+    return fused_allreduce_scan(cs, c->api, c->comm, c->d_sync_key, pose, first, count, hole_width, quality, max_hits, out_pose, out_dist, out_index);
+}
+
+// The same for a single-process group: one scan on every GPU of the group at the same time (a worker thread each) -- its block of
+// the flat list, its end of the collective, the winner decoded on its device, its replica's map updates queued behind; back with
+// rank 0's copy of key and pose (every rank holds the same).
+extern "C" int32_t slamhip_group_search_and_update(slamhip_group *g, const float pose[3], float hole_width, int32_t quality, int32_t max_hits,
+                                                   float out_pose[3], int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(g && pose);
+    SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
+    const int K = g->n_offs + 1;
+    const float p3[3] = { pose[0], pose[1], pose[2] };
+    std::vector<float> poses((size_t)g->n * 3, 0.0f);
+    std::vector<int32_t> dist((size_t)g->n, 0), idx((size_t)g->n, 0);
+    float *pp = poses.data(); int32_t *pd = dist.data(), *pi = idx.data();
+    SH_TRY(group_run(g, [g, K, p3, hole_width, quality, max_hits, pp, pd, pi](int r) -> int32_t {
+        const int first = (int)((long long)K * r / g->n), last = (int)((long long)K * (r + 1) / g->n);
+        return fused_allreduce_scan(g->cs[r], g->api, g->comm[r], g->d_key[r], p3, first, last - first, hole_width, quality, max_hits,
+                                    pp + 3 * r, pd + r, pi + r);
+    }));
+    for (int r = 1; r < g->n; r++)
+        if (pd[r] != pd[0] || pi[r] != pi[0]) SH_FAIL(SLAMHIP_ERR_RCCL, "rank %d decoded another winner than rank 0 (%d/%d vs %d/%d)", r, pi[r], pd[r], pi[0], pd[0]);
+    if (out_pose) { out_pose[0] = pp[0]; out_pose[1] = pp[1]; out_pose[2] = pp[2]; }
+    if (out_dist) *out_dist = pd[0];
+    if (out_index) *out_index = pi[0];
     return SLAMHIP_OK;
 }
 

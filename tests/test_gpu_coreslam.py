@@ -681,6 +681,17 @@ def test_group_single_gpu(cs_mod, ctx, det, sim):
         capi.call("slamhip_group_search", g, capi.fptr(base), capi.fptr(out_pose), C.byref(dist), C.byref(idx))
         rbi, rpose, rbd, _ = oc.search(ref, size, scale, xy, base, offs)
         assert idx.value == rbi and dist.value == rbd and (out_pose == rpose).all()
+        # the whole scan in one call: search, exchange, winner decoded on the device, the replica's map updates behind it
+        fp = np.zeros(3, np.float32)
+        capi.call("slamhip_group_search_and_update", g, capi.fptr(base), C.c_float(0.6), 50, 60, capi.fptr(fp), C.byref(dist), C.byref(idx))
+        wp = np.array([rpose[0], rpose[1], oc.normalize_angle(float(rpose[2]))], np.float32)
+        assert idx.value == rbi and dist.value == rbd and (fp == wp).all()
+        oc.update_holemap(ref, size, scale, xy, wp, 0.6, 50)
+        cs0 = C.c_void_p()
+        capi.call("slamhip_group_cs", g, 0, C.byref(cs0))
+        got = np.empty(size * size, np.uint16)
+        capi.call("slamhip_cs_holemap_download", cs0, got.ctypes.data_as(C.POINTER(C.c_uint16)), got.size)
+        assert (got == ref).all()
     finally:
         capi.call("slamhip_group_destroy", g)
 
@@ -1125,6 +1136,21 @@ def test_group_two_gpus(det, sim):
         capi.call("slamhip_group_replicas_equal", g, C.byref(eq))  # the library's own replica check
         assert eq.value == 1
         for r in range(2):                                         # the replicas hold the same, oracle-equal map
+            h = C.c_void_p()
+            capi.call("slamhip_group_cs", g, r, C.byref(h))
+            pix = np.empty(size * size, np.uint16)
+            capi.call("slamhip_cs_holemap_download", h, pix.ctypes.data_as(C.POINTER(C.c_uint16)), pix.size)
+            assert (pix == ref).all(), r
+        # the whole scan in one call on both GPUs: same winner, pose normalised, both replicas updated from it
+        fp = np.zeros(3, np.float32)
+        dist, idx = C.c_int32(), C.c_int32()
+        capi.call("slamhip_group_search_and_update", g, capi.fptr(base), C.c_float(0.6), 50, 60, capi.fptr(fp), C.byref(dist), C.byref(idx))
+        wp = np.array([rpose[0], rpose[1], oc.normalize_angle(float(rpose[2]))], np.float32)
+        assert idx.value == rbi and dist.value == rbd and (fp == wp).all()
+        oc.update_holemap(ref, size, scale, xy, wp, 0.6, 50)
+        capi.call("slamhip_group_replicas_equal", g, C.byref(eq))
+        assert eq.value == 1
+        for r in range(2):
             h = C.c_void_p()
             capi.call("slamhip_group_cs", g, r, C.byref(h))
             pix = np.empty(size * size, np.uint16)
