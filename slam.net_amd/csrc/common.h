@@ -37,6 +37,7 @@ struct slamhip_ctx {
     // one context may be driven from different threads (slamhip.h) -- their blocking calls then take turns, as they do on the
     // context's one stream anyway.
     uint32_t *mailbox; uint32_t mail_seq; bool mail_off;
+    bool large_bar;           // the host can store straight into device memory (hipDeviceAttributeIsLargeBar): per-scan uploads without a launch
     pthread_mutex_t mail_lock;
 };
 // RAII guard of slamhip_ctx::mail_lock (see there)

@@ -56,6 +56,11 @@ extern "C" int32_t slamhip_ctx_create(int32_t device, slamhip_ctx **out)
         pthread_mutexattr_destroy(&at);
     }
     c->mail_off = getenv("SLAMHIP_NO_HOSTWAIT") && atoi(getenv("SLAMHIP_NO_HOSTWAIT"));
+    {
+        int lb = 0;
+        if (hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, device) != hipSuccess) { lb = 0; (void)hipGetLastError(); }
+        c->large_bar = lb != 0 && !c->mail_off && !getenv("SLAMHIP_NO_DIRECT_UPLOAD");
+    }
     *out = c;
     return SLAMHIP_OK;
 }

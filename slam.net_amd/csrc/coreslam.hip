@@ -73,15 +73,37 @@ __global__ void k_generate_offsets(float *__restrict__ offs_flat, int n, float s
 // search pose of the launch without reading the candidates (k1_search_tiled).
 // GEN: the whole device-generated list is evaluated (first = 0, count = n + 1), so the jitters are produced here, in
 // evaluation order, and stored to the flat list as well: one launch instead of two per scan.
+// Launched on the side stream (ensure_shard), the launch tells the HOST when everything it wrote is visible to a launch that has
+// not started yet: every workgroup waits for its stores, writes its XCD's L2 back (agent-scope release) and arrives; the last
+// arriver stores side_seq into a pinned word.  (The runtime's own completion tracking -- hipStreamQuery, or an event the other
+// stream waits for -- was measured 10 - 16 us slower per scan than the launch saves.)
+__device__ static inline void k_side_arrive(unsigned *__restrict__ arrive, uint32_t *__restrict__ flag, uint32_t seq)
+{
+    if (!flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned n = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == gridDim.x - 1) {
+            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <bool GEN>
 __global__ void __launch_bounds__(1024)
 k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_in, int first, int count, int zero_pos,
                  float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds, int grp,
                  int gen_n, float gen_sxy, float gen_sth, uint64_t gen_seed, uint64_t gen_stream,
-                 const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst, int up_n16, uint32_t *__restrict__ up_flag, uint32_t up_seq)
+                 const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst, int up_n16, uint32_t *__restrict__ up_flag, uint32_t up_seq,
+                 unsigned *__restrict__ side_arrive, uint32_t *__restrict__ side_flag, uint32_t side_seq)
 {
     if (up_n16 > 0 && (int)blockIdx.x >= (int)gridDim.x - SH_UPLOAD_PARTS) {   // riding along: the scan upload (the two are independent, K1 needs both)
         sh_upload16_part(up_src, up_dst, up_n16, (int)blockIdx.x - ((int)gridDim.x - SH_UPLOAD_PARTS), up_flag, up_seq);
+        k_side_arrive(side_arrive, side_flag, side_seq);
         return;
     }
     __shared__ float red[16][6];
@@ -116,6 +138,7 @@ k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_i
         for (int w = 1; w < 16; w++) v = (threadIdx.x & 1) ? fmaxf(v, red[w][threadIdx.x]) : fminf(v, red[w][threadIdx.x]);
         grp_bounds[8 * (size_t)blockIdx.x + threadIdx.x] = v;          // (NaN jitters never reach the tiled kernel: sanity flags)
     }
+    k_side_arrive(side_arrive, side_flag, side_seq);
 }
 
 // winner pose from the packed key: search_pose + offs[index-1] (:635-637), theta normalised (:746)
@@ -144,6 +167,9 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_k1_gmin); (void)hipFree(cs->d_k1_acc); (void)hipFree(cs->d_k1_ring);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
     if (cs->mirror_stream) { (void)hipStreamSynchronize(cs->mirror_stream); (void)hipStreamDestroy(cs->mirror_stream); }
+    if (cs->side_stream) { (void)hipStreamSynchronize(cs->side_stream); (void)hipStreamDestroy(cs->side_stream); }
+    (void)hipFree(cs->d_side_arrive);
+    (void)hipFree(cs->spec_offs_flat); (void)hipFree(cs->spec_ev_off); (void)hipFree(cs->spec_ev_idx); (void)hipFree(cs->spec_grp_bounds);
     if (cs->ev_snap) (void)hipEventDestroy(cs->ev_snap);
     if (cs->ev_push) (void)hipEventDestroy(cs->ev_push);
     (void)hipFree(cs->d_hole_span); (void)hipFree(cs->d_hole_span_snap); (void)hipFree(cs->d_hole_shadow); (void)hipFree(cs->d_mirror_sum); (void)hipFree(cs->d_mirror_mask);
@@ -579,16 +605,25 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->d_scan_blob = nullptr; cs->h_scan_blob = nullptr; cs->cap_points = 0;
         const int cap = n + n / 4 + 64;
         const size_t bytes = (((size_t)cap * (16 + 8 + 8) + sizeof(int) * (size_t)(cap + 2)) + 15) & ~(size_t)15;      // (the upload moves 16-byte units)
-        SH_HIP(hipMalloc(&cs->d_scan_blob, bytes));
+        // (two device blocks, used in turn: the upload of scan n + 1 may run -- on the side stream, see ensure_shard -- while the
+        // map updates of scan n still read theirs)
+        SH_HIP(hipMalloc(&cs->d_scan_blob, 2 * bytes));
         SH_HIP(hipHostMalloc(&cs->h_scan_blob, bytes));
         if (!cs->ev_scan) SH_HIP(hipEventCreateWithFlags(&cs->ev_scan, hipEventDisableTiming));
-        char *d = (char *)cs->d_scan_blob;
-        cs->d_ray_blk = (int4 *)d;                     d += (size_t)cap * 16;
-        cs->d_pts = (float2 *)d;                       d += (size_t)cap * 8;
-        cs->d_pts_sorted = (float2 *)d;                d += (size_t)cap * 8;
-        cs->d_rb_start = (int *)d;
+        cs->scan_blob_bytes = bytes;
+        cs->blob_use[0] = cs->blob_use[1] = 0;                  // (fresh blocks; the stream has been drained above)
         cs->cap_points = cap;
         cs->scan_in_flight = false;
+    }
+    {
+        cs->scan_buf ^= 1;
+        char *d = (char *)cs->d_scan_blob + (size_t)cs->scan_buf * cs->scan_blob_bytes;
+        const size_t cap = (size_t)cs->cap_points;
+        cs->d_scan_cur = d;
+        cs->d_ray_blk = (int4 *)d;                     d += cap * 16;
+        cs->d_pts = (float2 *)d;                       d += cap * 8;
+        cs->d_pts_sorted = (float2 *)d;                d += cap * 8;
+        cs->d_rb_start = (int *)d;
     }
     if (cs->upload_pending) cs->upload_pending = false; // (the staged scan was never consumed: nothing was launched, the block is ours)
     else if (cs->scan_in_flight) {                      // the previous copy has left the staging block
@@ -735,7 +770,20 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     const size_t used = (size_t)cap_ * 32 + sizeof(int) * rb.size();
     // (a blocking call that returned through the mailbox leaves a stream the runtime has not yet seen finish; the copy takes
     // its immediate path only on a stream the runtime knows to be idle: one query lets it find out)
-    if (!cs->ctx->mail_off) {
+    if (cs->ctx->large_bar && cs->blob_use[cs->scan_buf] <= cs->launch_done) {
+        // The device block of this scan is idle (nothing that read it is still running: see launch_done) and the host can store
+        // into device memory: the upload is a copy by the CPU through the PCIe aperture -- write-combined, 32 KB in ~1 us,
+        // tools/scratch/bar_test.hip -- and the launches that follow find the data in memory (their doorbell is ordered behind the
+        // posted writes; they start with the L2 invalidated).  No upload launch, no flags, nothing in flight.
+        const size_t c_ = (size_t)cap_, n_ = (size_t)n;
+        const char *hb = (const char *)cs->h_scan_blob;
+        memcpy(cs->d_scan_cur, hb, n_ * 16);                                         // ray -> block table
+        memcpy(cs->d_scan_cur + c_ * 16, hb + c_ * 16, n_ * 8);                      // rays, original order
+        memcpy(cs->d_scan_cur + c_ * 24, hb + c_ * 24, n_ * 8);                      // rays, sorted
+        memcpy(cs->d_scan_cur + c_ * 32, hb + c_ * 32, sizeof(int) * rb.size());     // block starts
+        __builtin_ia32_sfence();
+        cs->upload_pending = false;
+    } else if (!cs->ctx->mail_off) {
         // The upload is a launch that pulls the staging block and then tells the host (h_key words 28 .. 31, one per workgroup of the upload) that it may be refilled.
         // It is left pending: the first launch that reads the scan issues it (cs_flush_scan) -- or the candidate gather of the
         // coming search carries it as an extra workgroup (ensure_shard): one launch and one launch boundary less per scan in the
@@ -743,7 +791,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->upload_pending = true;
         cs->upload_bytes = (used + 15) & ~(size_t)15;
     } else {
-        SH_HIP(hipMemcpyAsync(cs->d_scan_blob, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
+        SH_HIP(hipMemcpyAsync(cs->d_scan_cur, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
         SH_HIP(hipEventRecord(cs->ev_scan, cs->ctx->stream));
         cs->scan_in_flight = true;
     }
@@ -751,11 +799,29 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     return SLAMHIP_OK;
 }
 
+// The search may be put into the operator's stream once the side stream's launch (ensure_shard) has COMPLETED: the host watches
+// for that -- it has nothing else to do, the map updates of the previous scan are still running in the operator's stream -- rather
+// than tying the streams with an event (measured: event record + cross-stream wait cost 10 us per scan, twice what the launch beside
+// the updates saves).
+thread_local cs_stage_times g_cst;
+
+int32_t cs_side_join(slamhip_cs *cs)
+{
+    if (!cs->side_join) return SLAMHIP_OK;
+    cs->side_join = false;
+    volatile uint32_t *flag = (volatile uint32_t *)cs->h_key + 24;
+    for (int spins = 0; spins < 200000; spins++) { if (*flag == cs->side_seq) return SLAMHIP_OK; __builtin_ia32_pause(); }
+    SH_HIP(hipStreamSynchronize(cs->side_stream));             // (far past any launch of this kind: let the runtime report what happened)
+    if (*flag == cs->side_seq) return SLAMHIP_OK;
+    SH_FAIL(SLAMHIP_ERR_HIP, "the side stream is idle but its completion word never arrived");
+}
+
 int32_t cs_flush_scan(slamhip_cs *cs)
 {
+    cs->blob_use[cs->scan_buf] = ++cs->launch_count;             // (called by every launcher that reads the scan)
     if (!cs->upload_pending) return SLAMHIP_OK;
     // (the upload state is committed once the launch that carries it is in the stream: on an error the scan stays pending)
-    SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_blob, cs->upload_bytes, (uint32_t *)cs->h_key + 28, cs->upload_seq + 1));
+    SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_cur, cs->upload_bytes, (uint32_t *)cs->h_key + 28, cs->upload_seq + 1));
     cs->upload_pending = false;
     cs->upload_seq++;
     cs->scan_in_flight = true;
@@ -843,6 +909,7 @@ extern "C" int32_t slamhip_cs_set_offsets(slamhip_cs *cs, const float *offs, int
     cs->offs_theta_small = true;
     for (size_t i = 0; i < (size_t)n * 3; i++) if (!(fabsf(offs[i]) < (i % 3 == 2 ? 1.0e4f : 1.0e6f))) { cs->offs_theta_small = false; break; }
     cs->offs_on_device_sorted = false; cs->gen_pending = false;
+    cs->spec_valid = false; cs->spec_base_ok = false;
     cs->shard_first = cs->shard_count = -1;
     if (n > 0) SH_HIP(hipMemcpy(cs->d_offs_flat, offs, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     return SLAMHIP_OK;
@@ -857,6 +924,23 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
         SH_HIP(hipStreamSynchronize(cs->ctx->stream));
         SH_TRY(ensure_offsets_capacity(cs, n));
     }
+    // (bit patterns: the sigmas must be the very floats the prepared list was made from)
+    const bool hit = cs->spec_valid && n == cs->spec_n && n == cs->n_offs && memcmp(&sigma_xy, &cs->spec_sxy, 4) == 0 &&
+                     memcmp(&sigma_theta, &cs->spec_sth, 4) == 0 && seed == cs->spec_seed && stream == cs->spec_stream &&
+                     cs->spec_cap_offs == cs->cap_offs && cs->spec_cap_cand == cs->cap_cand && cs->spec_cap_grp == cs->cap_grp &&
+                     cs->offs_on_device_sorted && cs->shard_first == 0 && cs->shard_count == n + 1 && cs->k1_group == cs->spec_grp;
+    cs->spec_valid = false;
+    if (hit) {
+        // the list asked for has been prepared (cs_speculate_next): swap the buffer sets -- the search that read the old set has
+        // delivered its result -- and leave everything ensure_shard derived from (n, sigmas, group size) as it is
+        std::swap(cs->d_offs_flat, cs->spec_offs_flat); std::swap(cs->d_ev_off, cs->spec_ev_off);
+        std::swap(cs->d_ev_idx, cs->spec_ev_idx); std::swap(cs->d_grp_bounds, cs->spec_grp_bounds);
+        cs->gen_stream = stream; cs->gen_pending = false;
+        cs->k1_layout_dirty = true;
+        cs->side_join = true;                                     // (the search launch checks the side launch's word: cs_side_join)
+        return SLAMHIP_OK;
+    }
+    cs->spec_base_ok = false;
     cs->n_offs = n;
     cs->h_offs.clear();
     cs->offs_theta_small = fabsf(sigma_theta) < 1.0e3f && fabsf(sigma_xy) < 1.0e5f;     // |normcdfinvf| < 6 for float quantiles
@@ -865,6 +949,55 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
     cs->shard_first = cs->shard_count = -1;
     // produced on first use: a full-range search generates the list inside its gather launch (ensure_shard)
     cs->gen_pending = n > 0; cs->gen_seed = seed; cs->gen_stream = stream;
+    return SLAMHIP_OK;
+}
+
+// The processor's flow asks for a fresh candidate list per scan -- slamhip_cs_generate_offsets(n, sigmas, seed, stream) with the
+// stream counting up -- and the list depends on nothing else.  A fused scan that is about to wait for its pose therefore prepares
+// the NEXT list (same parameters, stream + 1) into a second set of buffers, on a stream of its own, beside the search and the map
+// updates in flight; when the next generate_offsets call asks for exactly that list the sets are swapped and the search finds
+// its candidates in place: one launch (3.5 us of host time, 5 us in the operator's stream) less between two scans.  A call with
+// other parameters simply drops the prepared list.  The side launch reports through a pinned word (k_side_arrive) which the
+// search launch checks (cs_side_join); by then it has long arrived.
+static void spec_free(slamhip_cs *cs)
+{
+    (void)hipFree(cs->spec_offs_flat); (void)hipFree(cs->spec_ev_off); (void)hipFree(cs->spec_ev_idx); (void)hipFree(cs->spec_grp_bounds);
+    cs->spec_offs_flat = nullptr; cs->spec_ev_off = nullptr; cs->spec_ev_idx = nullptr; cs->spec_grp_bounds = nullptr;
+    cs->spec_cap_offs = cs->spec_cap_cand = cs->spec_cap_grp = 0;
+}
+
+static int32_t cs_speculate_next(slamhip_cs *cs)
+{
+    slamhip_ctx *ctx = cs->ctx;
+    static const bool off = getenv("SLAMHIP_NO_SPECULATION") != nullptr;
+    const int n = cs->n_offs;
+    cs->spec_valid = false;
+    if (off || !cs->spec_base_ok || !cs->offs_on_device_sorted || cs->gen_pending || n <= 0 || cs->shard_first != 0 || cs->shard_count != n + 1 ||
+        ctx->timing != 0 || ctx->mail_off) return SLAMHIP_OK;
+    if (!cs->side_stream) {
+        SH_HIP(hipStreamCreateWithFlags(&cs->side_stream, hipStreamNonBlocking));
+        SH_HIP(hipMalloc(&cs->d_side_arrive, 64));
+        SH_HIP(hipMemset(cs->d_side_arrive, 0, 64));
+    }
+    if (cs->spec_cap_offs != cs->cap_offs || cs->spec_cap_cand != cs->cap_cand || cs->spec_cap_grp != cs->cap_grp) {
+        SH_HIP(hipStreamSynchronize(cs->side_stream));
+        spec_free(cs);
+        SH_HIP(hipMalloc(&cs->spec_offs_flat, sizeof(float) * 3 * (size_t)cs->cap_offs));
+        SH_HIP(hipMalloc(&cs->spec_ev_off, sizeof(float) * 3 * (size_t)cs->cap_cand));
+        SH_HIP(hipMalloc(&cs->spec_ev_idx, sizeof(int) * (size_t)cs->cap_cand));
+        SH_HIP(hipMalloc(&cs->spec_grp_bounds, sizeof(float) * 8 * (size_t)cs->cap_grp));
+        cs->spec_cap_offs = cs->cap_offs; cs->spec_cap_cand = cs->cap_cand; cs->spec_cap_grp = cs->cap_grp;
+    }
+    const int count = n + 1, grp = cs->k1_group, ng = sh_div_up(count, grp);
+    const int zero_pos = count - 1 < n / 2 ? count - 1 : n / 2;
+    hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng), dim3(1024), 0, cs->side_stream,
+                       cs->spec_offs_flat, (const int *)nullptr, 0, count, zero_pos, cs->spec_ev_off, cs->spec_ev_idx, cs->spec_grp_bounds, grp,
+                       n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream + 1, (const uint4 *)nullptr, (uint4 *)nullptr, 0,
+                       (uint32_t *)nullptr, 0u, cs->d_side_arrive, (uint32_t *)cs->h_key + 24, cs->side_seq + 1);
+    SH_HIP(hipGetLastError());
+    cs->side_seq++;
+    cs->spec_valid = true; cs->spec_n = n; cs->spec_sxy = cs->gen_sigma_xy; cs->spec_sth = cs->gen_sigma_theta;
+    cs->spec_seed = cs->gen_seed; cs->spec_stream = cs->gen_stream + 1; cs->spec_grp = grp;
     return SLAMHIP_OK;
 }
 
@@ -947,7 +1080,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
     const int up_wg = cs->upload_pending ? SH_UPLOAD_PARTS : 0;
     const uint4 *up_src = nullptr; uint4 *up_dst = nullptr; int up_n16 = 0; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
     if (up_wg) {                                                   // (committed below, once the gather launch is in the stream)
-        up_src = (const uint4 *)cs->h_scan_blob; up_dst = (uint4 *)cs->d_scan_blob; up_n16 = (int)(cs->upload_bytes / 16);
+        up_src = (const uint4 *)cs->h_scan_blob; up_dst = (uint4 *)cs->d_scan_cur; up_n16 = (int)(cs->upload_bytes / 16);
         up_flag = (uint32_t *)cs->h_key + 28; up_seq = cs->upload_seq + 1;
     }
     if (cs->offs_on_device_sorted) {
@@ -958,12 +1091,14 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             cs->gen_pending = false;
             hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
-                               n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream, up_src, up_dst, up_n16, up_flag, up_seq);
+                               n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream, up_src, up_dst, up_n16, up_flag, up_seq,
+                               (unsigned *)nullptr, (uint32_t *)nullptr, 0u);
+            cs->spec_base_ok = true;                              // (the full generated list is in place: cs_speculate_next may prepare its successor)
         } else {
             SH_TRY(cs_flush_generate(cs));
             hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
-                               0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq);
+                               0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq, (unsigned *)nullptr, (uint32_t *)nullptr, 0u);
         }
         // the jitters are the strata of N(0, sigma): group ranges from the quantile function (layout balance only)
         for (int g = 0; g < ng; g++) {
@@ -1001,7 +1136,8 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         SH_HIP(hipMemcpyAsync(cs->d_ev_idx, perm.data(), sizeof(int) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                            cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds, grp,
-                           0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq);
+                           0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq,
+                           (unsigned *)nullptr, (uint32_t *)nullptr, 0u);
         const hipError_t le = hipGetLastError();
         if (le == hipSuccess && up_wg) { cs->upload_pending = false; cs->upload_seq = up_seq; cs->scan_in_flight = true; }
         SH_HIP(le);
@@ -1021,7 +1157,9 @@ static int32_t search_enqueue(slamhip_cs *cs, const float pose[3], int first, in
     SH_CHECK_ARG(first >= 0 && count > 0 && first + count <= cs->n_offs + 1);
     SH_HIP(hipSetDevice(cs->ctx->device));
     if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
+    g_cst.start();
     SH_TRY(ensure_shard(cs, first, count));
+    g_cst.lap(0);
     const bool sane = fabsf(pose[0]) < 1.0e6f && fabsf(pose[1]) < 1.0e6f && fabsf(pose[2]) < 1.0e4f && cs->offs_theta_small;
     return cs_launch_distance(cs, 1, pose, count, false, sane, key_dst);
 }
@@ -1271,6 +1409,7 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     const int32_t rc_s = search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key);
     cs->k1_want_pose = false; cs->k1_done_flag = nullptr;
     SH_TRY(rc_s);
+    g_cst.lap(3);
     const bool delivered = early && cs->k1_done_armed && cs->k1_pose_written;
     if (!cs->k1_pose_written)                                    // (fallback search kernels: decode the key in a launch of its own)
         hipLaunchKernelGGL(k_best_pose, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)cs->d_key,
@@ -1285,11 +1424,18 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
         rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality);
         if (rc_u == SLAMHIP_OK) rc_u = cs_launch_obstacle_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), max_hits);
     }
+    g_cst.lap(4);
     cs_layout_idle_refresh(cs);                                  // (host work under the search: the launch layout for the next scan)
+    g_cst.lap(5);
     if (delivered) {
+        const int32_t rc_p = cs_speculate_next(cs);              // (host work under the search: the next scan's candidates, on the side stream)
+        g_cst.lap(7);
         SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));       // (the search's word arrives whatever became of the update launches)
+        g_cst.lap(6); g_cst.done();
+        SH_TRY(rc_p);
         SH_TRY(rc_u);
         cs->hole_pixels_pending = true;
+        cs->launch_done = cs->k1_launch_no;                      // (the search has delivered: every launch before it has finished)
     } else {
         SH_TRY(rc_u);
         // (K1 armed but without the pose -- it then stored `seq` with the key alone: the result block follows under a fresh number)

@@ -1,6 +1,9 @@
 // cs_internal.h -- device state of the CoreSLAM operator object (slamhip_cs).
 #pragma once
 #include "common.h"
+#include <time.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include <utility>
 
@@ -28,7 +31,16 @@ struct slamhip_cs {
 
     // ---- scan -------------------------------------------------------------------------------
     int n_points, cap_points;
-    void *d_scan_blob, *h_scan_blob;  // one device block / one pinned staging block for all per-scan uploads
+    void *d_scan_blob, *h_scan_blob;  // two device blocks used in turn / one pinned staging block for all per-scan uploads
+    char *d_scan_cur; size_t scan_blob_bytes; int scan_buf;   // the block of the current scan
+    // which launches read which block: a block may be refilled by the HOST (stores through the large BAR, set_scan) once the last
+    // launch that read it is known to have finished -- launch_done is the number of the newest search launch whose result the host
+    // has seen (everything before it in the stream has finished)
+    uint64_t launch_count, launch_done, blob_use[2], k1_launch_no;
+    hipStream_t side_stream; unsigned *d_side_arrive; uint32_t side_seq; bool side_join;
+    // the next scan's candidate list, prepared ahead on the side stream (cs_speculate_next, coreslam.hip)
+    float *spec_offs_flat, *spec_ev_off, *spec_grp_bounds; int *spec_ev_idx; int spec_cap_offs, spec_cap_cand, spec_cap_grp;
+    bool spec_valid, spec_base_ok; int spec_n, spec_grp; float spec_sxy, spec_sth; uint64_t spec_seed, spec_stream; // jitter generation + scan upload beside the previous scan's map updates (ensure_shard)
     hipEvent_t ev_scan; bool scan_in_flight;
     bool upload_pending; size_t upload_bytes;   // set_scan filled the staging block; the upload is launched by the first consumer (cs_flush_scan),
                                                 // or rides on the candidate gather's launch when one comes first (ensure_shard)
@@ -141,6 +153,23 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 void cs_layout_idle_refresh(slamhip_cs *cs);   // host only: call between a search's enqueue and the wait for its result
 // coreslam.hip: produces a device-generated jitter list that is still pending (slamhip_cs_generate_offsets)
 int32_t cs_flush_generate(slamhip_cs *cs);
+int32_t cs_side_join(slamhip_cs *cs);
+// developer switch SLAMHIP_FUSED_TIMES=1: host clock between the stages of the fused scan (mean over 64 calls, stderr)
+struct cs_stage_times {
+    bool on; double acc[8]; int n; timespec t;
+    cs_stage_times() : on(getenv("SLAMHIP_FUSED_TIMES") != nullptr), n(0) { for (double &a : acc) a = 0; }
+    void start() { if (on) clock_gettime(CLOCK_MONOTONIC, &t); }
+    void lap(int k) { if (!on) return; timespec u; clock_gettime(CLOCK_MONOTONIC, &u); acc[k] += (u.tv_sec - t.tv_sec) * 1e6 + (u.tv_nsec - t.tv_nsec) * 1e-3; t = u; }
+    void done()
+    {
+        if (!on || ++n < 64) return;
+        fprintf(stderr, "[slamhip] fused scan host stages (us): shard/gather launch %.1f | K1 host prep %.1f | side join %.1f | K1 launch %.1f | update launch %.1f | idle refresh %.1f | next candidates %.1f | wait for pose %.1f\n",
+                acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[7] / n, acc[6] / n);
+        for (double &a : acc) a = 0;
+        n = 0;
+    }
+};
+extern thread_local cs_stage_times g_cst;
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);
 int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all);

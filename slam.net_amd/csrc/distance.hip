@@ -1468,6 +1468,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     slamhip_ctx *ctx = cs->ctx;
     if (cs->n_points <= 0) SH_FAIL(SLAMHIP_ERR_STATE, "no scan set (slamhip_cs_set_scan)");
     SH_TRY(cs_flush_scan(cs));
+    cs->k1_launch_no = cs->launch_count;
     static const int force_global = env_int("SLAMHIP_K1_GLOBAL", 0);
     static const int verify = env_int("SLAMHIP_K1_VERIFY", 0);
     static const int tile_kb = env_int("SLAMHIP_K1_TILE_KB", 60);
@@ -1708,6 +1709,9 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             SH_HIP(hipMemsetAsync((char *)cs->d_k1_gmin + 8, 0, 8, ctx->stream));
         }
         a.gmin = cs->d_k1_gmin; a.done = (unsigned *)((char *)cs->d_k1_gmin + 8); a.acc = cs->d_k1_acc;
+        g_cst.lap(1);
+        SH_TRY(cs_side_join(cs));
+        g_cst.lap(2);
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
 #define K1_LAUNCH(M, V, C, G) hipLaunchKernelGGL((k1_search_tiled<M, V, C, G>), dim3(n_wgs), dim3(G / C), lds, ctx->stream, a)
@@ -1827,6 +1831,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
 fallback:
     // ---- fallback: candidate transform, bounds-checked global gathers, reduction -----------------------------------
     cs->k1_pose_written = false; cs->k1_done_armed = false; cs->k1_sig_armed = false;
+    SH_TRY(cs_side_join(cs));
     {
         sh_timer t(ctx, SLAMHIP_K_CS_PREP);
         const dim3 grid(sh_div_up(count, K1_THREADS));
