@@ -773,7 +773,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     if (cs->ctx->large_bar && cs->blob_use[cs->scan_buf] <= cs->launch_done) {
         // The device block of this scan is idle (nothing that read it is still running: see launch_done) and the host can store
         // into device memory: the upload is a copy by the CPU through the PCIe aperture -- write-combined, 32 KB in ~1 us,
-        // tools/scratch/bar_test.hip -- and the launches that follow find the data in memory (their doorbell is ordered behind the
+        // tools/ubench_bar.hip -- and the launches that follow find the data in memory (their doorbell is ordered behind the
         // posted writes; they start with the L2 invalidated).  No upload launch, no flags, nothing in flight.
         const size_t c_ = (size_t)cap_, n_ = (size_t)n;
         const char *hb = (const char *)cs->h_scan_blob;
