@@ -594,6 +594,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
 {
     SH_CHECK_ARG(cs && n >= 0 && (xy || n == 0));
     SH_HIP(hipSetDevice(cs->ctx->device));
+    g_sst.start();
     cs->n_points = 0;                                  // (stays "no scan" if anything below fails)
     cs->n_rb = 0;
     if (n == 0) return SLAMHIP_OK;
@@ -636,6 +637,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     float *h_pts = (float *)((char *)cs->h_scan_blob + (size_t)cap_ * 16);
     float *sorted = (float *)((char *)cs->h_scan_blob + (size_t)cap_ * 24);
     int *h_rb = (int *)((char *)cs->h_scan_blob + (size_t)cap_ * 32);
+    g_sst.lap(0);
     memcpy(h_pts, xy, sizeof(float) * 2 * (size_t)n);
     // K1 sums integers, so it may visit the rays in any order: sort them along a Z-order curve at
     // 64-pixel granularity so that a ray block's end points stay close together in the map (the rigid
@@ -670,6 +672,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     // the codes are COMPRESSED: with every cell within 2^m of 32768 in both directions, bits m .. 15 of a coordinate all follow
     // bit 15, so subtracting 32768 - 2^m keeps every comparison and leaves 2 (m + 1) bits: two 8-bit passes for scans up to
     // 128 cells (160 m at 2048^2 / 40 m) instead of three 11-bit ones with their 2048-bin prefix sums.
+    g_sst.lap(1);
     int dmax = 0;
     for (int i = 0; i < 2 * n; i++) { const int d = cellxy[(size_t)i] >= 32768 ? cellxy[(size_t)i] - 32768 : 32767 - cellxy[(size_t)i]; dmax = d > dmax ? d : dmax; }
     int mbits = 0;
@@ -681,6 +684,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         const uint32_t code = part1by1((uint32_t)(cellxy[2 * (size_t)i] - shift_c)) | (part1by1((uint32_t)(cellxy[2 * (size_t)i + 1] - shift_c)) << 1);
         keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
     }
+    g_sst.lap(2);
     {   // LSD radix sort on the code (stable 8-bit passes over the bits in use; ties keep ray order)
         std::vector<uint64_t> &tmp = cs->h_sort_tmp;
         tmp.resize((size_t)n);
@@ -698,6 +702,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         }
         if (src != keys.data()) memcpy(keys.data(), src, sizeof(uint64_t) * (size_t)n);
     }
+    g_sst.lap(3);
     std::vector<int> &rb = cs->h_rb_start;
     rb.clear();
     rb.push_back(0);
@@ -744,6 +749,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cur++;
     }
     rb.push_back(n);
+    g_sst.lap(4);
     cs->n_rb = (int)rb.size() - 1;
     cs->pts_sane = sane;
     // K1's view: per sorted ray its block (a workgroup's chunk is a ray range, cut into pieces at block
@@ -767,6 +773,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     cs->k1_scan_dirty = true;
     cs->scan_gen++;
     memcpy(h_rb, rb.data(), sizeof(int) * rb.size());
+    g_sst.lap(5);
     const size_t used = (size_t)cap_ * 32 + sizeof(int) * rb.size();
     // (a blocking call that returned through the mailbox leaves a stream the runtime has not yet seen finish; the copy takes
     // its immediate path only on a stream the runtime knows to be idle: one query lets it find out)
@@ -796,6 +803,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         cs->scan_in_flight = true;
     }
     cs->n_points = n;
+    g_sst.lap(6); g_sst.done();
     return SLAMHIP_OK;
 }
 
@@ -803,7 +811,8 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
 // for that -- it has nothing else to do, the map updates of the previous scan are still running in the operator's stream -- rather
 // than tying the streams with an event (measured: event record + cross-stream wait cost 10 us per scan, twice what the launch beside
 // the updates saves).
-thread_local cs_stage_times g_cst;
+thread_local cs_stage_times g_cst("fused scan");
+thread_local cs_stage_times g_sst("set_scan");
 
 int32_t cs_side_join(slamhip_cs *cs)
 {
@@ -936,7 +945,6 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
         std::swap(cs->d_offs_flat, cs->spec_offs_flat); std::swap(cs->d_ev_off, cs->spec_ev_off);
         std::swap(cs->d_ev_idx, cs->spec_ev_idx); std::swap(cs->d_grp_bounds, cs->spec_grp_bounds);
         cs->gen_stream = stream; cs->gen_pending = false;
-        cs->k1_layout_dirty = true;
         cs->side_join = true;                                     // (the search launch checks the side launch's word: cs_side_join)
         return SLAMHIP_OK;
     }
@@ -1073,9 +1081,23 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
                     : count >= 65536 ? K1_GROUP_BIG : count <= 12288 ? K1_GROUP_SMALL : K1_GROUP;
     cs->k1_group = grp;
     const int ng = sh_div_up(count, grp);
+    // (the launch layout is made from these per-group figures: it stays valid when a new list leaves them as they were -- the
+    // per-scan flow regenerates the list with the same sigmas -- see the end of this function)
+    cs->h_grp_prev.clear();
+    cs->h_grp_prev.insert(cs->h_grp_prev.end(), cs->h_grp_dth.begin(), cs->h_grp_dth.end());
+    cs->h_grp_prev.insert(cs->h_grp_prev.end(), cs->h_grp_dxy.begin(), cs->h_grp_dxy.end());
+    cs->h_grp_prev.insert(cs->h_grp_prev.end(), cs->h_grp_lohi.begin(), cs->h_grp_lohi.end());
+    cs->h_grp_prev.push_back((float)cs->k1_group_prev);
+    cs->k1_group_prev = grp;
     cs->h_grp_dth.assign((size_t)ng, 0.0f); cs->h_grp_dxy.assign((size_t)ng, 0.0f);
     cs->h_grp_lohi.assign((size_t)ng * 6, 0.0f);                   // per group: min / max of dx, dy, dtheta (host lists: exact; generated lists: from the quantiles)
-    cs->k1_layout_dirty = true;
+    auto figures_changed = [cs, grp]() {
+        const std::vector<float> &p = cs->h_grp_prev;
+        const size_t a = cs->h_grp_dth.size(), b = cs->h_grp_dxy.size(), c = cs->h_grp_lohi.size();
+        if (p.size() != a + b + c + 1 || p.back() != (float)grp) return true;
+        return memcmp(p.data(), cs->h_grp_dth.data(), 4 * a) != 0 || memcmp(p.data() + a, cs->h_grp_dxy.data(), 4 * b) != 0 ||
+               memcmp(p.data() + a + b, cs->h_grp_lohi.data(), 4 * c) != 0;
+    };
     // a pending scan upload rides on the gather launch as one more workgroup
     const int up_wg = cs->upload_pending ? SH_UPLOAD_PARTS : 0;
     const uint4 *up_src = nullptr; uint4 *up_dst = nullptr; int up_n16 = 0; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
@@ -1143,8 +1165,10 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         SH_HIP(le);
         SH_HIP(hipStreamSynchronize(ctx->stream));      // perm dies here
         cs->shard_first = first; cs->shard_count = count;
+        cs->k1_layout_dirty = true;
         return SLAMHIP_OK;
     }
+    if (figures_changed()) cs->k1_layout_dirty = true;
     SH_HIP(hipGetLastError());
     if (up_wg) { cs->upload_pending = false; cs->upload_seq = up_seq; cs->scan_in_flight = true; }
     cs->shard_first = first; cs->shard_count = count;

@@ -87,6 +87,7 @@ struct slamhip_cs {
     std::vector<double> k1_cut_wsc;             // (scratch)
     std::vector<double> k1_cut_wb;              // per ray block: the weight of one more tile step, in ray units (k1_cut_weights)
     uint32_t scan_gen;                          // scans set so far (slamhip_cs_set_scan)
+    std::vector<float> h_grp_prev; int k1_group_prev;   // the groups' figures before the last ensure_shard (layout kept when unchanged)
     bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups; float k1_layout_theta;
     bool k1_scan_dirty;                         // a new scan since the layout was made (set_scan): it is kept if still legal, see cs_launch_distance
     bool k1_layout_stale;                       // ... and the one for the scan now set is made in the host's next idle wait (cs_layout_idle_refresh)
@@ -154,21 +155,25 @@ void cs_layout_idle_refresh(slamhip_cs *cs);   // host only: call between a sear
 // coreslam.hip: produces a device-generated jitter list that is still pending (slamhip_cs_generate_offsets)
 int32_t cs_flush_generate(slamhip_cs *cs);
 int32_t cs_side_join(slamhip_cs *cs);
-// developer switch SLAMHIP_FUSED_TIMES=1: host clock between the stages of the fused scan (mean over 64 calls, stderr)
+// developer switch SLAMHIP_FUSED_TIMES=1: host clock between the stages of the per-scan calls (mean over 64 calls, stderr)
 struct cs_stage_times {
-    bool on; double acc[8]; int n; timespec t;
-    cs_stage_times() : on(getenv("SLAMHIP_FUSED_TIMES") != nullptr), n(0) { for (double &a : acc) a = 0; }
+    bool on; double acc[12]; int n; timespec t; const char *what;
+    explicit cs_stage_times(const char *w) : on(getenv("SLAMHIP_FUSED_TIMES") != nullptr), n(0), what(w) { for (double &a : acc) a = 0; }
     void start() { if (on) clock_gettime(CLOCK_MONOTONIC, &t); }
     void lap(int k) { if (!on) return; timespec u; clock_gettime(CLOCK_MONOTONIC, &u); acc[k] += (u.tv_sec - t.tv_sec) * 1e6 + (u.tv_nsec - t.tv_nsec) * 1e-3; t = u; }
     void done()
     {
         if (!on || ++n < 64) return;
-        fprintf(stderr, "[slamhip] fused scan host stages (us): shard/gather launch %.1f | K1 host prep %.1f | side join %.1f | K1 launch %.1f | update launch %.1f | idle refresh %.1f | next candidates %.1f | wait for pose %.1f\n",
-                acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[7] / n, acc[6] / n);
+        fprintf(stderr, "[slamhip] host stages (us), %s:", what);
+        for (int k = 0; k < 12; k++) fprintf(stderr, " %.2f", acc[k] / n);
+        fprintf(stderr, "\n");
         for (double &a : acc) a = 0;
         n = 0;
     }
 };
+// g_cst, the fused scan: 0 shard / gather launch | 1 K1 host preparation | 2 side join | 3 K1 launch | 4 update launch | 5 idle refresh |
+// 6 wait for the pose | 7 next candidates | 8 .. 11 inside the K1 preparation.  g_sst, set_scan: see the laps there.
+extern thread_local cs_stage_times g_sst;
 extern thread_local cs_stage_times g_cst;
 // holemap.hip
 int32_t cs_holemap_alloc(slamhip_cs *cs);

@@ -1531,6 +1531,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         int target = n_groups <= K1_TABLE_G ? target_wgs : target_wgs_uniform;
         const long long by_work = (long long)n_groups * cs->n_points / 12;
         if (by_work < target) target = (int)(by_work > n_groups ? by_work : n_groups);
+        g_cst.lap(8);
         bool remake = cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread ||
                       cs->k1_layout_target != target || (have_spread && !(fabsf(bth - cs->k1_layout_theta) < 0.1f));
         if (!remake && cs->k1_scan_dirty) {
@@ -1551,6 +1552,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             cs->k1_layout_groups = n_groups; cs->k1_layout_budget = budget; cs->k1_layout_spread = have_spread; cs->k1_layout_target = target;
             cs->k1_layout_band_parts = band_parts;
         }
+        g_cst.lap(9);
         {   // the accumulators count up to 2^14 - 1 arrivals per candidate and sum up to 2^20 rays (pathological scans: fallback kernels)
             int nc_max = cs->k1_uni_nc;
             for (size_t i = 0; i < cs->k1_tab_nc.size(); i++) nc_max = std::max(nc_max, cs->k1_tab_nc[i]);
