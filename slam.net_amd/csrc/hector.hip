@@ -55,13 +55,14 @@ struct slamhip_hs {
     float odds_free, odds_occ, lo_free, lo_occ;          // OccGridMap.cs:24-27
     int n_points, cap_points;
     float2 *d_pts; float origin[2];
+    float2 *d_pts_base; int pts_buf; uint64_t launch_count, launch_done, pts_use[2], match_launch_no;   // two device blocks used in turn; which launches read which (see slamhip_cs_set_scan)
     float *h_pts; hipEvent_t ev_pts; bool pts_in_flight;   // pinned staging of the scan: one async copy (or upload launch), no wait in set_scan
     bool upload_pending; size_t upload_bytes;              // set_scan filled the staging block; the first launch that reads the points issues the upload (hs_flush_scan) -- a single match pulls the block itself
     uint32_t upload_seq;                                   // upload launches issued; the launch stores it behind the staged points (h_pts + 2 * cap) when it has read them
     float *d_io; float *h_io; int cap_io;                // hints in / poses out (floats)
     // K5 line tables, per level: lines by index, lines sorted by (direction class, slope bucket), bucket starts, header
     void *d_k5_byidx, *d_k5_cand; int *d_k5_start, *d_k5_hdr; int cap_lines;
-    int *d_k5_sec; int k5_sec_parity;                        // [2][HS_MAX_LEVELS][K5_SEC] sector records of the cell kernel: an update reads the set the last one wrote
+    int *d_k5_sec; int k5_sec_parity; bool k5_toggle_pending;                        // [2][HS_MAX_LEVELS][K5_SEC] sector records of the cell kernel: an update reads the set the last one wrote
 };
 
 struct hs_levels_arg { hs_level_dev lv[HS_MAX_LEVELS]; int n; };
@@ -338,6 +339,24 @@ k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, co
 // the smallest index of a line that ends in it, and their order -- no atomics, no per-cell scratch, coalesced rows.
 struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; float *prob; int mark_free, mark_occ; int wg0, wgn; };
 struct k5_arg { k5_level lv[HS_MAX_LEVELS]; int n; };
+// The update gated on the device (HectorSLAMProcessor's per-scan flow, slamhip_hsproc_update): the launch is enqueued right
+// behind the match, before the host has the pose -- the kernel reads the matched pose the match left in device memory, applies
+// the processor's own test (HectorSLAMProcessor.cs:107-109: moved more than min_dist or turned more than min_angle since the
+// last update) with the very float operations the host applies to the pose it receives, and either returns at once or forms
+// the level transforms (OccGridMap.cs:120-123) itself.  Without it the update waited for host round trip + launch: 11.5 us of
+// idle device between the two kernels of a scan.
+struct k5_gate { const float *d_pose; float last[3]; float min_dist, min_angle; float stm[HS_MAX_LEVELS]; int on; };
+__host__ __device__ static inline float hs_deg_diff(float a, float b)      // MathEx.DegDiff (BaseSLAM/MathEx.cs:69-73)
+{
+    float d = ((a - b) + 180.0f) / 360.0f;
+    return ((d - floorf(d)) * 360.0f) - 180.0f;
+}
+__host__ __device__ static inline bool hs_moved_enough(const float pose[3], const float last[3], float min_dist, float min_angle)
+{
+    const float ddx = pose[0] - last[0], ddy = pose[1] - last[1];
+    const float dist2 = ddx * ddx + ddy * ddy;                            // Vector2.DistanceSquared :107
+    return dist2 > min_dist * min_dist || hs_deg_diff(pose[2], last[2]) > min_angle;   // :108 (radians through DegDiff, as the reference does)
+}
 struct k5_line { int da, sdb, ray, flags; };      // major length, signed minor length, line index, valid | major_x << 1 | (smaj + 1) << 2
 #define K5_ZONE 16                     // Chebyshev radius around the begin cell handled one wavefront per cell
 #define K5_LDS_LINES 3072
@@ -547,7 +566,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)
 k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox, float oy,
          const k5_line *__restrict__ byidx_all, const k5_line *__restrict__ cand_all,
          const int *__restrict__ start_all, const int *__restrict__ hdr_all, float lo_free, float lo_occ,
-         const int *__restrict__ sec_in, int *__restrict__ sec_out)
+         const int *__restrict__ sec_in, int *__restrict__ sec_out, const k5_gate gate)
 {
     extern __shared__ __attribute__((aligned(16))) char k5_smem[];
     int *start = (int *)k5_smem;
@@ -564,6 +583,12 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     const k5_level &L = A.lv[lvl];
     int bx, by, R, nv, first_line;
     K5_STAMP(0)
+    sh_m3x2 T = L.t;
+    if (BUILD && gate.on) {                                                 // (uniform: scalar loads, every wavefront the same answer)
+        const float pose[3] = { gate.d_pose[0], gate.d_pose[1], gate.d_pose[2] };
+        if (!hs_moved_enough(pose, gate.last, gate.min_dist, gate.min_angle)) return;
+        T = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]), sh_m3x2_translation(pose[0], pose[1])), sh_m3x2_scale(gate.stm[lvl]));   // OccGridMap.cs:120-123
+    }
     if (BUILD) {
         const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
         constexpr int RPT = (K5_LDS_LINES + 1023) / 1024;
@@ -575,7 +600,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         if (t < 10 && sec_in) rec_v = sec_in[lvl * K5_SEC + t];            //  requested here, stored behind the lines loop: no wait of its own)
         __syncthreads();
         float bxf, byf;
-        sh_v2_transform(ox, oy, L.t, &bxf, &byf);                          // :126
+        sh_v2_transform(ox, oy, T, &bxf, &byf);                            // :126
         bx = sh_f2i(rintf(bxf)); by = sh_f2i(rintf(byf));                  // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
         int bkt[RPT];
 #pragma unroll
@@ -589,7 +614,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             if (i + 1024 < n_pts) p_next = pts[i + 1024];
             if (i < n_pts) {
                 float exf, eyf;
-                sh_v2_transform(p.x, p.y, L.t, &exf, &eyf);                // :133
+                sh_v2_transform(p.x, p.y, T, &exf, &eyf);                  // :133
                 const int ex = sh_f2i(rintf(exf)), ey = sh_f2i(rintf(eyf));    // :134
                 const bool same = (bx == ex) & (by == ey);                 // :137
                 const bool inside = (bx >= 0) & (by >= 0) & (bx < L.w) & (by < L.h) & (ex >= 0) & (ey >= 0) & (ex < L.w) & (ey < L.h);   // :158-161
@@ -892,7 +917,7 @@ extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
     for (int l = 0; l < hs->n_levels; l++) {
         (void)hipFree(hs->lv[l].d_value); (void)hipFree(hs->lv[l].d_upd); (void)hipFree(hs->lv[l].d_prob);
     }
-    (void)hipFree(hs->d_pts); (void)hipFree(hs->d_io);
+    (void)hipFree(hs->d_pts_base); (void)hipFree(hs->d_io);
     if (hs->h_pts) (void)hipHostFree(hs->h_pts);
     if (hs->ev_pts) (void)hipEventDestroy(hs->ev_pts);
     (void)hipFree(hs->d_k5_sec);
@@ -1109,10 +1134,11 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
     if (n == 0) return SLAMHIP_OK;
     if (n > hs->cap_points) {
         SH_HIP(hipStreamSynchronize(hs->ctx->stream));
-        (void)hipFree(hs->d_pts); hs->d_pts = nullptr; hs->cap_points = 0;
+        (void)hipFree(hs->d_pts_base); hs->d_pts_base = nullptr; hs->d_pts = nullptr; hs->cap_points = 0;
         if (hs->h_pts) { (void)hipHostFree(hs->h_pts); hs->h_pts = nullptr; }
         const int cap = (n + n / 4 + 64 + 1) & ~1;                         // (even: the upload launch moves 16-byte units)
-        SH_HIP(hipMalloc(&hs->d_pts, sizeof(float2) * (size_t)cap));
+        SH_HIP(hipMalloc(&hs->d_pts_base, sizeof(float2) * (size_t)cap * 2));
+        hs->pts_use[0] = hs->pts_use[1] = 0;
         SH_HIP(hipHostMalloc(&hs->h_pts, sizeof(float2) * (size_t)cap + 64, hipHostMallocMapped | hipHostMallocCoherent));   // (+ the upload's completion word)
         memset(hs->h_pts + 2 * (size_t)cap, 0, 64);
         hs->upload_seq = 0;
@@ -1128,7 +1154,15 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
         hs->pts_in_flight = false;
     }
     memcpy(hs->h_pts, xy, sizeof(float) * 2 * (size_t)n);
-    if (!hs->ctx->mail_off) {                           // (see slamhip_cs_set_scan: the per-scan path is launches only, and the upload is left pending)
+    hs->pts_buf ^= 1;
+    hs->d_pts = hs->d_pts_base + (size_t)hs->pts_buf * (size_t)hs->cap_points;
+    if (hs->ctx->large_bar && hs->pts_use[hs->pts_buf] <= hs->launch_done) {
+        // (the block is idle and the host can store into device memory: the upload is a copy by the CPU through the PCIe aperture,
+        // see slamhip_cs_set_scan -- the match then reads its points from device memory instead of pulling them over PCIe)
+        memcpy(hs->d_pts, xy, sizeof(float) * 2 * (size_t)n);
+        __builtin_ia32_sfence();
+        hs->upload_pending = false;
+    } else if (!hs->ctx->mail_off) {                    // (see slamhip_cs_set_scan: the per-scan path is launches only, and the upload is left pending)
         hs->upload_pending = true;
         hs->upload_bytes = (sizeof(float) * 2 * (size_t)n + 15) & ~(size_t)15;
     } else {
@@ -1143,6 +1177,7 @@ extern "C" int32_t slamhip_hs_set_scan(slamhip_hs *hs, const float *xy, int32_t 
 // launches the scan upload that slamhip_hs_set_scan left pending (every launch that reads the points calls it first)
 static int32_t hs_flush_scan(slamhip_hs *hs)
 {
+    hs->pts_use[hs->pts_buf] = ++hs->launch_count;
     if (!hs->upload_pending) return SLAMHIP_OK;
     // (the upload state is committed once the launch that carries it is in the stream: on an error the scan stays pending)
     SH_TRY(sh_upload(hs->ctx, hs->h_pts, hs->d_pts, hs->upload_bytes, (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points), hs->upload_seq + 1));
@@ -1163,7 +1198,18 @@ static int32_t ensure_io(slamhip_hs *hs, int floats)
     return SLAMHIP_OK;
 }
 
-static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, int only_level, int iters)
+// defer_seq: (single match through the mailbox only) return after the launch with the completion number in *defer_seq -- the
+// caller holds the mailbox lock, enqueues what it wants behind the match and then calls match_collect
+static int32_t match_collect(slamhip_hs *hs, uint32_t seq, float *out)
+{
+    slamhip_ctx *ctx = hs->ctx;
+    SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));
+    const volatile float *m = (const volatile float *)ctx->mailbox;
+    out[0] = m[0]; out[1] = m[1]; out[2] = m[2];
+    hs->launch_done = hs->match_launch_no;                                 // (the match has delivered: every launch before it has finished)
+    return SLAMHIP_OK;
+}
+static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, int only_level, int iters, uint32_t *defer_seq = nullptr)
 {
     SH_HIP(hipSetDevice(hs->ctx->device));
     slamhip_ctx *ctx = hs->ctx;
@@ -1177,11 +1223,15 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     if (pull) {                                                           // (committed below, once the launch is in the stream)
         up_src = (const float2 *)hs->h_pts; up_dst = hs->d_pts; up_flag = (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points);
         up_seq = hs->upload_seq + 1;
+        hs->pts_use[hs->pts_buf] = ++hs->launch_count;
     } else SH_TRY(hs_flush_scan(hs));
+    hs->match_launch_no = hs->launch_count;
     if (B > 1) {
         memcpy(hs->h_io, hints, sizeof(float) * 3 * (size_t)B);
         SH_HIP(hipMemcpyAsync(d_in, hs->h_io, sizeof(float) * 3 * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
     }
+    uint32_t mail_seq = 0;
+    if (defer_seq && !mail1) SH_FAIL(SLAMHIP_ERR_STATE, "a deferred match is a single match through the mailbox");
     {
         sh_timer t(ctx, SLAMHIP_K_HS_MATCH);
         // a single match is a latency chain (levels x iterations): 1024 lanes leave one or two scan points per lane;
@@ -1189,7 +1239,7 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
         if (B <= 64)
             hipLaunchKernelGGL(k4_match<1024>, dim3(B), dim3(1024), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
                                B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters,
-                               mail1 ? ctx->mailbox : (uint32_t *)nullptr, mail1 ? sh_mail_seq_next(ctx) : 0u, up_src, up_dst, up_flag, up_seq);
+                               mail1 ? ctx->mailbox : (uint32_t *)nullptr, mail1 ? (mail_seq = sh_mail_seq_next(ctx)) : 0u, up_src, up_dst, up_flag, up_seq);
         else
             hipLaunchKernelGGL(k4_match<256>, dim3(B), dim3(256), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
                                (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters, (uint32_t *)nullptr, 0u,
@@ -1214,10 +1264,8 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     }
 #endif
     if (mail1) {
-        SH_TRY(sh_host_wait(ctx));
-        const volatile float *m = (const volatile float *)ctx->mailbox;
-        out[0] = m[0]; out[1] = m[1]; out[2] = m[2];
-        return SLAMHIP_OK;
+        if (defer_seq) { *defer_seq = mail_seq; return SLAMHIP_OK; }
+        return match_collect(hs, mail_seq, out);
     }
     SH_HIP(hipMemcpyAsync(hs->h_io + 3 * (size_t)B, d_out, sizeof(float) * 3 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     SH_HIP(hipStreamSynchronize(ctx->stream));
@@ -1263,7 +1311,20 @@ extern "C" int32_t slamhip_hs_hessian(slamhip_hs *hs, int32_t level, const float
 }
 
 // the launches of UpdateByScan on the operator's stream; nothing comes back to the host
-static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
+// gate_in: the device-gated form (k5_gate) -- `pose` is then only a stand-in, and the update indices are advanced by
+// hs_update_commit once the host knows that the update took place
+static void hs_update_commit(slamhip_hs *hs)
+{
+    for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144
+    if (hs->k5_toggle_pending) hs->k5_sec_parity ^= 1;       // (the one-launch form wrote the other record set)
+    hs->k5_toggle_pending = false;
+}
+static bool hs_update_gateable(slamhip_hs *hs)
+{
+    static const bool two_launch = getenv("SLAMHIP_K5_TWO_LAUNCHES") != nullptr, off = getenv("SLAMHIP_HS_NO_GATED_UPDATE") != nullptr;
+    return !off && !two_launch && hs->n_points > 0 && hs->n_points <= K5_LDS_LINES && hs->ctx->timing == 0 && !hs->ctx->mail_off;
+}
+static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3], const k5_gate *gate_in = nullptr)
 {
     SH_CHECK_ARG(hs && pose);
     SH_HIP(hipSetDevice(hs->ctx->device));
@@ -1331,17 +1392,24 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
             hipLaunchKernelGGL(k5_prepare, dim3(hs->n_levels), dim3(1024), 0, ctx->stream, A, (const float2 *)hs->d_pts, n, hs->origin[0],
                                hs->origin[1], hs->cap_lines, (k5_line *)hs->d_k5_byidx, (k5_line *)hs->d_k5_cand, hs->d_k5_start, hs->d_k5_hdr);
         static const bool no_sectors = getenv("SLAMHIP_K5_EQUAL_SECTORS") != nullptr;       // (tuning: the sectors of phase 2 by count, as scans too large for the LDS tables have them)
+        hs->k5_toggle_pending = build;
+        k5_gate gate;
+        memset(&gate, 0, sizeof(gate));
+        if (gate_in) {
+            if (!build) SH_FAIL(SLAMHIP_ERR_STATE, "the gated update needs the one-launch form");
+            gate = *gate_in; gate.on = 1;
+            for (int l = 0; l < hs->n_levels; l++) gate.stm[l] = hs->lv[l].stm;
+        }
         if (build) {
             const int *sec_in = no_sectors ? nullptr : hs->d_k5_sec + (size_t)hs->k5_sec_parity * HS_MAX_LEVELS * K5_SEC;
             int *sec_out = no_sectors ? nullptr : hs->d_k5_sec + (size_t)(hs->k5_sec_parity ^ 1) * HS_MAX_LEVELS * K5_SEC;
             hipLaunchKernelGGL(k5_cells<true>, cgrid, dim3(1024), k5_lds_bytes(true, n), ctx->stream, A, hs->cap_lines, (const float2 *)hs->d_pts, n,
                                hs->origin[0], hs->origin[1], (const k5_line *)hs->d_k5_byidx, (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start,
-                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ, sec_in, sec_out);
-            hs->k5_sec_parity ^= 1;
+                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ, sec_in, sec_out, gate);
         } else
             hipLaunchKernelGGL(k5_cells<false>, cgrid, dim3(1024), k5_lds_bytes(false, n), ctx->stream, A, hs->cap_lines, (const float2 *)hs->d_pts, n,
                                hs->origin[0], hs->origin[1], (const k5_line *)hs->d_k5_byidx, (const k5_line *)hs->d_k5_cand, (const int *)hs->d_k5_start,
-                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ, (const int *)nullptr, (int *)nullptr);
+                               (const int *)hs->d_k5_hdr, hs->lo_free, hs->lo_occ, (const int *)nullptr, (int *)nullptr, gate);
     }
     SH_HIP(hipGetLastError());
 #ifdef K5_TIMES
@@ -1375,7 +1443,7 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3])
         }
     }
 #endif
-    for (int l = 0; l < hs->n_levels; l++) hs->lv[l].curr_update_index += 3;   // :144
+    if (!gate_in) hs_update_commit(hs);
     return SLAMHIP_OK;
 }
 
@@ -1394,6 +1462,7 @@ struct slamhip_hsproc {
     float start_pose[3], match_pose[3], last_update_pose[3];
     float match_timing, update_timing;
     float min_dist, min_angle;
+    unsigned upd_hist;                                     // the last scans' update decisions, newest in bit 0
 };
 
 static const float F_MIN = -3.40282347e+38f;       // float.MinValue
@@ -1429,13 +1498,8 @@ extern "C" int32_t slamhip_hsproc_reset(slamhip_hsproc *p)
     SH_TRY(slamhip_hs_reset(p->hs));                                      // :133
     memcpy(p->match_pose, p->start_pose, sizeof(float) * 3);              // :136
     p->last_update_pose[0] = p->last_update_pose[1] = p->last_update_pose[2] = F_MIN;   // :137
+    p->upd_hist = 0;
     return SLAMHIP_OK;
-}
-
-static float deg_diff(float a, float b)                                   // MathEx.DegDiff (BaseSLAM/MathEx.cs:69-73)
-{
-    float d = ((a - b) + 180.0f) / 360.0f;
-    return ((d - floorf(d)) * 360.0f) - 180.0f;
 }
 
 extern "C" int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int32_t n, const float origin[2],
@@ -1443,6 +1507,44 @@ extern "C" int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int
 {
     SH_CHECK_ARG(p && hint);
     SH_TRY(slamhip_hs_set_scan(p->hs, xy, n, origin));
+    static const bool wait_update = getenv("SLAMHIP_HS_WAIT_UPDATE") != nullptr;
+    // (worth it when the update does take place: a gated launch that returns at once still costs the stream ~15 us -- 512 workgroups
+    // of 1024 lanes are dispatched to find that out -- so the flow is taken while the last two scans both updated the map: measured,
+    // every scan updating 70 -> 66 us per scan; one scan in five, where it is never taken, 55 either way, 71 if it always were)
+    if (!map_without_matching && !wait_update && (p->upd_hist & 3u) == 3u && hs_update_gateable(p->hs)) {
+        // The per-scan flow on the device: match, then the grid update gated by the processor's own test (k5_gate) -- both enqueued
+        // before the host has the pose, which it then takes from the mailbox and puts to the same test for its own books.
+        slamhip_hs *hs = p->hs;
+        sh_mail_guard lock(hs->ctx);
+        auto t0 = std::chrono::steady_clock::now();
+        float m[3];
+        uint32_t seq = 0;
+        SH_TRY(run_match(hs, hint, 1, m, -1, 0, &seq));                   // :93
+        k5_gate g;
+        memset(&g, 0, sizeof(g));
+        g.d_pose = hs->d_io + 3;                                          // (the single match's result in device memory: run_match)
+        memcpy(g.last, p->last_update_pose, sizeof(g.last));
+        g.min_dist = p->min_dist; g.min_angle = p->min_angle;
+        const int32_t rc_u = hs_update_enqueue(hs, hint, &g);
+        auto t1 = std::chrono::steady_clock::now();
+        SH_TRY(match_collect(hs, seq, m));
+        SH_TRY(rc_u);
+        memcpy(p->match_pose, m, sizeof(m));
+        auto t2 = std::chrono::steady_clock::now();
+        const float ms_u = std::chrono::duration<float, std::milli>(t1 - t0).count();      // (launches of match + update; the match's share is a few us)
+        const float ms_m = std::chrono::duration<float, std::milli>(t2 - t0).count();
+        p->match_timing = (3.0f * p->match_timing + ms_m) / 4.0f;         // :96
+        int updated = 0;
+        if (hs_moved_enough(p->match_pose, p->last_update_pose, p->min_dist, p->min_angle)) {   // :107-108, as the kernel decided
+            hs_update_commit(hs);
+            p->update_timing = (3.0f * p->update_timing + ms_u) / 4.0f;   // :115 (the time of the enqueue)
+            memcpy(p->last_update_pose, p->match_pose, sizeof(float) * 3);    // :118
+            updated = 1;                                                  // :122
+        } else hs->k5_toggle_pending = false;
+        p->upd_hist = (p->upd_hist << 1) | (unsigned)updated;
+        if (out_updated) *out_updated = updated;
+        return SLAMHIP_OK;
+    }
     if (!map_without_matching) {                                          // :89
         auto t0 = std::chrono::steady_clock::now();
         float m[3];
@@ -1453,16 +1555,12 @@ extern "C" int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int
     } else {
         memcpy(p->match_pose, hint, sizeof(float) * 3);                   // :100
     }
-    const float ddx = p->match_pose[0] - p->last_update_pose[0], ddy = p->match_pose[1] - p->last_update_pose[1];
-    const float dist2 = ddx * ddx + ddy * ddy;                            // Vector2.DistanceSquared :107
     int updated = 0;
-    if (dist2 > p->min_dist * p->min_dist ||
-        deg_diff(p->match_pose[2], p->last_update_pose[2]) > p->min_angle ||   // :108 (radians through DegDiff, as the reference does)
+    if (hs_moved_enough(p->match_pose, p->last_update_pose, p->min_dist, p->min_angle) ||   // :107-108
         map_without_matching) {                                           // :109
         // The grid update returns nothing to the host: it is enqueued and runs on while the caller prepares its next scan --
         // the next match, a download or an export is ordered behind it on the operator's stream (UpdateTiming :115 is then
         // the time of the enqueue; SLAMHIP_HS_WAIT_UPDATE=1 waits for the update as before).
-        static const bool wait_update = getenv("SLAMHIP_HS_WAIT_UPDATE") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
         if (wait_update) { SH_TRY(slamhip_hs_update_by_scan(p->hs, p->match_pose)); }   // :112
         else { SH_TRY(hs_update_enqueue(p->hs, p->match_pose)); }
@@ -1471,6 +1569,7 @@ extern "C" int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int
         memcpy(p->last_update_pose, p->match_pose, sizeof(float) * 3);    // :118
         updated = 1;                                                      // :122
     }
+    p->upd_hist = (p->upd_hist << 1) | (unsigned)updated;
     if (out_updated) *out_updated = updated;
     return SLAMHIP_OK;
 }
