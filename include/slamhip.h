@@ -171,6 +171,12 @@ int32_t slamhip_cs_set_offsets(slamhip_cs *cs, const float *offs, int32_t n);
  * (seed, stream, index), so a shard of the list has the same values on every GPU. */
 int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta,
                                     uint64_t seed, uint64_t stream);
+/* The per-scan flow (CoreSLAMProcessor.Update: a fresh list per scan, :662-665) asks for (n, sigmas, seed, stream), then
+ * stream + 1, + 2, ...: a slamhip_cs_search_and_update on a generated list prepares the list of stream + 1 ahead, on a stream of
+ * its own, while it waits for the pose, and the next slamhip_cs_generate_offsets that asks for exactly that list finds it in
+ * place (any other request simply gets what it asks for).  Diagnostics: how many requests were served that way, and how many
+ * lists were prepared, since the handle was created. */
+int32_t slamhip_cs_prepared_lists(slamhip_cs *cs, uint64_t *out_served, uint64_t *out_prepared);
 int32_t slamhip_cs_offsets_download(slamhip_cs *cs, float *offs, int32_t n);
 
 /* ParallelMonteCarloSearch / SingleMonteCarloSearch (CoreSLAMProcessor.cs:624-710) over the flat
@@ -325,7 +331,10 @@ int32_t slamhip_hsproc_reset(slamhip_hsproc *p);                                
 /* Update(scan, poseHintWorld, mapWithoutMatching) (:86-126); *out_map_updated = return value.  The match is waited
  * for (its pose gates the update); the grid update is enqueued and the call returns -- later calls that touch the
  * pyramid are ordered behind it on the operator's stream; UpdateTiming (:115) then reports the enqueue.
- * SLAMHIP_HS_WAIT_UPDATE=1 waits for the update. */
+ * SLAMHIP_HS_WAIT_UPDATE=1 waits for the update.  While consecutive scans keep updating the map, the update is enqueued
+ * behind the match BEFORE the pose is back: the kernel reads the matched pose from device memory and applies the test of
+ * :107-109 itself (the same float operations the host then applies to the pose it receives); SLAMHIP_HS_NO_GATED_UPDATE=1
+ * keeps the decision on the host. */
 int32_t slamhip_hsproc_update(slamhip_hsproc *p, const float *xy, int32_t n_points, const float scan_origin[2],
                               const float pose_hint_world[3], int32_t map_without_matching,
                               int32_t *out_map_updated);

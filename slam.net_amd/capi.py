@@ -96,6 +96,7 @@ def _declare(L):
         "slamhip_cs_maps_checksum": (i32, [vp, P(u64)]),
         "slamhip_cs_search_and_update": (i32, [vp, fp, f, i32, i32, fp, ip, ip]),
         "slamhip_cs_selfcheck_failures": (i32, [vp, P(C.c_uint32)]),
+        "slamhip_cs_prepared_lists": (i32, [vp, P(C.c_uint64), P(C.c_uint64)]),
         "slamhip_csproc_create": (i32, [vp, f, i32, i32, fp, f, f, i32, i32, vpp]),
         "slamhip_csproc_destroy": (i32, [vp]),
         "slamhip_csproc_reset": (i32, [vp]),

@@ -242,6 +242,12 @@ class CoreSlamDevice:
         capi.call("slamhip_cs_maps_checksum", self._h, out)
         return int(out[0]), int(out[1])
 
+    def prepared_lists(self):
+        """(served, prepared): candidate lists the per-scan flow found prepared ahead / prepared in all (slamhip_cs_prepared_lists)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        capi.call("slamhip_cs_prepared_lists", self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     @property
     def selfcheck_failures(self):
         v = C.c_uint32()

@@ -944,7 +944,7 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
         // delivered its result -- and leave everything ensure_shard derived from (n, sigmas, group size) as it is
         std::swap(cs->d_offs_flat, cs->spec_offs_flat); std::swap(cs->d_ev_off, cs->spec_ev_off);
         std::swap(cs->d_ev_idx, cs->spec_ev_idx); std::swap(cs->d_grp_bounds, cs->spec_grp_bounds);
-        cs->gen_stream = stream; cs->gen_pending = false;
+        cs->gen_stream = stream; cs->gen_pending = false; cs->spec_hits++;
         cs->side_join = true;                                     // (the search launch checks the side launch's word: cs_side_join)
         return SLAMHIP_OK;
     }
@@ -1003,9 +1003,17 @@ static int32_t cs_speculate_next(slamhip_cs *cs)
                        n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream + 1, (const uint4 *)nullptr, (uint4 *)nullptr, 0,
                        (uint32_t *)nullptr, 0u, cs->d_side_arrive, (uint32_t *)cs->h_key + 24, cs->side_seq + 1);
     SH_HIP(hipGetLastError());
-    cs->side_seq++;
+    cs->side_seq++; cs->spec_made++;
     cs->spec_valid = true; cs->spec_n = n; cs->spec_sxy = cs->gen_sigma_xy; cs->spec_sth = cs->gen_sigma_theta;
     cs->spec_seed = cs->gen_seed; cs->spec_stream = cs->gen_stream + 1; cs->spec_grp = grp;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_prepared_lists(slamhip_cs *cs, uint64_t *out_served, uint64_t *out_prepared)
+{
+    SH_CHECK_ARG(cs);
+    if (out_served) *out_served = cs->spec_hits;
+    if (out_prepared) *out_prepared = cs->spec_made;
     return SLAMHIP_OK;
 }
 

@@ -708,6 +708,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         for (int i = t; i < 4 * K2_NBUCK; i += 1024) pos_s[i] = 0;  // (the histogram, then the running positions)
         if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; }
         __syncthreads();
+        K2_STAMP(6)
         int bkt[RPT];                                               // a ray's bucket (class * 1024 + slope bucket), -1: not valid
         int my_R = 0, my_total = 0;
 #pragma unroll
@@ -742,6 +743,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         }
         if (lane_ == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_total, my_total); }
         __syncthreads();
+        K2_STAMP(7)
         {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
             int v[4], sum = 0;
 #pragma unroll
@@ -1050,6 +1052,13 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
             for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8]) {
                 for (int k = 0; k < 5; k++) { const double d = (double)(h[i * 8 + k + 1] - h[i * 8 + k]) * 0.01; acc[k] += d; mx[k] = std::max(mx[k], d); }
                 smax = std::max(smax, (double)(h[i * 8] - t0) * 0.01);
+            }
+            {
+                double a6 = 0, a7 = 0, a1 = 0; int c = 0;
+                for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8] && h[i * 8 + 6]) {
+                    a6 += (double)(h[i * 8 + 6] - h[i * 8]) * 0.01; a7 += (double)(h[i * 8 + 7] - h[i * 8 + 6]) * 0.01; a1 += (double)(h[i * 8 + 1] - h[i * 8 + 7]) * 0.01; c++;
+                }
+                if (c) fprintf(stderr, "[k2 times] inside the table phase, mean: start .. first barrier %.2f | rays .. second barrier %.2f | prefix, scatter, third + fourth barrier %.2f\n", a6 / c, a7 / c, a1 / c);
             }
             fprintf(stderr, "[k2 times] %d workgroups, span %.2f us; first thread of each workgroup, mean (max):", nb, (double)(t1 - t0) * 0.01);
             for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f (%.2f) |", nm[k], acc[k] / std::max(nb, 1), mx[k]);

@@ -232,6 +232,52 @@ def test_search_changing_scans_one_candidate_list(cs_mod, ctx, det, sim):
     dev.close()
 
 
+def test_prepared_candidate_list(cs_mod, ctx, det, sim):
+    """The per-scan flow's candidate list prepared ahead (cs_speculate_next, coreslam.hip): a fused scan on a generated list prepares
+    the list of stream + 1 on a side stream; generate_offsets(stream + 1) then swaps it in -- it must be the very list a fresh
+    handle generates, the searches on it must equal the oracle's, and a request for any other list (other stream, other sigma) must
+    get THAT list, not the prepared one.  Scans change in between: the scan blocks alternate and are stored by the CPU."""
+    oc = det
+    size, R, K = 512, 720, 3001
+    segs = sim.default_field()
+    rng = sim.PCG32(99)
+    dev = make_dev(cs_mod, ctx, size, 128)
+    fresh = make_dev(cs_mod, ctx, size, 128)
+    ref_h = dev.holemap_download().copy()
+    ref_o = dev.obstaclemap_download().copy()
+    traj = sim.trajectory(16)
+    scans = [sim.make_scan(segs, p, R, rng)[1] for p in traj]
+    for p, xy in zip(traj[:5], scans[:5]):
+        dev.set_scan(xy); dev.update_holemap(p); dev.update_obstaclemap(p)
+        oc.update_holemap(ref_h, size, dev.hole_scale, xy, p); oc.update_obstaclemap(ref_o, 128, dev.obst_scale, xy, p)
+
+    def expected_list(sxy, sth, seed, stream):
+        fresh.generate_offsets(K - 1, sxy, sth, seed=seed, stream=stream)
+        return fresh.offsets_download().copy()
+
+    # (stream, sigma_xy, sigma_theta): 5, 6, 7 hit the prepared list from the second on; 9 skips one (miss); then another sigma
+    # (miss), its successor (hit), and a repeat of an old stream (miss)
+    plan = [(5, 0.1, 0.17), (6, 0.1, 0.17), (7, 0.1, 0.17), (9, 0.1, 0.17), (10, 0.05, 0.17), (11, 0.05, 0.17), (6, 0.05, 0.17),
+            (7, 0.05, 0.17), (8, 0.05, 0.17), (9, 0.05, 0.17)]
+    for (stream, sxy, sth), p, xy in zip(plan, traj[5:], scans[5:]):
+        base = (p + np.array([0.02, -0.03, 0.01], np.float32)).astype(np.float32)
+        dev.set_scan(xy)
+        dev.generate_offsets(K - 1, sxy, sth, seed=42, stream=stream)
+        pose, dist, idx = dev.search_and_update(base, 0.6, 50, 10)
+        offs = expected_list(sxy, sth, 42, stream)
+        assert (dev.offsets_download() == offs).all(), (stream, sxy)
+        rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, offs)
+        rpose[2] = oc.normalize_angle(rpose[2])
+        assert idx == rbi and dist == rbd and (pose == rpose).all(), (stream, sxy)
+        oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, 128, dev.obst_scale, xy, rpose)
+    assert (dev.holemap_download() == ref_h).all() and (dev.obstaclemap_download() == ref_o).all()
+    assert dev.selfcheck_failures == 0
+    served, prepared = dev.prepared_lists()
+    if "SLAMHIP_NO_SPECULATION" not in os.environ and "SLAMHIP_NO_HOSTWAIT" not in os.environ and "SLAMHIP_FUSED_WAIT_UPDATES" not in os.environ:
+        assert prepared == len(plan) and served == 6, (served, prepared)     # streams 6, 7 | 11 | 7, 8, 9 of the plan
+    dev.close(); fresh.close()
+
+
 def test_search_enqueue_ring(cs_mod, ctx, det, sim):
     """slamhip_cs_search_shard_enqueue (the ring of result words: finishing workgroups min straight into the word, no final
     arriver): every key equals the blocking search's and the oracle's -- back to back launches from different poses (each launch
