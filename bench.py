@@ -586,9 +586,27 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
     ctx.synchronize()
     dt_pm = (time.perf_counter() - t0) / 200
     pm_ok = bool((pm == proc.device.holemap_download()).all())
+    # ... and the mirror refreshed WHEN IT IS READ (the shim's default MirrorMode.OnRead: the `Pixels` getter requests what changed
+    # since its last read and waits for it; the scans themselves only keep the row spans): a reader every 33 scans -- a display
+    # at 30 frames per second beside a 1 kHz scan loop
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    reads, t_read = 0, 0.0
+    for i in range(198):
+        proc.Update([cs.ScanSegment(pscans[10 + i % 60], zero)])
+        if i % 33 == 32:
+            tr = time.perf_counter()
+            proc.device.holemap_mirror_async(pm)
+            proc.device.holemap_mirror_wait()
+            t_read += time.perf_counter() - tr; reads += 1
+    ctx.synchronize()
+    dt_or = (time.perf_counter() - t0) / 198
+    or_ok = bool((pm == proc.device.holemap_download()).all())
     proc.device.holemap_mirror_release()
     out["coreslam_processor_update_2048_map_1080_rays_16384_candidates"].update({
-        "us_per_scan_with_async_mirror": dt_pm * 1e6, "async_mirror_pixels_per_scan_sampled": px_acc // 10, "async_mirror_equals_full_download": pm_ok})
+        "us_per_scan_with_async_mirror": dt_pm * 1e6, "async_mirror_pixels_per_scan_sampled": px_acc // 10, "async_mirror_equals_full_download": pm_ok,
+        "us_per_scan_with_mirror_read_every_33_scans": dt_or * 1e6, "us_per_mirror_read": t_read / max(reads, 1) * 1e6,
+        "mirror_on_read_equals_full_download": or_ok})
     proc.Dispose()
     # ... and from a NATIVE caller of the C-ABI (tests/abi_harness.c --bench-proc: gcc, dlopen, slamhip_csproc_update in a C loop):
     # what a P/Invoke caller pays per scan.  A process of its own, while this one is idle.

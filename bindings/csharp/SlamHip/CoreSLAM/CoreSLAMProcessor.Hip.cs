@@ -8,8 +8,8 @@
 //  * the candidate jitters come from the library's seeded Philox generator (slamhip_cs_generate_offsets) instead of
 //    Redzen's entropy-seeded Ziggurat sampler (:136-137) -- the reference's stream is not reproducible either; set Seed
 //    for repeatable runs, or hand in your own list with SetOffsets (flat thread-major order, X, Y, theta per jitter);
-//  * HoleMap.Pixels / ObstacleMap.Pixels are mirrors: refreshed after every Update while MirrorMaps is true (default),
-//    otherwise by their Download();
+//  * HoleMap.Pixels / ObstacleMap.Pixels are mirrors of the device maps, brought up to date when they are READ (MirrorMode.OnRead,
+//    the default), by a request after every Update (EveryScan) or only on demand (Manual);
 //  * NumSearchThreads only sizes the candidate list (threads x iterations, as in :674-710); there is no thread pool.
 using System;
 using System.Collections.Generic;
@@ -20,6 +20,9 @@ using SlamHip;
 
 namespace CoreSLAM
 {
+    /// <summary>When HoleMap.Pixels / ObstacleMap.Pixels follow the device maps (CoreSLAMProcessor.MirrorMode).</summary>
+    public enum MirrorMode { OnRead, EveryScan, Manual }
+
     public class CoreSLAMProcessor : IDisposable
     {
         private readonly Device device;
@@ -55,12 +58,26 @@ namespace CoreSLAM
 
         /// <summary>Seed of the candidate generator (new: the reference seeds from entropy).</summary>
         public ulong Seed { get; set; } = 0x5EED5EEDUL;
-        /// <summary>Refresh the managed map mirrors after every Update (source compatibility).  The HoleMap mirror is asynchronous
-        /// (slamhip_cs_holemap_mirror_async: the 16-byte units that changed, pushed from a copy stream while the next scan runs;
-        /// HoleMap.Pixels waits for the push in flight), the ObstacleMap is small and comes whole -- its download waits for the
-        /// map updates that Update would otherwise leave running while the host prepares its next scan
-        /// (bench.py, other_workloads: us_per_scan_with_async_mirror against us_per_scan).</summary>
-        public bool MirrorMaps { get; set; } = true;
+        /// <summary>When the managed map mirrors (HoleMap.Pixels, ObstacleMap.Pixels) are brought up to date.
+        /// OnRead (default): an Update only marks them stale; the `Pixels` getters fetch what changed since their last read --
+        /// the HoleMap through slamhip_cs_holemap_mirror_async + _wait (the 16-byte units that changed, ~0.25 ms at 2048 x 2048 for
+        /// a display that reads every few dozen scans), the small ObstacleMap whole -- so a caller that does not look at the maps
+        /// pays nothing and a reader always sees the current map (bench.py: us_per_scan_with_mirror_read_every_33_scans).
+        /// EveryScan: additionally every Update issues the HoleMap's asynchronous request, so that a read right after a scan finds
+        /// the push already under way (a request per scan throttles a 20 k scans/s loop: the push is PCIe-store bound).
+        /// Manual: only Download() / Mirror() / MirrorAsync() refresh the arrays.</summary>
+        public MirrorMode MirrorMode
+        {
+            get => mirrorMode;
+            set { mirrorMode = value; HoleMap.Mode = value; ObstacleMap.Mode = value; }
+        }
+        private MirrorMode mirrorMode = MirrorMode.OnRead;
+        /// <summary>Source compatibility with the earlier shim: false = MirrorMode.Manual, true = OnRead.</summary>
+        public bool MirrorMaps
+        {
+            get => mirrorMode != MirrorMode.Manual;
+            set => MirrorMode = value ? MirrorMode.OnRead : MirrorMode.Manual;
+        }
 
         public CoreSLAMProcessor(float physicalMapSize, int holeMapSize, int obstacleMapSize, Vector3 startPose,
                                  float sigmaXY, float sigmaTheta, int iterationsPerThread, int numSearchThreads)
@@ -96,7 +113,7 @@ namespace CoreSLAM
             Pose = startPose;
             lastOdometryPose = Vector3.Zero;
             scanCount = 0;
-            if (MirrorMaps) { HoleMap.MirrorAsync(); ObstacleMap.Download(); }
+            MapsChanged();
         }
 
         /// <summary>Use this jitter list (n x (dx, dy, dtheta), flat thread-major order) instead of generated ones.</summary>
@@ -154,7 +171,15 @@ namespace CoreSLAM
                     Native.Check(Native.slamhip_cs_update_obstaclemap(cs.Ptr, Pose, MaxObstacleHits));         // :751
                 }
             }
-            if (MirrorMaps) { HoleMap.MirrorAsync(); ObstacleMap.Download(); }
+            MapsChanged();
+        }
+
+        // the maps on the device moved on: the mirrors are stale (and, in EveryScan mode, the HoleMap's push starts now)
+        private void MapsChanged()
+        {
+            HoleMap.MarkStale();
+            ObstacleMap.MarkStale();
+            if (mirrorMode == MirrorMode.EveryScan) HoleMap.MirrorAsync();
         }
 
         // ScanSegmentsToCloud (:187-207): every segment's rays in the frame of the last odometry pose.

@@ -2,9 +2,10 @@
 // living in device memory.  `Pixels` stays a managed ushort[] because callers read it directly
 // (Simulation/MainWindow.xaml.cs:229): it is a MIRROR, refreshed by Download() (everything), Mirror() (blocking: the rectangle
 // the scans since the last refresh touched) or MirrorAsync() (the 16-byte units that changed, pushed from a copy stream while
-// the next scan runs) -- CoreSLAMProcessor.Update calls MirrorAsync() after every scan when MirrorMaps is set (the default, for
-// source compatibility), and the `Pixels` getter waits for the push that is in flight: a reader never sees a half-written map,
-// and a caller that does not look at the map pays nothing for it.
+// the next scan runs).  By default (MirrorMode.OnRead) the `Pixels` getter itself asks for what changed since its last read and
+// waits for it; with MirrorMode.EveryScan CoreSLAMProcessor.Update issues MirrorAsync() after every scan and the getter only waits
+// for the push in flight.  A reader never sees a half-written or outdated map, and a caller that does not look at the map pays
+// nothing for it.
 using System;
 using SlamHip;
 
@@ -16,12 +17,21 @@ namespace CoreSLAM
 
         private readonly ushort[] pixels;
         private bool pushInFlight;
+        private bool stale = true;                                      // the device map has moved on since the last refresh
+        internal MirrorMode Mode = MirrorMode.OnRead;
+
+        internal void MarkStale() { stale = true; }
 
         /// <summary>Host mirror of the device pixels, row-major [y * Size + x] (HoleMap.cs:27).  Reading it waits for an
         /// asynchronous refresh that is still in flight (slamhip_cs_holemap_mirror_wait).</summary>
         public ushort[] Pixels
         {
-            get { WaitMirror(); return pixels; }
+            get
+            {
+                if (stale && Mode == MirrorMode.OnRead && !pushInFlight) MirrorAsync();
+                WaitMirror();
+                return pixels;
+            }
         }
 
         /// <summary>Side length in pixels (HoleMap.cs:32).</summary>
@@ -48,17 +58,19 @@ namespace CoreSLAM
             WaitMirror();
             fixed (ushort* p = pixels)
                 Native.Check(Native.slamhip_cs_holemap_download(cs.Ptr, p, (nuint)pixels.Length));
+            stale = false;
         }
 
         /// <summary>Bring Pixels up to date by copying only what the updates since the last Mirror()/Download() call can have
         /// changed: the bounding rectangle of the scans drawn (the update kernel keeps it on the device).  The whole map on the
-        /// first call and after Reset/Upload.  This is what CoreSLAMProcessor.Update calls when MirrorMaps is set.</summary>
+        /// first call and after Reset/Upload.</summary>
         public unsafe void Mirror()
         {
             int* rect = stackalloc int[4];
             WaitMirror();
             fixed (ushort* p = pixels)
                 Native.Check(Native.slamhip_cs_holemap_mirror(cs.Ptr, p, (nuint)pixels.Length, rect));
+            stale = false;
         }
 
         /// <summary>Asynchronous refresh: enqueues the snapshot of what changed since the last refresh behind the map updates in
@@ -69,6 +81,7 @@ namespace CoreSLAM
             fixed (ushort* p = pixels)
                 Native.Check(Native.slamhip_cs_holemap_mirror_async(cs.Ptr, p, (nuint)pixels.Length));
             pushInFlight = true;
+            stale = false;                                              // (everything up to this request is on its way)
         }
 
         /// <summary>Waits for the refresh in flight, if any (the `Pixels` getter calls it).</summary>

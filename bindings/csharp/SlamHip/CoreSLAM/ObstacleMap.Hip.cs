@@ -9,8 +9,19 @@ namespace CoreSLAM
     {
         private readonly Handle cs;
 
-        /// <summary>Host mirror, indexed [y, x] (ObstacleMap.cs:31); row-major in memory like the device copy.</summary>
-        public readonly sbyte[,] Pixels;
+        private readonly sbyte[,] pixels;
+        private bool stale = true;                                      // the device map has moved on since the last download
+        internal MirrorMode Mode = MirrorMode.OnRead;
+
+        internal void MarkStale() { stale = true; }
+
+        /// <summary>Host mirror, indexed [y, x] (ObstacleMap.cs:31: a readonly field there, a property here -- reads compile
+        /// unchanged); row-major in memory like the device copy.  Unless the processor's MirrorMode is Manual, a read after the
+        /// device map has moved on downloads it first (one byte per pixel: 256 KB at 512 x 512).</summary>
+        public sbyte[,] Pixels
+        {
+            get { if (stale && Mode != MirrorMode.Manual) Download(); return pixels; }
+        }
 
         public int Size { get; }
 
@@ -21,19 +32,20 @@ namespace CoreSLAM
             this.cs = cs;
             Size = sizePixels;
             Scale = scale;
-            Pixels = new sbyte[sizePixels, sizePixels];
+            pixels = new sbyte[sizePixels, sizePixels];
         }
 
         public unsafe void Download()
         {
-            fixed (sbyte* p = Pixels)
-                Native.Check(Native.slamhip_cs_obstaclemap_download(cs.Ptr, p, (nuint)Pixels.Length));
+            fixed (sbyte* p = pixels)
+                Native.Check(Native.slamhip_cs_obstaclemap_download(cs.Ptr, p, (nuint)pixels.Length));
+            stale = false;
         }
 
         public unsafe void Upload()
         {
-            fixed (sbyte* p = Pixels)
-                Native.Check(Native.slamhip_cs_obstaclemap_upload(cs.Ptr, p, (nuint)Pixels.Length));
+            fixed (sbyte* p = pixels)
+                Native.Check(Native.slamhip_cs_obstaclemap_upload(cs.Ptr, p, (nuint)pixels.Length));
         }
     }
 }
