@@ -177,6 +177,17 @@ int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float sigma_xy, f
  * place (any other request simply gets what it asks for).  Diagnostics: how many requests were served that way, and how many
  * lists were prepared, since the handle was created. */
 int32_t slamhip_cs_prepared_lists(slamhip_cs *cs, uint64_t *out_served, uint64_t *out_prepared);
+/* Opt-in, no reference counterpart (the reference draws every candidate's heading independently, :599-612): the same generator
+ * with the headings on a LATTICE -- the candidates one lane of the search kernel evaluates (2 per lane below 65 536 candidates, 4
+ * from there on) share their dtheta bit for bit and differ in their translation; the headings are the strata of
+ * N(0, sigma_theta), one per lane position (n / 2 or n / 4 distinct headings instead of n), the translations N(0, sigma_xy) as
+ * before.  A full-range search over such a list forms the products c*X, s*Y, s*X, c*Y of a ray point once per lane instead of
+ * once per candidate: 2 (3) of the ~12.75 vector operations per candidate and ray less, every candidate's distance the float
+ * arithmetic of :240-241 as ever (the list can be downloaded and handed to any checker).  Same (seed, stream, index) keying.
+ * Up to 12 288 candidates the search evaluates one candidate per lane (smaller groups, faster there) and the call produces the
+ * plain list of slamhip_cs_generate_offsets. */
+int32_t slamhip_cs_generate_offsets_lattice(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta,
+                                            uint64_t seed, uint64_t stream);
 int32_t slamhip_cs_offsets_download(slamhip_cs *cs, float *offs, int32_t n);
 
 /* ParallelMonteCarloSearch / SingleMonteCarloSearch (CoreSLAMProcessor.cs:624-710) over the flat
@@ -263,6 +274,8 @@ int32_t slamhip_csproc_set_params(slamhip_csproc *p, int32_t quality, float hole
                                   int32_t position_search_beginning, int32_t unmapped_obstacle_hits,
                                   int32_t max_obstacle_hits);
 int32_t slamhip_csproc_set_seed(slamhip_csproc *p, uint64_t seed);
+/* candidates per scan from slamhip_cs_generate_offsets_lattice instead of slamhip_cs_generate_offsets (default: off) */
+int32_t slamhip_csproc_set_lattice(slamhip_csproc *p, int32_t on);
 /* pin the jitter list used by the next searching Update (parity tests feed the oracle the same list) */
 int32_t slamhip_csproc_set_offsets(slamhip_csproc *p, const float *offs, int32_t n);
 /* the underlying operator-level object (HoleMap / ObstacleMap properties :45,:50) */

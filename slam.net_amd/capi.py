@@ -81,6 +81,7 @@ def _declare(L):
         "slamhip_cs_distance_poses": (i32, [vp, fp, i32, ip, ip, ip]),
         "slamhip_cs_set_offsets": (i32, [vp, fp, i32]),
         "slamhip_cs_generate_offsets": (i32, [vp, i32, f, f, u64, u64]),
+        "slamhip_cs_generate_offsets_lattice": (i32, [vp, i32, f, f, u64, u64]),
         "slamhip_cs_offsets_download": (i32, [vp, fp, i32]),
         "slamhip_cs_search": (i32, [vp, fp, fp, ip, ip]),
         "slamhip_cs_search_shard": (i32, [vp, fp, i32, i32, u64p]),
@@ -104,6 +105,7 @@ def _declare(L):
         "slamhip_csproc_get_pose": (i32, [vp, fp]),
         "slamhip_csproc_set_params": (i32, [vp, i32, f, i32, i32, i32]),
         "slamhip_csproc_set_seed": (i32, [vp, u64]),
+        "slamhip_csproc_set_lattice": (i32, [vp, i32]),
         "slamhip_csproc_set_offsets": (i32, [vp, fp, i32]),
         "slamhip_csproc_cs": (i32, [vp, vpp]),
         "slamhip_hs_create": (i32, [vp, f, i32, i32, i32, vpp]),

@@ -170,14 +170,16 @@ class CoreSlamDevice:
         capi.call("slamhip_cs_set_offsets", self._h, capi.fptr(offs), offs.shape[0])
         self.n_offsets = offs.shape[0]
 
-    def generate_offsets(self, n, sigma_xy, sigma_theta, seed=0, stream=0):
-        capi.call("slamhip_cs_generate_offsets", self._h, int(n), C.c_float(sigma_xy), C.c_float(sigma_theta),
-                  C.c_uint64(seed), C.c_uint64(stream))
+    def generate_offsets(self, n, sigma_xy, sigma_theta, seed=0, stream=0, lattice=False):
+        """Device-generated jitters; lattice=True: the heading lattice (slamhip_cs_generate_offsets_lattice)."""
+        capi.call("slamhip_cs_generate_offsets_lattice" if lattice else "slamhip_cs_generate_offsets", self._h, int(n),
+                  C.c_float(sigma_xy), C.c_float(sigma_theta), C.c_uint64(seed), C.c_uint64(stream))
         self.n_offsets = int(n)
 
-    def offsets_download(self):
-        out = np.empty((self.n_offsets, 3), np.float32)
-        capi.call("slamhip_cs_offsets_download", self._h, capi.fptr(out), self.n_offsets)
+    def offsets_download(self, n=None):
+        n = self.n_offsets if n is None else int(n)
+        out = np.empty((n, 3), np.float32)
+        capi.call("slamhip_cs_offsets_download", self._h, capi.fptr(out), n)
         return out
 
     def search(self, search_pose):
@@ -352,6 +354,10 @@ class CoreSLAMProcessor:
     # extensions used by parity tests (the reference's sampler is entropy-seeded)
     def SetSeed(self, seed):
         capi.call("slamhip_csproc_set_seed", self._h, C.c_uint64(seed))
+
+    def SetLattice(self, on):
+        """Opt-in: the per-scan candidates as a heading lattice (slamhip_csproc_set_lattice)."""
+        capi.call("slamhip_csproc_set_lattice", self._h, 1 if on else 0)
 
     def SetOffsets(self, offs):
         offs = capi.f32(offs, (-1, 3))

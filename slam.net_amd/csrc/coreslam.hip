@@ -55,13 +55,37 @@ __device__ static inline void k_jitter(int i, int n, float sigma_xy, float sigma
     o[1] = sigma_xy * rad * sn;
     o[2] = sigma_theta * normcdfinvf(q);
 }
+// The heading lattice (opt-in: slamhip_cs_generate_offsets_lattice): the candidates that ONE LANE of the search kernel evaluates --
+// evaluation positions t, t + lanes, ... of a candidate group -- share their dtheta, bit for bit, and differ in their translation.
+// The kernel then forms the four products c*X, s*Y, s*X, c*Y of a ray point once per lane instead of once per candidate (the sums
+// stay per candidate and in the reference's order, :240-241: every candidate's coordinates are the floats they always were).
+// The headings are the strata of N(0, sigma_theta) as before, one per lane position: stratum u = group * lanes + lane of
+// U = the number of lane positions in use; the stratum that holds the un-jittered pose has dtheta = 0 for all its members.
+// lat = candidates per lane (2 or 4; 0: no lattice), grp = candidates per group, zero_pos = evaluation position of the un-jittered pose.
+struct k_lattice { int cpl, grp, count, zero_pos; };
+__device__ static inline int k_lat_stratum(const k_lattice L, int j) { const int lanes = L.grp / L.cpl; return (j / L.grp) * lanes + (j % lanes); }
+__device__ static inline void k_jitter_lat(int i, int n, float sigma_xy, float sigma_theta, uint64_t seed, uint64_t stream, const k_lattice L, float o[3])
+{
+    k_jitter(i, n, sigma_xy, sigma_theta, seed, stream, o);              // dx, dy as ever (keyed by the jitter's index)
+    const int j = i < L.zero_pos ? i : i + 1;                            // the jitter's evaluation position (flat i + 1)
+    const int u = k_lat_stratum(L, j), u0 = k_lat_stratum(L, L.zero_pos);
+    const int lanes = L.grp / L.cpl, full = L.count / L.grp, rest = L.count - full * L.grp;
+    const int U = full * lanes + (rest < lanes ? rest : lanes);
+    if (u == u0) { o[2] = 0.0f; return; }
+    uint32_t c[4] = { (uint32_t)u, 0x4C415454u, (uint32_t)stream, (uint32_t)(stream >> 32) };      // (keyed by the stratum: "LATT")
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u3 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float q = fminf(((float)u + u3) / (float)U, 0.99999994f);
+    o[2] = sigma_theta * normcdfinvf(q);
+}
 __global__ void k_generate_offsets(float *__restrict__ offs_flat, int n, float sigma_xy, float sigma_theta,
-                                   uint64_t seed, uint64_t stream)
+                                   uint64_t seed, uint64_t stream, const k_lattice L)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float o[3];
-    k_jitter(i, n, sigma_xy, sigma_theta, seed, stream, o);
+    if (L.cpl) k_jitter_lat(i, n, sigma_xy, sigma_theta, seed, stream, L, o);
+    else k_jitter(i, n, sigma_xy, sigma_theta, seed, stream, o);
     offs_flat[3 * i + 0] = o[0]; offs_flat[3 * i + 1] = o[1]; offs_flat[3 * i + 2] = o[2];
 }
 
@@ -99,7 +123,7 @@ k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_i
                  float *__restrict__ ev_off, int *__restrict__ ev_idx_out, float *__restrict__ grp_bounds, int grp,
                  int gen_n, float gen_sxy, float gen_sth, uint64_t gen_seed, uint64_t gen_stream,
                  const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst, int up_n16, uint32_t *__restrict__ up_flag, uint32_t up_seq,
-                 unsigned *__restrict__ side_arrive, uint32_t *__restrict__ side_flag, uint32_t side_seq)
+                 unsigned *__restrict__ side_arrive, uint32_t *__restrict__ side_flag, uint32_t side_seq, const k_lattice lat)
 {
     if (up_n16 > 0 && (int)blockIdx.x >= (int)gridDim.x - SH_UPLOAD_PARTS) {   // riding along: the scan upload (the two are independent, K1 needs both)
         sh_upload16_part(up_src, up_dst, up_n16, (int)blockIdx.x - ((int)gridDim.x - SH_UPLOAD_PARTS), up_flag, up_seq);
@@ -117,7 +141,8 @@ k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_i
             if (flat > 0) {
                 if (GEN) {
                     float o[3];
-                    k_jitter(flat - 1, gen_n, gen_sxy, gen_sth, gen_seed, gen_stream, o);
+                    if (lat.cpl) k_jitter_lat(flat - 1, gen_n, gen_sxy, gen_sth, gen_seed, gen_stream, lat, o);
+                    else k_jitter(flat - 1, gen_n, gen_sxy, gen_sth, gen_seed, gen_stream, o);
                     ox = o[0]; oy = o[1]; ot = o[2];
                     offs_flat[3 * (size_t)(flat - 1)] = ox; offs_flat[3 * (size_t)(flat - 1) + 1] = oy; offs_flat[3 * (size_t)(flat - 1) + 2] = ot;
                 } else { ox = offs_flat[3 * (size_t)(flat - 1)]; oy = offs_flat[3 * (size_t)(flat - 1) + 1]; ot = offs_flat[3 * (size_t)(flat - 1) + 2]; }
@@ -917,15 +942,37 @@ extern "C" int32_t slamhip_cs_set_offsets(slamhip_cs *cs, const float *offs, int
     cs->h_offs.assign(offs, offs + (size_t)n * 3);
     cs->offs_theta_small = true;
     for (size_t i = 0; i < (size_t)n * 3; i++) if (!(fabsf(offs[i]) < (i % 3 == 2 ? 1.0e4f : 1.0e6f))) { cs->offs_theta_small = false; break; }
-    cs->offs_on_device_sorted = false; cs->gen_pending = false;
+    cs->offs_on_device_sorted = false; cs->gen_pending = false; cs->gen_lattice = false; cs->k1_lattice = 0;
     cs->spec_valid = false; cs->spec_base_ok = false;
     cs->shard_first = cs->shard_count = -1;
     if (n > 0) SH_HIP(hipMemcpy(cs->d_offs_flat, offs, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     return SLAMHIP_OK;
 }
 
+// the lattice of a full-range search over n jitters (host mirror of what the kernels are told): none unless asked for
+static k_lattice cs_lattice(const slamhip_cs *cs, int n, bool on)
+{
+    k_lattice L = { 0, 0, 0, 0 };
+    if (!on || n + 1 <= 12288) return L;                          // (small searches run one candidate per lane -- 512-candidate groups, faster there: nothing to share)
+    L.count = n + 1;
+    L.grp = L.count >= 65536 ? K1_GROUP_BIG : K1_GROUP;            // (never the 512-candidate groups: a lane needs two candidates to share anything)
+    L.cpl = L.grp == K1_GROUP_BIG ? 4 : 2;
+    L.zero_pos = L.count - 1 < n / 2 ? L.count - 1 : n / 2;
+    return L;
+}
+
+static int32_t cs_generate(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta, uint64_t seed, uint64_t stream, bool lattice);
 extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta,
                                                uint64_t seed, uint64_t stream)
+{
+    return cs_generate(cs, n, sigma_xy, sigma_theta, seed, stream, false);
+}
+extern "C" int32_t slamhip_cs_generate_offsets_lattice(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta,
+                                                       uint64_t seed, uint64_t stream)
+{
+    return cs_generate(cs, n, sigma_xy, sigma_theta, seed, stream, true);
+}
+static int32_t cs_generate(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta, uint64_t seed, uint64_t stream, bool lattice)
 {
     SH_CHECK_ARG(cs && n >= 0);
     SH_HIP(hipSetDevice(cs->ctx->device));
@@ -937,7 +984,8 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
     const bool hit = cs->spec_valid && n == cs->spec_n && n == cs->n_offs && memcmp(&sigma_xy, &cs->spec_sxy, 4) == 0 &&
                      memcmp(&sigma_theta, &cs->spec_sth, 4) == 0 && seed == cs->spec_seed && stream == cs->spec_stream &&
                      cs->spec_cap_offs == cs->cap_offs && cs->spec_cap_cand == cs->cap_cand && cs->spec_cap_grp == cs->cap_grp &&
-                     cs->offs_on_device_sorted && cs->shard_first == 0 && cs->shard_count == n + 1 && cs->k1_group == cs->spec_grp;
+                     cs->offs_on_device_sorted && cs->shard_first == 0 && cs->shard_count == n + 1 && cs->k1_group == cs->spec_grp &&
+                     lattice == cs->spec_lattice && lattice == cs->gen_lattice;
     cs->spec_valid = false;
     if (hit) {
         // the list asked for has been prepared (cs_speculate_next): swap the buffer sets -- the search that read the old set has
@@ -957,6 +1005,7 @@ extern "C" int32_t slamhip_cs_generate_offsets(slamhip_cs *cs, int32_t n, float 
     cs->shard_first = cs->shard_count = -1;
     // produced on first use: a full-range search generates the list inside its gather launch (ensure_shard)
     cs->gen_pending = n > 0; cs->gen_seed = seed; cs->gen_stream = stream;
+    cs->gen_lattice = lattice;
     return SLAMHIP_OK;
 }
 
@@ -1001,11 +1050,11 @@ static int32_t cs_speculate_next(slamhip_cs *cs)
     hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng), dim3(1024), 0, cs->side_stream,
                        cs->spec_offs_flat, (const int *)nullptr, 0, count, zero_pos, cs->spec_ev_off, cs->spec_ev_idx, cs->spec_grp_bounds, grp,
                        n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream + 1, (const uint4 *)nullptr, (uint4 *)nullptr, 0,
-                       (uint32_t *)nullptr, 0u, cs->d_side_arrive, (uint32_t *)cs->h_key + 24, cs->side_seq + 1);
+                       (uint32_t *)nullptr, 0u, cs->d_side_arrive, (uint32_t *)cs->h_key + 24, cs->side_seq + 1, cs_lattice(cs, n, cs->gen_lattice));
     SH_HIP(hipGetLastError());
     cs->side_seq++; cs->spec_made++;
     cs->spec_valid = true; cs->spec_n = n; cs->spec_sxy = cs->gen_sigma_xy; cs->spec_sth = cs->gen_sigma_theta;
-    cs->spec_seed = cs->gen_seed; cs->spec_stream = cs->gen_stream + 1; cs->spec_grp = grp;
+    cs->spec_seed = cs->gen_seed; cs->spec_stream = cs->gen_stream + 1; cs->spec_grp = grp; cs->spec_lattice = cs->gen_lattice;
     return SLAMHIP_OK;
 }
 
@@ -1022,7 +1071,8 @@ int32_t cs_flush_generate(slamhip_cs *cs)
     if (!cs->gen_pending) return SLAMHIP_OK;
     cs->gen_pending = false;
     hipLaunchKernelGGL(k_generate_offsets, dim3(sh_div_up(cs->n_offs, 256)), dim3(256), 0, cs->ctx->stream,
-                       cs->d_offs_flat, cs->n_offs, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream);
+                       cs->d_offs_flat, cs->n_offs, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream,
+                       cs_lattice(cs, cs->n_offs, cs->gen_lattice));
     SH_HIP(hipGetLastError());
     return SLAMHIP_OK;
 }
@@ -1085,9 +1135,14 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
     // 512: 4096 candidates 22.7 -> 18.8, the simulator's 4000 candidates on a 256^2 map with 400 rays 14.6 -> 13.3, 8192:
     // 23.2 -> 22.8 (1024^2 map: 22.0 -> 19.0), 12 288: 25.7 -> 24.0, but 16 384: 25.3 -> 26.6).
     static const int grp_env = getenv("SLAMHIP_K1_GROUP") ? atoi(getenv("SLAMHIP_K1_GROUP")) : 0;
-    const int grp = grp_env == K1_GROUP || grp_env == K1_GROUP_BIG || grp_env == K1_GROUP_SMALL ? grp_env
+    // (a heading lattice is laid out for the group size of its full-range search: cs_lattice)
+    const k_lattice lat = cs_lattice(cs, cs->n_offs, cs->offs_on_device_sorted && cs->gen_lattice);
+    const bool lat_list = lat.cpl != 0;
+    const int grp = lat_list ? lat.grp
+                    : grp_env == K1_GROUP || grp_env == K1_GROUP_BIG || grp_env == K1_GROUP_SMALL ? grp_env
                     : count >= 65536 ? K1_GROUP_BIG : count <= 12288 ? K1_GROUP_SMALL : K1_GROUP;
     cs->k1_group = grp;
+    cs->k1_lattice = lat_list && first == 0 && count == cs->n_offs + 1 ? lat.cpl : 0;     // (the search kernel's lanes line up with the lattice)
     const int ng = sh_div_up(count, grp);
     // (the launch layout is made from these per-group figures: it stays valid when a new list leaves them as they were -- the
     // per-scan flow regenerates the list with the same sigmas -- see the end of this function)
@@ -1122,19 +1177,25 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
             hipLaunchKernelGGL(k_gather_offsets<true>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
                                n, cs->gen_sigma_xy, cs->gen_sigma_theta, cs->gen_seed, cs->gen_stream, up_src, up_dst, up_n16, up_flag, up_seq,
-                               (unsigned *)nullptr, (uint32_t *)nullptr, 0u);
+                               (unsigned *)nullptr, (uint32_t *)nullptr, 0u, lat);
             cs->spec_base_ok = true;                              // (the full generated list is in place: cs_speculate_next may prepare its successor)
         } else {
             SH_TRY(cs_flush_generate(cs));
             hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                                cs->d_offs_flat, (const int *)nullptr, first, count, zero_pos, cs->d_ev_off, cs->d_ev_idx, cs->d_grp_bounds, grp,
-                               0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq, (unsigned *)nullptr, (uint32_t *)nullptr, 0u);
+                               0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq, (unsigned *)nullptr, (uint32_t *)nullptr, 0u, lat);
         }
         // the jitters are the strata of N(0, sigma): group ranges from the quantile function (layout balance only)
         for (int g = 0; g < ng; g++) {
             const int k0 = first + g * grp, k1 = (first + count < k0 + grp ? first + count : k0 + grp) - 1;
-            const double q0 = fmin(fmax((k0 - 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
-            const double q1 = fmin(fmax((k1 + 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
+            double q0 = fmin(fmax((k0 - 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
+            double q1 = fmin(fmax((k1 + 0.5) / (n > 0 ? n : 1), 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
+            if (cs->k1_lattice) {                                  // (a lattice group holds the strata of its lane positions, each cpl times)
+                const int lanes = grp / lat.cpl, full = lat.count / grp, rest = lat.count - full * grp;
+                const double U = (double)(full * lanes + (rest < lanes ? rest : lanes));
+                q0 = fmin(fmax((double)g * lanes / U, 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
+                q1 = fmin(fmax((double)(g + 1) * lanes / U, 0.5 / (n + 1)), 1.0 - 0.5 / (n + 1));
+            }
             cs->h_grp_dth[(size_t)g] = (float)(fabs(cs->gen_sigma_theta) * (host_normcdfinv(q1) - host_normcdfinv(q0)));
             cs->h_grp_dxy[(size_t)g] = 7.0f * fabsf(cs->gen_sigma_xy) * cs->hscale;
             float *lh = &cs->h_grp_lohi[(size_t)g * 6];
@@ -1167,7 +1228,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         hipLaunchKernelGGL(k_gather_offsets<false>, dim3(ng + up_wg), dim3(1024), 0, ctx->stream,
                            cs->d_offs_flat, (const int *)cs->d_ev_idx, first, count, -1, cs->d_ev_off, (int *)nullptr, cs->d_grp_bounds, grp,
                            0, 0.f, 0.f, (uint64_t)0, (uint64_t)0, up_src, up_dst, up_n16, up_flag, up_seq,
-                           (unsigned *)nullptr, (uint32_t *)nullptr, 0u);
+                           (unsigned *)nullptr, (uint32_t *)nullptr, 0u, lat);
         const hipError_t le = hipGetLastError();
         if (le == hipSuccess && up_wg) { cs->upload_pending = false; cs->upload_seq = up_seq; cs->scan_in_flight = true; }
         SH_HIP(le);

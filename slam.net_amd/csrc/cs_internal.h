@@ -41,7 +41,7 @@ struct slamhip_cs {
     // the next scan's candidate list, prepared ahead on the side stream (cs_speculate_next, coreslam.hip)
     float *spec_offs_flat, *spec_ev_off, *spec_grp_bounds; int *spec_ev_idx; int spec_cap_offs, spec_cap_cand, spec_cap_grp;
     uint64_t spec_hits, spec_made;
-    bool spec_valid, spec_base_ok; int spec_n, spec_grp; float spec_sxy, spec_sth; uint64_t spec_seed, spec_stream; // jitter generation + scan upload beside the previous scan's map updates (ensure_shard)
+    bool spec_valid, spec_base_ok, spec_lattice; int spec_n, spec_grp; float spec_sxy, spec_sth; uint64_t spec_seed, spec_stream; // jitter generation + scan upload beside the previous scan's map updates (ensure_shard)
     hipEvent_t ev_scan; bool scan_in_flight;
     bool upload_pending; size_t upload_bytes;   // set_scan filled the staging block; the upload is launched by the first consumer (cs_flush_scan),
                                                 // or rides on the candidate gather's launch when one comes first (ensure_shard)
@@ -62,6 +62,7 @@ struct slamhip_cs {
     bool offs_on_device_sorted;   // generated on the device: flat list already theta-sorted
     float *d_offs_flat;           // [n_offs x 3] flat order
     int cap_offs;                 // jitters d_offs_flat has room for
+    bool gen_lattice; int k1_lattice;   // the generated list is a heading lattice (slamhip_cs_generate_offsets_lattice); candidates per lane the current shard's search may share products over (0: none)
     bool gen_pending; uint64_t gen_seed, gen_stream;   // device-generated list requested but not produced yet (see ensure_shard)
     int shard_first, shard_count; // evaluation list currently materialised
     float *d_ev_off;              // [cap_cand x 3] offsets in evaluation (theta-sorted) order

@@ -217,6 +217,7 @@ struct k1_args {
     int count, n_groups;
     int budget;                        // tile bytes
     int noden;                         // developer / test switch: tile addresses from the integer pixel coordinates (k1_tile_addr) everywhere
+    int nopad;                         // tuning switch: tiles as wide as their box (no pitch padding against LDS bank conflicts)
     float band_stage;                  // cost of staging one band of a banded tile, in ray units (a large value: always band when it fits)
     unsigned long long *acc;           // [n_groups][K1_GROUP] per-candidate accumulators (sum | in-map | arrived); zero between launches
     unsigned long long *gmin;          // running minimum of the finished candidates' keys; all ones between launches
@@ -364,7 +365,11 @@ template <bool MAX> __device__ static inline float k1_wave_redf(float x)      //
 
 typedef unsigned int k1_u32x4 __attribute__((ext_vector_type(4)));   // a staging register quad (native vector: stays in VGPRs)
 
-template <int MODE, bool VERIFY, int CPL, int GROUP>
+// LAT: the candidates of a lane share their heading, bit for bit (a heading lattice: slamhip_cs_generate_offsets_lattice) -- the
+// four products c*X, s*Y, s*X, c*Y of a ray point are formed once per lane, from the lane's first candidate, and every candidate
+// adds them to its own px, py in the reference's order (:240-241): the same floats as k1_coords, 2 (CPL = 2) or 3 (CPL = 4) of the
+// ~12.75 VALU operations per candidate and ray less.
+template <int MODE, bool VERIFY, int CPL, int GROUP, bool LAT = false>
 __global__ void __launch_bounds__(GROUP / CPL, GROUP / CPL / 64 / 2)          // two workgroups per CU
 k1_search_tiled(const k1_args a)
 {
@@ -579,10 +584,26 @@ k1_search_tiled(const k1_args a)
         int x0a = 0, w8 = 8, y0 = 0, h = 0, shift = 0;
         if (cx1 < cx0 || cy1 < cy0) nsteps = 0;                    // no candidate has an end point of this piece in the map
         else {
-            const int xa = cx0 & ~7, ww = ((cx1 - xa + 1) + 7) & ~7, vpr = ww >> 3;
+            // The tile's width is its pitch in the LDS, and the gathers of a wavefront -- one ray, 64 candidates: end points a few dozen
+            // pixels apart in BOTH directions -- meet the LDS banks by (row * pitch / 4 + x / 2) mod 32.  A pitch that is a multiple of 16
+            // pixels moves a row by a multiple of 8 banks: the rows fall on 4, 2 or 1 distinct bank offsets (192 pixels: every row
+            // on the same banks).  Eight more columns make the row step an odd multiple of 4 banks -- 8 distinct offsets -- at the
+            // price of one more 16-byte vector per row to stage.
+            // (Only where the wider tile needs no more bands than the plain one: at 262 144 candidates, whose tiles fill the budget,
+            // padding everywhere cost 4 % -- more tiles banded -- where it gains 8 % at 65 536.)
+            int xa = cx0 & ~7, ww = ((cx1 - xa + 1) + 7) & ~7;
+            const int H = cy1 - cy0 + 1;
+            // (And only for groups of 1024 candidates or more: a tile of the 512-candidate groups of small searches serves too few
+            // gathers to pay for the extra vector -- 4001 candidates: 14.1 -> 14.9 us with it.)
+            if (GROUP >= 1024 && !(ww & 8) && !a.nopad && ww < 512 && (xa + ww + 8 <= S || xa >= 8)) {
+                const int wp = ww + 8, vp = wp >> 3, vu = ww >> 3;
+                const int shp = 32 - __clz(vp - 1), shu = vu <= 1 ? 0 : 32 - __clz(vu - 1);
+                const int hp = min(k1_div(a.budget, wp * 2), PF * NW * (64 >> (shp & 31))), hu = min(k1_div(a.budget, ww * 2), PF * NW * (64 >> (shu & 31)));
+                if (hp >= 1 && hu >= 1 && k1_div(H + hp - 1, hp) == k1_div(H + hu - 1, hu)) { if (xa + ww + 8 <= S) ww += 8; else { xa -= 8; ww += 8; } }
+            }
+            const int vpr = ww >> 3;
             const int sh = vpr <= 1 ? 0 : 32 - __clz(vpr - 1);
             const int hmax = min(k1_div(a.budget, ww * 2), PF * NW * (64 >> (sh & 31)));
-            const int H = cy1 - cy0 + 1;
             // bands pay for themselves only when the rays of the piece amortise the staging of every band: a band costs about
             // as much as K1_BAND_STAGE rays of gathers to stage, a range-tested gather 1.9 and a global gather 4.5 ray units
             const int nb_ = hmax >= 1 ? k1_div(H + hmax - 1, hmax) : K1_MAXBANDS + 1;
@@ -621,6 +642,12 @@ k1_search_tiled(const k1_args a)
     uint32_t sum[CPL], cnt[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) { sum[k] = 0; cnt[k] = 0; }
+    if (LAT && !(MODE != 0 && a.grp_bounds != nullptr)) {          // (with the bounds the candidates are made under the first tile's loads: checked there)
+#pragma unroll
+        for (int k = 1; k < CPL; k++)
+            if (g * GROUP + k * LANES + t < count && (__float_as_uint(q[k].z) != __float_as_uint(q[0].z) || __float_as_uint(q[k].w) != __float_as_uint(q[0].w)))
+                atomicAdd(a.verify, 1u);                            // a lattice whose lane does not share its heading: slamhip_cs_selfcheck_failures
+    }
     uint32_t cnt_all = 0;                                          // rays of the unchecked steps: in the map for every candidate
     if (nsteps > 0) {
         k1_u32x4 R[PF];
@@ -656,6 +683,12 @@ k1_search_tiled(const k1_args a)
         if (MODE != 0 && pre) {                                    // (the first tile's loads are in flight)
 #pragma unroll
             for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
+            if (LAT) {
+#pragma unroll
+                for (int k = 1; k < CPL; k++)
+                    if (g * GROUP + k * LANES + t < count && (__float_as_uint(q[k].z) != __float_as_uint(q[0].z) || __float_as_uint(q[k].w) != __float_as_uint(q[0].w)))
+                        atomicAdd(a.verify, 1u);                    // a lattice whose lane does not share its heading: slamhip_cs_selfcheck_failures
+            }
         }
 #ifdef K1_TIMES
         const unsigned long long sclk0 = clock64();
@@ -731,10 +764,20 @@ k1_search_tiled(const k1_args a)
 #define K1_DPAIR(P, NEXTREAD)                                                                       \
                     {                                                                               \
                         unsigned ada[CPL], adb[CPL];                                                \
+                        float cxa_ = 0.f, sya_ = 0.f, sxa_ = 0.f, cya_ = 0.f, cxb_ = 0.f, syb_ = 0.f, sxb_ = 0.f, cyb_ = 0.f; \
+                        if (LAT) {                                                                  \
+                            cxa_ = q[0].z * (P).x; sya_ = q[0].w * (P).y; sxa_ = q[0].w * (P).x; cya_ = q[0].z * (P).y; \
+                            cxb_ = q[0].z * (P).z; syb_ = q[0].w * (P).w; sxb_ = q[0].w * (P).z; cyb_ = q[0].z * (P).w; \
+                        }                                                                           \
                         _Pragma("unroll") for (int k = 0; k < CPL; k++) {                           \
                             float fxa, fya, fxb, fyb;                                               \
-                            k1_coords(q[k], make_float2((P).x, (P).y), fxa, fya);                   \
-                            k1_coords(q[k], make_float2((P).z, (P).w), fxb, fyb);                   \
+                            if (LAT) {                                                              \
+                                fxa = q[k].x + cxa_; fxa = fxa - sya_; fya = q[k].y + sxa_; fya = fya + cya_; \
+                                fxb = q[k].x + cxb_; fxb = fxb - syb_; fyb = q[k].y + sxb_; fyb = fyb + cyb_; \
+                            } else {                                                                \
+                                k1_coords(q[k], make_float2((P).x, (P).y), fxa, fya);               \
+                                k1_coords(q[k], make_float2((P).z, (P).w), fxb, fyb);               \
+                            }                                                                       \
                             ada[k] = k1_tile_addr_d(fxa, fya, two_v, p2d_v, cd_v);                  \
                             adb[k] = k1_tile_addr_d(fxb, fyb, two_v, p2d_v, cd_v);                  \
                             if (VERIFY) {                                                           \
@@ -1199,6 +1242,7 @@ static k1_host_bounds k1_group_bounds_host(const slamhip_cs *cs, int g, const fl
     b.cmin = (float)cl * scale - pad; b.cmax = (float)ch * scale + pad; b.smin = (float)sl * scale - pad; b.smax = (float)sh * scale + pad;
     return b;
 }
+static int k1_nopad() { static const int v = env_int("SLAMHIP_K1_NOPAD", 0); return v; }     // (tuning: tiles without the pitch padding)
 static bool k1_piece_banded(const slamhip_cs *cs, const k1_host_bounds &b, int r0, int r1, int budget)
 {
     const float *pts = (const float *)((const char *)cs->h_scan_blob + (size_t)cs->cap_points * 24);     // the sorted rays (set_scan's staging block)
@@ -1212,7 +1256,9 @@ static bool k1_piece_banded(const slamhip_cs *cs, const k1_host_bounds &b, int r
     }
     const int ix0 = std::max((int)x0, 0), iy0 = std::max((int)y0, 0), ix1 = std::min((int)x1, S - 1), iy1 = std::min((int)y1, S - 1);
     if (ix1 < ix0 || iy1 < iy0) return false;
-    const int xa = ix0 & ~7, ww = ((ix1 - xa + 1) + 7) & ~7, vpr = ww >> 3;
+    // (the kernel's pitch padding never changes the number of bands: the plain width decides)
+    const int xa = ix0 & ~7, ww = ((ix1 - xa + 1) + 7) & ~7;
+    const int vpr = ww >> 3;
     int shf = 0; while ((1 << shf) < vpr) shf++;
     const int hmax = std::min(budget / (ww * 2), 4096 >> shf), H = iy1 - iy0 + 1;
     return vpr > 64 || hmax < 1 || H > hmax;
@@ -1512,6 +1558,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.band_stage = k1_band_stage();
         static const int noden = env_int("SLAMHIP_K1_NODEN", 0);
         a.noden = noden;
+        a.nopad = k1_nopad();
         a.ev_idx = cs->d_ev_idx; a.dist_out = dist; a.key_out = key; a.verify = cs->d_verify;
         static const int no_bounds = env_int("SLAMHIP_K1_NOBOUNDS", 0);
         a.grp_bounds = (mode == 1 && !no_bounds) ? cs->d_grp_bounds : nullptr;
@@ -1717,10 +1764,17 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
 #define K1_LAUNCH(M, V, C, G) hipLaunchKernelGGL((k1_search_tiled<M, V, C, G>), dim3(n_wgs), dim3(G / C), lds, ctx->stream, a)
+#define K1_LAUNCH_LAT(C, G) hipLaunchKernelGGL((k1_search_tiled<1, false, C, G, true>), dim3(n_wgs), dim3(G / C), lds, ctx->stream, a)
 #define K1_LAUNCH_C(M, V) { if (group == K1_GROUP_BIG) K1_LAUNCH(M, V, 4, K1_GROUP_BIG); else if (group == K1_GROUP_SMALL) K1_LAUNCH(M, V, 1, K1_GROUP_SMALL); else if (cpl == 4) K1_LAUNCH(M, V, 4, K1_GROUP); else if (cpl == 2) K1_LAUNCH(M, V, 2, K1_GROUP); else K1_LAUNCH(M, V, 1, K1_GROUP); }
-            if (verify) { if (mode == 0) K1_LAUNCH_C(0, true) else if (mode == 1) K1_LAUNCH_C(1, true) else K1_LAUNCH_C(2, true) }
+            static const int no_lat = env_int("SLAMHIP_K1_NO_LATTICE", 0);       // (a lattice list through the ordinary kernel: same results, for comparison)
+            const bool lat2 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 2 && group == K1_GROUP && cpl == 2;
+            const bool lat4 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 4 && group == K1_GROUP_BIG;
+            if (lat2) K1_LAUNCH_LAT(2, K1_GROUP);
+            else if (lat4) K1_LAUNCH_LAT(4, K1_GROUP_BIG);
+            else if (verify) { if (mode == 0) K1_LAUNCH_C(0, true) else if (mode == 1) K1_LAUNCH_C(1, true) else K1_LAUNCH_C(2, true) }
             else        { if (mode == 0) K1_LAUNCH_C(0, false) else if (mode == 1) K1_LAUNCH_C(1, false) else K1_LAUNCH_C(2, false) }
 #undef K1_LAUNCH_C
+#undef K1_LAUNCH_LAT
 #undef K1_LAUNCH
         }
         SH_HIP(hipGetLastError());

@@ -37,6 +37,7 @@ struct slamhip_csproc {
     int quality; float hole_width; int search_beginning, unmapped_hits, max_hits;   // :80-101
     uint64_t seed, scan_no;
     bool pinned;
+    bool lattice;                                         // candidates as a heading lattice (slamhip_csproc_set_lattice)
     std::vector<float> cloud;
     // ScanSegmentsToCloud: a lidar's ray angles repeat from scan to scan, so the deterministic sine / cosine of ray r is kept with
     // the angle it was made for and reused while the angle is bit-identical (the same floats by construction; 6 -> 1.5 us per scan)
@@ -96,6 +97,13 @@ extern "C" int32_t slamhip_csproc_set_seed(slamhip_csproc *p, uint64_t seed)
 {
     SH_CHECK_ARG(p);
     p->seed = seed;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_csproc_set_lattice(slamhip_csproc *p, int32_t on)
+{
+    SH_CHECK_ARG(p);
+    p->lattice = on != 0;
     return SLAMHIP_OK;
 }
 
@@ -162,7 +170,8 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
         for (int i = 0; i < 3; i++) search[i] = p->pose[i] + (odo[i] - p->last_odo[i]);   // :728
         if (!p->pinned) {
             const int nj = (p->threads > 0 ? p->threads : 1) * p->iters;  // :143-160, :662-665
-            SH_TRY(slamhip_cs_generate_offsets(p->cs, nj, p->sigma_xy, p->sigma_theta, p->seed, p->scan_no));
+            if (p->lattice) SH_TRY(slamhip_cs_generate_offsets_lattice(p->cs, nj, p->sigma_xy, p->sigma_theta, p->seed, p->scan_no));
+            else SH_TRY(slamhip_cs_generate_offsets(p->cs, nj, p->sigma_xy, p->sigma_theta, p->seed, p->scan_no));
         }
         p->scan_no++;
         memcpy(p->last_odo, odo, sizeof(odo));                            // :745

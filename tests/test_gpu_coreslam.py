@@ -232,6 +232,108 @@ def test_search_changing_scans_one_candidate_list(cs_mod, ctx, det, sim):
     dev.close()
 
 
+@pytest.mark.parametrize("size,R,K", [(512, 720, 3001), (1024, 1080, 16385), (400, 360, 12289), (512, 500, 20000), (256, 200, 65536), (512, 360, 70001)])
+def test_heading_lattice(cs_mod, ctx, det, sim, size, R, K):
+    """The opt-in heading lattice (slamhip_cs_generate_offsets_lattice): the candidates a lane of the search kernel evaluates share
+    their dtheta bit for bit (2 per lane below 65 536 candidates, 4 from there on), the un-jittered pose's stratum has dtheta = 0;
+    the search over it -- through the kernel variant that forms the ray products once per lane -- returns what the oracle returns
+    for the downloaded list, and what the ordinary kernel returns for it (SLAMHIP_K1_NO_LATTICE is read once per process, so the
+    comparison is with the same list handed back through slamhip_cs_set_offsets: an explicit list never takes the lattice kernel)."""
+    oc = det
+    segs = sim.default_field()
+    dev = make_dev(cs_mod, ctx, size, size // 4)
+    rng = sim.PCG32(4321)
+    traj = sim.trajectory(8)
+    for p in traj:
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy); dev.update_holemap(p)
+    pix = dev.holemap_download()
+    true_pose = sim.trajectory(9)[-1]
+    _, xy = sim.make_scan(segs, true_pose, R, sim.PCG32(99))
+    base = (true_pose + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
+    dev.set_scan(xy)
+    n = K - 1
+    dev.generate_offsets(n, 0.1, math.radians(10.0), seed=77, stream=4, lattice=True)
+    pose, dist, idx = dev.search(base)                       # (the list is produced inside the search's gather launch)
+    offs = dev.offsets_download()
+    assert np.isfinite(offs).all()
+    if K <= 12288:                                           # small searches: one candidate per lane, the plain (sorted) list
+        assert (np.diff(offs[:, 2]) >= 0).all()
+        rbi, rpose, rbd, _ = oc.search(pix, size, dev.hole_scale, xy, base, offs)
+        assert idx == rbi and dist == rbd and (pose == rpose).all()
+        dev.close()
+        return
+    # structure: evaluation position j of flat f (the un-jittered pose, flat 0, sits at zero_pos); lanes = group / candidates per lane
+    grp, cpl = (2048, 4) if K >= 65536 else (1024, 2)
+    lanes = grp // cpl
+    zero_pos = min(K - 1, n // 2)
+    dth = np.empty(K, np.float32)
+    j = np.arange(K)
+    flat = np.where(j < zero_pos, j + 1, np.where(j == zero_pos, 0, j))
+    dth[:] = np.where(flat > 0, offs[np.maximum(flat - 1, 0), 2], np.float32(0.0))
+    stratum = (j // grp) * lanes + (j % lanes)
+    bits = dth.view(np.uint32)
+    for u in np.unique(stratum)[:: max(1, len(np.unique(stratum)) // 400)]:
+        b = bits[stratum == u]
+        assert (b == b[0]).all(), u                          # one heading per lane position, bit for bit
+    us = np.unique(stratum)
+    first_of = np.array([dth[stratum == u][0] for u in us if u != stratum[zero_pos]])
+    assert (np.diff(first_of) >= 0).all()                    # the strata ascend (the un-jittered pose's own stratum is pinned to 0)
+    assert dth[stratum == stratum[zero_pos]].tolist() == [0.0] * int((stratum == stratum[zero_pos]).sum())
+    assert abs(offs[:, 0].std() - 0.1) < 0.01 and abs(offs[:, 2].std() - math.radians(10.0)) < 0.012
+    # the same list from the stand-alone generator launch (the list read before it is searched)
+    dev.generate_offsets(n, 0.1, math.radians(10.0), seed=77, stream=4, lattice=True)
+    assert (dev.offsets_download() == offs).all()
+    # parity: oracle on the downloaded list; and the ordinary kernel on the same list as an explicit one
+    rbi, rpose, rbd, _ = oc.search(pix, size, dev.hole_scale, xy, base, offs)
+    assert idx == rbi and dist == rbd and (pose == rpose).all()
+    pose_l, dist_l, idx_l = dev.search(base)                 # (searched again after the download: the lattice kernel once more)
+    assert (idx_l, dist_l) == (idx, dist) and (pose_l == pose).all()
+    dev.set_offsets(offs)
+    pose_e, dist_e, idx_e = dev.search(base)
+    assert (idx_e, dist_e) == (idx, dist) and (pose_e == pose).all()
+    assert dev.selfcheck_failures == 0                       # (the lattice kernel counts lanes whose candidates do not share a heading)
+    # a plain generated list afterwards is sorted again, and a sharded search over a lattice list (ordinary kernel) agrees
+    dev.generate_offsets(n, 0.1, math.radians(10.0), seed=77, stream=4, lattice=True)
+    keys = [dev.search_shard(base, K * r // 3, K * (r + 1) // 3 - K * r // 3) for r in range(3)]
+    p2, d2, i2 = dev.pose_from_key(base, min(keys))
+    assert i2 == rbi and d2 == rbd and (p2 == rpose).all()
+    dev.generate_offsets(n, 0.1, math.radians(10.0), seed=77, stream=4)
+    assert (np.diff(dev.offsets_download()[:, 2]) >= 0).all()
+    dev.close()
+
+
+def test_processor_with_lattice(cs_mod, ctx, det, sim):
+    """CoreSLAMProcessor with SetLattice(True): every scan's candidates are a heading lattice (prepared ahead like the plain
+    lists); the poses equal those of the oracle state machine fed the downloaded lists."""
+    oc = det
+    segs = sim.default_field()
+    start = np.array([20.0, 20.0, 0.0], np.float32)
+    proc = cs_mod.CoreSLAMProcessor(40.0, 256, 64, start, 0.1, math.radians(10), 3200, 4, ctx=ctx)   # (12 801 candidates: a lattice from 12 289 on)
+    proc.HoleWidth = 2.0
+    proc.SetLattice(True)
+    ref = oc.CSProc(40.0, 256, 64, start)
+    ref.set_params(hole_width=2.0)
+    rng = sim.PCG32(21)
+    true_traj = sim.trajectory(14, step=(0.08, 0.03, math.radians(1.0)))
+    for i, tp in enumerate(true_traj):
+        rays, _ = sim.make_scan(segs, tp, 400, rng)
+        est = proc.Pose.copy()
+        assert (est == ref.pose).all()
+        seg_pose = (est + np.array([0.08, 0.03, math.radians(1.0)], np.float32)).astype(np.float32) if i else est
+        proc.Update([cs_mod.ScanSegment(rays, seg_pose)])
+        offs = proc.device.offsets_download(12800) if i >= 5 else None      # (the list the searching Update just used)
+        ref.update(seg_pose[None], [0, rays.shape[0]], rays, offs)
+        assert (proc.Pose == ref.pose).all(), i
+    assert (proc.HoleMap.Pixels == ref.holemap).all()
+    served, prepared = proc.device.prepared_lists()
+    assert served >= 7, (served, prepared)
+    assert proc.device.selfcheck_failures == 0
+    dth = proc.device.offsets_download(12800)[:, 2]
+    assert not (np.diff(dth) >= 0).all()                     # (a lattice, not the sorted plain list)
+    proc.Dispose()
+
+
 def test_prepared_candidate_list(cs_mod, ctx, det, sim):
     """The per-scan flow's candidate list prepared ahead (cs_speculate_next, coreslam.hip): a fused scan on a generated list prepares
     the list of stream + 1 on a side stream; generate_offsets(stream + 1) then swaps it in -- it must be the very list a fresh
