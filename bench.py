@@ -429,6 +429,17 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
         dev.set_offsets(sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=42))
         sweep[str(K)] = time_search(dev, base, K, steps)
     out["search_candidates_per_step_sweep_%d_map" % a.size] = sweep
+    # BESIDE the Monte-Carlo figures, never instead of them: the same search over the device generator's lists -- headings stratified
+    # (slamhip_cs_generate_offsets) and on the opt-in heading lattice (slamhip_cs_generate_offsets_lattice: the candidates of a lane
+    # share their heading, the kernel forms the ray products once per lane).  Same sigmas, same kernel otherwise.
+    lat = {}
+    for K, steps in ((65536, 100), (262144, 50)):
+        dev.generate_offsets(K - 1, 0.1, math.radians(10.0), seed=42, stream=1)
+        plain = time_search(dev, base, K, steps)
+        dev.generate_offsets(K - 1, 0.1, math.radians(10.0), seed=42, stream=1, lattice=True)
+        lattice = time_search(dev, base, K, steps)
+        lat[str(K)] = {"generated_stratified_headings": plain, "generated_heading_lattice": lattice}
+    out["search_generated_lists_%d_map_not_the_headline" % a.size] = lat
 
     def mapped(size, rays=1080, updates=30):
         d = cs.CoreSlamDevice(ctx, 40.0, size, max(size // 4, 1))
