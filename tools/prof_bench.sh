@@ -26,6 +26,7 @@ run tcc       --kernel-trace --pmc TCC_HIT TCC_MISS --output-format csv -d $out/
 run sq1       --kernel-trace --pmc $SQ1 --output-format csv -d $out/sq1 -o p -- $bench
 run sq2       --kernel-trace --pmc $SQ2 --output-format csv -d $out/sq2 -o p -- $bench
 run sq1_262k  --kernel-trace --pmc $SQ1 --output-format csv -d $out/sq1_262k -o p -- $bench --cands 262144 --steps 50
+run sq2_262k  --kernel-trace --pmc $SQ2 --output-format csv -d $out/sq2_262k -o p -- $bench --cands 262144 --steps 50
 k2="python3 $root/tools/prof_k2.py"
 run k2stats   --kernel-trace --stats --output-format csv -d $out/k2stats -o stats -- $k2
 run k2fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/k2fetch -o p -- $k2

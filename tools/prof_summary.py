@@ -57,7 +57,7 @@ def bench_line(name):
 
 if "--collect" in sys.argv:
     out = {"stats": stats("stats"), "stats262k": stats("stats262k"), "k2stats": stats("k2stats")}
-    for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2"):
+    for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2"):
         out[sub] = pmc(sub)
     for name in ("bench.json", "stats.out", "stats262k.out", "fetch.out", "sq1.out"):
         out["line_" + name] = bench_line(name)
@@ -148,7 +148,7 @@ if k1s:
     json.dump({
         "command": "tools/prof_bench.sh: rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes) -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras [--cands 262144 --steps 50]",
         "headline_16384_candidates": sq_summary(c["sq1"], c["sq2"], k1s, float(k1row["AverageNs"]) if k1row else None),
-        "at_262144_candidates": sq_summary(c["sq1_262k"], None, k1_of(c["sq1_262k"]) or "", float(k1row262["AverageNs"]) if k1row262 else None),
+        "at_262144_candidates": sq_summary(c["sq1_262k"], c.get("sq2_262k") or None, k1_of(c["sq1_262k"]) or "", float(k1row262["AverageNs"]) if k1row262 else None),
     }, open(os.path.join(dst, tag + "_k1_sq.json"), "w"), indent=1)
 
 # 5. the HoleMap update: traffic and SQ counters of its kernel(s)
@@ -167,6 +167,6 @@ if k2:
         "sq": sq_summary(c["k2sq1"], c["k2sq2"], k2, float(k2row["AverageNs"]) if k2row else None),
     }, open(os.path.join(dst, tag + "_k2_counters.json"), "w"), indent=1)
 
-json.dump({k: c[k] for k in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2")},
+json.dump({k: c[k] for k in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2")},
           open(os.path.join(dst, tag + "_bench_pmc_per_kernel.json"), "w"), indent=1)
 print("wrote profiles/%s_*; K1 rocprof avg %s ns (262144 candidates: %s ns)" % (tag, k1row["AverageNs"] if k1row else "?", k1row262["AverageNs"] if k1row262 else "?"))
