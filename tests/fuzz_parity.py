@@ -141,7 +141,7 @@ def main():
                 ok = False; why.append("obstaclemap: %d cells differ, first %s got %s want %s" % (bad.size, [(int(b) % osize, int(b) // osize) for b in bad[:4]], gob[bad[:4]], oref[bad[:4]]))
             desc = "maps size %d/%d rays %d hw %.1f q %d pose %s" % (size, osize, R, hw, q, np.round(pose, 2))
             if ok and kind == 1 and xy.shape[0] > 0:
-                K = int(rng.choice([1, 2, 300, 1023, 1024, 1025, 2049, 4096, 20000, 70000, 98304, 120000]))     # (65 536 and more: groups of 2048 candidates; up to 12 288: 512)
+                K = int(rng.choice([1, 2, 300, 1023, 1024, 1025, 2049, 4096, 12289, 16384, 20000, 65536, 70000, 98304, 120000]))     # (65 536 and more: groups of 2048 candidates; up to 12 288: 512)
                 sxy, sth = float(rng.choice([0.0, 0.02, 0.1, 0.5])), float(rng.choice([0.0, 0.01, 0.17, 0.8, 3.0]))
                 base = (pose + np.array([0.03, -0.02, 0.017], np.float32)).astype(np.float32)
                 if rng.random() < 0.5:
@@ -150,7 +150,8 @@ def main():
                     gp, gd, gi = dev.search(base)
                     fused = False
                 else:
-                    dev.generate_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)), stream=n_cases)
+                    lattice = rng.random() < 0.5                      # (round 4: the opt-in heading lattice -- the search kernel's LAT variant from 12 289 candidates on)
+                    dev.generate_offsets(K - 1, sxy, sth, seed=int(rng.integers(1, 1 << 30)), stream=n_cases, lattice=lattice)
                     fused = rng.random() < 0.5
                     gp, gd, gi = dev.search_and_update(base, hw, q, mh)[:3] if fused else dev.search(base)
                     offs = dev.offsets_download()
