@@ -993,8 +993,8 @@ static int32_t cs_generate(slamhip_cs *cs, int32_t n, float sigma_xy, float sigm
         std::swap(cs->d_offs_flat, cs->spec_offs_flat); std::swap(cs->d_ev_off, cs->spec_ev_off);
         std::swap(cs->d_ev_idx, cs->spec_ev_idx); std::swap(cs->d_grp_bounds, cs->spec_grp_bounds);
         cs->gen_stream = stream; cs->gen_pending = false; cs->spec_hits++;
-        cs->side_join = true;                                     // (the search launch checks the side launch's word: cs_side_join)
-        return SLAMHIP_OK;
+        cs->side_join = true;
+        return cs_side_join(cs);                                  // (the side launch's word: there since the previous scan -- checked before anything reads the list)
     }
     cs->spec_base_ok = false;
     cs->n_offs = n;
