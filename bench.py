@@ -754,13 +754,16 @@ def valu_ceiling(a, bytes_per_launch):
 
 
 def measured_peak():
-    """Read bandwidth of a stream over 4 GiB on this box (tools/hbm_probe.py, committed as profiles/r01_hbm_probe.json):
-    the ceiling the hardware delivers, next to the 8 TB/s specification `peak` is quoted from.  GB/s or null."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_probe.json")) as f:
-            return float(json.load(f)["4_GiB"]["sum_GBps_read"]), "replayed from profiles/r01_hbm_probe.json (tools/hbm_probe.py, round 1; not measured in this run)"
-    except Exception:
-        return None, None
+    """Read bandwidth of a stream over 4 GiB on this box (tools/hbm_probe.py, committed as profiles/rNN_hbm_probe.json, newest
+    round first): the ceiling the hardware delivers, next to the 8 TB/s specification `peak` is quoted from.  GB/s or null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_probe.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return float(json.load(f)["4_GiB"]["sum_GBps_read"]), "replayed from %s (tools/hbm_probe.py; not measured in this run)" % os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None, None
 
 
 def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=(), pix=None):
