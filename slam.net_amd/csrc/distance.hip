@@ -192,7 +192,7 @@ k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_poin
 #define K1_MAXP 16                     // pieces (ray block fragments) per chunk
 #define K1_MAXR 512                    // rays per chunk
 #define K1_MAXBANDS 4
-#define K1_MAXSTEPS (K1_MAXP * K1_MAXBANDS)
+#define K1_MAXSTEPS (K1_MAXP * K1_MAXBANDS * 2)   // (a piece may be planned as two halves)
 static_assert(K1_MAXBANDS == 4, "the step threads split t into (piece, band) with shifts");
 #define K1_TABLE_G 64                  // groups with their own chunk count (the rest: one uniform count)
 #define K1_TABLE_WGS 2048
@@ -218,6 +218,7 @@ struct k1_args {
     int budget;                        // tile bytes
     int noden;                         // developer / test switch: tile addresses from the integer pixel coordinates (k1_tile_addr) everywhere
     int nopad;                         // tuning switch: tiles as wide as their box (no pitch padding against LDS bank conflicts)
+    int nosplit;                       // tuning switch: a piece that does not fit one tile is never planned as two halves
     float band_stage;                  // cost of staging one band of a banded tile, in ray units (a large value: always band when it fits)
     unsigned long long *acc;           // [n_groups][K1_GROUP] per-candidate accumulators (sum | in-map | arrived); zero between launches
     unsigned long long *gmin;          // running minimum of the finished candidates' keys; all ones between launches
@@ -571,19 +572,15 @@ k1_search_tiled(const k1_args a)
         bx0 = k1_wave_red<false>(bx0); by0 = k1_wave_red<false>(by0);
         bx1 = k1_wave_red<true>(bx1);  by1 = k1_wave_red<true>(by1);
         K1_STAMP(4)
-        if (lane < 64 - K1_MAXBANDS) continue;
-        // The last K1_MAXBANDS lanes of the wave (row 3 holds the reduced box) make the piece's steps, one lane per band; the lanes of
-        // a piece take the same decision.  Steps are appended in arrival order: any order gives the same integer sums.  (The boxes
-        // used to go through the LDS and a barrier to one thread per (piece, band).)
-        const int pc = p, band = lane - (64 - K1_MAXBANDS);
-        const int4 bx = make_int4(bx0, by0, bx1, by1);
-        const int prec = pieces[pc].x | (pieces[pc].y << 16);
-        // the box clipped to the map, cut into row bands that fit the tile budget (one band, not clipped: SHARED)
-        const int cx0 = max(bx.x, 0), cy0 = max(bx.y, 0), cx1 = min(bx.z, S - 1), cy1 = min(bx.w, S - 1);
-        int kind = K1_KIND_GLOBAL, nsteps = 1;
-        int x0a = 0, w8 = 8, y0 = 0, h = 0, shift = 0;
-        if (cx1 < cx0 || cy1 < cy0) nsteps = 0;                    // no candidate has an end point of this piece in the map
-        else {
+        // The last lanes of the wave (row 3 holds the reduced boxes) make the piece's steps, one lane per band; the lanes of a piece
+        // take the same decision from the same box.  Steps are appended in arrival order: any order gives the same integer sums.
+        // (The boxes used to go through the LDS and a barrier to one thread per (piece, band).)
+        // k1_plan: the box clipped to the map, cut into row bands that fit the tile budget (one band, not clipped: SHARED).
+        struct k1_plan_t { int nsteps, kind, x0a, y0, w8, h, shift; float cost; };
+        auto k1_plan = [&](const int4 bx, const int nr_, const int band) -> k1_plan_t {
+            k1_plan_t P; P.nsteps = 1; P.kind = K1_KIND_GLOBAL; P.x0a = 0; P.y0 = 0; P.w8 = 8; P.h = 0; P.shift = 0; P.cost = 4.5f * (float)nr_;
+            const int cx0 = max(bx.x, 0), cy0 = max(bx.y, 0), cx1 = min(bx.z, S - 1), cy1 = min(bx.w, S - 1);
+            if (cx1 < cx0 || cy1 < cy0) { P.nsteps = 0; P.cost = 0.0f; return P; }   // no candidate has an end point of this piece in the map
             // The tile's width is its pitch in the LDS, and the gathers of a wavefront -- one ray, 64 candidates: end points a few dozen
             // pixels apart in BOTH directions -- meet the LDS banks by (row * pitch / 4 + x / 2) mod 32.  A pitch that is a multiple of 16
             // pixels moves a row by a multiple of 8 banks: the rows fall on 4, 2 or 1 distinct bank offsets (192 pixels: every row
@@ -607,23 +604,82 @@ k1_search_tiled(const k1_args a)
             // bands pay for themselves only when the rays of the piece amortise the staging of every band: a band costs about
             // as much as K1_BAND_STAGE rays of gathers to stage, a range-tested gather 1.9 and a global gather 4.5 ray units
             const int nb_ = hmax >= 1 ? k1_div(H + hmax - 1, hmax) : K1_MAXBANDS + 1;
-            const int nr_ = pieces[pc].y;
             const bool bands_pay = nb_ == 1 || (float)nb_ * (a.band_stage + 1.9f * (float)nr_) < 4.5f * (float)nr_;      // (the host's cost estimate mirrors this: k1_group_cost)
             if (vpr <= 64 && hmax >= 1 && nb_ <= K1_MAXBANDS && bands_pay) {
-                nsteps = nb_;
-                const int hb = k1_div(H + nsteps - 1, nsteps);
-                const bool whole = nsteps == 1 && cx0 == bx.x && cy0 == bx.y && cx1 == bx.z && cy1 == bx.w;
-                kind = whole ? K1_KIND_SHARED : K1_KIND_BAND;
-                x0a = xa; w8 = ww; shift = sh;
-                y0 = cy0 + band * hb;
-                h = min(hb, cy1 + 1 - y0);
-                if (h <= 0) nsteps = 0;                            // (rounding can leave the last band empty)
+                P.nsteps = nb_;
+                const int hb = k1_div(H + nb_ - 1, nb_);
+                const bool whole = nb_ == 1 && cx0 == bx.x && cy0 == bx.y && cx1 == bx.z && cy1 == bx.w;
+                P.kind = whole ? K1_KIND_SHARED : K1_KIND_BAND;
+                P.x0a = xa; P.w8 = ww; P.shift = sh;
+                P.y0 = cy0 + band * hb;
+                P.h = min(hb, cy1 + 1 - P.y0);
+                // (cost in ray units, for the choice between a piece and its halves: a tile step has a fixed part -- barriers, the
+                // step's set-up -- plus a part per full budget of bytes staged (a step of a full 60 KB tile weighs ~26 rays of
+                // gathers at two candidates per lane: the cuts' calibration), a plain gather 1, a range-tested one 1.9 and it is
+                // made in every band)
+                const float stage = (float)nb_ * 6.0f + 20.0f * (float)(ww * 2) * (float)H / (float)a.budget;
+                P.cost = stage * (2.0f / (float)CPL) + (whole ? (float)nr_ : 1.9f * (float)nb_ * (float)nr_);
+                if (P.h <= 0 && band < nb_) P.h = 0;               // (rounding can leave the last band empty: see the emit test)
+            }
+            return P;
+        };
+        const int pc = p;
+        const int nr_all = pieces[pc].y, r_first = pieces[pc].x;
+        const bool planner = lane >= 64 - K1_MAXBANDS;
+        const int4 bx = make_int4(bx0, by0, bx1, by1);
+        k1_plan_t full = k1_plan(bx, nr_all, planner ? lane - (64 - K1_MAXBANDS) : 0);
+        // A BANDED piece -- its box does not fit one tile: every band walks ALL its rays with range-tested gathers -- is tried as two:
+        // the rays of a block are in Z order, so each half of them spans about half the box, and two plain tiles cost 2 stagings
+        // + 1 x the gathers where four bands cost 4 + 4 x (the slowest workgroups of a launch at the headline size were the ones
+        // holding such a piece: 14 us of compute against a mean of 8).  The halves' boxes are two more rounds of wave reductions,
+        // made only when a piece needs them; the halves are taken when their estimated cost is lower (in practice always: the
+        // decision did not move with the weights).  Measured, sustained clocks: 16 384 candidates 17.97 -> 17.02 us, 65 536:
+        // 39.2 -> 37.6, 262 144 / 1024^2 / 4096^2: unchanged.  Pieces too wide for any tile (global gathers) are left alone:
+        // splitting those gained nothing at 2048^2 and cost 3 % at 4096^2, 32 768 candidates.  SLAMHIP_K1_NOSPLIT=1 for the A/B.
+        // (Groups of 1024 candidates or more: with 512-candidate groups -- small searches, whose launch is mostly prologue -- the extra
+        // planning and steps cost more than the gathers they save: 4001 candidates 14.4 -> 15.4 us.)
+        const bool want = GROUP >= 1024 && planner && lane == 63 && !a.nosplit && nr_all >= 8 && full.nsteps != 0 && full.nsteps > 1;
+        bool split = false;
+        k1_plan_t half;
+        half.nsteps = 0; half.kind = K1_KIND_GLOBAL; half.x0a = 0; half.y0 = 0; half.w8 = 8; half.h = 0; half.shift = 0; half.cost = 0.0f;
+        int h_first = r_first, h_nr = nr_all;
+        if (__builtin_amdgcn_ballot_w64(want) != 0) {             // (uniform)
+            const int h1 = (nr_all / 2 + 1) & ~1;                  // (even: the gather loops take ray pairs)
+            int ax0, ay0, ax1, ay1;
+            k1_ray_box(bb8, pt, ax0, ay0, ax1, ay1);
+            const bool inA = lane < h1;
+            const int A0 = k1_wave_red<false>(inA ? ax0 : 0x7fffffff), A1 = k1_wave_red<false>(inA ? ay0 : 0x7fffffff);
+            const int A2 = k1_wave_red<true>(inA ? ax1 : (int)0x80000000), A3 = k1_wave_red<true>(inA ? ay1 : (int)0x80000000);
+            const int B0 = k1_wave_red<false>(inA ? 0x7fffffff : ax0), B1 = k1_wave_red<false>(inA ? 0x7fffffff : ay0);
+            const int B2 = k1_wave_red<true>(inA ? (int)0x80000000 : ax1), B3 = k1_wave_red<true>(inA ? (int)0x80000000 : ay1);
+            const int idx = lane - (64 - 2 * K1_MAXBANDS);         // lanes 56 .. 63: half = idx / K1_MAXBANDS, band = idx % K1_MAXBANDS
+            const int hb_ = idx >= K1_MAXBANDS ? 1 : 0, band_ = idx >= 0 ? idx - hb_ * K1_MAXBANDS : 0;
+            const k1_plan_t pa = k1_plan(make_int4(A0, A1, A2, A3), h1, hb_ == 0 ? band_ : 0);
+            const k1_plan_t pb = k1_plan(make_int4(B0, B1, B2, B3), nr_all - h1, hb_ == 1 ? band_ : 0);
+            split = pa.cost + pb.cost < full.cost;                 // (the same in every lane of row 3: same boxes)
+            half = hb_ ? pb : pa;
+            h_first = hb_ ? r_first + h1 : r_first; h_nr = hb_ ? nr_all - h1 : h1;
+            if (split) {
+                if (idx < 0) continue;
+                const int band = band_;
+                if (band < half.nsteps && (half.kind == K1_KIND_GLOBAL || half.h > 0) && (half.kind == K1_KIND_BAND ? (nbp == 2 ? (band & 1) == bp : band % nbp == bp) : bp == 0)) {
+                    int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
+                    dst[0] = make_int4(half.x0a, half.y0, half.w8, half.h);
+                    dst[1] = make_int4(half.shift, half.kind, h_first | (h_nr << 16), 0);
+                }
+                continue;
             }
         }
-        if (band < nsteps && (kind == K1_KIND_BAND ? (nbp == 2 ? (band & 1) == bp : band % nbp == bp) : bp == 0)) {
-            int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
-            dst[0] = make_int4(x0a, y0, w8, h);
-            dst[1] = make_int4(shift, kind, prec, 0);
+        if (!planner) continue;
+        {
+            const int band = lane - (64 - K1_MAXBANDS);
+            const int prec = r_first | (nr_all << 16);
+            const bool live = full.kind == K1_KIND_GLOBAL ? true : full.h > 0;
+            if (band < full.nsteps && live && (full.kind == K1_KIND_BAND ? (nbp == 2 ? (band & 1) == bp : band % nbp == bp) : bp == 0)) {
+                int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
+                dst[0] = make_int4(full.x0a, full.y0, full.w8, full.h);
+                dst[1] = make_int4(full.shift, full.kind, prec, 0);
+            }
         }
     }
     __syncthreads();
@@ -1559,6 +1615,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         static const int noden = env_int("SLAMHIP_K1_NODEN", 0);
         a.noden = noden;
         a.nopad = k1_nopad();
+        static const int nosplit = env_int("SLAMHIP_K1_NOSPLIT", 0);
+        a.nosplit = nosplit;
         a.ev_idx = cs->d_ev_idx; a.dist_out = dist; a.key_out = key; a.verify = cs->d_verify;
         static const int no_bounds = env_int("SLAMHIP_K1_NOBOUNDS", 0);
         a.grp_bounds = (mode == 1 && !no_bounds) ? cs->d_grp_bounds : nullptr;
