@@ -1497,6 +1497,42 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     const bool early = !ctx->mail_off && ctx->timing == 0 && !wait_updates;
     sh_mail_guard lock(ctx);
     const uint32_t seq = sh_mail_seq_next(ctx);                    // (taken when K1 is armed; the result block's publish reuses it otherwise)
+    // The winner decoded by the map update (round 4, late): the search runs in its result-ring form -- its workgroups min their keys
+    // into a word and the end of the launch is the completion; no final arriver, whose chain (minimum acknowledged, count, minimum
+    // read back, jitter loaded: four dependent round trips behind the launch's slowest workgroup) made the search 2.2 us longer in
+    // this call than in the headline loop -- and every workgroup of the HoleMap update, which must start with the pose anyway,
+    // decodes it from the key (two loads in a row where it had one, under the 1.3 us its sixteen wavefronts take to start); its
+    // first workgroup stores the pose for later readers and delivers key + pose to the mailbox.  One-launch updates only
+    // (scans of up to 2400 rays); SLAMHIP_FUSED_K1_DELIVERS=1 keeps the search's own delivery.
+    static const bool k1_delivers = getenv("SLAMHIP_FUSED_K1_DELIVERS") != nullptr;
+    const bool decode = early && !k1_delivers && cs_holemap_one_launch(cs) && cs->n_points > 0;
+    if (decode) {
+        cs->k1_ring_request = true;
+        SH_TRY(search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key));
+        g_cst.lap(3);
+        cs_k2_winner win;
+        win.d_key = cs->k1_ring_last; win.d_offs_flat = cs->d_offs_flat; win.bx = pose[0]; win.by = pose[1]; win.bth = pose[2];
+        win.mail = ctx->mailbox; win.seq = seq;
+        const int32_t rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality, true, max_hits, &win);
+        g_cst.lap(4);
+        cs_layout_idle_refresh(cs);                                // (host work under the search: the launch layout for the next scan)
+        g_cst.lap(5);
+        SH_TRY(rc_u);                                              // (no update launch, no delivery: nothing to wait for)
+        const int32_t rc_p = cs_speculate_next(cs);                // (... and the next scan's candidates, on the side stream)
+        g_cst.lap(7);
+        SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));
+        g_cst.lap(6); g_cst.done();
+        SH_TRY(rc_p);
+        cs->hole_pixels_pending = true;
+        cs->launch_done = cs->k1_launch_no;                        // (the update that delivered runs behind the search: every launch before THAT has finished)
+        const volatile uint64_t *hk = (const volatile uint64_t *)ctx->mailbox;
+        const float *hp = (const float *)(ctx->mailbox + 2);
+        const uint64_t key = hk[0];
+        if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
+        if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);
+        if (out_index) *out_index = (int32_t)(uint32_t)key;
+        return SLAMHIP_OK;
+    }
     if (early) { cs->k1_done_flag = ctx->mailbox + 15; cs->k1_done_val = seq; }
     cs->k1_want_pose = true;
     const int32_t rc_s = search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key);

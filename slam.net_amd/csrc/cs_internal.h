@@ -186,8 +186,12 @@ int32_t cs_update_maps_enqueue(slamhip_cs *cs, const float pose[3], float hole_w
 int32_t cs_update_maps_finish(slamhip_cs *cs);
 struct k3_ride;
 // with_obstacle: the ObstacleMap update of the same scan and pose rides along (or follows in launches of its own when it cannot)
+// win: the fused scan's form (d_pose_or_null must then be a pose buffer to receive the decoded winner: the launch decodes the
+// search's key itself and delivers key + pose to the mailbox; one-launch form only: cs_holemap_one_launch)
+struct cs_k2_winner { const uint64_t *d_key; const float *d_offs_flat; float bx, by, bth; uint32_t *mail; uint32_t seq; };
+bool cs_holemap_one_launch(const slamhip_cs *cs);
 int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float4 h_pxcs_obst, float hole_width, int quality,
-                                 bool with_obstacle = false, int max_hits = 0);
+                                 bool with_obstacle = false, int max_hits = 0, const cs_k2_winner *win = nullptr);
 void cs_obstacle_ride(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, int max_hits, k3_ride *out);
 void cs_obstacle_ride_commit(slamhip_cs *cs, const k3_ride *ride, int max_hits);   // after the carrying launch is in the stream
 int32_t cs_obstacle_flush(slamhip_cs *cs);                        // applies a pending cell pass (before anything reads or writes the ObstacleMap)

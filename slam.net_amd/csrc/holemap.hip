@@ -563,7 +563,23 @@ static inline size_t k2_lds_bytes(bool build, int n_rays) { return build ? (size
 struct k2_t3 { int ptr, dx, dy, ray, lim2; uint16_t pix; };
 
 // what the kernel needs of the scan when it makes the tables itself
-struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, rc_num; int2 *span; };
+struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, rc_num; int2 *span;
+                 // the fused scan's form: the pose is not in memory yet -- the search (result-ring form: no final arriver, no chain)
+                 // left only its key; every workgroup decodes the winner itself, the first one also stores the pose for later
+                 // readers and delivers key + pose to the host's mailbox (k2_winner_pose)
+                 const unsigned long long *win_key; const float *win_offs; float win_bx, win_by, win_bth; float *win_pose_out;
+                 uint32_t *win_mail; uint32_t win_seq; };
+
+// The winner of the search from its key, as MonteCarloSearch returns it and Update normalises it (CoreSLAMProcessor.cs:635-637, :746):
+// search_pose + offs[index - 1], theta normalised.  pose[3] keeps the un-normalised theta.
+__device__ static inline void k2_winner_pose(const k2_scan &sc, float pose[4], unsigned long long &key)
+{
+    key = __hip_atomic_load(sc.win_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t flat = (uint32_t)key;
+    float bx = sc.win_bx, by = sc.win_by, th = sc.win_bth;
+    if (flat > 0) { bx = sc.win_bx + sc.win_offs[3 * (size_t)(flat - 1)]; by = sc.win_by + sc.win_offs[3 * (size_t)(flat - 1) + 1]; th = sc.win_bth + sc.win_offs[3 * (size_t)(flat - 1) + 2]; }
+    pose[0] = bx; pose[1] = by; pose[2] = sh_normalize_angle(th); pose[3] = th;
+}
 
 // BUILD: ONE launch per HoleMap update.  Every workgroup makes the scan's ray tables itself, in LDS -- per ray the literal
 // arithmetic of :519-530 / :361-399 (k2_make_ray), a counting sort into 4 direction classes x 1024 slope buckets -- instead of
@@ -683,6 +699,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     k2_byidx *byidx_s = (k2_byidx *)(vprof_s + (BUILD ? n4 : 0));
     __shared__ __attribute__((aligned(16))) int sval[16][64];
     __shared__ int s_last, s_nextA, s_nextB, s_R, s_total, wsum[16];
+    __shared__ float s_wpose[4];
     K2_STAMP(0)
     // Riding along: the ObstacleMap update (obstacle_dev.h).  Every wavefront of the launch takes 64 cells of the pending cell
     // pass and (the rays going round the workgroups) at most one ray's walk: the loads are requested at the head, behind the scan
@@ -701,7 +718,23 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         constexpr int RPT = (K2_LDS_RAYS + 1023) / 1024;            // rays per thread
         float2 p_next = make_float2(0.f, 0.f);
         if (t < n_rays) p_next = sc.pts[t];                         // (a thread's next point is requested one iteration ahead)
-        const float4 q = k2_pxcs(sc.d_pose, sc.h_pxcs, sc.scale);
+        float4 q;
+        if (sc.win_key) {                                          // (uniform)
+            float wp[4]; unsigned long long wkey;
+            k2_winner_pose(sc, wp, wkey);
+            float s_, c_;
+            sh_det_sincosf(wp[2], &s_, &c_);
+            q.x = wp[0] * sc.scale + 0.5f; q.y = wp[1] * sc.scale + 0.5f; q.z = c_ * sc.scale; q.w = s_ * sc.scale;   // :499-502, as k2_pxcs
+            if (t == 0) { s_wpose[0] = wp[0]; s_wpose[1] = wp[1]; s_wpose[2] = wp[2]; s_wpose[3] = wp[3]; }          // (the ride reads it behind the barriers below)
+            if (blockIdx.x == 0 && t == 0) {
+                sc.win_pose_out[0] = wp[0]; sc.win_pose_out[1] = wp[1]; sc.win_pose_out[2] = wp[2]; sc.win_pose_out[3] = wp[3];
+                if (sc.win_mail) {                                 // key and pose into the context's mailbox, then the completion word (common.h)
+                    *(unsigned long long *)sc.win_mail = wkey;
+                    float *mp = (float *)(sc.win_mail + 2); mp[0] = wp[0]; mp[1] = wp[1]; mp[2] = wp[2];
+                    __hip_atomic_store(sc.win_mail + 15, sc.win_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        } else q = k2_pxcs(sc.d_pose, sc.h_pxcs, sc.scale);
         // (the ride's loads, behind the ones the tables wait for; consumed when the wavefront has drawn its last pixel)
         if (ride_cells) { ride_h = ride.cell_hits[ride_cell]; ride_nh = ride.cell_nohit[ride_cell]; ride_v = ride.map[ride_cell]; }
         if (ride_ray) ride_p = ride.pts[ride_r];
@@ -786,7 +819,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         __syncthreads();
         n_valid = (int)start[4 * K2_NBUCK];
         if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) {         // robot outside the map: nothing is drawn (:509-512)
-            if (ride.on) k2_ride_tail(ride, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p);   // (the ObstacleMap has its own test, at its own scale :557-560)
+            if (ride.on) { k3_ride rd = ride; if (sc.win_key) rd.d_pose = s_wpose; k2_ride_tail(rd, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p); }   // (the ObstacleMap has its own test, at its own scale :557-560)
             return;
         }
     } else {
@@ -925,7 +958,7 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     // per pixel.  Queue entries are published write-through and the count is an agent-scope atomic; every wave
     // drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
     K2_STAMP(3)
-    if (BUILD && ride.on) k2_ride_tail(ride, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p);
+    if (BUILD && ride.on) { k3_ride rd = ride; if (sc.win_key) rd.d_pose = s_wpose; k2_ride_tail(rd, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p); }
     if (sc.span) k2_row_spans<T>(byidx, n_rays, x1, y1, size, n_pix_wgs, sc.span);    // (only while a host mirror is being kept: slamhip_cs_holemap_mirror_async)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -977,15 +1010,21 @@ void cs_holemap_free(slamhip_cs *cs)
 
 // with_obstacle: the ObstacleMap update of this scan rides on the launch (obstacle_dev.h); scans too large for the in-kernel
 // tables take k2_prepare + the pixel kernel, and their ObstacleMap update its own launches
+bool cs_holemap_one_launch(const slamhip_cs *cs)
+{
+    static const bool two_launch = getenv("SLAMHIP_K2_TWO_LAUNCHES") != nullptr;          // (tests: the large-scan path on ordinary scans)
+    return cs->n_points > 0 && cs->n_points <= K2_LDS_RAYS && !two_launch;
+}
+
 int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_pxcs, float4 h_pxcs_obst, float hole_width, int quality,
-                                 bool with_obstacle, int max_hits)
+                                 bool with_obstacle, int max_hits, const cs_k2_winner *win)
 {
     slamhip_ctx *ctx = cs->ctx;
     const int n = cs->n_points;
     if (n <= 0) return SLAMHIP_OK;
     SH_TRY(cs_flush_scan(cs));
-    static const bool two_launch = getenv("SLAMHIP_K2_TWO_LAUNCHES") != nullptr;          // (tests: the large-scan path on ordinary scans)
-    const bool build = n <= K2_LDS_RAYS && !two_launch;
+    const bool build = cs_holemap_one_launch(cs);
+    if (win && (!build || !d_pose)) SH_FAIL(SLAMHIP_ERR_STATE, "the key-decoding update needs the one-launch form and a pose buffer");
     k3_ride ride;
     memset(&ride, 0, sizeof(ride));
     if (with_obstacle && build) cs_obstacle_ride(cs, d_pose, h_pxcs_obst, max_hits, &ride);
@@ -1004,6 +1043,11 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     sc.pts = cs->d_pts; sc.scale = cs->hscale; sc.hole_width = hole_width; sc.d_pose = d_pose; sc.h_pxcs = h_pxcs;
     sc.total_out = (int *)cs->d_key + 6; sc.dirty = cs->d_hole_dirty;
     sc.span = cs->mirror_on ? cs->d_hole_span : nullptr;
+    sc.win_key = nullptr; sc.win_offs = nullptr; sc.win_bx = sc.win_by = sc.win_bth = 0.0f; sc.win_pose_out = nullptr; sc.win_mail = nullptr; sc.win_seq = 0;
+    if (win) {
+        sc.win_key = (const unsigned long long *)win->d_key; sc.win_offs = win->d_offs_flat; sc.win_bx = win->bx; sc.win_by = win->by; sc.win_bth = win->bth;
+        sc.win_pose_out = const_cast<float *>(d_pose); sc.win_mail = win->mail; sc.win_seq = win->seq;
+    }
     static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, rc_env = getenv("SLAMHIP_K2_RC") ? atoi(getenv("SLAMHIP_K2_RC")) : 28;
     sc.rb_num = rb_env; sc.rc_num = rc_env;                        // (radii, per 1080 rays, from which a wavefront takes two / four zone pixels)
     {
