@@ -1511,7 +1511,7 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
         SH_TRY(search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key));
         g_cst.lap(3);
         cs_k2_winner win;
-        win.d_key = cs->k1_ring_last; win.d_offs_flat = cs->d_offs_flat; win.bx = pose[0]; win.by = pose[1]; win.bth = pose[2];
+        win.d_key = cs->k1_ring_last; win.d_offs_flat = cs->d_offs_flat; win.n_offs = cs->n_offs; win.bx = pose[0]; win.by = pose[1]; win.bth = pose[2];
         win.mail = ctx->mailbox; win.seq = seq;
         const int32_t rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality, true, max_hits, &win);
         g_cst.lap(4);

@@ -188,7 +188,7 @@ struct k3_ride;
 // with_obstacle: the ObstacleMap update of the same scan and pose rides along (or follows in launches of its own when it cannot)
 // win: the fused scan's form (d_pose_or_null must then be a pose buffer to receive the decoded winner: the launch decodes the
 // search's key itself and delivers key + pose to the mailbox; one-launch form only: cs_holemap_one_launch)
-struct cs_k2_winner { const uint64_t *d_key; const float *d_offs_flat; float bx, by, bth; uint32_t *mail; uint32_t seq; };
+struct cs_k2_winner { const uint64_t *d_key; const float *d_offs_flat; int n_offs; float bx, by, bth; uint32_t *mail; uint32_t seq; };
 bool cs_holemap_one_launch(const slamhip_cs *cs);
 int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose_or_null, float4 h_pxcs, float4 h_pxcs_obst, float hole_width, int quality,
                                  bool with_obstacle = false, int max_hits = 0, const cs_k2_winner *win = nullptr);

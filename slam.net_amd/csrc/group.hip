@@ -591,10 +591,22 @@ static int32_t fused_allreduce_scan(slamhip_cs *cs, rccl_api &api, ncclComm_t co
         if (r_ != ncclSuccess) { slamhip_set_error("ncclAllReduce failed: %s", api.GetErrorString(r_)); return SLAMHIP_ERR_RCCL; }
     }
     const uint32_t seq = sh_mail_seq_next(ctx);
+    // (the reduced key is decoded by the HoleMap update itself where that is one launch -- every workgroup decodes, the first one
+    // delivers key + pose to the mailbox: see slamhip_cs_search_and_update -- and by a launch of its own otherwise)
+    static const bool k1_delivers = getenv("SLAMHIP_FUSED_K1_DELIVERS") != nullptr;
+    const bool decode = !ctx->mail_off && ctx->timing == 0 && rc_local == SLAMHIP_OK && cs->n_points > 0 && cs_holemap_one_launch(cs) && !k1_delivers;
+    int32_t rc_u = SLAMHIP_OK;
+    if (decode) {
+        cs_k2_winner win;
+        win.d_key = d_key; win.d_offs_flat = cs->d_offs_flat; win.n_offs = cs->n_offs; win.bx = pose[0]; win.by = pose[1]; win.bth = pose[2]; win.mail = ctx->mailbox; win.seq = seq;
+        rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality, true, max_hits, &win);
+        if (rc_u != SLAMHIP_OK) return rc_u;                       // (nothing was launched that would deliver)
+    } else {
     hipLaunchKernelGGL(k_winner_from_key, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *)d_key, (const float *)cs->d_offs_flat,
                        cs->n_offs, pose[0], pose[1], pose[2], (unsigned long long *)cs->d_key, ctx->mail_off ? (uint32_t *)nullptr : ctx->mailbox, seq);
-    int32_t rc_u = hipGetLastError() == hipSuccess ? SLAMHIP_OK : SLAMHIP_ERR_HIP;
-    if (rc_u == SLAMHIP_OK && rc_local == SLAMHIP_OK && cs->n_points > 0) {
+    rc_u = hipGetLastError() == hipSuccess ? SLAMHIP_OK : SLAMHIP_ERR_HIP;
+    }
+    if (!decode && rc_u == SLAMHIP_OK && rc_local == SLAMHIP_OK && cs->n_points > 0) {
         if (ctx->timing == 0) rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality, true, max_hits);
         else {
             rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality);

@@ -567,7 +567,7 @@ struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose
                  // the fused scan's form: the pose is not in memory yet -- the search (result-ring form: no final arriver, no chain)
                  // left only its key; every workgroup decodes the winner itself, the first one also stores the pose for later
                  // readers and delivers key + pose to the host's mailbox (k2_winner_pose)
-                 const unsigned long long *win_key; const float *win_offs; float win_bx, win_by, win_bth; float *win_pose_out;
+                 const unsigned long long *win_key; const float *win_offs; int win_n_offs; float win_bx, win_by, win_bth; float *win_pose_out;
                  uint32_t *win_mail; uint32_t win_seq; };
 
 // The winner of the search from its key, as MonteCarloSearch returns it and Update normalises it (CoreSLAMProcessor.cs:635-637, :746):
@@ -577,7 +577,8 @@ __device__ static inline void k2_winner_pose(const k2_scan &sc, float pose[4], u
     key = __hip_atomic_load(sc.win_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t flat = (uint32_t)key;
     float bx = sc.win_bx, by = sc.win_by, th = sc.win_bth;
-    if (flat > 0) { bx = sc.win_bx + sc.win_offs[3 * (size_t)(flat - 1)]; by = sc.win_by + sc.win_offs[3 * (size_t)(flat - 1) + 1]; th = sc.win_bth + sc.win_offs[3 * (size_t)(flat - 1) + 2]; }
+    if (flat > 0 && flat <= (uint32_t)sc.win_n_offs) {             // (a key nobody armed -- all ones: a rank without candidates in a group of one -- decodes to the search pose, as k_winner_from_key has it)
+        bx = sc.win_bx + sc.win_offs[3 * (size_t)(flat - 1)]; by = sc.win_by + sc.win_offs[3 * (size_t)(flat - 1) + 1]; th = sc.win_bth + sc.win_offs[3 * (size_t)(flat - 1) + 2]; }
     pose[0] = bx; pose[1] = by; pose[2] = sh_normalize_angle(th); pose[3] = th;
 }
 
@@ -1043,9 +1044,9 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     sc.pts = cs->d_pts; sc.scale = cs->hscale; sc.hole_width = hole_width; sc.d_pose = d_pose; sc.h_pxcs = h_pxcs;
     sc.total_out = (int *)cs->d_key + 6; sc.dirty = cs->d_hole_dirty;
     sc.span = cs->mirror_on ? cs->d_hole_span : nullptr;
-    sc.win_key = nullptr; sc.win_offs = nullptr; sc.win_bx = sc.win_by = sc.win_bth = 0.0f; sc.win_pose_out = nullptr; sc.win_mail = nullptr; sc.win_seq = 0;
+    sc.win_key = nullptr; sc.win_offs = nullptr; sc.win_n_offs = 0; sc.win_bx = sc.win_by = sc.win_bth = 0.0f; sc.win_pose_out = nullptr; sc.win_mail = nullptr; sc.win_seq = 0;
     if (win) {
-        sc.win_key = (const unsigned long long *)win->d_key; sc.win_offs = win->d_offs_flat; sc.win_bx = win->bx; sc.win_by = win->by; sc.win_bth = win->bth;
+        sc.win_key = (const unsigned long long *)win->d_key; sc.win_offs = win->d_offs_flat; sc.win_n_offs = win->n_offs; sc.win_bx = win->bx; sc.win_by = win->by; sc.win_bth = win->bth;
         sc.win_pose_out = const_cast<float *>(d_pose); sc.win_mail = win->mail; sc.win_seq = win->seq;
     }
     static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, rc_env = getenv("SLAMHIP_K2_RC") ? atoi(getenv("SLAMHIP_K2_RC")) : 28;

@@ -709,13 +709,14 @@ def test_fused_scans_back_to_back(cs_mod, ctx, det, sim):
 
 
 def test_fused_completion_modes():
-    """The fused call and the processor with the result block after the updates (SLAMHIP_FUSED_WAIT_UPDATES=1) and without
-    the host mailbox (SLAMHIP_NO_HOSTWAIT=1: copy + synchronise): same results as the default (pose from K1's final arriver)."""
+    """The fused call and the processor with the result block after the updates (SLAMHIP_FUSED_WAIT_UPDATES=1), without the host
+    mailbox (SLAMHIP_NO_HOSTWAIT=1: copy + synchronise), on the fallback search kernels and with the pose delivered by the search's
+    final arriver (SLAMHIP_FUSED_K1_DELIVERS=1): same results as the default (the winner decoded and delivered by the map update)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sel = "test_search_and_update_fused or test_processor_vs_oracle or test_fused_scans_back_to_back"
-    for env_extra in ({"SLAMHIP_FUSED_WAIT_UPDATES": "1"}, {"SLAMHIP_NO_HOSTWAIT": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}):
+    for env_extra in ({"SLAMHIP_FUSED_WAIT_UPDATES": "1"}, {"SLAMHIP_NO_HOSTWAIT": "1"}, {"SLAMHIP_K1_GLOBAL": "1"}, {"SLAMHIP_FUSED_K1_DELIVERS": "1"}):
         env = dict(os.environ); env.update(env_extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q",
                             "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
