@@ -6,6 +6,7 @@
     python tools/exp.py proc [map_size candidates]                       CoreSLAMProcessor.Update, us per scan end to end
     python tools/exp.py prochost                                         host-side cost of the per-scan steps around the fused call
     python tools/exp.py hsproc [side levels rays min_dist]               HectorSLAMProcessor.Update, us per scan
+    python tools/exp.py c3 [calls]                                       slamhip_cs_search_and_update on one scan, back to back: us per call, and the calls' distribution
     python tools/exp.py pcie                                             PCIe-inclusive rate of slamhip_cs_distance_pxcs (never bench.py's `value`)
 
 Build with SLAMHIP_K1_TIMES=1 / SLAMHIP_K2_TIMES=1 / SLAMHIP_K4_TIMES=1 (python -m slam.net_amd.build --force) to get the
@@ -145,6 +146,31 @@ def exp_hsproc(argv):
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / 200
     print("HectorSLAMProcessor.Update (%d^2 x %d, %d rays, %d of 200 scans update the map): %.1f us per scan" % (side, levels, rays, n_up, dt * 1e6))
+
+def exp_c3(argv):
+    """Configuration C3: the fused search + both map updates on the headline scan, `calls` times back to back (what bench.py's
+    c3 entry times), then the same calls timed one by one: median / p90 / p99 of a call."""
+    import slam.net_amd.coreslam as cs, slam.net_amd.sim as sim  # noqa: E401
+    calls = int(argv[0]) if argv else 300
+    K, size, R = 16384, 2048, 1080
+    ctx = cs.Context(0); dev = cs.CoreSlamDevice(ctx, 40.0, size, size // 4)
+    segs = sim.default_field(); rng = sim.PCG32(1234); traj = sim.trajectory(31)
+    for p in traj[:-1]:
+        _, xy = sim.make_scan(segs, p, R, rng); dev.set_scan(xy); dev.update_holemap(p)
+    _, xy = sim.make_scan(segs, traj[-1], R, rng)
+    base = (traj[-1] + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
+    dev.set_scan(xy); dev.set_offsets(sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0)))
+    for _ in range(30): dev.search_and_update(base)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls): dev.search_and_update(base)
+    ctx.synchronize()
+    print("fused us per call %.2f (%d calls back to back, the last call's updates included)" % ((time.perf_counter() - t0) / calls * 1e6, calls))
+    ts = []
+    for _ in range(max(calls, 1000)):
+        t1 = time.perf_counter(); dev.search_and_update(base); ts.append((time.perf_counter() - t1) * 1e6)
+    ts = np.array(ts)
+    print("one call, us: median %.1f | p90 %.1f | p99 %.1f | mean %.1f | max %.1f" % (np.median(ts), np.percentile(ts, 90), np.percentile(ts, 99), ts.mean(), ts.max()))
 
 def exp_pcie(argv):
     """PCIe-inclusive rate of the explicit-candidate entry point: slamhip_cs_distance_pxcs with 16 384 host candidates per call (256 KB up, 8 bytes back), blocking; never the `value` of bench.py."""
