@@ -195,6 +195,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     if (cs->side_stream) { (void)hipStreamSynchronize(cs->side_stream); (void)hipStreamDestroy(cs->side_stream); }
     (void)hipFree(cs->d_side_arrive);
     (void)hipFree(cs->spec_offs_flat); (void)hipFree(cs->spec_ev_off); (void)hipFree(cs->spec_ev_idx); (void)hipFree(cs->spec_grp_bounds);
+    (void)hipFree(cs->cool_offs_flat); (void)hipFree(cs->cool_ev_off); (void)hipFree(cs->cool_ev_idx); (void)hipFree(cs->cool_grp_bounds);
     if (cs->ev_snap) (void)hipEventDestroy(cs->ev_snap);
     if (cs->ev_push) (void)hipEventDestroy(cs->ev_push);
     (void)hipFree(cs->d_hole_span); (void)hipFree(cs->d_hole_span_snap); (void)hipFree(cs->d_hole_shadow); (void)hipFree(cs->d_mirror_sum); (void)hipFree(cs->d_mirror_mask);
@@ -990,8 +991,13 @@ static int32_t cs_generate(slamhip_cs *cs, int32_t n, float sigma_xy, float sigm
     if (hit) {
         // the list asked for has been prepared (cs_speculate_next): swap the buffer sets -- the search that read the old set has
         // delivered its result -- and leave everything ensure_shard derived from (n, sigmas, group size) as it is
-        std::swap(cs->d_offs_flat, cs->spec_offs_flat); std::swap(cs->d_ev_off, cs->spec_ev_off);
-        std::swap(cs->d_ev_idx, cs->spec_ev_idx); std::swap(cs->d_grp_bounds, cs->spec_grp_bounds);
+        // (THREE sets in rotation: the set just searched cools for one scan before a list is prepared into it again -- its
+        // jitters are still read by the map update that decodes that scan's winner, and what proves THAT launch finished is a pose
+        // delivered two scans later; the set a list is prepared into was last read two scans ago)
+        { float *t_ = cs->d_offs_flat; cs->d_offs_flat = cs->spec_offs_flat; cs->spec_offs_flat = cs->cool_offs_flat; cs->cool_offs_flat = t_; }
+        { float *t_ = cs->d_ev_off; cs->d_ev_off = cs->spec_ev_off; cs->spec_ev_off = cs->cool_ev_off; cs->cool_ev_off = t_; }
+        { int *t_ = cs->d_ev_idx; cs->d_ev_idx = cs->spec_ev_idx; cs->spec_ev_idx = cs->cool_ev_idx; cs->cool_ev_idx = t_; }
+        { float *t_ = cs->d_grp_bounds; cs->d_grp_bounds = cs->spec_grp_bounds; cs->spec_grp_bounds = cs->cool_grp_bounds; cs->cool_grp_bounds = t_; }
         cs->gen_stream = stream; cs->gen_pending = false; cs->spec_hits++;
         cs->side_join = true;
         return cs_side_join(cs);                                  // (the side launch's word: there since the previous scan -- checked before anything reads the list)
@@ -1019,7 +1025,9 @@ static int32_t cs_generate(slamhip_cs *cs, int32_t n, float sigma_xy, float sigm
 static void spec_free(slamhip_cs *cs)
 {
     (void)hipFree(cs->spec_offs_flat); (void)hipFree(cs->spec_ev_off); (void)hipFree(cs->spec_ev_idx); (void)hipFree(cs->spec_grp_bounds);
+    (void)hipFree(cs->cool_offs_flat); (void)hipFree(cs->cool_ev_off); (void)hipFree(cs->cool_ev_idx); (void)hipFree(cs->cool_grp_bounds);
     cs->spec_offs_flat = nullptr; cs->spec_ev_off = nullptr; cs->spec_ev_idx = nullptr; cs->spec_grp_bounds = nullptr;
+    cs->cool_offs_flat = nullptr; cs->cool_ev_off = nullptr; cs->cool_ev_idx = nullptr; cs->cool_grp_bounds = nullptr;
     cs->spec_cap_offs = cs->spec_cap_cand = cs->spec_cap_grp = 0;
 }
 
@@ -1043,6 +1051,10 @@ static int32_t cs_speculate_next(slamhip_cs *cs)
         SH_HIP(hipMalloc(&cs->spec_ev_off, sizeof(float) * 3 * (size_t)cs->cap_cand));
         SH_HIP(hipMalloc(&cs->spec_ev_idx, sizeof(int) * (size_t)cs->cap_cand));
         SH_HIP(hipMalloc(&cs->spec_grp_bounds, sizeof(float) * 8 * (size_t)cs->cap_grp));
+        SH_HIP(hipMalloc(&cs->cool_offs_flat, sizeof(float) * 3 * (size_t)cs->cap_offs));
+        SH_HIP(hipMalloc(&cs->cool_ev_off, sizeof(float) * 3 * (size_t)cs->cap_cand));
+        SH_HIP(hipMalloc(&cs->cool_ev_idx, sizeof(int) * (size_t)cs->cap_cand));
+        SH_HIP(hipMalloc(&cs->cool_grp_bounds, sizeof(float) * 8 * (size_t)cs->cap_grp));
         cs->spec_cap_offs = cs->cap_offs; cs->spec_cap_cand = cs->cap_cand; cs->spec_cap_grp = cs->cap_grp;
     }
     const int count = n + 1, grp = cs->k1_group, ng = sh_div_up(count, grp);

@@ -40,6 +40,7 @@ struct slamhip_cs {
     hipStream_t side_stream; unsigned *d_side_arrive; uint32_t side_seq; bool side_join;
     // the next scan's candidate list, prepared ahead on the side stream (cs_speculate_next, coreslam.hip)
     float *spec_offs_flat, *spec_ev_off, *spec_grp_bounds; int *spec_ev_idx; int spec_cap_offs, spec_cap_cand, spec_cap_grp;
+    float *cool_offs_flat, *cool_ev_off, *cool_grp_bounds; int *cool_ev_idx;   // the third set of the rotation: last scan's, not written yet (see cs_generate)
     uint64_t spec_hits, spec_made;
     bool spec_valid, spec_base_ok, spec_lattice; int spec_n, spec_grp; float spec_sxy, spec_sth; uint64_t spec_seed, spec_stream; // jitter generation + scan upload beside the previous scan's map updates (ensure_shard)
     hipEvent_t ev_scan; bool scan_in_flight;
