@@ -436,7 +436,7 @@ def test_k1_tile_boxes_selfcheck():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size or test_search_changing_scans or test_search_enqueue_ring"
+    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size or test_search_changing_scans or test_search_enqueue_ring or test_heading_lattice"
     for env_extra in ({"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "1"}, {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "2"},
                       {"SLAMHIP_K1_LAYOUT_SYNC": "1", "SLAMHIP_K1_VERIFY": "1"},   # every scan's launch layout made before its launch
                       {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "4"}, {"SLAMHIP_K1_GLOBAL": "1"},
@@ -453,6 +453,11 @@ def test_k1_tile_boxes_selfcheck():
                       {"SLAMHIP_K1_CUT_ALWAYS": "1", "SLAMHIP_K1_CUT_TAB": "1", "SLAMHIP_K1_CUT_WFIX": "40"},   # ... the listed groups' too, heavy weights
                       {"SLAMHIP_K1_CUT_ALWAYS": "1", "SLAMHIP_K1_CUT_WFIX": "3", "SLAMHIP_K1_CUT_WKB": "1.5", "SLAMHIP_K1_CUT_KEEP": "100"},
                       {"SLAMHIP_K1_CUT_WFIX": "0"},                                # the equal-count formula everywhere
+                      {"SLAMHIP_K1_NOSPLIT": "1", "SLAMHIP_K1_VERIFY": "1"},       # banded pieces never planned as two halves
+                      {"SLAMHIP_K1_NOPAD": "1", "SLAMHIP_K1_VERIFY": "1"},         # tiles as wide as their box
+                      {"SLAMHIP_K1_TILE_KB": "16", "SLAMHIP_K1_VERIFY": "1"},      # many banded pieces: the halves' plans under the self-check
+                      {"SLAMHIP_K1_TILE_KB": "16"},                                # ... and the lattice kernel over them
+                      {"SLAMHIP_NO_DIRECT_UPLOAD": "1"},                           # scans through the upload launch (no CPU stores into device memory)
                       {"SLAMHIP_K1_TARGET_WGS": "64", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "64"},
                       {"SLAMHIP_K1_TARGET_WGS": "100000", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "100000", "SLAMHIP_K1_CPL": "1"}):
         env = dict(os.environ); env.update(env_extra); env["SLAMHIP_EXPECT_SELFCHECK"] = "1"
