@@ -327,7 +327,8 @@ def test_processor_with_lattice(cs_mod, ctx, det, sim):
         assert (proc.Pose == ref.pose).all(), i
     assert (proc.HoleMap.Pixels == ref.holemap).all()
     served, prepared = proc.device.prepared_lists()
-    assert served >= 7, (served, prepared)
+    if not any(k in os.environ for k in ("SLAMHIP_NO_SPECULATION", "SLAMHIP_NO_HOSTWAIT", "SLAMHIP_FUSED_WAIT_UPDATES")):
+        assert served >= 7, (served, prepared)               # (the lattice lists are prepared ahead like the plain ones)
     assert proc.device.selfcheck_failures == 0
     dth = proc.device.offsets_download(12800)[:, 2]
     assert not (np.diff(dth) >= 0).all()                     # (a lattice, not the sorted plain list)
