@@ -45,6 +45,7 @@ def main():
                     "its first PositionSearchBeginning (5) scans and Hector its first 10 loops at the given pose without matching")
     ap.add_argument("--every", type=int, default=25)
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--lattice", action="store_true", help="CoreSLAM's candidates as a heading lattice (slamhip_csproc_set_lattice; from 12 289 candidates on)")
     a = ap.parse_args()
 
     import slam.net_amd.coreslam as cs
@@ -59,6 +60,8 @@ def main():
     core = cs.CoreSLAMProcessor(40.0, a.hole_map, a.obstacle_map, start, 0.1, math.radians(10.0), a.iterations, a.threads, ctx=ctx)
     core.HoleWidth = 2.0                                                 # :71
     core.SetSeed(a.seed)
+    if a.lattice:
+        core.SetLattice(True)
     ctx_h = cs.Context(0)
     hect = hs.HectorSLAMProcessor(40.0 / a.hector_side, (a.hector_side, a.hector_side), start, a.hector_levels, a.threads, ctx=ctx_h)
     hect.MinDistanceDiffForMapUpdate = 0.4                               # :78-79
@@ -105,7 +108,7 @@ def main():
     n_t = max(len(traj) - 10, 1)
     out = {
         "scenario": "one lap (%.1f m, %d scans, %.2f m apart) around the inner obstacle of the default field" % (lap_len, len(traj), a.step),
-        "config": {"rays": a.rays, "hole_map": a.hole_map, "obstacle_map": a.obstacle_map, "candidates_per_scan": a.iterations * a.threads,
+        "config": {"rays": a.rays, "hole_map": a.hole_map, "obstacle_map": a.obstacle_map, "candidates_per_scan": a.iterations * a.threads, "heading_lattice": bool(a.lattice),
                    "hector": "%d^2 x %d levels" % (a.hector_side, a.hector_levels), "measure_error_m": sim.MEASURE_ERROR},
         "coreslam": stats(err["core"]), "hector": stats(err["hector"]), "hector_first_large_difference_at": hector_lost_at,
         "us_per_update": {"coreslam": round(t_core / n_t * 1e6, 1), "hector": round(t_hect / n_t * 1e6, 1)},
