@@ -58,6 +58,11 @@ namespace CoreSLAM
 
         /// <summary>Seed of the candidate generator (new: the reference seeds from entropy).</summary>
         public ulong Seed { get; set; } = 0x5EED5EEDUL;
+        /// <summary>Opt-in (new): the candidates' headings on a lattice -- the candidates one lane of the search kernel evaluates share
+        /// their heading and differ in translation (slamhip_cs_generate_offsets_lattice): 5 - 7 % faster searches from 65 536
+        /// candidates on, the same localisation quality on the simulator's lap.  Off: every candidate has its own (stratified)
+        /// heading, as close to the reference's independent draws as a reproducible generator gets.</summary>
+        public bool UseHeadingLattice { get; set; } = false;
         /// <summary>When the managed map mirrors (HoleMap.Pixels, ObstacleMap.Pixels) are brought up to date.
         /// OnRead (default): an Update only marks them stale; the `Pixels` getters fetch what changed since their last read --
         /// the HoleMap through slamhip_cs_holemap_mirror_async + _wait (the 16-byte units that changed, ~0.25 ms at 2048 x 2048 for
@@ -139,7 +144,10 @@ namespace CoreSLAM
                 if (!pinnedOffsets)
                 {
                     int n = Math.Max(NumSearchThreads, 1) * SearchIterationsPerThread;
-                    Native.Check(Native.slamhip_cs_generate_offsets(cs.Ptr, n, SigmaXY, SigmaTheta, Seed, scanNumber));
+                    // (asked for with the scan number as the stream: the library prepares the list of scanNumber + 1 ahead, under
+                    // this scan's search, and the next call finds it in place)
+                    if (UseHeadingLattice) Native.Check(Native.slamhip_cs_generate_offsets_lattice(cs.Ptr, n, SigmaXY, SigmaTheta, Seed, scanNumber));
+                    else Native.Check(Native.slamhip_cs_generate_offsets(cs.Ptr, n, SigmaXY, SigmaTheta, Seed, scanNumber));
                 }
                 scanNumber++;
                 lastOdometryPose = odometry;                                        // :745

@@ -147,7 +147,10 @@ int32_t slamhip_cs_obstaclemap_upload(slamhip_cs *cs, const int8_t *pixels, size
 int32_t slamhip_cs_obstaclemap_download(slamhip_cs *cs, int8_t *pixels, size_t n_pixels);
 
 /* The ScanCloud of the current Update (output of ScanSegmentsToCloud, CoreSLAMProcessor.cs:187-207):
- * n_points robot-frame points (x,y).  Kept on the device for the search and both map updates. */
+ * n_points robot-frame points (x,y).  Kept on the device for the search and both map updates.  xy may be reused as soon as the
+ * call returns.  (On a device with a large BAR the call stores the scan straight into one of two alternating device blocks --
+ * CPU stores, no upload launch -- whenever it knows that block idle; otherwise the first launch that reads the scan uploads it.
+ * SLAMHIP_NO_DIRECT_UPLOAD=1 always takes the second way.) */
 int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t n_points);
 
 /* CalculateDistance (CoreSLAMProcessor.cs:215-259) for K candidates in one batched kernel.
