@@ -208,8 +208,10 @@ int32_t slamhip_cs_search_shard(slamhip_cs *cs, const float search_pose[3], int3
 int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float search_pose[3], int32_t first,
                                       int32_t count, uint64_t *d_out_key);
 /* Enqueue-only form with a result word owned by the handle: *d_key receives the DEVICE address of the word that holds the packed
- * key once the stream reaches that point -- one of a ring of 4 words, valid until three further calls of this function on the
- * handle have been enqueued.  No caller memory is involved, so the kernel needs no final arriver: the workgroups that complete
+ * key once the stream reaches that point -- one of a ring of 4 words, valid until three further RING LAUNCHES on the handle have
+ * been enqueued: calls of this function, fused scans (slamhip_cs_search_and_update and its _pxcs form) and the all-reduce forms
+ * (slamhip_cs_search_allreduce*, which also overwrite the slot in place with the reduced key) all advance the same ring.  A caller
+ * that keeps a word across such calls copies it first (slamhip_cs_key_read).  No caller memory is involved, so the kernel needs no final arriver: the workgroups that complete
  * candidates min their keys straight into the word (the previous call's launch left it all ones), and the end of the launch is
  * the completion (the cross-thread arg-min of :695-705 as fire-and-forget atomics).  slamhip_cs_key_read waits for the handle's
  * stream and copies one such word to the host. */

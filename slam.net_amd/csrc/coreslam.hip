@@ -320,13 +320,22 @@ static int32_t mirror_target(slamhip_cs *cs, uint16_t *pix, size_t n, unsigned f
         if (cs->mirror_reg != (void *)pix || cs->mirror_reg_bytes != bytes || cs->mirror_reg_flags != flags) {
             if (cs->mirror_reg) (void)hipHostUnregister(cs->mirror_reg);
             cs->mirror_reg = nullptr; cs->mirror_reg_bytes = 0; cs->mirror_dev_ptr = nullptr;
-            SH_HIP(hipHostRegister(pix, bytes, flags));
-            cs->mirror_reg = pix; cs->mirror_reg_bytes = bytes; cs->mirror_reg_flags = flags;
-            if (flags & hipHostRegisterMapped) SH_HIP(hipHostGetDevicePointer(&cs->mirror_dev_ptr, pix, 0));
+            // An array the caller page-locked itself (hipHostMalloc, a registered or pinned-tensor buffer) answers
+            // hipErrorHostMemoryAlreadyRegistered, and any other refusal (a locked-memory limit) is no reason to fail the mirror
+            // either: such an array is served through the staging buffer, like one that does not own its pages.
+            const hipError_t er = hipHostRegister(pix, bytes, flags);
+            bool ok = er == hipSuccess;
+            if (ok && (flags & hipHostRegisterMapped) && hipHostGetDevicePointer(&cs->mirror_dev_ptr, pix, 0) != hipSuccess) {
+                (void)hipHostUnregister(pix); cs->mirror_dev_ptr = nullptr; ok = false;
+            }
+            if (!ok) (void)hipGetLastError();                      // (the runtime's sticky error word)
+            else { cs->mirror_reg = pix; cs->mirror_reg_bytes = bytes; cs->mirror_reg_flags = flags; }
         }
-        *out_dev = (flags & hipHostRegisterMapped) ? (uint16_t *)cs->mirror_dev_ptr : pix;
-        *out_direct = true;
-        return SLAMHIP_OK;
+        if (cs->mirror_reg == (void *)pix) {
+            *out_dev = (flags & hipHostRegisterMapped) ? (uint16_t *)cs->mirror_dev_ptr : pix;
+            *out_direct = true;
+            return SLAMHIP_OK;
+        }
     }
     SH_TRY(mirror_stage(cs));
     *out_dev = cs->h_mirror_stage;
@@ -368,8 +377,10 @@ extern "C" int32_t slamhip_cs_holemap_mirror(slamhip_cs *cs, uint16_t *pix, size
         if (!direct) {
             const size_t c2 = (size_t)(r[2] - r[0] + 1) * sizeof(uint16_t);
             for (int y = r[1]; y <= r[3]; y++) memcpy(pix + (size_t)y * cs->hs + r[0], dst + (size_t)y * cs->hs + r[0], c2);
-            cs->mirror_user = nullptr;         // (the staging buffer no longer equals the asynchronous form's shadow: its next request starts from everything)
         }
+        // (what the caller's array holds no longer equals the asynchronous form's shadow -- in the staged form the staging buffer,
+        // in the direct form the array itself was written behind the shadow's back: the next asynchronous request starts from everything)
+        cs->mirror_user = nullptr;
     } else { r[0] = r[1] = 0; r[2] = r[3] = -1; }
     if (out_rect) memcpy(out_rect, r, sizeof(r));
     return SLAMHIP_OK;
@@ -999,6 +1010,7 @@ static int32_t cs_generate(slamhip_cs *cs, int32_t n, float sigma_xy, float sigm
         { int *t_ = cs->d_ev_idx; cs->d_ev_idx = cs->spec_ev_idx; cs->spec_ev_idx = cs->cool_ev_idx; cs->cool_ev_idx = t_; }
         { float *t_ = cs->d_grp_bounds; cs->d_grp_bounds = cs->spec_grp_bounds; cs->spec_grp_bounds = cs->cool_grp_bounds; cs->cool_grp_bounds = t_; }
         cs->gen_stream = stream; cs->gen_pending = false; cs->spec_hits++;
+        cs->h_offs.clear();                                        // (the host copy, if one was fetched, held the PREVIOUS list's jitters: host_offsets() must fetch again)
         cs->side_join = true;
         return cs_side_join(cs);                                  // (the side launch's word: there since the previous scan -- checked before anything reads the list)
     }
@@ -1520,7 +1532,9 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     const bool decode = early && !k1_delivers && cs_holemap_one_launch(cs) && cs->n_points > 0;
     if (decode) {
         cs->k1_ring_request = true;
-        SH_TRY(search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key));
+        const int32_t rc_r = search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key);
+        cs->k1_ring_request = false;                               // (a search that failed before its launch must not leave the request to the next one)
+        SH_TRY(rc_r);
         g_cst.lap(3);
         cs_k2_winner win;
         win.d_key = cs->k1_ring_last; win.d_offs_flat = cs->d_offs_flat; win.n_offs = cs->n_offs; win.bx = pose[0]; win.by = pose[1]; win.bth = pose[2];

@@ -1176,7 +1176,7 @@ static int k1_legal_chunks(const slamhip_cs *cs, int nc)
     return nc;
 }
 
-static double g_cut_t[4] = { 0, 0, 0, 0 };   // developer aid (SLAMHIP_K1_CUT_TIMES): host microseconds in weights / balanced cuts / banded check
+static thread_local double g_cut_t[4] = { 0, 0, 0, 0 };   // developer aid (SLAMHIP_K1_CUT_TIMES): host microseconds in weights / balanced cuts / banded check
 static inline double k1_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec * 1e6 + (double)t.tv_nsec * 1e-3; }
 // Ray ranges cut by cost.  A workgroup's compute phase is its rays PLUS its tile steps -- one per ray block it touches -- and a
 // step costs as much as a dozen or two rays of gathers (barrier, tile write, barrier, the next tile's loads; SLAMHIP_K1_TIMES at
@@ -1754,7 +1754,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             }
         }
         if (cut_times) {
-            static double acc = 0.0; static int nacc = 0;
+            static thread_local double acc = 0.0; static thread_local int nacc = 0;   // (per host thread, like g_cut_t: a group drives one thread per GPU)
             timespec ct1; clock_gettime(CLOCK_MONOTONIC, &ct1);
             acc += (double)(ct1.tv_sec - ct0.tv_sec) * 1e6 + (double)(ct1.tv_nsec - ct0.tv_nsec) * 1e-3;
             if (++nacc == 64) {
@@ -1839,7 +1839,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         if (ring) { cs->k1_ring_last = (uint64_t *)ring_slot; cs->k1_ring_pos++; }
 #ifdef K1_TIMES
         {
-            static int calls = 0;
+            static thread_local int calls = 0;
             if (++calls == 8) {
                 (void)hipStreamSynchronize(ctx->stream);
                 const int nw = n_wgs < 4096 ? n_wgs : 4096;

@@ -1249,7 +1249,7 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     if (pull) { hs->upload_pending = false; hs->upload_seq = up_seq; hs->pts_in_flight = true; }
 #ifdef K4_TIMES
     {
-        static int calls = 0;
+        static thread_local int calls = 0;
         if (B == 1 && ++calls == 20) {
             (void)hipStreamSynchronize(ctx->stream);
             unsigned long long h[16];
@@ -1414,7 +1414,7 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3], const k5_g
     SH_HIP(hipGetLastError());
 #ifdef K5_TIMES
     {
-        static int calls = 0;
+        static thread_local int calls = 0;
         if (n > 0 && ++calls == 12) {
             (void)hipStreamSynchronize(ctx->stream);
             std::vector<unsigned long long> h(1024 * 4);

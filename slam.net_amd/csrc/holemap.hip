@@ -1083,7 +1083,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     }
 #ifdef K2_TIMES
     {
-        static int calls = 0;
+        static thread_local int calls = 0;
         if (++calls == 12) {
             (void)hipStreamSynchronize(ctx->stream);
             std::vector<unsigned long long> h(512 * 8);
