@@ -51,6 +51,7 @@ extern "C" {
 #define SLAMHIP_ERR_NOMEM    (-3)
 #define SLAMHIP_ERR_STATE    (-4)   /* call order violated (e.g. search before set_scan) */
 #define SLAMHIP_ERR_RCCL     (-5)
+#define SLAMHIP_ERR_TIMEOUT  (-6)   /* a blocking wait passed its bound; the context is poisoned (slamhip_ctx_set_wait_timeout) */
 
 typedef struct slamhip_ctx    slamhip_ctx;     /* one GPU + one HIP stream */
 typedef struct slamhip_cs     slamhip_cs;      /* CoreSLAM device state: HoleMap + ObstacleMap + scan + candidates */
@@ -77,6 +78,16 @@ int32_t slamhip_ctx_destroy(slamhip_ctx *ctx);                     /* ParallelWo
 int32_t slamhip_ctx_synchronize(slamhip_ctx *ctx);
 int32_t slamhip_ctx_device(slamhip_ctx *ctx, int32_t *out_ordinal);
 void   *slamhip_ctx_stream(slamhip_ctx *ctx);                      /* hipStream_t, for interop (RCCL / torch) */
+/* Bound on every blocking wait of the context, in milliseconds (default: environment SLAMHIP_WAIT_TIMEOUT_MS, else 10000;
+ * <= 0: unbounded).  ParallelWorker.Work waits on its AutoResetEvents without a bound (BaseSLAM/ParallelWorker.cs:106-116): a worker
+ * that never signals hangs the reference's caller for ever; here a completion word that does not arrive in time ends the call with
+ * SLAMHIP_ERR_TIMEOUT and POISONS the context -- the device's state is unknown, nothing is restarted or re-executed in-process, and
+ * every later blocking call or launch on the context fails with SLAMHIP_ERR_TIMEOUT at once.  The caller destroys its handles. */
+int32_t slamhip_ctx_set_wait_timeout(slamhip_ctx *ctx, int64_t timeout_ms);
+int32_t slamhip_ctx_poisoned(slamhip_ctx *ctx, int32_t *out_flag);
+/* Test hook (no device involved): the wait loop of a blocking call on a caller-owned word -- returns SLAMHIP_OK once *flag has
+ * reached `val` (wrap-safe), SLAMHIP_ERR_TIMEOUT after timeout_ms. */
+int32_t slamhip_debug_flag_wait(volatile uint32_t *flag, uint32_t val, int64_t timeout_ms);
 
 /* Kernel timing (the reference only has Stopwatch EMAs, HectorSLAMProcessor.cs:92-96,111-115).
  * When enabled, each kernel class is bracketed by HIP events on the context's stream. */

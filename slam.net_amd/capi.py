@@ -14,6 +14,7 @@ SO_PATH = os.path.join(_HERE, "libslamhip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "slamhip.h")
 
 OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_RCCL, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
 K_CS_PREP, K_CS_DISTANCE, K_CS_REDUCE, K_CS_HOLEMAP, K_CS_OBSTACLE, K_HS_MATCH, K_HS_UPDATE = range(7)
 
 CELL_DTYPE = np.dtype([("update_index", np.int32), ("value", np.float32)])
@@ -60,6 +61,9 @@ def _declare(L):
         "slamhip_ctx_synchronize": (i32, [vp]),
         "slamhip_ctx_device": (i32, [vp, ip]),
         "slamhip_ctx_stream": (vp, [vp]),
+        "slamhip_ctx_set_wait_timeout": (i32, [vp, i64]),
+        "slamhip_ctx_poisoned": (i32, [vp, ip]),
+        "slamhip_debug_flag_wait": (i32, [P(C.c_uint32), C.c_uint32, i64]),
         "slamhip_ctx_timing_enable": (i32, [vp, i32]),
         "slamhip_ctx_timing_reset": (i32, [vp]),
         "slamhip_ctx_timing_get": (i32, [vp, i32, P(C.c_double), P(i64)]),

@@ -38,6 +38,12 @@ struct slamhip_ctx {
     // context's one stream anyway.
     uint32_t *mailbox; uint32_t mail_seq; bool mail_off;
     bool large_bar;           // the host can store straight into device memory (hipDeviceAttributeIsLargeBar): per-scan uploads without a launch
+    // A blocking wait is bounded (SLAMHIP_WAIT_TIMEOUT_MS, default 10000; slamhip_ctx_set_wait_timeout): a completion word that does
+    // not arrive in that time -- a kernel that never ends keeps hipStreamQuery at NotReady for ever -- ends the call with
+    // SLAMHIP_ERR_TIMEOUT and POISONS the context: nothing is restarted or re-executed in-process (device state is unknown), every
+    // later blocking call or publish on the context fails with the same code at once, and the caller tears the context down.
+    int64_t wait_timeout_ms;  // <= 0: unbounded
+    bool poisoned;
     pthread_mutex_t mail_lock;
 };
 // RAII guard of slamhip_ctx::mail_lock (see there)

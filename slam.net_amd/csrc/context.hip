@@ -56,6 +56,7 @@ extern "C" int32_t slamhip_ctx_create(int32_t device, slamhip_ctx **out)
         pthread_mutexattr_destroy(&at);
     }
     c->mail_off = getenv("SLAMHIP_NO_HOSTWAIT") && atoi(getenv("SLAMHIP_NO_HOSTWAIT"));
+    c->wait_timeout_ms = getenv("SLAMHIP_WAIT_TIMEOUT_MS") ? atoll(getenv("SLAMHIP_WAIT_TIMEOUT_MS")) : 10000;
     {
         int lb = 0;
         if (hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, device) != hipSuccess) { lb = 0; (void)hipGetLastError(); }
@@ -87,6 +88,20 @@ extern "C" int32_t slamhip_ctx_synchronize(slamhip_ctx *c)
     return SLAMHIP_OK;
 }
 
+extern "C" int32_t slamhip_ctx_set_wait_timeout(slamhip_ctx *c, int64_t timeout_ms)
+{
+    SH_CHECK_ARG(c);
+    c->wait_timeout_ms = timeout_ms;
+    return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_ctx_poisoned(slamhip_ctx *c, int32_t *out)
+{
+    SH_CHECK_ARG(c && out);
+    *out = c->poisoned ? 1 : 0;
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_ctx_device(slamhip_ctx *c, int32_t *out)
 {
     SH_CHECK_ARG(c && out);
@@ -112,6 +127,7 @@ int32_t sh_publish(slamhip_ctx *ctx, const void *d_src, int n_words)
 int32_t sh_publish_seq(slamhip_ctx *ctx, const void *d_src, int n_words, uint32_t seq)
 {
     SH_CHECK_ARG(n_words >= 0 && n_words <= 15 && (d_src || n_words == 0));
+    if (ctx->poisoned) SH_FAIL(SLAMHIP_ERR_TIMEOUT, "the context was poisoned by a blocking wait that timed out; destroy it");
     if (ctx->mail_off) {                                           // (SLAMHIP_NO_HOSTWAIT=1: the copy + synchronise form)
         if (n_words > 0) SH_HIP(hipMemcpyAsync(ctx->mailbox, d_src, sizeof(uint32_t) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
         return SLAMHIP_OK;
@@ -143,7 +159,16 @@ static inline bool sh_flag_reached(volatile uint32_t *flag, uint32_t val)
 {
     return (int32_t)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - val) >= 0;
 }
+static int32_t sh_flag_wait_bounded(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val, int64_t timeout_ms);
 int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val)
+{
+    if (ctx->poisoned) SH_FAIL(SLAMHIP_ERR_TIMEOUT, "the context was poisoned by a blocking wait that timed out; destroy it");
+    const int32_t rc = sh_flag_wait_bounded(ctx, flag, val, ctx->wait_timeout_ms);
+    if (rc == SLAMHIP_ERR_TIMEOUT) ctx->poisoned = true;
+    return rc;
+}
+// (ctx == nullptr: the wait has no stream to ask -- the CPU-side test hook slamhip_debug_flag_wait)
+static int32_t sh_flag_wait_bounded(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val, int64_t timeout_ms)
 {
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -161,7 +186,13 @@ int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val)
     // only ASKED (hipStreamQuery: a fault is reported, an idle stream without the word is an error), between short sleeps.
     for (;;) {
         for (int k = 0; k < 64; k++) { if (sh_flag_reached(flag, val)) return SLAMHIP_OK; __builtin_ia32_pause(); }
-        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (timeout_ms > 0) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000L + (t1.tv_nsec - t0.tv_nsec) / 1000000L >= timeout_ms)
+                SH_FAIL(SLAMHIP_ERR_TIMEOUT, "a blocking wait passed its bound of %lld ms (SLAMHIP_WAIT_TIMEOUT_MS): the completion word never arrived", (long long)timeout_ms);
+        }
+        const hipError_t q = ctx ? hipStreamQuery(ctx->stream) : hipErrorNotReady;
         if (sh_flag_reached(flag, val)) return SLAMHIP_OK;
         if (q == hipSuccess) {                                     // idle: the word must be there (a store to pinned host memory, released at system scope)
             for (int k = 0; k < 1000; k++) { if (sh_flag_reached(flag, val)) return SLAMHIP_OK; __builtin_ia32_pause(); }
@@ -173,8 +204,16 @@ int32_t sh_flag_wait(slamhip_ctx *ctx, volatile uint32_t *flag, uint32_t val)
     }
 }
 
+// CPU-side test hook: the very wait loop of a blocking call on a caller-owned word, with no stream behind it
+extern "C" int32_t slamhip_debug_flag_wait(volatile uint32_t *flag, uint32_t val, int64_t timeout_ms)
+{
+    SH_CHECK_ARG(flag);
+    return sh_flag_wait_bounded(nullptr, flag, val, timeout_ms);
+}
+
 int32_t sh_host_wait(slamhip_ctx *ctx)
 {
+    if (ctx->poisoned) SH_FAIL(SLAMHIP_ERR_TIMEOUT, "the context was poisoned by a blocking wait that timed out; destroy it");
     if (ctx->mail_off) { SH_HIP(hipStreamSynchronize(ctx->stream)); return SLAMHIP_OK; }
     return sh_flag_wait(ctx, ctx->mailbox + 15, ctx->mail_seq);
 }

@@ -43,6 +43,37 @@ def test_no_gpu_fails_loudly(capi):
         capi.call("slamhip_ctx_create", 0, C.byref(h))
 
 
+def test_blocking_wait_is_bounded(capi):
+    """The wait loop of every blocking call (sh_flag_wait, context.hip) through its CPU-side hook: a completion word that never
+    advances ends the wait with SLAMHIP_ERR_TIMEOUT after the bound (the host is not left spinning for ever behind a kernel that
+    never ends); a word that is already there, or arrives from another thread, ends it with SLAMHIP_OK; sequence numbers compare
+    wrap-safe."""
+    import threading
+    import time
+    L = capi.lib()
+    flag = C.c_uint32(5)
+    t0 = time.perf_counter()
+    assert L.slamhip_debug_flag_wait(C.byref(flag), 6, 150) == capi.ERR_TIMEOUT          # never advanced
+    dt = time.perf_counter() - t0
+    assert 0.14 <= dt < 2.0, dt
+    assert b"bound" in L.slamhip_last_error()
+    assert L.slamhip_debug_flag_wait(C.byref(flag), 5, 150) == 0                          # already reached
+    assert L.slamhip_debug_flag_wait(C.byref(flag), 4, 150) == 0                          # a later number landed first
+    flag.value = 0xFFFFFFFE
+    assert L.slamhip_debug_flag_wait(C.byref(flag), 2, 100) == capi.ERR_TIMEOUT           # 2 is AHEAD of 0xFFFFFFFE across the wrap
+    flag.value = 3
+    assert L.slamhip_debug_flag_wait(C.byref(flag), 0xFFFFFFFE, 100) == 0                 # ... and 0xFFFFFFFE behind 3
+    flag.value = 10
+
+    def later():
+        time.sleep(0.05)
+        flag.value = 11
+    th = threading.Thread(target=later)
+    th.start()
+    assert L.slamhip_debug_flag_wait(C.byref(flag), 11, 5000) == 0                        # arrives while waiting (past the spin budget)
+    th.join()
+
+
 def test_product_does_not_import_oracle():
     """The product package must never reach into oracle/ (the judge checks this)."""
     import os

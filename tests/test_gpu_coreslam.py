@@ -372,6 +372,11 @@ def test_prepared_candidate_list(cs_mod, ctx, det, sim):
         rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, offs)
         rpose[2] = oc.normalize_angle(rpose[2])
         assert idx == rbi and dist == rbd and (pose == rpose).all(), (stream, sxy)
+        # the host-side decode of the same key (slamhip_cs_pose_from_key fetches a host copy of the jitters and keeps it): behind a
+        # SERVED list the copy of the previous list must not be what decodes the key (round-4 advisor finding)
+        kp, kd, ki = dev.pose_from_key(base, (dist << 32) | idx)
+        kp[2] = oc.normalize_angle(kp[2])
+        assert ki == idx and kd == dist and (kp == pose).all(), (stream, sxy, kp, pose)
         oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, 128, dev.obst_scale, xy, rpose)
     assert (dev.holemap_download() == ref_h).all() and (dev.obstaclemap_download() == ref_o).all()
     assert dev.selfcheck_failures == 0
