@@ -120,8 +120,7 @@ struct slamhip_cs {
     void *d_k2_cand;                            // rays as the pixel kernels test them, sorted by (direction class, slope bucket)
     void *d_k2_vprof;                           // V-profile parameters by ray index
     int *d_k2_start;                            // [4 x 1024 + 1] first table entry of every bucket
-    int *d_k2_counters;           // [0] longest ray, [1] conflict pixels, [2] blended pixels, [3] x1, [4] y1
-    int *d_conflict_pix; int cap_conflict;
+    int *d_k2_counters;           // [0] longest ray, [1] unused, [2] blended pixels, [3] x1, [4] y1
     void *mirror_reg; size_t mirror_reg_bytes;   // the caller's mirror array, page-locked on first use (slamhip_cs_holemap_mirror)
     // asynchronous host mirror (slamhip_cs_holemap_mirror_async): per-row column spans of what the updates since the last snapshot
     // may have changed (K2 keeps them while mirror_on), a shadow map the snapshot launch copies the spans into, the spans as

@@ -38,14 +38,23 @@
 #define K2_NBUCK RS_NBUCK
 #define K2_ZONE 48                     // Chebyshev radius around the robot handled one wavefront per pixel
 #define K2_MAXHIT 4                    // hits a lane-per-pixel thread orders in registers
+#define K2_MIXQ 192                    // zone pixels with hits inside a V that a workgroup queues in LDS for its ordered one-pixel path
 
-// ray as the pixel kernels test it: clipped major length, signed clipped minor length (smin * dyc), the step beyond
+// ray as the hit test takes it: clipped major length, signed clipped minor length (smin * dyc), the step beyond
 // which pixval leaves TS_NO_OBSTACLE (:406), ray index (= blend order)
 struct k2_cand { int dxc, sdyc, lim2, ray; };
-// V-profile of a ray, by ray index: derrorv (:379/:386), incv (:398), lim2 = dx - 2*derrorv, lim1 = dx - derrorv (:406,:408)
-struct k2_vprof { int derrorv, incv, lim2, lim1; };
-// ray by index, for the pixels that scan all rays: flags = valid | major_x << 1 | (smaj + 1) << 2
-struct k2_byidx { int dxc, sdyc, lim2, flags; };
+// A ray's record, by ray index, in three parts (structure of arrays: each part is read with one aligned LDS access):
+//   A  what a hit test needs: dxc, sdyc, lim2 = dx - 2*derrorv (:406), flags = valid | major_x << 1 | (smaj + 1) << 2 | wild << 4
+//   B  the V-profile's closed form beyond lim2: lim1 = dx - derrorv (:408), incv (:398), J = the number of carries of the ascending
+//      half (a per-ray constant: k2_vconst), d = derrorv (:379/:386)
+//   C  1 / (2 * dxc) in binary64, correctly rounded: the minor offset of a step without a division (k2_minor_step)
+// The sorted table (`order`: rays by direction class and slope bucket) holds ray indices only.
+struct k2_vprof { int derrorv, incv, lim2, lim1; };   // (argument of the literal-capable closed form k2_pixval_closed)
+struct k2_rayA { int dxc, sdyc, lim2, flags; };
+struct k2_rayB { int lim1, incv, J, d; };
+#define K2_F_VALID 1
+#define K2_F_MAJX 2
+#define K2_F_WILD 16                   // derrorv beyond 2^22: the V-profile is walked literally (k2_pixval_closed)
 
 struct cs_ray {
     int valid;
@@ -200,6 +209,68 @@ __device__ static __forceinline__ int k2_pixval_closed(const k2_vprof p, int x)
     return TS_NO_OBSTACLE + (n1 - j) * p.incv + f;                             // sincv = -1 (:374)
 }
 
+// The same closed form with its per-ray constants taken from the ray's record.  On the ascending half (x > lim1) the count of
+// descending steps is the constant N1 = max(lim1 - xs + 1, 0), hence u0 and the carry bound J are constants of the ray: k2_vconst
+// evaluates the very expressions of k2_pixval_closed once per ray, and a pixel's value needs no division.
+__device__ static __forceinline__ int k2_vconst_J(int d, int incv, int lim2, int lim1)
+{
+    const int incerrorv = sh_wsub(TS_OBSTACLE - TS_NO_OBSTACLE, sh_wmul(d, incv));       // :399
+    const int xs = lim2 < 0 ? 0 : lim2 + 1;
+    const int n1 = lim1 - xs + 1 > 0 ? lim1 - xs + 1 : 0;
+    const int u0 = d / 2 + n1 * incerrorv, g = -incerrorv;
+    int J = 0;
+    if (d - u0 > 0 && g + d != 0) J = (d - u0 + (g + d) - 1) / (g + d) - 1;
+    return J;
+}
+__device__ static __forceinline__ int k2_pixval_fast(int lim2, int flags, const k2_rayB B, int x)      // x > lim2
+{
+    if (flags & K2_F_WILD) { k2_vprof p; p.derrorv = B.d; p.incv = B.incv; p.lim2 = lim2; p.lim1 = B.lim1; return k2_pixval_closed(p, x); }
+    const int xs = lim2 < 0 ? 0 : lim2 + 1;
+    const int xm = x < B.lim1 ? x : B.lim1;
+    const int n1 = xm - xs + 1 > 0 ? xm - xs + 1 : 0;
+    const int j = (x - xs + 1) - n1;
+    const int f = j < B.J ? j : B.J;
+    return TS_NO_OBSTACLE + __mul24(n1 - j, B.incv) + f;                                  // (|n1 - j| < 2^23, |incv| <= 65500)
+}
+// value of step x of the ray (A, B)
+__device__ static __forceinline__ int k2_value(const k2_rayA A, const k2_rayB B, int x)
+{
+    return x <= A.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(A.lim2, A.flags, B, x);
+}
+// a ray's record from the literal arithmetic of k2_make_ray
+__device__ static __forceinline__ void k2_ray_record(const cs_ray &r, k2_rayA &A, k2_rayB &B, double &C)
+{
+    A.dxc = r.dxc; A.sdyc = r.smin * r.dyc; A.lim2 = r.lim2;
+    A.flags = (r.valid ? K2_F_VALID : 0) | (r.major_x ? K2_F_MAJX : 0) | ((r.smaj + 1) << 2);
+    B.lim1 = r.lim1; B.incv = r.incv; B.J = 0; B.d = r.derrorv;
+    C = 0.0;
+    if (r.valid) {
+        if (r.derrorv > (1 << 22)) A.flags |= K2_F_WILD;
+        else B.J = k2_vconst_J(r.derrorv, r.incv, r.lim2, r.lim1);
+        if (r.dxc > 0) C = 1.0 / (2.0 * (double)r.dxc);
+    }
+}
+// Minor offset of step x >= 1 of a ray: m(x) = min(x, max(0, ceil((2*dyc*x - dxc) / (2*dxc)))), the closed form of the error
+// recurrence (:394-396, :433-441).  Maps up to 16384 pixels a side (T = int): N = 2*dyc*x - dxc is exact in binary64, rc = 1/(2*dxc)
+// correctly rounded, so N*rc is within 2^-38 of N/D (N/D < 2^14); quotients are integers or at least 1/D >= 2^-15 apart from one:
+// ceil(N*rc - 2^-18) is the exact ceiling.  Five full-rate binary64 instructions instead of a float estimate with an integer
+// remainder fix-up (two dozen).  Larger maps (T = long long) divide.
+template <typename T>
+__device__ static __forceinline__ int k2_minor_step(int x, int dxc, int dyc, double rc)
+{
+    if (sizeof(T) == 4) {
+        const double N = __builtin_fma((double)x, (double)(2 * dyc), -(double)dxc);
+        double q = __builtin_ceil(__builtin_fma(N, rc, -0x1p-18));
+        q = __builtin_fmax(q, 0.0);
+        q = __builtin_fmin(q, (double)x);
+        return (int)q;
+    }
+    const T N = (T)2 * dyc * x - dxc, D = (T)2 * dxc;
+    if (N <= 0) return 0;
+    const T q = (N + D - 1) / D;
+    return q < (T)x ? (int)q : x;
+}
+
 __device__ static __forceinline__ uint16_t k2_blend(uint16_t pix, int pixval, int alpha)
 {
     return (uint16_t)(sh_wadd(sh_wmul(256 - alpha, (int)pix), sh_wmul(alpha, pixval)) >> 8);   // :431
@@ -224,11 +295,17 @@ __device__ static __forceinline__ bool k2_hit(const k2_cand c, int a, int b)
     return N > (T)(B - 1) * D && N <= (T)B * D;
 }
 
-// counters: [0] R = longest clipped major length, [1] conflict pixels, [2] blended pixels (every step x = 0..dxc of
+// counters: [0] R = longest clipped major length, [1] unused, [2] blended pixels (every step x = 0..dxc of
 // a valid ray blends exactly one pixel, :404,:431), [3] x1, [4] y1, [5] robot inside the map
+__device__ static __forceinline__ int k2_ray_bucket(const k2_rayA e)
+{
+    const int smaj = ((e.flags >> 2) & 3) - 1;
+    const float tt = e.dxc > 0 ? (float)e.sdyc / (float)e.dxc : 0.0f;
+    return ((e.flags & K2_F_MAJX) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3)) * K2_NBUCK + rs_bucket(tt);
+}
 __global__ void __launch_bounds__(1024)
 k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const float *d_pose, float4 h_pxcs, float hole_width,
-           k2_byidx *__restrict__ byidx, k2_cand *__restrict__ cand, k2_vprof *__restrict__ vprof,
+           k2_rayA *__restrict__ recA, k2_rayB *__restrict__ recB, double *__restrict__ recC, int *__restrict__ order,
            int *__restrict__ start,
            int *__restrict__ counters, int *__restrict__ total_out, int *__restrict__ dirty)
 {
@@ -241,20 +318,13 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
     __syncthreads();
     const float4 q = k2_pxcs(d_pose, h_pxcs, scale);
     int my_R = 0, my_total = 0;
-    k2_byidx keep[2];                                              // a thread's first two rays stay in registers for the second pass (scans of up to 2048 rays)
-    keep[0].flags = 0; keep[1].flags = 0;
-    for (int i = t, it = 0; i < n; i += 1024, it++) {
+    for (int i = t; i < n; i += 1024) {
         const cs_ray r = k2_make_ray(pts[i], size, q, scale, hole_width);
-        k2_byidx e; e.dxc = r.dxc; e.sdyc = r.smin * r.dyc; e.lim2 = r.lim2;
-        e.flags = (r.valid ? 1 : 0) | (r.major_x ? 2 : 0) | ((r.smaj + 1) << 2);
-        byidx[i] = e;
-        if (it == 0) keep[0] = e; else if (it == 1) keep[1] = e;
+        k2_rayA A; k2_rayB B; double C;
+        k2_ray_record(r, A, B, C);
+        recA[i] = A; recB[i] = B; recC[i] = C;
         if (r.valid) {
-            k2_vprof vp; vp.derrorv = r.derrorv; vp.incv = r.incv; vp.lim2 = r.lim2; vp.lim1 = r.lim1;
-            vprof[i] = vp;
-            const int cls = r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3);
-            const float tt = r.dxc > 0 ? (float)e.sdyc / (float)r.dxc : 0.0f;
-            atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
+            atomicAdd(&hist[k2_ray_bucket(A)], 1);
             my_R = max(my_R, r.dxc);
             my_total += r.dxc + 1;
         }
@@ -283,16 +353,9 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
         if (t == 1023) start[4 * K2_NBUCK] = base;
     }
     __syncthreads();
-    for (int i = t, it = 0; i < n; i += 1024, it++) {
-        const k2_byidx e = it == 0 ? keep[0] : it == 1 ? keep[1] : byidx[i];      // (its own store: no other thread wrote byidx[i])
-        if (e.flags & 1) {
-            const int smaj = ((e.flags >> 2) & 3) - 1;
-            const int cls = (e.flags & 2) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3);
-            const float tt = e.dxc > 0 ? (float)e.sdyc / (float)e.dxc : 0.0f;
-            const int pos = atomicAdd(&hist[cls * K2_NBUCK + rs_bucket(tt)], 1);
-            k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
-            cand[pos] = c;
-        }
+    for (int i = t; i < n; i += 1024) {
+        const k2_rayA e = recA[i];                                 // (its own store: no other thread wrote recA[i])
+        if (e.flags & K2_F_VALID) order[atomicAdd(&hist[k2_ray_bucket(e)], 1)] = i;
     }
     if (t == 0) {
         counters[0] = s_R; counters[1] = 0; counters[2] = s_total;
@@ -311,10 +374,10 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
 // One wavefront draws one pixel: lanes test the candidate rays, hits are rank-sorted by ray index and blended in that
 // order; the robot's pixel (step 0 of every ray) and its closest neighbours (more than 64 candidates) scan all rays in
 // index order.  `sval` is 64 ints of LDS private to the wavefront.
-// (byidx / cand / vprof: LDS when the kernel made the scan's tables itself, else global; vprof goes by ray index)
-template <typename T, typename CT, typename BT, typename VT, typename ST>
-__device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, int size, BT byidx,
-                                            VT vprof, int n_rays, CT cand, const ST *start,
+// (recA / recB / order: LDS when the kernel made the scan's tables itself, else global)
+template <typename T, typename OT, typename ST>
+__device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, int size, const k2_rayA *recA, const k2_rayB *recB,
+                                            int n_rays, const OT *order, const ST *start,
                                             uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int lane = threadIdx.x & 63;
@@ -328,55 +391,70 @@ __device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y
     uint16_t pix = map[ptr];
     bool stable = false;
     int last_v = 0;
+    // Blends of ONE value commute, and near the robot nearly every fragment carries TS_NO_OBSTACLE (step x of a ray lies below its
+    // V: x <= lim2): the hits are COUNTED first, and only a pixel with a hit inside some ray's V takes the ordered path.
     if (ncls == 0 || nc > 64) {
-        k2_byidx e_next = byidx[lane < n_rays ? lane : 0];             // (the table is read one iteration ahead)
-        for (int base = 0; base < n_rays; base += 64) {
-            const int i = base + lane;
-            bool hit = false;
-            int v = 0;
-            const k2_byidx e = e_next;
-            e_next = byidx[i + 64 < n_rays ? i + 64 : 0];
-            if (i < n_rays) {
-                if (e.flags & 1) {
-                    const int smaj = ((e.flags >> 2) & 3) - 1;
-                    const int aa = (e.flags & 2) ? dx : dy, bb = (e.flags & 2) ? dy : dx;
-                    int x = -1;
-                    if (smaj != 0) x = aa * smaj; else if (aa == 0) x = 0;
-                    k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
-                    if (x == 0 ? bb == 0 : (x > 0 && k2_hit<T>(c, x, bb))) {
-                        hit = true;
-                        v = x <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[i], x);
+        for (int pass = 0; pass < 2; pass++) {                      // pass 0 counts; pass 1 (a hit inside a V) blends in ray order
+            const bool ordered = pass == 1;
+            int nh = 0;
+            unsigned long long anyv = 0ull;
+            k2_rayA e_next = recA[lane < n_rays ? lane : 0];           // (the table is read one iteration ahead)
+            for (int base = 0; base < n_rays; base += 64) {
+                const int i = base + lane;
+                bool hit = false, inv = false;
+                int x = -1;
+                const k2_rayA e = e_next;
+                e_next = recA[i + 64 < n_rays ? i + 64 : 0];
+                if (i < n_rays) {
+                    if (e.flags & K2_F_VALID) {
+                        const int smaj = ((e.flags >> 2) & 3) - 1;
+                        const int aa = (e.flags & K2_F_MAJX) ? dx : dy, bb = (e.flags & K2_F_MAJX) ? dy : dx;
+                        if (smaj != 0) x = aa * smaj; else if (aa == 0) x = 0;
+                        k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = i;
+                        if (x == 0 ? bb == 0 : (x > 0 && k2_hit<T>(c, x, bb))) { hit = true; inv = x > e.lim2; }
                     }
                 }
-            }
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                // the leading run of hits with one value (near the robot nearly every ray carries TS_NO_OBSTACLE): the
-                // blend of a run converges -- once it no longer changes the pixel the rest of the run cannot either
-                const int src = __ffsll((long long)mask) - 1;
-                const int vv = __builtin_amdgcn_readlane(v, src);
-                const unsigned long long same = __ballot(hit && v == vv) & mask, diff = mask & ~same;
-                const unsigned long long run = diff ? (same & ((diff & (0ull - diff)) - 1ull)) : same;
-                for (int k = __popcll(run); k > 0 && !(stable && vv == last_v); k--) {
-                    const uint16_t np = k2_blend(pix, vv, alpha);
-                    stable = np == pix; pix = np; last_v = vv;
+                unsigned long long mask = __ballot(hit);
+                if (!ordered) { nh += __popcll(mask); anyv |= __ballot(inv); continue; }
+                if (mask == 0ull) continue;
+                int v = TS_NO_OBSTACLE;
+                if (inv) v = k2_pixval_fast(e.lim2, e.flags, recB[i], x);
+                while (mask) {
+                    // the leading run of hits with one value: the blend of a run converges -- once it no longer changes the
+                    // pixel the rest of the run cannot either
+                    const int src = __ffsll((long long)mask) - 1;
+                    const int vv = __builtin_amdgcn_readlane(v, src);
+                    const unsigned long long same = __ballot(hit && v == vv) & mask, diff = mask & ~same;
+                    const unsigned long long run = diff ? (same & ((diff & (0ull - diff)) - 1ull)) : same;
+                    for (int k = __popcll(run); k > 0 && !(stable && vv == last_v); k--) {
+                        const uint16_t np = k2_blend(pix, vv, alpha);
+                        stable = np == pix; pix = np; last_v = vv;
+                    }
+                    mask &= ~run;
                 }
-                mask &= ~run;
+            }
+            if (!ordered && anyv == 0ull) {
+                for (int k = 0; k < nh; k++) { const uint16_t np = k2_blend(pix, TS_NO_OBSTACLE, alpha); if (np == pix) break; pix = np; }
+                break;
             }
         }
     } else if (nc > 0) {
         int ci = -1, kk = 0;
         if (lane < hi[0] - lo[0]) { ci = lo[0] + lane; kk = 0; }
         else if (ncls > 1 && lane - (hi[0] - lo[0]) < hi[1] - lo[1]) { ci = lo[1] + lane - (hi[0] - lo[0]); kk = 1; }
-        bool hit = false;
-        int idx = 0x7fffffff, v = 0;
+        bool hit = false, inv = false;
+        int idx = 0x7fffffff, v = TS_NO_OBSTACLE;
         if (ci >= 0) {
-            const k2_cand c = cand[ci];
+            const int ray = (int)order[ci];
+            const k2_rayA e = recA[ray];
+            k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
             const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
-            if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], aa); }
+            if (k2_hit<T>(c, aa, bb)) { hit = true; idx = ray; inv = aa > e.lim2; if (inv) v = k2_pixval_fast(e.lim2, e.flags, recB[ray], aa); }
         }
         const unsigned long long mask = __ballot(hit);
-        if (mask) {
+        if (mask && __ballot(inv) == 0ull) {
+            for (int k = __popcll(mask); k > 0; k--) { const uint16_t np = k2_blend(pix, TS_NO_OBSTACLE, alpha); if (np == pix) break; pix = np; }
+        } else if (mask) {
             int rank = 0;
             unsigned long long m = mask;
             while (m) {
@@ -416,7 +494,7 @@ __device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y
 //                          of a quadrant meet) the candidates are tested; the lane of the LOWEST ray index among the hits owns the
 //                          pixel and blends all hits in ray order, the other hitting rays' lanes drop it.  The lookup is a function
 //                          of the pixel alone, so every lane that lands on a pixel sees the same hit list and exactly one owns it.
-// Pixels with more hits than a T3 lane orders go to the conflict list (drawn by the last workgroup, one wavefront per pixel).
+// A pixel with more hits than a T3 lane orders in registers is drawn by its owner lane all the same (k2_lane_draw_ordered).
 // The bucket table, the sorted ray table, the V-profiles (in table order) and the rays by index live in LDS: a pixel's
 // lookup is a chain of dependent small reads (bucket bounds -> candidates -> V-profile -> map), which global-memory latency
 // would dominate.
@@ -439,8 +517,8 @@ __device__ unsigned long long g_k2_sub[512 * 16 * 8];   // per wavefront: [0] T1
 
 // Which rays draw the pixel at offset (dx, dy) from the robot?  Up to H hits, kept sorted by ray index (compile-time
 // subscripts: the lists stay in registers); `min_ray` = the lowest hitting ray index, also when the list overflowed.
-template <typename T, int H, typename CT, typename VT, typename ST>
-__device__ static __forceinline__ void k2_lookup(CT cand, VT vprof, const ST *start, int dx, int dy,
+template <typename T, int H, typename OT, typename ST>
+__device__ static __forceinline__ void k2_lookup(const k2_rayA *recA, const k2_rayB *recB, const OT *order, const ST *start, int dx, int dy,
                                         int (&hidx)[H], int (&hval)[H], int &nh, bool &overflow, int &min_ray)
 {
     int cls[2], a[2], b[2];
@@ -450,18 +528,20 @@ __device__ static __forceinline__ void k2_lookup(CT cand, VT vprof, const ST *st
         int lo, hi;
         rs_range(start, cls[k], a[k], b[k], 0.0f, lo, hi);
         for (int ci = lo; ci < hi; ci++) {
-            const k2_cand c = cand[ci];
+            const int ray = (int)order[ci];
+            const k2_rayA e = recA[ray];
+            k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
             if (!k2_hit<T>(c, a[k], b[k])) continue;
-            min_ray = c.ray < min_ray ? c.ray : min_ray;
+            min_ray = ray < min_ray ? ray : min_ray;
             if (nh == H) { overflow = true; continue; }            // (keep scanning: the owner is the lowest index of ALL hits)
-            const int v = a[k] <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vprof[c.ray], a[k]);
+            const int v = a[k] <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(e.lim2, e.flags, recB[ray], a[k]);
             int posn = 0;
 #pragma unroll
-            for (int s = 0; s < H; s++) if (s < nh && hidx[s] < c.ray) posn++;
+            for (int s = 0; s < H; s++) if (s < nh && hidx[s] < ray) posn++;
 #pragma unroll
             for (int s = H - 1; s >= 1; s--) if (s > posn && s <= nh) { hidx[s] = hidx[s - 1]; hval[s] = hval[s - 1]; }
 #pragma unroll
-            for (int s = 0; s < H; s++) if (s == posn) { hidx[s] = c.ray; hval[s] = v; }
+            for (int s = 0; s < H; s++) if (s == posn) { hidx[s] = ray; hval[s] = v; }
             nh++;
         }
     }
@@ -480,20 +560,19 @@ __device__ static __forceinline__ void k2_ring_pixel(int i, int &ddx, int &ddy)
     ddy = side == 0 ? -r : side == 1 ? -r + p : side == 2 ? r : r - p;
 }
 
-// One wavefront draws G = 1 << lg pixels (numbers pix0 .. pix0 + G - 1 of the zone), W = 64 / G lanes each.  A pixel with more
-// candidates than its lanes -- and every G = 1 item -- goes down the one-pixel path, pixel after pixel: ONE call site for it (the
+// One wavefront draws G = 1 << lg pixels in the ordered way, W = 64 / G lanes each: the lanes test a pixel's candidates, the hits
+// are ranked by ray index and blended in that order by the group's first lane.  (ddx, ddy, exists) are a lane's group's pixel.
+// A pixel with more candidates than its lanes goes down the one-pixel path, pixel after pixel: ONE call site for it per use (the
 // kernel's code is executed once or twice per wavefront, from a cold instruction cache: its size is latency; nine inlined copies
 // of the one-pixel path made a 47 KB kernel that ran 10 us slower than the 20 KB one).
-template <typename T, typename CT, typename BT, typename VT, typename ST>
-__device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg, int x1, int y1, int size, BT byidx,
-                                                     VT vps, int n_rays, CT cand, const ST *start, uint16_t *__restrict__ map, int alpha, int *sval)
+template <typename T, typename OT, typename ST>
+__device__ static __forceinline__ void k2_wave_group(int ddx, int ddy, bool exists, int lg, int x1, int y1, int size, const k2_rayA *recA, const k2_rayB *recB,
+                                                     int n_rays, const OT *order, const ST *start, uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int W = 64 >> lg, G = 1 << lg;
     const int lane = threadIdx.x & 63, g = lane >> (6 - lg), l = lane & (W - 1);
-    int ddx, ddy;
-    k2_ring_pixel(pix0 + g, ddx, ddy);
     const int X = x1 + ddx, Y = y1 + ddy;
-    const bool valid = pix0 + g < n_pix && X >= 0 && X < size && Y >= 0 && Y < size;
+    const bool valid = exists && X >= 0 && X < size && Y >= 0 && Y < size;
     int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
     int ncls = 0, nc = 0;
     if (valid && lg > 0) {
@@ -505,7 +584,7 @@ __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg
         for (int gg = 0; gg < G; gg++) {
             const int Xg = __builtin_amdgcn_readlane(X, gg * W), Yg = __builtin_amdgcn_readlane(Y, gg * W);
             const int vg = __builtin_amdgcn_readlane(valid ? 1 : 0, gg * W);
-            if (vg) k2_wave_pixel<T>(Xg, Yg, x1, y1, size, byidx, vps, n_rays, cand, start, map, alpha, sval);
+            if (vg) k2_wave_pixel<T>(Xg, Yg, x1, y1, size, recA, recB, n_rays, order, start, map, alpha, sval);
         }
         return;
     }
@@ -518,9 +597,11 @@ __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg
     bool hit = false;
     int idx = 0x7fffffff, v = 0;
     if (ci >= 0) {
-        const k2_cand c = cand[ci];
+        const int ray = (int)order[ci];
+        const k2_rayA e = recA[ray];
+        k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
         const int aa = kk ? a[1] : a[0], bb = kk ? b[1] : b[0];
-        if (k2_hit<T>(c, aa, bb)) { hit = true; idx = c.ray; v = aa <= c.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[c.ray], aa); }
+        if (k2_hit<T>(c, aa, bb)) { hit = true; idx = ray; v = aa <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(e.lim2, e.flags, recB[ray], aa); }
     }
     const unsigned long long mask = __ballot(hit);
     if (mask == 0ull) return;
@@ -551,19 +632,174 @@ __device__ static __forceinline__ void k2_wave_group(int pix0, int n_pix, int lg
     __builtin_amdgcn_wave_barrier();
 }
 
+// A lane draws a pixel by itself, all hits in ray order, however many: the lowest ray index above the last one blended is looked
+// for again and again (hits x candidates tests).  The way out for what the fast paths cannot hold -- a far pixel with more hits
+// than a step lane orders in registers, a zone pixel that found the workgroup's queue full -- rare by construction, and any lane
+// has the tables it needs (the device-wide conflict list of rounds 3 - 4 was drawn by the LAST workgroup to finish, which under arcs
+// holds another octant's rays; it also put an arrival ticket, a dependent round trip, at the end of every workgroup).
+template <typename T, typename OT, typename ST>
+__device__ static __noinline__ uint16_t k2_lane_draw_ordered(const k2_rayA *recA, const k2_rayB *recB, const OT *order, const ST *start,
+                                                             int dx, int dy, uint16_t pix, int alpha)
+{
+    int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
+    const int ncls = rs_classes(dx, dy, cls, a, b);
+#pragma unroll
+    for (int k = 0; k < 2; k++) if (k < ncls) rs_range(start, cls[k], a[k], b[k], 0.0f, lo[k], hi[k]);
+    int prev = -1;
+    for (;;) {
+        int best = 0x7fffffff, bv = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (k < ncls) {
+            for (int ci = lo[k]; ci < hi[k]; ci++) {
+                const int ray = (int)order[ci];
+                if (ray <= prev || ray >= best) continue;
+                const k2_rayA e = recA[ray];
+                k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
+                if (!k2_hit<T>(c, a[k], b[k])) continue;
+                best = ray;
+                bv = a[k] <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(e.lim2, e.flags, recB[ray], a[k]);
+            }
+        }
+        if (best == 0x7fffffff) break;
+        pix = k2_blend(pix, bv, alpha);
+        prev = best;
+    }
+    return pix;
+}
+
+// ---- directions as one coordinate round the robot ------------------------------------------------------------------------------
+// u in [0, 8): the direction class and the signed slope sigma = minor / |major| of a pixel or ray as ONE number that is continuous
+// across the class borders -- class 0 (+x): 1 + sigma, class 2 (+y): 3 - sigma, class 1 (-x): 5 - sigma, class 3 (-y): 7 + sigma -- so
+// that [k, k + 1) is the k-th octant.  XCD k (the workgroups b with b % 8 == k) draws octant k: its zone pixels from rB outwards and
+// the steps beyond the zone of the rays that point into it.  A pixel at major offset a is drawn only by rays whose (class, slope)
+// lies within 1 / (2a) of its own u (raster.h), so a workgroup needs the rays of its octant and a margin -- and it selects them by
+// the direction of the ray's FLOAT end point (two multiply-adds and a reciprocal per ray), before any of k2_make_ray's arithmetic:
+//   |u(float direction) - u(class, clipped integer slope)| <= 6.1 / dxc
+// (the unclipped integer deltas are the float ones + two truncations each: |s_u - t| <= (2 + 2|t|) / dx; ClipRay :320-345 moves the
+// end point along the line up to a truncation in y (1 / dxc') and one in x (|s| / dxc); a ray whose class the roundings flip lies
+// that close to the diagonal, where u is continuous) -- valid while nothing wraps: robot and end points within 16000 pixels, the
+// hole's half width (the extension :525-530 keeps the direction for a non-negative width) below 8000, else every ray is selected.
+// A ray that draws a pixel at major offset a has dxc >= a: a workgroup whose pixels start at offset a_min takes the margin
+// 8 / a_min (6.1 + the pixel's own 1/2 + the bucket slack).  Who is selected only has to be a SUPERSET of who can draw.
+__device__ static __forceinline__ bool k2_arc_member(const float2 p, const float4 q, float centre, float halfw)
+{
+    const float X = q.z * p.x - q.w * p.y, Y = q.w * p.x + q.z * p.y;      // (:519-520)
+    const float ax = fabsf(X), ay = fabsf(Y);
+    float u;
+    if (ax > ay) { const float sg = Y * __builtin_amdgcn_rcpf(ax); u = X > 0.0f ? 1.0f + sg : 5.0f - sg; }
+    else         { const float sg = X * __builtin_amdgcn_rcpf(ay); u = Y > 0.0f ? 3.0f - sg : 7.0f + sg; }
+    float d = u - centre;
+    d -= 8.0f * rintf(d * 0.125f);                                         // (the shorter way round)
+    const bool sane = ax < 16000.0f && ay < 16000.0f;                      // (a NaN compares false: selected)
+    return !sane || !(fabsf(d) > halfw);                                   // (a NaN direction: selected)
+}
+// octant of a ray by its exact class and slope sign (any fixed rule would do: it only says which XCD draws the ray's far steps)
+__device__ static __forceinline__ int k2_ray_octant(const k2_rayA e)
+{
+    const int smaj = ((e.flags >> 2) & 3) - 1;
+    if (e.flags & K2_F_MAJX) return smaj >= 0 ? (e.sdyc < 0 ? 0 : 1) : (e.sdyc > 0 ? 4 : 5);
+    return smaj >= 0 ? (e.sdyc > 0 ? 2 : 3) : (e.sdyc < 0 ? 6 : 7);
+}
+// pixel number j (from 0) of octant o, counted ring by ring from ring r0: ring a holds a pixels of every octant
+__device__ static __forceinline__ void k2_octant_pixel(int o, int j, int r0, int &ddx, int &ddy)
+{
+    const int jj = j + (r0 * (r0 - 1)) / 2;
+    int a = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)jj)) * 0.5f);
+    if ((a * (a - 1)) / 2 > jj) a--; else if ((a * (a + 1)) / 2 <= jj) a++;
+    const int t = jj - (a * (a - 1)) / 2;
+    const int bq = (o == 0 || o == 6) ? -(t + 1) : (o == 1 || o == 7) ? t : (o == 2 || o == 4) ? t + 1 : -t;    // signed minor offset
+    const int cls = o >> 1;                                                // 0: +x, 1: +y, 2: -x, 3: -y  (octants in the order of u)
+    ddx = cls == 0 ? a : cls == 2 ? -a : bq;
+    ddy = cls == 1 ? a : cls == 3 ? -a : bq;
+}
+
+// One LANE draws one zone pixel (numbers pix0 .. pix0 + 63, ring by ring: the 64 pixels of an item see about the same number of
+// rays).  Out from rB a pixel has a dozen or two candidates, and nearly all of a zone's fragments carry TS_NO_OBSTACLE (step x of a
+// ray is below its V, x <= lim2, unless an obstacle stands within the zone's radius plus the hole's half width of the robot): blends
+// of ONE value commute, so the lane only COUNTS its hits -- no ranking, no ordering -- and blends the value that many times (the
+// blend converges: it stops at its fixed point).  A pixel with a hit inside some ray's V is not drawn here: it goes to the
+// workgroup's queue (LDS; beyond its capacity the lane draws it itself: k2_lane_draw_ordered) and is drawn in the ordered way, four
+// pixels to a wavefront, when the workgroup has finished.  3277 wavefront items of ~3 us became ~660: the zone occupies two or three wavefronts of a workgroup
+// while the others draw the steps beyond it (the two phases used to run one after the other: 5.6 + 5.6 us of a 21 us launch).
+template <typename T, typename OT, typename ST>
+__device__ static __forceinline__ void k2_lane_pixels(int ddx, int ddy, bool exists, int x1, int y1, int size, const k2_rayA *recA,
+                                                      const k2_rayB *recB, const OT *order, const ST *start, uint16_t *__restrict__ map, int alpha,
+                                                      int *mixq, int *n_mixq, int cap_mixq)
+{
+    const int X = x1 + ddx, Y = y1 + ddy;
+    if (!(exists && X >= 0 && X < size && Y >= 0 && Y < size)) return;
+    const int ptr = Y * size + X;
+    uint16_t pix = map[ptr];                                        // (requested now, needed after the candidates)
+    int cls[2], a[2], b[2];
+    const int ncls = rs_classes(ddx, ddy, cls, a, b);
+    int nh = 0;
+    bool mixed = false;
+#pragma unroll
+    for (int k = 0; k < 2; k++) if (k < ncls) {
+        int lo, hi;
+        rs_range(start, cls[k], a[k], b[k], 0.0f, lo, hi);
+        for (int ci = lo; ci < hi; ci++) {
+            const int ray = (int)order[ci];
+            const k2_rayA e = recA[ray];
+            k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
+            if (k2_hit<T>(c, a[k], b[k])) { nh++; mixed = mixed || a[k] > e.lim2; }
+        }
+    }
+    if (mixed) {
+        const int slot = atomicAdd(n_mixq, 1);
+        if (slot < cap_mixq) mixq[slot] = ptr;
+        else map[ptr] = k2_lane_draw_ordered<T>(recA, recB, order, start, ddx, ddy, pix, alpha);     // (queue full: drawn here, slowly)
+    } else if (nh > 0) {
+        for (int k = 0; k < nh; k++) {
+            const uint16_t np = k2_blend(pix, TS_NO_OBSTACLE, alpha);
+            if (np == pix) break;
+            pix = np;
+        }
+        map[ptr] = pix;
+    }
+}
+
 // dynamic LDS of the pixel kernel.  !BUILD: the bucket table (int).  BUILD (the kernel makes the scan's tables itself): the
 // histogram / running positions of the counting sort (int: LDS atomics), the bucket table as unsigned short (a scan has at most
-// K2_LDS_RAYS rays), the sorted ray table, the V-profiles and the rays by index (16 bytes per ray each) -- 80.7 KB with the
-// kernel's static 4.3 KB at 1080 rays.
+// K2_LDS_RAYS rays), the sorted table of ray indices (unsigned short) and the rays' records by index (16 + 16 + 8 bytes per ray)
+// -- 70 KB with the kernel's static 4.3 KB at 1080 rays.
 #define K2_LDS_FIXED ((4 * K2_NBUCK + 4) * 4)
 #define K2_LDS_START16 ((4 * K2_NBUCK + 8) * 2)
-static inline size_t k2_lds_bytes(bool build, int n_rays) { return build ? (size_t)4 * K2_NBUCK * 4 + K2_LDS_START16 + (size_t)48 * (size_t)((n_rays + 3) & ~3) : (size_t)K2_LDS_FIXED; }
+static inline size_t k2_lds_bytes(bool build, int n_rays)
+{
+    // BUILD: + the selected rays' points (8 bytes per ray; their indices share the sorted table's space) and the list of the rays
+    // whose far steps the workgroup's XCD draws (2 bytes per ray)
+    return build ? (size_t)4 * K2_NBUCK * 4 + K2_LDS_START16 + (size_t)4 * (size_t)((n_rays + 7) & ~7) + (size_t)48 * (size_t)((n_rays + 3) & ~3) : (size_t)K2_LDS_FIXED;
+}
 
-// a T3 work item as a lane holds it between its fetch (the pixel's load is issued there) and its turn
-struct k2_t3 { int ptr, dx, dy, ray, lim2; uint16_t pix; };
+// developer experiments (SLAMHIP_K2_EXP=n at build time, WRONG RESULTS): what bounds the kernel -- 1: the step lanes' stores dropped,
+// 2: their loads dropped, 3: both, 4: a wavefront's loads and stores folded into one 128-byte line, 5: no zone items, 6: no step
+// items, 7: tables only
+#ifndef K2_EXP
+#define K2_EXP 0
+#endif
+#if K2_EXP == 1
+#define K2_EXP_LOAD(map, p) (map)[p]
+#define K2_EXP_STORE(map, p, v) { if ((v) == 12345 && alpha == 77777) (map)[p] = (v); }
+#elif K2_EXP == 2
+#define K2_EXP_LOAD(map, p) (uint16_t)((p) & 0x7fff)
+#define K2_EXP_STORE(map, p, v) (map)[p] = (v)
+#elif K2_EXP == 3
+#define K2_EXP_LOAD(map, p) (uint16_t)((p) & 0x7fff)
+#define K2_EXP_STORE(map, p, v) { if ((v) == 12345 && alpha == 77777) (map)[p] = (v); }
+#elif K2_EXP == 4
+#define K2_EXP_LOAD(map, p) (map)[((p) & ~0xfff) | (threadIdx.x & 63)]
+#define K2_EXP_STORE(map, p, v) (map)[((p) & ~0xfff) | (threadIdx.x & 63)] = (v)
+#else
+#define K2_EXP_LOAD(map, p) (map)[p]
+#define K2_EXP_STORE(map, p, v) (map)[p] = (v)
+#endif
+// a T3 work item as a lane holds it between its fetch (the pixel's load is issued there) and its turn: step x of ray `ray`, at
+// signed minor offset b
+struct k2_t3 { int ptr, x, b, ray, lim2, flags; uint16_t pix; };
 
 // what the kernel needs of the scan when it makes the tables itself
-struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, rc_num; int2 *span;
+struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, ncore; int2 *span;
                  // the fused scan's form: the pose is not in memory yet -- the search (result-ring form: no final arriver, no chain)
                  // left only its key; every workgroup decodes the winner itself, the first one also stores the pose for later
                  // readers and delivers key + pose to the host's mailbox (k2_winner_pose)
@@ -627,7 +863,7 @@ __device__ static inline T k2_floor_div(T N, T D)                   // N >= 0, D
     return N / D;
 }
 template <typename T>
-__device__ static __noinline__ void k2_row_spans(const k2_byidx *byidx, int n_rays, int x1, int y1, int size, int n_pix_wgs, int2 *__restrict__ span)
+__device__ static __noinline__ void k2_row_spans(const k2_rayA *byidx, int n_rays, int x1, int y1, int size, int n_pix_wgs, int2 *__restrict__ span)
 {
     __shared__ int s_lo[128], s_hi[128];
     const int t = threadIdx.x;
@@ -638,7 +874,7 @@ __device__ static __noinline__ void k2_row_spans(const k2_byidx *byidx, int n_ra
         if (t < 128) { s_lo[t] = size; s_hi[t] = -1; }
         __syncthreads();
         for (int i = t; i < n_rays; i += 1024) {
-            const k2_byidx e = byidx[i];
+            const k2_rayA e = byidx[i];
             if (!(e.flags & 1)) continue;
             const int smaj = ((e.flags >> 2) & 3) - 1, major_x = (e.flags >> 1) & 1;
             const int dxc = e.dxc, sd = e.sdyc, dyc = sd < 0 ? -sd : sd, sgn = sd < 0 ? -1 : 1;
@@ -685,21 +921,25 @@ __device__ static __noinline__ void k2_row_spans(const k2_byidx *byidx, int n_ra
 
 template <bool BUILD, typename T>
 __global__ void __launch_bounds__(1024)
-k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof *__restrict__ vprof_g,
-          const k2_cand *__restrict__ cand_g, int n_rays,
+k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *__restrict__ recB_g, const double *__restrict__ recC_g,
+          const int *__restrict__ order_g, int n_rays,
           const int *__restrict__ start_g, int *__restrict__ counters, int size, uint16_t *__restrict__ map, int alpha,
-          int *__restrict__ conflict_pix, int cap_conflict, int n_pix_wgs, const k3_ride ride)
+          int n_pix_wgs, const k3_ride ride)
 {
     extern __shared__ __attribute__((aligned(16))) char k2_smem[];
     typedef typename std::conditional<BUILD, unsigned short, int>::type start_t;
-    const int n4 = (n_rays + 3) & ~3;
+    typedef typename std::conditional<BUILD, unsigned short, int>::type order_t;
+    const int n4 = (n_rays + 3) & ~3, n8 = (n_rays + 7) & ~7;
     int *pos_s = (int *)k2_smem;                                   // BUILD: histogram, then the buckets' running positions
     start_t *start = (start_t *)(k2_smem + (BUILD ? 4 * K2_NBUCK * 4 : 0));
-    k2_cand *cand_s = (k2_cand *)(k2_smem + 4 * K2_NBUCK * 4 + K2_LDS_START16);
-    k2_vprof *vprof_s = (k2_vprof *)(cand_s + (BUILD ? n4 : 0));
-    k2_byidx *byidx_s = (k2_byidx *)(vprof_s + (BUILD ? n4 : 0));
+    unsigned short *order_s = (unsigned short *)(k2_smem + 4 * K2_NBUCK * 4 + K2_LDS_START16);
+    unsigned short *own_s = order_s + (BUILD ? n8 : 0);             // BUILD: the rays whose steps beyond the zone this workgroup's XCD draws
+    k2_rayA *recA_s = (k2_rayA *)(own_s + (BUILD ? n8 : 0));
+    k2_rayB *recB_s = (k2_rayB *)(recA_s + (BUILD ? n4 : 0));
+    double *recC_s = (double *)(recB_s + (BUILD ? n4 : 0));
+    float2 *selp_s = (float2 *)(recC_s + (BUILD ? n4 : 0));        // BUILD: the points of the selected rays (their indices: order_s, until the sort)
     __shared__ __attribute__((aligned(16))) int sval[16][64];
-    __shared__ int s_last, s_nextA, s_nextB, s_R, s_total, wsum[16];
+    __shared__ int s_nextA, s_nextB, s_R, s_total, wsum[16], wown[16], s_nmix, s_nsel, s_mixq[K2_MIXQ];
     __shared__ float s_wpose[4];
     K2_STAMP(0)
     // Riding along: the ObstacleMap update (obstacle_dev.h).  Every wavefront of the launch takes 64 cells of the pending cell
@@ -713,12 +953,23 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     const bool ride_cells = BUILD && ride.on && ride_cell < ride.n_cells, ride_ray = BUILD && ride.on && ride_r < ride.n_points;
     uint32_t ride_h = 0; uint8_t ride_nh = 0; int ride_v = 0;
     float2 ride_p = make_float2(0.f, 0.f);
-    int R, x1, y1, n_valid;
+    // Who draws what (BUILD with sc.ncore > 0: "arcs").  Workgroup b runs on XCD b % 8.  The first sc.ncore workgroups of every XCD
+    // are CORE workgroups: tables of all rays, the zone's central pixels (one per wavefront, r < rB: a window there spans up to the
+    // whole circle), no far steps.  The others are SECTOR workgroups of their XCD's octant: tables of the rays of that octant and a
+    // margin (k2_arc_member), the octant's zone pixels from rB on (one per lane) and the far steps of the octant's rays.  Without
+    // arcs (large scans whose tables k2_prepare made, a host mirror's row spans -- k2_row_spans walks every ray --, developer grids,
+    // absurd hole widths) every workgroup holds every ray and everything is dealt round-robin, as before round 5.
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_in_xcd = (n_pix_wgs - xcd + 7) >> 3;
+    const bool arcs = BUILD && sc.ncore > 0, is_core = !arcs || wg_in_xcd < sc.ncore;
+    int rB = (sc.rb_num * n_rays + 1079) / 1080;                    // (the radius from which a zone pixel is one lane's: by the ray COUNT, so that every workgroup agrees)
+    rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB;
+    int R, x1, y1, n_own = 0;
     if (BUILD) {
         const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
         constexpr int RPT = (K2_LDS_RAYS + 1023) / 1024;            // rays per thread
-        float2 p_next = make_float2(0.f, 0.f);
-        if (t < n_rays) p_next = sc.pts[t];                         // (a thread's next point is requested one iteration ahead)
+        float2 pa[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { const int i = t + k * 1024; pa[k] = i < n_rays ? sc.pts[i] : make_float2(0.f, 0.f); }
         float4 q;
         if (sc.win_key) {                                          // (uniform)
             float wp[4]; unsigned long long wkey;
@@ -740,36 +991,54 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         if (ride_cells) { ride_h = ride.cell_hits[ride_cell]; ride_nh = ride.cell_nohit[ride_cell]; ride_v = ride.map[ride_cell]; }
         if (ride_ray) ride_p = ride.pts[ride_r];
         for (int i = t; i < 4 * K2_NBUCK; i += 1024) pos_s[i] = 0;  // (the histogram, then the running positions)
-        if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; }
+        if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; s_nmix = 0; s_nsel = 0; }
         __syncthreads();
         K2_STAMP(6)
-        int bkt[RPT];                                               // a ray's bucket (class * 1024 + slope bucket), -1: not valid
+        // selection: the rays this workgroup needs, compacted (wave by wave: the order does not matter, the records go by ray index)
+        {
+            const float centre = (float)xcd + 0.5f, halfw = 0.5f + 8.0f / (float)rB + 0.02f;
+            const bool all = is_core || !(fabsf(q.x) < 16000.0f && fabsf(q.y) < 16000.0f);
+#pragma unroll
+            for (int k = 0; k < RPT; k++) {
+                const int i = t + k * 1024;
+                if (k * 1024 < n_rays) {                            // (uniform)
+                    const bool in = i < n_rays, member = in && (all || k2_arc_member(pa[k], q, centre, halfw));
+                    const unsigned long long mb = __ballot(member);
+                    if (mb) {
+                        int base;
+                        SH_WAVE_FETCH(base, atomicAdd(&s_nsel, (int)__popcll(mb)))
+                        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+                        if (member) { order_s[slot] = (unsigned short)i; selp_s[slot] = pa[k]; }
+                    }
+                    if (in && !member) { k2_rayA z; z.dxc = 0; z.sdyc = 0; z.lim2 = 0; z.flags = 0; recA_s[i] = z; }
+                }
+            }
+        }
+        __syncthreads();
+        const int n_sel = s_nsel;
+        int bkt[RPT], bray[RPT];                                    // a selected ray's bucket (class * 1024 + slope bucket; -1: not valid) and index
         int my_R = 0, my_total = 0;
 #pragma unroll
-        for (int k = 0; k < RPT; k++) bkt[k] = -1;
+        for (int k = 0; k < RPT; k++) { bkt[k] = -1; bray[k] = 0; }
 #pragma unroll 1
-        for (int it = 0; it * 1024 < n_rays; it++) {                // (rolled: k2_make_ray is kilobytes of code, fetched once per launch)
-            const int i = t + it * 1024;
-            int bb = -1;
-            const float2 p = p_next;
-            if (i + 1024 < n_rays) p_next = sc.pts[i + 1024];
-            if (i < n_rays) {
-                const cs_ray r = k2_make_ray(p, size, q, sc.scale, sc.hole_width);
-                k2_byidx ee; ee.dxc = r.dxc; ee.sdyc = r.smin * r.dyc; ee.lim2 = r.lim2;
-                ee.flags = (r.valid ? 1 : 0) | (r.major_x ? 2 : 0) | ((r.smaj + 1) << 2);
-                byidx_s[i] = ee;
+        for (int it = 0; it * 1024 < n_sel; it++) {                 // (rolled: k2_make_ray is kilobytes of code, fetched once per launch)
+            const int j = t + it * 1024;
+            int bb = -1, ri = 0;
+            if (j < n_sel) {
+                ri = (int)order_s[j];
+                const cs_ray r = k2_make_ray(selp_s[j], size, q, sc.scale, sc.hole_width);
+                k2_rayA ee; k2_rayB eb; double ec;
+                k2_ray_record(r, ee, eb, ec);
+                recA_s[ri] = ee; recB_s[ri] = eb; recC_s[ri] = ec;
                 if (r.valid) {
-                    k2_vprof vv; vv.derrorv = r.derrorv; vv.incv = r.incv; vv.lim2 = r.lim2; vv.lim1 = r.lim1;
-                    vprof_s[i] = vv;
-                    const float tt = r.dxc > 0 ? (float)ee.sdyc / (float)r.dxc : 0.0f;
-                    bb = (r.major_x ? (r.smaj >= 0 ? 0 : 1) : (r.smaj >= 0 ? 2 : 3)) * K2_NBUCK + rs_bucket(tt);
+                    bb = k2_ray_bucket(ee);
                     atomicAdd(&pos_s[bb], 1);
                     my_R = max(my_R, r.dxc);
                     my_total += r.dxc + 1;
                 }
             }
 #pragma unroll
-            for (int k = 0; k < RPT; k++) if (k == it) bkt[k] = bb;
+            for (int k = 0; k < RPT; k++) if (k == it) { bkt[k] = bb; bray[k] = ri; }
         }
         for (int off = 32; off > 0; off >>= 1) {                   // one LDS atomic per wave, not per ray (same address)
             my_R = max(my_R, __shfl_down(my_R, off, 64));
@@ -778,6 +1047,26 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
         if (lane_ == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_total, my_total); }
         __syncthreads();
         K2_STAMP(7)
+        // the rays whose far steps this workgroup's XCD draws: with arcs the octant's (none for a core workgroup), else the XCD's
+        // eighth of the scan by index -- valid rays that reach beyond the zone, in an order every workgroup of the XCD agrees on
+        // (wavefront, pass, lane: the threads' rays are the same in all of them)
+        unsigned long long ownb[RPT];
+        int own_cnt = 0;
+        {
+            const int c0 = (int)(((long long)n_rays * xcd) >> 3), c1 = (int)(((long long)n_rays * (xcd + 1)) >> 3);
+#pragma unroll
+            for (int k = 0; k < RPT; k++) {
+                const int i = t + k * 1024;
+                bool own = false;
+                if (i < n_rays && !(arcs && is_core)) {
+                    const k2_rayA e = recA_s[i];
+                    own = (e.flags & K2_F_VALID) && e.dxc >= K2_ZONE && (arcs ? k2_ray_octant(e) == xcd : (i >= c0 && i < c1));
+                }
+                ownb[k] = __ballot(own);
+                own_cnt += (int)__popcll(ownb[k]);
+            }
+            if (lane_ == 0) wown[wid] = own_cnt;
+        }
         {   // exclusive prefix over the 4096 bins: 4 consecutive bins per thread
             int v[4], sum = 0;
 #pragma unroll
@@ -795,19 +1084,22 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
             for (int k = 0; k < 4; k++) { start[4 * t + k] = (start_t)base; pos_s[4 * t + k] = base; base += v[k]; }     // (each thread its own four bins)
             if (t == 1023) start[4 * K2_NBUCK] = (start_t)base;
         }
-        __syncthreads();
+        {
+            int obase = 0;
+            for (int w = 0; w < 16; w++) { const int c = wown[w]; n_own += c; obase += w < wid ? c : 0; }
 #pragma unroll
-        for (int it = 0; it < RPT; it++) {
-            const int i = t + it * 1024;
-            if (i < n_rays && bkt[it] >= 0) {
-                const k2_byidx ee = byidx_s[i];                    // (this thread's own store)
-                const int pos = atomicAdd(&pos_s[bkt[it]], 1);
-                k2_cand c; c.dxc = ee.dxc; c.sdyc = ee.sdyc; c.lim2 = ee.lim2; c.ray = i;
-                cand_s[pos] = c;
+            for (int k = 0; k < RPT; k++) {
+                if ((ownb[k] >> lane_) & 1ull)
+                    own_s[obase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ownb[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ownb[k], 0u))] = (unsigned short)(t + k * 1024);
+                obase += (int)__popcll(ownb[k]);
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < RPT; it++)
+            if (bkt[it] >= 0) order_s[atomicAdd(&pos_s[bkt[it]], 1)] = (unsigned short)bray[it];
         R = s_R; x1 = sh_f2i(q.x); y1 = sh_f2i(q.y);
-        if (blockIdx.x == 0 && t == 0) {                           // what the host reads: reach, blended pixels, the robot's pixel
+        if (blockIdx.x == 0 && t == 0) {                           // what the host reads: reach, blended pixels, the robot's pixel (workgroup 0 holds every ray)
             counters[0] = R; counters[2] = s_total; counters[3] = x1; counters[4] = y1;
             if (sc.total_out) *sc.total_out = s_total;
             // the pixels this update can change lie in the scan's bounding square: the partial host mirror
@@ -818,7 +1110,6 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
             }
         }
         __syncthreads();
-        n_valid = (int)start[4 * K2_NBUCK];
         if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) {         // robot outside the map: nothing is drawn (:509-512)
             if (ride.on) { k3_ride rd = ride; if (sc.win_key) rd.d_pose = s_wpose; k2_ride_tail(rd, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p); }   // (the ObstacleMap has its own test, at its own scale :557-560)
             return;
@@ -826,43 +1117,33 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     } else {
         R = counters[0]; x1 = counters[3]; y1 = counters[4];
         if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) return;   // robot outside the map: nothing is drawn (:509-512)
-        if (threadIdx.x == 0) { s_nextA = 0; s_nextB = 0; }
+        if (threadIdx.x == 0) { s_nextA = 0; s_nextB = 0; s_nmix = 0; }
         for (int i = threadIdx.x; i <= 4 * K2_NBUCK; i += 1024) start[i] = (start_t)start_g[i];
         __syncthreads();
-        n_valid = (int)start[4 * K2_NBUCK];
     }
     K2_STAMP(1)
-    const k2_cand *cand = BUILD ? cand_s : cand_g;
-    const k2_vprof *vps = BUILD ? vprof_s : vprof_g;
-    const k2_byidx *byidx = BUILD ? byidx_s : byidx_g;
+    const k2_rayA *recA = BUILD ? recA_s : recA_g;
+    const k2_rayB *recB = BUILD ? recB_s : recB_g;
+    const double *recC = BUILD ? recC_s : recC_g;
+    const order_t *order = BUILD ? (const order_t *)order_s : (const order_t *)order_g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // Work items are dealt to the workgroups round-robin and inside a workgroup to whichever wavefront is free (an LDS
     // counter): an item costs what its pixels' hit lists cost, and a workgroup is only as fast as its slowest wavefront.
-    // T1: the zone, from the centre outwards (the closer to the robot, the more rays cross a pixel: the longest items start
-    // first).  About n / (2 pi r) rays cross a pixel at distance r, and a pixel has a fifth more candidates than that: two pixels
-    // per wavefront from rB on (~17 candidates for 32 lanes), four from rC on (~7 for 16 lanes) -- a pixel with more candidates
-    // than its lanes sends the whole item down the one-pixel path, which costs as much as the pixels it holds.
+    // The zone: the central pixels (Chebyshev radius < rB, numbered from the robot's pixel outwards -- the closer, the more rays cross
+    // a pixel: the longest items start first) are one wavefront's each; from rB on one lane's (k2_lane_pixels).
     const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R, n_pix = (2 * Z + 1) * (2 * Z + 1);
-    int rB = (sc.rb_num * n_valid + 1079) / 1080, rC = (sc.rc_num * n_valid + 1079) / 1080;
-    rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB; rC = rC < rB ? rB : rC > K2_ZONE ? K2_ZONE : rC;
-    const int pA = min((2 * rB - 1) * (2 * rB - 1), n_pix), pB = min((2 * rC - 1) * (2 * rC - 1), n_pix);
-    const int nA = pA, nB = (pB - pA + 1) / 2, nC = (n_pix - pB + 3) / 4;
-    for (;;) {
-        int k;
-        SH_WAVE_FETCH(k, atomicAdd(&s_nextA, 1))
-        const int item = blockIdx.x + k * n_pix_wgs;
-        if (item >= nA + nB + nC) break;
-        K2_ITEM_T0
-        int pix0 = item, lim = n_pix, lg = 0;
-        if (item >= nA + nB) { pix0 = pB + 4 * (item - nA - nB); lg = 2; }
-        else if (item >= nA) { pix0 = pA + 2 * (item - nA); lim = pB; lg = 1; }
-        k2_wave_group<T>(pix0, lim, lg, x1, y1, size, byidx, vps, n_rays, cand, start, map, alpha, sval[wv]);
-        K2_ITEM_T1(0, item)
-    }
-    K2_STAMP(2)
+    const int pA = min((2 * rB - 1) * (2 * rB - 1), n_pix);
+    const int nA = pA;                                              // central pixels: one item each
+    const int nL = (n_pix - pA + 63) / 64;                          // no arcs: the rest of the zone in ring order, 64 pixels an item
+    const int npo = Z >= rB ? (Z * (Z + 1) - rB * (rB - 1)) / 2 : 0, nLo = (npo + 63) / 64;    // arcs: an octant's pixels of the rings rB .. Z
+    // (the dealing: a core workgroup's items are the central ones, a sector workgroup's its octant's; without arcs everything goes round)
+    const int zone_first = !arcs ? (int)blockIdx.x : is_core ? wg_in_xcd * 8 + xcd : wg_in_xcd - sc.ncore;
+    const int zone_step = !arcs ? n_pix_wgs : is_core ? sc.ncore * 8 : wgs_in_xcd - sc.ncore;
+    const int zone_items = !arcs ? nA + nL : is_core ? nA : nLo;
     // T3: one lane per (ray, step) beyond the zone, ray = an entry of the sorted table, steps in blocks of 64.  Software
-    // pipeline: an item's pixel is requested when the item is fetched, one iteration before its turn -- the map sits in HBM /
-    // Infinity Cache, a microsecond away.
+    // pipeline: an item's pixel is requested when the item is fetched, TWO iterations before its turn -- the map sits in HBM /
+    // Infinity Cache, a microsecond away, and the phase is bound by that latency, not by its instructions (an item took 1.15 us with
+    // one item in flight per wavefront whether its lanes ran 250 or 60 instructions).
     // (Measured and rejected, round 3: sectors of equal WORK instead of equal counts -- a prefix sum over the rays' blocks of 64
     // steps in the table phase, bounds where it passes k/8 of the total, a sector's blocks ending with its own longest ray.  On the
     // benchmark scan the equal-count sectors hold 574 .. 1620 non-empty blocks, but their XCDs finish within 1.5 us of each other
@@ -872,126 +1153,155 @@ k2_pixels(const k2_scan sc, const k2_byidx *__restrict__ byidx_g, const k2_vprof
     // the XCDs by sector -- XCD s (workgroup b runs on XCD b % 8) draws the s-th eighth of the scan: a ray's pixels share their
     // 128-byte lines with its neighbours' (at r = 600 px adjacent rays are 3.5 px apart), and a line should meet one L2.
     const int nblk = R >= K2_ZONE ? (R - K2_ZONE) / 64 + 1 : 0;      // steps K2_ZONE .. R
-    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_in_xcd = (n_pix_wgs - xcd + 7) >> 3;
-    const int c0 = (int)(((long long)n_rays * xcd) >> 3), n_sec = (int)(((long long)n_rays * (xcd + 1)) >> 3) - c0;
-    const int n_t3 = nblk * n_sec;
+    const int c0 = (int)(((long long)n_rays * xcd) >> 3);            // (!BUILD: the XCD's eighth of the scan by index; BUILD: the list own_s)
+    const int n_sec = BUILD ? n_own : (int)(((long long)n_rays * (xcd + 1)) >> 3) - c0;
+    const int t3_first = arcs ? wg_in_xcd - sc.ncore : wg_in_xcd, t3_step = arcs ? wgs_in_xcd - sc.ncore : wgs_in_xcd;
+    const int n_t3 = (K2_EXP == 6 || K2_EXP == 7) ? 0 : nblk * n_sec;      // (K2_EXP 5 / 6 / 7: no zone items / no step items / tables only)
     const float rcp_nv = __builtin_amdgcn_rcpf((float)(n_sec > 0 ? n_sec : 1));
 #define K2_FETCH(it, more_)                                                                              \
     {                                                                                                   \
         int k_;                                                                                         \
         SH_WAVE_FETCH(k_, atomicAdd(&s_nextB, 1))                                                       \
-        const int item_ = wg_in_xcd + k_ * wgs_in_xcd;                                                  \
+        const int item_ = t3_first + k_ * t3_step;                                                      \
         (it).ptr = -1;                                                                                  \
         more_ = item_ < n_t3;                                                                           \
         if (more_) {                                                                                    \
             int blk_ = (int)((float)item_ * rcp_nv);       /* item / n_sec (item < 2^24: settled exactly below) */ \
             int ri_ = item_ - blk_ * n_sec;                                                             \
             if (ri_ < 0) { blk_--; ri_ += n_sec; } else if (ri_ >= n_sec) { blk_++; ri_ -= n_sec; }     \
-            ri_ += c0;                                                                                  \
-            const k2_byidx me_ = byidx[ri_];               /* (uniform: an LDS broadcast) */             \
+            ri_ = BUILD ? (int)own_s[ri_] : ri_ + c0;                                                   \
+            const k2_rayA me_ = recA[ri_];                 /* (uniform: an LDS broadcast) */             \
             const int x_ = K2_ZONE + blk_ * 64 + lane;                                                  \
-            if ((me_.flags & 1) && x_ <= me_.dxc) {                                                     \
+            if ((me_.flags & K2_F_VALID) && x_ <= me_.dxc) {                                            \
                 const int smaj_ = ((me_.flags >> 2) & 3) - 1;                                           \
                 const int dyc_ = me_.sdyc < 0 ? -me_.sdyc : me_.sdyc;                                   \
-                const T N_ = (T)2 * dyc_ * x_ - me_.dxc, D_ = (T)2 * me_.dxc;                           \
-                int m_ = 0;                                                                             \
-                if (N_ > 0) {      /* m(x) = min(x, ceil(N / D)), the closed form of the error recurrence (:394-396, :433-441) */ \
-                    T q_;                                                                               \
-                    if (sizeof(T) == 4) {  /* N < 2^29, D < 2^16: the float estimate of floor(N / D) is within one; one multiply settles it */ \
-                        q_ = (T)((float)N_ * __builtin_amdgcn_rcpf((float)D_));                         \
-                        T r_ = N_ - q_ * D_;                                                            \
-                        if (r_ < 0) { q_--; r_ += D_; } else if (r_ >= D_) { q_++; r_ -= D_; }          \
-                        q_ += r_ > 0 ? 1 : 0;                      /* ceil */                            \
-                    } else q_ = (N_ + D_ - 1) / D_;                                                     \
-                    m_ = q_ < (T)x_ ? (int)q_ : x_;                                                     \
-                }                                                                                       \
+                const int m_ = k2_minor_step<T>(x_, me_.dxc, dyc_, recC[ri_]);                          \
                 const int b_ = me_.sdyc < 0 ? -m_ : m_, a_ = smaj_ < 0 ? -x_ : x_;                      \
-                (it).dx = (me_.flags & 2) ? a_ : b_; (it).dy = (me_.flags & 2) ? b_ : a_;               \
-                (it).ray = ri_; (it).lim2 = me_.lim2;                                                   \
-                (it).ptr = (y1 + (it).dy) * size + (x1 + (it).dx);         /* (step pixels of a clipped ray lie inside the map) */ \
-                (it).pix = map[(it).ptr];                                                               \
+                const int dx_ = (me_.flags & K2_F_MAJX) ? a_ : b_, dy_ = (me_.flags & K2_F_MAJX) ? b_ : a_; \
+                (it).x = x_; (it).b = b_; (it).ray = ri_; (it).lim2 = me_.lim2; (it).flags = me_.flags;  \
+                (it).ptr = (y1 + dy_) * size + (x1 + dx_);                 /* (step pixels of a clipped ray lie inside the map) */ \
+                (it).pix = K2_EXP_LOAD(map, (it).ptr);                                                  \
             }                                                                                           \
         }                                                                                               \
     }
-    k2_t3 cur, nxt;
-    cur.ptr = -1; cur.dx = cur.dy = cur.ray = cur.lim2 = 0; cur.pix = 0; nxt = cur;
-    bool more = false;
-    if (n_t3 > 0) K2_FETCH(cur, more)
-    while (more) {
+    // (the first two items' pixels are requested before the zone is drawn: disjoint pixels -- steps below K2_ZONE there, from
+    // K2_ZONE on here -- and the zone's dependent chains hide the map's latency)
+    k2_t3 cur, nxt, nx2;
+    cur.ptr = -1; cur.x = cur.b = cur.ray = cur.lim2 = cur.flags = 0; cur.pix = 0; nxt = cur; nx2 = cur;
+    bool more0 = false, more1 = false, more2 = false;
+    if (n_t3 > 0) K2_FETCH(cur, more0)
+    if (more0) K2_FETCH(nxt, more1)
+    for (;;) {
+        int k;
+        SH_WAVE_FETCH(k, atomicAdd(&s_nextA, 1))
+        const int item = zone_first + k * zone_step;
+        if (item >= zone_items || K2_EXP == 5 || K2_EXP == 7) break;
         K2_ITEM_T0
-        K2_FETCH(nxt, more)
+        if (is_core && item < nA) {
+            int ddx, ddy;
+            k2_ring_pixel(item, ddx, ddy);
+            const int X = x1 + ddx, Y = y1 + ddy;
+            if (X >= 0 && X < size && Y >= 0 && Y < size) k2_wave_pixel<T>(X, Y, x1, y1, size, recA, recB, n_rays, order, start, map, alpha, sval[wv]);
+        } else {
+            int ddx, ddy;
+            bool exists;
+            if (arcs) { const int j = 64 * item + lane; exists = j < npo; k2_octant_pixel(xcd, exists ? j : 0, rB, ddx, ddy); }
+            else      { const int j = pA + 64 * (item - nA) + lane; exists = j < n_pix; k2_ring_pixel(exists ? j : 0, ddx, ddy); }
+            k2_lane_pixels<T>(ddx, ddy, exists, x1, y1, size, recA, recB, order, start, map, alpha, s_mixq, &s_nmix, K2_MIXQ);
+        }
+        K2_ITEM_T1(0, item)
+    }
+    K2_STAMP(2)
+    // T3 (see above: its first two items were fetched before the zone)
+    while (more0) {
+        K2_ITEM_T0
+        more2 = false; nx2.ptr = -1;
+        if (more1) K2_FETCH(nx2, more2)
         if (cur.ptr >= 0) {
             // Out here rays are more than a pixel apart: nearly every pixel's candidate range holds its own ray and nothing else
             // -- then it is blended at once (no hit test, no ordering).  A diagonal pixel (the quadrant's other class draws there
-            // too) or a range with company goes through the full lookup.
-            const int adx = cur.dx < 0 ? -cur.dx : cur.dx, ady = cur.dy < 0 ? -cur.dy : cur.dy;
+            // too) or a range with company goes through the full lookup.  (The lane knows its pixel in its ray's own frame --
+            // class, major offset x, minor offset b: the range needs no classification.)
+            const int smaj = ((cur.flags >> 2) & 3) - 1, ab = cur.b < 0 ? -cur.b : cur.b;
             int lo = 0, hi = 2;
-            if (adx != ady) {
-                const bool xm = adx > ady;
-                rs_range(start, xm ? (cur.dx > 0 ? 0 : 1) : (cur.dy > 0 ? 2 : 3), xm ? adx : ady, xm ? cur.dy : cur.dx, 0.0f, lo, hi);
-            }
+            if (ab != cur.x) rs_range(start, (cur.flags & K2_F_MAJX) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3), cur.x, cur.b, 0.0f, lo, hi);
+            const int v = cur.x <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(cur.lim2, cur.flags, recB[cur.ray], cur.x);
             if (hi - lo == 1) {
-                const int a = adx > ady ? adx : ady;
-                const int v = a <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_closed(vps[cur.ray], a);
-                map[cur.ptr] = k2_blend(cur.pix, v, alpha);
+                K2_EXP_STORE(map, cur.ptr, k2_blend(cur.pix, v, alpha));
+            } else if (ab != cur.x && hi - lo <= K2_MAXHIT) {
+                // Company in the range (up to step ~170 the neighbouring rays are less than a pixel away): the OTHER rays of the
+                // range are tested -- this lane's own ray draws the pixel by construction.  A hit of a lower ray index ends the
+                // matter (that ray's lane owns the pixel); hits of higher indices are blended after this lane's value, in index
+                // order (at most K2_MAXHIT - 1 of them: kept sorted in registers).
+                int oidx[K2_MAXHIT - 1], oval[K2_MAXHIT - 1], no = 0;
+                bool owner = true;
+                for (int ci = lo; ci < hi && owner; ci++) {
+                    const int ray = (int)order[ci];
+                    if (ray == cur.ray) continue;
+                    const k2_rayA e = recA[ray];
+                    k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
+                    if (!k2_hit<T>(c, cur.x, cur.b)) continue;
+                    if (ray < cur.ray) { owner = false; break; }
+                    const int ov = cur.x <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(e.lim2, e.flags, recB[ray], cur.x);
+                    int posn = 0;
+#pragma unroll
+                    for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 < no && oidx[s2] < ray) posn++;
+#pragma unroll
+                    for (int s2 = K2_MAXHIT - 2; s2 >= 1; s2--) if (s2 > posn && s2 <= no) { oidx[s2] = oidx[s2 - 1]; oval[s2] = oval[s2 - 1]; }
+#pragma unroll
+                    for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 == posn) { oidx[s2] = ray; oval[s2] = ov; }
+                    no++;
+                }
+                if (owner) {
+                    uint16_t pix = k2_blend(cur.pix, v, alpha);
+#pragma unroll
+                    for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 < no) pix = k2_blend(pix, oval[s2], alpha);
+                    K2_EXP_STORE(map, cur.ptr, pix);
+                }
             } else {
                 int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh, min_ray;
                 bool overflow;
-                k2_lookup<T, K2_MAXHIT>(cand, vps, start, cur.dx, cur.dy, hidx, hval, nh, overflow, min_ray);
+                const int a_s = smaj < 0 ? -cur.x : cur.x;
+                const int cdx = (cur.flags & K2_F_MAJX) ? a_s : cur.b, cdy = (cur.flags & K2_F_MAJX) ? cur.b : a_s;
+                k2_lookup<T, K2_MAXHIT>(recA, recB, order, start, cdx, cdy, hidx, hval, nh, overflow, min_ray);
                 if (min_ray == cur.ray) {                          // the owner
                     if (overflow) {
-                        const int slot = __hip_atomic_fetch_add(&counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (slot < cap_conflict) __hip_atomic_store(&conflict_pix[slot], cur.ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        K2_EXP_STORE(map, cur.ptr, k2_lane_draw_ordered<T>(recA, recB, order, start, cdx, cdy, cur.pix, alpha));
                     } else {
                         uint16_t pix = cur.pix;
 #pragma unroll
                         for (int s2 = 0; s2 < K2_MAXHIT; s2++) if (s2 < nh) pix = k2_blend(pix, hval[s2], alpha);
-                        map[cur.ptr] = pix;
+                        K2_EXP_STORE(map, cur.ptr, pix);
                     }
                 }
             }
         }
-        cur = nxt;
+        cur = nxt; nxt = nx2; more0 = more1; more1 = more2;
         K2_ITEM_T1(2, 0)
     }
 #undef K2_FETCH
-    // pixels with more hits than a lane orders, queued above: the last workgroup to finish draws them, one wavefront
-    // per pixel.  Queue entries are published write-through and the count is an agent-scope atomic; every wave
-    // drains its stores before the workgroup takes its arrival ticket (counters[6], zero between launches).
     K2_STAMP(3)
     if (BUILD && ride.on) { k3_ride rd = ride; if (sc.win_key) rd.d_pose = s_wpose; k2_ride_tail(rd, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p); }
-    if (sc.span) k2_row_spans<T>(byidx, n_rays, x1, y1, size, n_pix_wgs, sc.span);    // (only while a host mirror is being kept: slamhip_cs_holemap_mirror_async)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sc.span) k2_row_spans<T>(recA, n_rays, x1, y1, size, n_pix_wgs, sc.span);    // (only while a host mirror is being kept: slamhip_cs_holemap_mirror_async)
     __syncthreads();
     K2_STAMP(4)
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(&counters[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == n_pix_wgs - 1;
-        if (s_last) __hip_atomic_store(&counters[6], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the zone pixels with hits inside a V that the one-lane items queued: the ordered way, four pixels to a wavefront
+    const int nq = s_nmix < K2_MIXQ ? s_nmix : K2_MIXQ;
+    for (int item = wv; item * 4 < nq; item += 16) {
+        const int qi = item * 4 + (lane >> 4);
+        const int ptr = s_mixq[qi < nq ? qi : 0];
+        const int py = ptr / size, px = ptr - py * size;
+        k2_wave_group<T>(px - x1, py - y1, qi < nq, 2, x1, y1, size, recA, recB, n_rays, order, start, map, alpha, sval[wv]);
     }
-    __syncthreads();
     K2_STAMP(5)
-    if (!s_last) return;
-    int n_conf = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n_conf > cap_conflict) n_conf = cap_conflict;
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&counters[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (at rest between launches, like the ticket)
-    if (threadIdx.x == 0) counters[5] = n_conf;                     // (developer statistics: SLAMHIP_K2_STATS)
-    for (int item = wv; item < n_conf; item += 16) {
-        const int ptr = __hip_atomic_load(&conflict_pix[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k2_wave_pixel<T>(ptr % size, ptr / size, x1, y1, size, byidx, vps, n_rays, cand, start, map, alpha, sval[wv]);
-    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
 int32_t cs_holemap_alloc(slamhip_cs *cs)
 {
-    const size_t npix = (size_t)cs->hs * cs->hs;
     SH_HIP(hipMalloc(&cs->d_k2_counters, sizeof(int) * 8));
     SH_HIP(hipMemsetAsync(cs->d_k2_counters, 0, sizeof(int) * 8, cs->ctx->stream));
     SH_HIP(hipMalloc(&cs->d_k2_start, sizeof(int) * (4 * K2_NBUCK + 1)));
-    cs->cap_conflict = (int)(npix < (1u << 22) ? npix : (1u << 22));
-    SH_HIP(hipMalloc(&cs->d_conflict_pix, sizeof(int) * (size_t)cs->cap_conflict));
     SH_HIP(hipMalloc(&cs->d_hole_dirty, sizeof(int) * 4));
     return cs_holemap_dirty_set(cs, true);
 }
@@ -1006,7 +1316,7 @@ int32_t cs_holemap_dirty_set(slamhip_cs *cs, bool all)
 void cs_holemap_free(slamhip_cs *cs)
 {
     (void)hipFree(cs->d_rays); (void)hipFree(cs->d_k2_cand); (void)hipFree(cs->d_k2_vprof); (void)hipFree(cs->d_k2_start);
-    (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_conflict_pix); (void)hipFree(cs->d_hole_dirty);
+    (void)hipFree(cs->d_k2_counters); (void)hipFree(cs->d_hole_dirty);
 }
 
 // with_obstacle: the ObstacleMap update of this scan rides on the launch (obstacle_dev.h); scans too large for the in-kernel
@@ -1035,9 +1345,9 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         if (cs->d_k2_vprof) (void)hipFree(cs->d_k2_vprof);
         cs->d_rays = nullptr; cs->d_k2_cand = nullptr; cs->d_k2_vprof = nullptr; cs->cap_rays = 0;
         const int cap = n + n / 4 + 64;
-        SH_HIP(hipMalloc(&cs->d_rays, sizeof(k2_byidx) * (size_t)cap));
-        SH_HIP(hipMalloc(&cs->d_k2_cand, sizeof(k2_cand) * (size_t)cap));
-        SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_vprof) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_rays, sizeof(k2_rayA) * (size_t)cap));               // the rays' records by index, parts A, B ...
+        SH_HIP(hipMalloc(&cs->d_k2_vprof, sizeof(k2_rayB) * (size_t)cap));
+        SH_HIP(hipMalloc(&cs->d_k2_cand, (sizeof(double) + sizeof(int)) * (size_t)cap));   // ... part C, and behind it the sorted table of ray indices
         cs->cap_rays = cap;
     }
     k2_scan sc;
@@ -1049,13 +1359,15 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         sc.win_key = (const unsigned long long *)win->d_key; sc.win_offs = win->d_offs_flat; sc.win_n_offs = win->n_offs; sc.win_bx = win->bx; sc.win_by = win->by; sc.win_bth = win->bth;
         sc.win_pose_out = const_cast<float *>(d_pose); sc.win_mail = win->mail; sc.win_seq = win->seq;
     }
-    static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, rc_env = getenv("SLAMHIP_K2_RC") ? atoi(getenv("SLAMHIP_K2_RC")) : 28;
-    sc.rb_num = rb_env; sc.rc_num = rc_env;                        // (radii, per 1080 rays, from which a wavefront takes two / four zone pixels)
+    static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, ncore_env = getenv("SLAMHIP_K2_NCORE") ? atoi(getenv("SLAMHIP_K2_NCORE")) : 4;
+    sc.rb_num = rb_env < 1 ? 1 : rb_env;                           // (radius, per 1080 rays, from which a zone pixel is one lane's)
+    sc.ncore = 0;                                                  // (set below, once the grid is known)
     {
         sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
         if (!build)
             hipLaunchKernelGGL(k2_prepare, dim3(1), dim3(1024), 0, ctx->stream, cs->d_pts, n, cs->hs, cs->hscale, d_pose, h_pxcs,
-                               hole_width, (k2_byidx *)cs->d_rays, (k2_cand *)cs->d_k2_cand, (k2_vprof *)cs->d_k2_vprof, cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty);
+                               hole_width, (k2_rayA *)cs->d_rays, (k2_rayB *)cs->d_k2_vprof, (double *)cs->d_k2_cand, (int *)((double *)cs->d_k2_cand + cs->cap_rays),
+                               cs->d_k2_start, cs->d_k2_counters, (int *)cs->d_key + 6, cs->d_hole_dirty);
         // One round of resident workgroups, one per CU (a second round would start when the first drains; with the tables in LDS
         // one workgroup per CU measured best).
         static const int grid_env = getenv("SLAMHIP_K2_GRID") ? atoi(getenv("SLAMHIP_K2_GRID")) : 0;
@@ -1066,12 +1378,22 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         // (the rays beyond the zone are dealt to eight XCD sectors, sector s to the workgroups b with b % 8 == s: fewer than eight
         // workgroups would leave sectors undrawn -- the developer override is clamped)
         const int grid = grid_env > 0 ? (grid_env < 8 ? 8 : grid_env) : build ? cus : 2 * cus;
+        // Arcs (k2_pixels): core workgroups with every ray + sector workgroups with their octant's rays.  Not while a host mirror's row
+        // spans are kept (k2_row_spans walks every ray in every workgroup), not for grids that leave an XCD without a sector
+        // workgroup, not for hole widths whose extension (:525-530) may turn a ray round or leave the range the margin is proved for.
+        {
+            const float hw_px = hole_width * cs->hscale * 0.5f;
+            const bool hw_ok = hw_px >= 0.0f && hw_px < 8000.0f;
+            const int nc = ncore_env < 0 ? 0 : ncore_env;
+            if (build && nc > 0 && !sc.span && hw_ok && cs->hs <= 16384 && grid % 8 == 0 && grid / 8 >= nc + 1) sc.ncore = nc;
+        }
 #define K2_PIXELS(B, T) {                                                                                                   \
             static std::atomic<unsigned long long> attr_set{0};              /* one bit per device (the attribute is the device's) */   \
             if (!((attr_set.load(std::memory_order_acquire) >> (ctx->device & 63)) & 1ull)) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); attr_set.fetch_or(1ull << (ctx->device & 63), std::memory_order_release); } \
-            hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_byidx *)cs->d_rays, \
-                               (const k2_vprof *)cs->d_k2_vprof, (const k2_cand *)cs->d_k2_cand, n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
-                               cs->hs, cs->d_hole, quality, cs->d_conflict_pix, cs->cap_conflict, grid, ride); }
+            hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_rayA *)cs->d_rays, \
+                               (const k2_rayB *)cs->d_k2_vprof, (const double *)cs->d_k2_cand, (const int *)((const double *)cs->d_k2_cand + cs->cap_rays), \
+                               n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
+                               cs->hs, cs->d_hole, quality, grid, ride); }
         if (build) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }
         else       { if (cs->hs <= 16384) K2_PIXELS(false, int) else K2_PIXELS(false, long long) }
 #undef K2_PIXELS
