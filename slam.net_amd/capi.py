@@ -39,10 +39,11 @@ def declared_symbols():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
+        so = os.environ.get("SLAMHIP_LIB") or SO_PATH            # (developer aid: an alternative build of the same ABI, for A/B timing on one box)
+        if not os.path.exists(so):
             raise ImportError("libslamhip.so not built at %s -- build it with hipcc (python -m slam.net_amd.build); "
-                              "slam.net_amd has no CPU fallback" % SO_PATH)
-        L = C.CDLL(SO_PATH)
+                              "slam.net_amd has no CPU fallback" % so)
+        L = C.CDLL(so)
         _declare(L)
         _lib = L
     return _lib

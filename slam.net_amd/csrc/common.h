@@ -122,6 +122,42 @@ __host__ __device__ static inline int32_t sh_abs(int32_t a) { return a < 0 ? sh_
         (dst) = __builtin_amdgcn_readfirstlane(v_);                                                 \
     }
 
+// Wave-wide sums / maxima / inclusive scans of an int in six DPP steps each (no LDS permutes: a ds_bpermute -- what __shfl_up / __shfl_down
+// compile to -- costs ~100 cycles of latency, and a reduction is six of them in a row).  Lanes whose source lies outside the row,
+// or whose row a broadcast step does not address, receive the identity.
+template <int CTRL, int ROWS> __device__ static __forceinline__ int sh_dpp_or0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false); }
+template <int CTRL, int ROWS> __device__ static __forceinline__ int sh_dpp_self(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }
+__device__ static __forceinline__ int sh_wave_scan_incl(int v)         // lane l: the sum of lanes 0 .. l
+{
+    v += sh_dpp_or0<0x111, 0xf>(v);         // row_shr:1
+    v += sh_dpp_or0<0x112, 0xf>(v);         // row_shr:2
+    v += sh_dpp_or0<0x114, 0xf>(v);         // row_shr:4
+    v += sh_dpp_or0<0x118, 0xf>(v);         // row_shr:8
+    v += sh_dpp_or0<0x142, 0xa>(v);         // row_bcast:15 -> rows 1, 3
+    v += sh_dpp_or0<0x143, 0xc>(v);         // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ static __forceinline__ int sh_wave_min_all(int v)            // in every lane (a readlane of lane 63: a uniform value)
+{
+    v = min(v, sh_dpp_self<0x111, 0xf>(v));
+    v = min(v, sh_dpp_self<0x112, 0xf>(v));
+    v = min(v, sh_dpp_self<0x114, 0xf>(v));
+    v = min(v, sh_dpp_self<0x118, 0xf>(v));
+    v = min(v, sh_dpp_self<0x142, 0xa>(v));
+    v = min(v, sh_dpp_self<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ static __forceinline__ int sh_wave_max_to_lane63(int v)     // valid in lane 63
+{
+    v = max(v, sh_dpp_self<0x111, 0xf>(v));
+    v = max(v, sh_dpp_self<0x112, 0xf>(v));
+    v = max(v, sh_dpp_self<0x114, 0xf>(v));
+    v = max(v, sh_dpp_self<0x118, 0xf>(v));
+    v = max(v, sh_dpp_self<0x142, 0xa>(v));
+    v = max(v, sh_dpp_self<0x143, 0xc>(v));
+    return v;
+}
+
 // Replica check (map updates run as replicas on every GPU; integer-exact kernels keep them bit-identical --
 // this is how a host verifies it).  Position-sensitive, order-independent: sum over i of mix64(i << 32 | word_i) mod 2^64, where
 // word_i is the element zero-extended from its own width (bit pattern for floats) and mix64 the SplitMix64 finaliser

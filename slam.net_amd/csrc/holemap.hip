@@ -44,17 +44,15 @@
 // which pixval leaves TS_NO_OBSTACLE (:406), ray index (= blend order)
 struct k2_cand { int dxc, sdyc, lim2, ray; };
 // A ray's record, by ray index, in three parts (structure of arrays: each part is read with one aligned LDS access):
-//   A  what a hit test needs: dxc, sdyc, lim2 = dx - 2*derrorv (:406), flags = valid | major_x << 1 | (smaj + 1) << 2 | wild << 4
-//   B  the V-profile's closed form beyond lim2: lim1 = dx - derrorv (:408), incv (:398), J = the number of carries of the ascending
-//      half (a per-ray constant: k2_vconst), d = derrorv (:379/:386)
+//   A  what a hit test needs: dxc, sdyc, lim2 = dx - 2*derrorv (:406), flags = valid | major_x << 1 | (smaj + 1) << 2
+//   B  d = derrorv (:379/:386): with lim2 everything the V-profile's closed form needs (lim1 = lim2 + d :408, incv = -65500 / d :398)
 //   C  1 / (2 * dxc) in binary64, correctly rounded: the minor offset of a step without a division (k2_minor_step)
 // The sorted table (`order`: rays by direction class and slope bucket) holds ray indices only.
 struct k2_vprof { int derrorv, incv, lim2, lim1; };   // (argument of the literal-capable closed form k2_pixval_closed)
 struct k2_rayA { int dxc, sdyc, lim2, flags; };
-struct k2_rayB { int lim1, incv, J, d; };
+struct k2_rayB { int d; };
 #define K2_F_VALID 1
 #define K2_F_MAJX 2
-#define K2_F_WILD 16                   // derrorv beyond 2^22: the V-profile is walked literally (k2_pixval_closed)
 
 struct cs_ray {
     int valid;
@@ -65,7 +63,7 @@ struct cs_ray {
     int incmaj, incmin;       // ptr increments after swap             (:372-373,:385)
     int major_x;              // 1: major axis is x
     int smaj, smin;           // coordinate signs along major / minor
-    int derrorv, incv, incerrorv, sincv;   // :379/:386, :398, :399, :374
+    int derrorv;              // :379/:386
     int lim2, lim1;           // dx - 2*derrorv, dx - derrorv          (:406,:408)
 };
 
@@ -116,10 +114,13 @@ __device__ static inline cs_ray k2_make_ray(const float2 p, int size, const floa
     const int xp = sh_f2i(px + x2p);                                       // :521
     const int yp = sh_f2i(py + y2p);                                       // :522
     // MathF.Sqrt is the IEEE square root.  (Not __fsqrt_rn: on this toolchain it lowers to the bare v_sqrt_f32, 1 ulp off
-    // for some inputs -- found by tests/fuzz_parity.py as a ray end one pixel out.  The binary64 square root of a binary32
-    // value, rounded once more to binary32, is the correctly rounded binary32 root: 53 >= 2 * 24 + 2.)
-    const float dist = (float)sqrt((double)(x2p * x2p + y2p * y2p));       // :524
-    const float add = __fdiv_rn(__fdiv_rn(hole_width * scale, 2.0f), dist); // :525
+    // for some inputs -- found by tests/fuzz_parity.py as a ray end one pixel out.  __builtin_sqrtf without fast-math IS the
+    // correctly rounded root -- v_sqrt_f32 plus a residual test of its neighbours: tools/ubench_sqrt.hip compares it with the
+    // binary64 root rounded once more for every one of the 2 139 095 040 non-negative finite inputs -- and a third of the
+    // binary64 detour's dependent chain, which is what a ray's making waits for since round 5.)
+    const float dist = __builtin_sqrtf(x2p * x2p + y2p * y2p);             // :524
+    // (:525 HoleWidth * Scale / 2 / dist: the halving is exact, so the uniform first division is a multiplication by 0.5f)
+    const float add = __fdiv_rn((hole_width * scale) * 0.5f, dist);         // :525
     x2p *= (1.0f + add);                                                   // :527
     y2p *= (1.0f + add);                                                   // :528
     const int x2 = sh_f2i(px + x2p);                                       // :529
@@ -160,9 +161,7 @@ __device__ static inline cs_ray k2_make_ray(const float2 p, int size, const floa
             r.incmaj = incmaj; r.incmin = incmin;
             r.major_x = major_x; r.smaj = smaj; r.smin = smin;
             r.derrorv = derrorv;
-            r.sincv = sh_sign(TS_OBSTACLE - TS_NO_OBSTACLE);               // :374
-            r.incv = (TS_OBSTACLE - TS_NO_OBSTACLE) / derrorv;             // :398
-            r.incerrorv = sh_wsub(TS_OBSTACLE - TS_NO_OBSTACLE, sh_wmul(derrorv, r.incv));   // :399
+            // (incv :398 and incerrorv :399 -- an integer division -- are formed where a value inside the V is needed: k2_pixval_fast)
             r.lim2 = sh_wsub(dx, sh_wmul(2, derrorv));                     // :406
             r.lim1 = sh_wsub(dx, derrorv);                                 // :408
         }
@@ -176,28 +175,31 @@ __device__ static inline cs_ray k2_make_ray(const float2 p, int size, const floa
 // descending half (x <= lim1) never carries, and on the ascending half the carry fires on the first J steps only:
 // before-correction error of step i while every step carries = u0 + i*g + d*(i-1), negative iff i*(g+d) < d - u0.
 static_assert(TS_OBSTACLE < TS_NO_OBSTACLE, "k2_pixval_closed assumes a falling V-profile");
+// absurd hole widths (half-width beyond 16M pixels): the closed form's intermediates could leave int32, where the
+// reference's unchecked arithmetic wraps -- the recurrence (:406-428) is walked literally instead (out of line: never taken in earnest)
+__device__ static __noinline__ int k2_pixval_literal(int d, int incv, int lim2, int lim1, int x)
+{
+    const int incerrorv = sh_wsub(TS_OBSTACLE - TS_NO_OBSTACLE, sh_wmul(d, incv));   // :399
+    int pixval = TS_NO_OBSTACLE, errorv = d / 2;                       // :402,:397
+    for (int xi = lim2 < 0 ? 0 : lim2 + 1; xi <= x; xi++) {
+        if (xi <= lim1) {                                              // :408
+            pixval = sh_wadd(pixval, incv);
+            errorv = sh_wadd(errorv, incerrorv);
+            if (errorv > d) { pixval = sh_wadd(pixval, -1); errorv = sh_wsub(errorv, d); }
+        } else {
+            pixval = sh_wsub(pixval, incv);
+            errorv = sh_wsub(errorv, incerrorv);
+            if (errorv < 0) { pixval = sh_wsub(pixval, -1); errorv = sh_wadd(errorv, d); }
+        }
+    }
+    return pixval;
+}
 __device__ static __forceinline__ int k2_pixval_closed(const k2_vprof p, int x)
 {
     if (x <= p.lim2) return TS_NO_OBSTACLE;
     const int d = p.derrorv;
+    if (d > (1 << 24)) return k2_pixval_literal(d, p.incv, p.lim2, p.lim1, x);
     const int incerrorv = sh_wsub(TS_OBSTACLE - TS_NO_OBSTACLE, sh_wmul(d, p.incv));   // :399, in (-d, 0]
-    if (d > (1 << 24)) {
-        // absurd hole widths (half-width beyond 16M pixels): the closed form's intermediates could leave int32, where the
-        // reference's unchecked arithmetic wraps -- walk the recurrence (:406-428) literally instead
-        int pixval = TS_NO_OBSTACLE, errorv = d / 2;                       // :402,:397
-        for (int xi = p.lim2 < 0 ? 0 : p.lim2 + 1; xi <= x; xi++) {
-            if (xi <= p.lim1) {                                            // :408
-                pixval = sh_wadd(pixval, p.incv);
-                errorv = sh_wadd(errorv, incerrorv);
-                if (errorv > d) { pixval = sh_wadd(pixval, -1); errorv = sh_wsub(errorv, d); }
-            } else {
-                pixval = sh_wsub(pixval, p.incv);
-                errorv = sh_wsub(errorv, incerrorv);
-                if (errorv < 0) { pixval = sh_wsub(pixval, -1); errorv = sh_wadd(errorv, d); }
-            }
-        }
-        return pixval;
-    }
     const int xs = p.lim2 < 0 ? 0 : p.lim2 + 1;
     const int xm = x < p.lim1 ? x : p.lim1;
     const int n1 = xm - xs + 1 > 0 ? xm - xs + 1 : 0;                          // steps of the descending half
@@ -208,29 +210,13 @@ __device__ static __forceinline__ int k2_pixval_closed(const k2_vprof p, int x)
     const int f = j < J ? j : J;
     return TS_NO_OBSTACLE + (n1 - j) * p.incv + f;                             // sincv = -1 (:374)
 }
-
-// The same closed form with its per-ray constants taken from the ray's record.  On the ascending half (x > lim1) the count of
-// descending steps is the constant N1 = max(lim1 - xs + 1, 0), hence u0 and the carry bound J are constants of the ray: k2_vconst
-// evaluates the very expressions of k2_pixval_closed once per ray, and a pixel's value needs no division.
-__device__ static __forceinline__ int k2_vconst_J(int d, int incv, int lim2, int lim1)
-{
-    const int incerrorv = sh_wsub(TS_OBSTACLE - TS_NO_OBSTACLE, sh_wmul(d, incv));       // :399
-    const int xs = lim2 < 0 ? 0 : lim2 + 1;
-    const int n1 = lim1 - xs + 1 > 0 ? lim1 - xs + 1 : 0;
-    const int u0 = d / 2 + n1 * incerrorv, g = -incerrorv;
-    int J = 0;
-    if (d - u0 > 0 && g + d != 0) J = (d - u0 + (g + d) - 1) / (g + d) - 1;
-    return J;
-}
+// A pixel's value inside a ray's V (x > lim2) from the ray's record: lim1 = lim2 + d (:406, :408), incv = -65500 / d (:398) -- one
+// integer division where a value is needed (a twentieth of the step lanes, the marked zone pixels) instead of two in every ray's
+// making, which is the table phase's critical chain.
 __device__ static __forceinline__ int k2_pixval_fast(int lim2, int flags, const k2_rayB B, int x)      // x > lim2
 {
-    if (flags & K2_F_WILD) { k2_vprof p; p.derrorv = B.d; p.incv = B.incv; p.lim2 = lim2; p.lim1 = B.lim1; return k2_pixval_closed(p, x); }
-    const int xs = lim2 < 0 ? 0 : lim2 + 1;
-    const int xm = x < B.lim1 ? x : B.lim1;
-    const int n1 = xm - xs + 1 > 0 ? xm - xs + 1 : 0;
-    const int j = (x - xs + 1) - n1;
-    const int f = j < B.J ? j : B.J;
-    return TS_NO_OBSTACLE + __mul24(n1 - j, B.incv) + f;                                  // (|n1 - j| < 2^23, |incv| <= 65500)
+    k2_vprof p; p.derrorv = B.d; p.incv = (TS_OBSTACLE - TS_NO_OBSTACLE) / B.d; p.lim2 = lim2; p.lim1 = sh_wadd(lim2, B.d);
+    return k2_pixval_closed(p, x);
 }
 // value of step x of the ray (A, B)
 __device__ static __forceinline__ int k2_value(const k2_rayA A, const k2_rayB B, int x)
@@ -242,12 +228,16 @@ __device__ static __forceinline__ void k2_ray_record(const cs_ray &r, k2_rayA &A
 {
     A.dxc = r.dxc; A.sdyc = r.smin * r.dyc; A.lim2 = r.lim2;
     A.flags = (r.valid ? K2_F_VALID : 0) | (r.major_x ? K2_F_MAJX : 0) | ((r.smaj + 1) << 2);
-    B.lim1 = r.lim1; B.incv = r.incv; B.J = 0; B.d = r.derrorv;
+    B.d = r.derrorv;
     C = 0.0;
-    if (r.valid) {
-        if (r.derrorv > (1 << 22)) A.flags |= K2_F_WILD;
-        else B.J = k2_vconst_J(r.derrorv, r.incv, r.lim2, r.lim1);
-        if (r.dxc > 0) C = 1.0 / (2.0 * (double)r.dxc);
+    if (r.valid && r.dxc > 0) {
+        // 1 / (2 dxc) by the hardware reciprocal and two Newton steps: relative error below 2^-50 (k2_minor_step needs 2^-33), a dozen
+        // dependent instructions instead of the IEEE division's three dozen
+        const double D = 2.0 * (double)r.dxc;
+        double y = __builtin_amdgcn_rcp(D);
+        y = __builtin_fma(__builtin_fma(-D, y, 1.0), y, y);
+        y = __builtin_fma(__builtin_fma(-D, y, 1.0), y, y);
+        C = y;
     }
 }
 // Minor offset of step x >= 1 of a ray: m(x) = min(x, max(0, ceil((2*dyc*x - dxc) / (2*dxc)))), the closed form of the error
@@ -376,18 +366,20 @@ k2_prepare(const float2 *__restrict__ pts, int n, int size, float scale, const f
 // index order.  `sval` is 64 ints of LDS private to the wavefront.
 // (recA / recB / order: LDS when the kernel made the scan's tables itself, else global)
 template <typename T, typename OT, typename ST>
-__device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, int size, const k2_rayA *recA, const k2_rayB *recB,
+__device__ static __noinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, int size, const k2_rayA *recA, const k2_rayB *recB,
                                             int n_rays, const OT *order, const ST *start,
-                                            uint16_t *__restrict__ map, int alpha, int *sval)
+                                            uint16_t *__restrict__ map, int alpha, int *sval, bool scan_all = false)
 {
     const int lane = threadIdx.x & 63;
     const int ptr = Y * size + X;
     const int dx = X - x1, dy = Y - y1;
     int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
-    const int ncls = rs_classes(dx, dy, cls, a, b);
-    int nc = 0;
+    int ncls = 0, nc = 0;
+    if (!scan_all) {                                                   // (scan_all: a core workgroup -- every ray by index, no sorted table)
+        ncls = rs_classes(dx, dy, cls, a, b);
 #pragma unroll
-    for (int k = 0; k < 2; k++) if (k < ncls) { rs_range(start, cls[k], a[k], b[k], 0.0f, lo[k], hi[k]); nc += hi[k] - lo[k]; }
+        for (int k = 0; k < 2; k++) if (k < ncls) { rs_range(start, cls[k], a[k], b[k], 0.0f, lo[k], hi[k]); nc += hi[k] - lo[k]; }
+    }
     uint16_t pix = map[ptr];
     bool stable = false;
     int last_v = 0;
@@ -499,53 +491,24 @@ __device__ static __forceinline__ void k2_wave_pixel(int X, int Y, int x1, int y
 // lookup is a chain of dependent small reads (bucket bounds -> candidates -> V-profile -> map), which global-memory latency
 // would dominate.
 #ifndef K2_LDS_RAYS
-#define K2_LDS_RAYS 2400               // largest scan whose tables fit the LDS: 2 x 16.4 KB of buckets + 48 B per ray + the kernel's static 4 KB <= 160 KB
+#define K2_LDS_RAYS 2048               // largest scan whose tables fit the LDS: 24 KB of buckets + 44 B per ray + 20 KB of the wavefronts' selections + the kernel's static 5 KB <= 160 KB
 #endif
 #ifdef K2_TIMES
 // developer instrumentation (build with SLAMHIP_K2_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
 __device__ unsigned long long g_k2_times[512 * 8];
+__device__ unsigned long long g_k2_fine[512 * 8];      // finer stamps inside the table phase: [0] points arrived + selection done [1] rays made [2] wave reductions done [3] prefix barrier passed [4] lists written
 #define K2_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 512) g_k2_times[blockIdx.x * 8 + (k)] = wall_clock64(); }
+#define K2_FINE(k) { if (threadIdx.x == 0 && blockIdx.x < 512) g_k2_fine[blockIdx.x * 8 + (k)] = wall_clock64(); }
 __device__ unsigned long long g_k2_sub[512 * 16 * 8];   // per wavefront: [0] T1 time [1] T1 items [2] - [3] - [4] T3 time [5] T3 items [6] longest item [7] its kind * 65536 + index
 #define K2_ITEM_T0 const unsigned long long it0_ = wall_clock64();
 #define K2_ITEM_T1(kind, idx) { if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) { unsigned long long *p_ = g_k2_sub + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8; \
         const unsigned long long d_ = wall_clock64() - it0_; p_[2 * (kind)] += d_; p_[2 * (kind) + 1] += 1; if (d_ > p_[6]) { p_[6] = d_; p_[7] = (unsigned long long)(kind) * 65536ull + (unsigned long long)((idx) & 65535); } } }
 #else
 #define K2_STAMP(k) {}
+#define K2_FINE(k) {}
 #define K2_ITEM_T0
 #define K2_ITEM_T1(kind, idx)
 #endif
-
-// Which rays draw the pixel at offset (dx, dy) from the robot?  Up to H hits, kept sorted by ray index (compile-time
-// subscripts: the lists stay in registers); `min_ray` = the lowest hitting ray index, also when the list overflowed.
-template <typename T, int H, typename OT, typename ST>
-__device__ static __forceinline__ void k2_lookup(const k2_rayA *recA, const k2_rayB *recB, const OT *order, const ST *start, int dx, int dy,
-                                        int (&hidx)[H], int (&hval)[H], int &nh, bool &overflow, int &min_ray)
-{
-    int cls[2], a[2], b[2];
-    const int ncls = rs_classes(dx, dy, cls, a, b);
-    nh = 0; overflow = false; min_ray = 0x7fffffff;
-    for (int k = 0; k < ncls; k++) {
-        int lo, hi;
-        rs_range(start, cls[k], a[k], b[k], 0.0f, lo, hi);
-        for (int ci = lo; ci < hi; ci++) {
-            const int ray = (int)order[ci];
-            const k2_rayA e = recA[ray];
-            k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
-            if (!k2_hit<T>(c, a[k], b[k])) continue;
-            min_ray = ray < min_ray ? ray : min_ray;
-            if (nh == H) { overflow = true; continue; }            // (keep scanning: the owner is the lowest index of ALL hits)
-            const int v = a[k] <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(e.lim2, e.flags, recB[ray], a[k]);
-            int posn = 0;
-#pragma unroll
-            for (int s = 0; s < H; s++) if (s < nh && hidx[s] < ray) posn++;
-#pragma unroll
-            for (int s = H - 1; s >= 1; s--) if (s > posn && s <= nh) { hidx[s] = hidx[s - 1]; hval[s] = hval[s - 1]; }
-#pragma unroll
-            for (int s = 0; s < H; s++) if (s == posn) { hidx[s] = ray; hval[s] = v; }
-            nh++;
-        }
-    }
-}
 
 // pixel number i of the zone, counted from the robot's pixel outwards: ring r (Chebyshev distance r) holds the numbers
 // (2r-1)^2 .. (2r+1)^2 - 1, walked along its four sides
@@ -566,7 +529,7 @@ __device__ static __forceinline__ void k2_ring_pixel(int i, int &ddx, int &ddy)
 // kernel's code is executed once or twice per wavefront, from a cold instruction cache: its size is latency; nine inlined copies
 // of the one-pixel path made a 47 KB kernel that ran 10 us slower than the 20 KB one).
 template <typename T, typename OT, typename ST>
-__device__ static __forceinline__ void k2_wave_group(int ddx, int ddy, bool exists, int lg, int x1, int y1, int size, const k2_rayA *recA, const k2_rayB *recB,
+__device__ static __noinline__ void k2_wave_group(int ddx, int ddy, bool exists, int lg, int x1, int y1, int size, const k2_rayA *recA, const k2_rayB *recB,
                                                      int n_rays, const OT *order, const ST *start, uint16_t *__restrict__ map, int alpha, int *sval)
 {
     const int W = 64 >> lg, G = 1 << lg;
@@ -637,14 +600,29 @@ __device__ static __forceinline__ void k2_wave_group(int ddx, int ddy, bool exis
 // than a step lane orders in registers, a zone pixel that found the workgroup's queue full -- rare by construction, and any lane
 // has the tables it needs (the device-wide conflict list of rounds 3 - 4 was drawn by the LAST workgroup to finish, which under arcs
 // holds another octant's rays; it also put an arrival ticket, a dependent round trip, at the end of every workgroup).
+// (`my_ray` >= 0: the caller is the lane of that ray on the pixel -- it draws only if no ray of a lower index hits, `owner` says so)
 template <typename T, typename OT, typename ST>
 __device__ static __noinline__ uint16_t k2_lane_draw_ordered(const k2_rayA *recA, const k2_rayB *recB, const OT *order, const ST *start,
-                                                             int dx, int dy, uint16_t pix, int alpha)
+                                                             int dx, int dy, uint16_t pix, int alpha, int my_ray, bool &owner)
 {
     int cls[2], a[2], b[2], lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
     const int ncls = rs_classes(dx, dy, cls, a, b);
 #pragma unroll
     for (int k = 0; k < 2; k++) if (k < ncls) rs_range(start, cls[k], a[k], b[k], 0.0f, lo[k], hi[k]);
+    owner = true;
+    if (my_ray >= 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (k < ncls) {
+            for (int ci = lo[k]; ci < hi[k] && owner; ci++) {
+                const int ray = (int)order[ci];
+                if (ray >= my_ray) continue;
+                const k2_rayA e = recA[ray];
+                k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
+                if (k2_hit<T>(c, a[k], b[k])) owner = false;
+            }
+        }
+        if (!owner) return pix;
+    }
     int prev = -1;
     for (;;) {
         int best = 0x7fffffff, bv = 0;
@@ -713,6 +691,19 @@ __device__ static __forceinline__ void k2_octant_pixel(int o, int j, int r0, int
     ddy = cls == 1 ? a : cls == 3 ? -a : bq;
 }
 
+// the octant that owns the pixel at offset (dx, dy) != (0, 0) (the inverse of k2_octant_pixel: a diagonal pixel belongs to the octant
+// that begins there), and the pixel's number among its octant's, ring by ring from ring 1
+__device__ static __forceinline__ int k2_pixel_octant(int dx, int dy, int &num)
+{
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy, a = adx > ady ? adx : ady;
+    int o, t;
+    if (adx > ady)      { if (dx > 0) { o = dy < 0 ? 0 : 1; t = dy < 0 ? -dy - 1 : dy; } else { o = dy > 0 ? 4 : 5; t = dy > 0 ? dy - 1 : -dy; } }
+    else if (ady > adx) { if (dy > 0) { o = dx > 0 ? 2 : 3; t = dx > 0 ? dx - 1 : -dx; } else { o = dx < 0 ? 6 : 7; t = dx < 0 ? -dx - 1 : dx; } }
+    else { o = dx > 0 ? (dy > 0 ? 2 : 0) : (dy > 0 ? 4 : 6); t = a - 1; }          // (a, a) 2 | (a, -a) 0 | (-a, a) 4 | (-a, -a) 6: the last pixel of its ring there
+    num = (a * (a - 1)) / 2 + t;
+    return o;
+}
+
 // One LANE draws one zone pixel (numbers pix0 .. pix0 + 63, ring by ring: the 64 pixels of an item see about the same number of
 // rays).  Out from rB a pixel has a dozen or two candidates, and nearly all of a zone's fragments carry TS_NO_OBSTACLE (step x of a
 // ray is below its V, x <= lim2, unless an obstacle stands within the zone's radius plus the hole's half width of the robot): blends
@@ -748,7 +739,7 @@ __device__ static __forceinline__ void k2_lane_pixels(int ddx, int ddy, bool exi
     if (mixed) {
         const int slot = atomicAdd(n_mixq, 1);
         if (slot < cap_mixq) mixq[slot] = ptr;
-        else map[ptr] = k2_lane_draw_ordered<T>(recA, recB, order, start, ddx, ddy, pix, alpha);     // (queue full: drawn here, slowly)
+        else { bool ow; map[ptr] = k2_lane_draw_ordered<T>(recA, recB, order, start, ddx, ddy, pix, alpha, -1, ow); }     // (queue full: drawn here, slowly)
     } else if (nh > 0) {
         for (int k = 0; k < nh; k++) {
             const uint16_t np = k2_blend(pix, TS_NO_OBSTACLE, alpha);
@@ -765,11 +756,14 @@ __device__ static __forceinline__ void k2_lane_pixels(int ddx, int ddy, bool exi
 // -- 70 KB with the kernel's static 4.3 KB at 1080 rays.
 #define K2_LDS_FIXED ((4 * K2_NBUCK + 4) * 4)
 #define K2_LDS_START16 ((4 * K2_NBUCK + 8) * 2)
+#define K2_RPT ((K2_LDS_RAYS + 1023) / 1024)        // rays per thread of the one-launch form
+#define K2_OWN_CAP ((16 * K2_RPT * 64 * 10 / 24) & ~7)   // own rays whose records fit the selection staging space (848 at two rays per thread)
 static inline size_t k2_lds_bytes(bool build, int n_rays)
 {
-    // BUILD: + the selected rays' points (8 bytes per ray; their indices share the sorted table's space) and the list of the rays
-    // whose far steps the workgroup's XCD draws (2 bytes per ray)
-    return build ? (size_t)4 * K2_NBUCK * 4 + K2_LDS_START16 + (size_t)4 * (size_t)((n_rays + 7) & ~7) + (size_t)48 * (size_t)((n_rays + 3) & ~3) : (size_t)K2_LDS_FIXED;
+    // BUILD: + the list of the rays whose far steps the workgroup's XCD draws (2 bytes per ray) and every wavefront's selection
+    // (index and point of the rays it makes: K2_RPT * 64 entries of 2 + 8 bytes), and the sorted table's slopes (4 bytes per ray)
+    return build ? (size_t)4 * K2_NBUCK * 4 + K2_LDS_START16 + (size_t)4 * (size_t)((n_rays + 7) & ~7) + (size_t)32 * (size_t)((n_rays + 3) & ~3) + (size_t)16 * K2_RPT * 64 * 10
+                 : (size_t)K2_LDS_FIXED;
 }
 
 // developer experiments (SLAMHIP_K2_EXP=n at build time, WRONG RESULTS): what bounds the kernel -- 1: the step lanes' stores dropped,
@@ -796,7 +790,7 @@ static inline size_t k2_lds_bytes(bool build, int n_rays)
 #endif
 // a T3 work item as a lane holds it between its fetch (the pixel's load is issued there) and its turn: step x of ray `ray`, at
 // signed minor offset b
-struct k2_t3 { int ptr, x, b, ray, lim2, flags; uint16_t pix; };
+struct k2_t3 { int ptr, x, b, ray, lim2, flags, xalone; uint16_t pix; bool valid; };
 
 // what the kernel needs of the scan when it makes the tables itself
 struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, ncore; int2 *span;
@@ -919,7 +913,7 @@ __device__ static __noinline__ void k2_row_spans(const k2_rayA *byidx, int n_ray
     }
 }
 
-template <bool BUILD, typename T>
+template <bool BUILD, typename T, bool ARCS>
 __global__ void __launch_bounds__(1024)
 k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *__restrict__ recB_g, const double *__restrict__ recC_g,
           const int *__restrict__ order_g, int n_rays,
@@ -937,9 +931,16 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     k2_rayA *recA_s = (k2_rayA *)(own_s + (BUILD ? n8 : 0));
     k2_rayB *recB_s = (k2_rayB *)(recA_s + (BUILD ? n4 : 0));
     double *recC_s = (double *)(recB_s + (BUILD ? n4 : 0));
-    float2 *selp_s = (float2 *)(recC_s + (BUILD ? n4 : 0));        // BUILD: the points of the selected rays (their indices: order_s, until the sort)
+    float2 *selp_s = (float2 *)(recC_s + (BUILD ? n4 : 0));        // BUILD: the wavefronts' selections -- points ...
+    unsigned short *seli_s = (unsigned short *)(selp_s + (BUILD ? 16 * K2_RPT * 64 : 0));   // ... and ray indices
+    // (once the rays are made the same space holds the own rays' records side by side -- part A with the ray index in the flags' upper
+    // half, part C -- so that a step item reads them by its position in the list: one LDS round trip instead of two)
+    float *slope_s = (float *)(seli_s + (BUILD ? 16 * K2_RPT * 64 : 0));   // BUILD: the sorted table's slopes (minor / major, as bucketed), by table position
+    k2_rayA *ownA_s = (k2_rayA *)selp_s;
+    double *ownC_s = (double *)(ownA_s + K2_OWN_CAP);
     __shared__ __attribute__((aligned(16))) int sval[16][64];
-    __shared__ int s_nextA, s_nextB, s_R, s_total, wsum[16], wown[16], s_nmix, s_nsel, s_mixq[K2_MIXQ];
+    __shared__ __attribute__((aligned(16))) int wsum[16], wown[16];
+    __shared__ int s_nextA, s_nextB, s_R, s_total, s_nmix, s_mixq[K2_MIXQ];
     __shared__ float s_wpose[4];
     K2_STAMP(0)
     // Riding along: the ObstacleMap update (obstacle_dev.h).  Every wavefront of the launch takes 64 cells of the pending cell
@@ -960,13 +961,15 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     // arcs (large scans whose tables k2_prepare made, a host mirror's row spans -- k2_row_spans walks every ray --, developer grids,
     // absurd hole widths) every workgroup holds every ray and everything is dealt round-robin, as before round 5.
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_in_xcd = (n_pix_wgs - xcd + 7) >> 3;
-    const bool arcs = BUILD && sc.ncore > 0, is_core = !arcs || wg_in_xcd < sc.ncore;
+    constexpr bool arcs = BUILD && ARCS;                            // (a template parameter: each form's dead paths drop out of its code -- the kernel's size is latency)
+    const bool is_core = !arcs || wg_in_xcd < sc.ncore;
+    const bool core_count = arcs && is_core;                        // this workgroup draws its octant's central pixels by counting (below)
     int rB = (sc.rb_num * n_rays + 1079) / 1080;                    // (the radius from which a zone pixel is one lane's: by the ray COUNT, so that every workgroup agrees)
     rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB;
     int R, x1, y1, n_own = 0;
     if (BUILD) {
         const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
-        constexpr int RPT = (K2_LDS_RAYS + 1023) / 1024;            // rays per thread
+        constexpr int RPT = K2_RPT;                                 // rays per thread
         float2 pa[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; k++) { const int i = t + k * 1024; pa[k] = i < n_rays ? sc.pts[i] : make_float2(0.f, 0.f); }
@@ -991,10 +994,16 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
         if (ride_cells) { ride_h = ride.cell_hits[ride_cell]; ride_nh = ride.cell_nohit[ride_cell]; ride_v = ride.map[ride_cell]; }
         if (ride_ray) ride_p = ride.pts[ride_r];
         for (int i = t; i < 4 * K2_NBUCK; i += 1024) pos_s[i] = 0;  // (the histogram, then the running positions)
-        if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; s_nmix = 0; s_nsel = 0; }
+        if (t == 0) { s_nextA = 0; s_nextB = 0; s_R = 0; s_total = 0; s_nmix = 0; }
         __syncthreads();
         K2_STAMP(6)
-        // selection: the rays this workgroup needs, compacted (wave by wave: the order does not matter, the records go by ray index)
+        // selection: the rays this workgroup needs, compacted INSIDE every wavefront (its threads' rays of all passes into its own
+        // stretch of LDS: no barrier, no atomics; the records go by ray index, so it does not matter who makes a ray) -- a sector
+        // workgroup's wavefronts hold about 40 selected rays of their 128 and make them in ONE pass (the 56 rays beyond 1024 of a
+        // 1080-ray scan used to be a second pass of the first wavefront alone: 1.3 us of the table phase)
+        float2 *wsel_p = selp_s + wid * (RPT * 64);
+        unsigned short *wsel_i = seli_s + wid * (RPT * 64);
+        int n_sel = 0;                                              // (of this wavefront)
         {
             const float centre = (float)xcd + 0.5f, halfw = 0.5f + 8.0f / (float)rB + 0.02f;
             const bool all = is_core || !(fabsf(q.x) < 16000.0f && fabsf(q.y) < 16000.0f);
@@ -1004,35 +1013,31 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
                 if (k * 1024 < n_rays) {                            // (uniform)
                     const bool in = i < n_rays, member = in && (all || k2_arc_member(pa[k], q, centre, halfw));
                     const unsigned long long mb = __ballot(member);
-                    if (mb) {
-                        int base;
-                        SH_WAVE_FETCH(base, atomicAdd(&s_nsel, (int)__popcll(mb)))
-                        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
-                        if (member) { order_s[slot] = (unsigned short)i; selp_s[slot] = pa[k]; }
-                    }
+                    const int slot = n_sel + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+                    if (member) { wsel_i[slot] = (unsigned short)i; wsel_p[slot] = pa[k]; }
+                    n_sel += (int)__popcll(mb);
                     if (in && !member) { k2_rayA z; z.dxc = 0; z.sdyc = 0; z.lim2 = 0; z.flags = 0; recA_s[i] = z; }
                 }
             }
         }
-        __syncthreads();
-        const int n_sel = s_nsel;
+        __builtin_amdgcn_wave_barrier();                            // (the wavefront's own LDS writes, read below by other lanes: in order)
+        K2_FINE(0)
         int bkt[RPT], bray[RPT];                                    // a selected ray's bucket (class * 1024 + slope bucket; -1: not valid) and index
         int my_R = 0, my_total = 0;
 #pragma unroll
         for (int k = 0; k < RPT; k++) { bkt[k] = -1; bray[k] = 0; }
 #pragma unroll 1
-        for (int it = 0; it * 1024 < n_sel; it++) {                 // (rolled: k2_make_ray is kilobytes of code, fetched once per launch)
-            const int j = t + it * 1024;
+        for (int it = 0; it * 64 < n_sel; it++) {                   // (rolled: k2_make_ray is kilobytes of code, fetched once per launch)
+            const int j = lane_ + it * 64;
             int bb = -1, ri = 0;
             if (j < n_sel) {
-                ri = (int)order_s[j];
-                const cs_ray r = k2_make_ray(selp_s[j], size, q, sc.scale, sc.hole_width);
+                ri = (int)wsel_i[j];
+                const cs_ray r = k2_make_ray(wsel_p[j], size, q, sc.scale, sc.hole_width);
                 k2_rayA ee; k2_rayB eb; double ec;
                 k2_ray_record(r, ee, eb, ec);
                 recA_s[ri] = ee; recB_s[ri] = eb; recC_s[ri] = ec;
                 if (r.valid) {
-                    bb = k2_ray_bucket(ee);
-                    atomicAdd(&pos_s[bb], 1);
+                    if (!core_count) { bb = k2_ray_bucket(ee); atomicAdd(&pos_s[bb], 1); }     // (a counting core workgroup sorts nothing)
                     my_R = max(my_R, r.dxc);
                     my_total += r.dxc + 1;
                 }
@@ -1040,17 +1045,22 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
 #pragma unroll
             for (int k = 0; k < RPT; k++) if (k == it) { bkt[k] = bb; bray[k] = ri; }
         }
-        for (int off = 32; off > 0; off >>= 1) {                   // one LDS atomic per wave, not per ray (same address)
-            my_R = max(my_R, __shfl_down(my_R, off, 64));
-            my_total += __shfl_down(my_total, off, 64);
-        }
-        if (lane_ == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_total, my_total); }
+        K2_FINE(1)
+        my_R = sh_wave_max_to_lane63(my_R);                         // one LDS atomic per wave, not per ray (same address)
+        my_total = sh_wave_scan_incl(my_total);
+        if (lane_ == 63) { atomicMax(&s_R, my_R); atomicAdd(&s_total, my_total); }
+        K2_FINE(2)
         __syncthreads();
         K2_STAMP(7)
+        unsigned long long ownb[K2_RPT];
+        k2_rayA ownrec[K2_RPT];
+        int ownpos[K2_RPT];
+#pragma unroll
+        for (int k = 0; k < K2_RPT; k++) { ownb[k] = 0ull; ownpos[k] = -1; ownrec[k].dxc = 0; ownrec[k].sdyc = 0; ownrec[k].lim2 = 0; ownrec[k].flags = 0; }
+        if (!core_count) {
         // the rays whose far steps this workgroup's XCD draws: with arcs the octant's (none for a core workgroup), else the XCD's
         // eighth of the scan by index -- valid rays that reach beyond the zone, in an order every workgroup of the XCD agrees on
         // (wavefront, pass, lane: the threads' rays are the same in all of them)
-        unsigned long long ownb[RPT];
         int own_cnt = 0;
         {
             const int c0 = (int)(((long long)n_rays * xcd) >> 3), c1 = (int)(((long long)n_rays * (xcd + 1)) >> 3);
@@ -1058,10 +1068,12 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
             for (int k = 0; k < RPT; k++) {
                 const int i = t + k * 1024;
                 bool own = false;
+                k2_rayA e; e.dxc = 0; e.sdyc = 0; e.lim2 = 0; e.flags = 0;
                 if (i < n_rays && !(arcs && is_core)) {
-                    const k2_rayA e = recA_s[i];
+                    e = recA_s[i];
                     own = (e.flags & K2_F_VALID) && e.dxc >= K2_ZONE && (arcs ? k2_ray_octant(e) == xcd : (i >= c0 && i < c1));
                 }
+                ownrec[k] = e;
                 ownb[k] = __ballot(own);
                 own_cnt += (int)__popcll(ownb[k]);
             }
@@ -1071,33 +1083,49 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
             int v[4], sum = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = pos_s[4 * t + k]; sum += v[k]; }
-            int incl = sum;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane_ >= off) incl += o;
-            }
+            const int incl = sh_wave_scan_incl(sum);
             if (lane_ == 63) wsum[wid] = incl;
             __syncthreads();
+            K2_FINE(3)
             int base = incl - sum;
-            for (int w = 0; w < wid; w++) base += wsum[w];
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) {                          // (the sixteen wave sums in four 16-byte reads)
+                const int4 ws = *(const int4 *)&wsum[4 * w4];
+                base += (4 * w4 < wid ? ws.x : 0) + (4 * w4 + 1 < wid ? ws.y : 0) + (4 * w4 + 2 < wid ? ws.z : 0) + (4 * w4 + 3 < wid ? ws.w : 0);
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) { start[4 * t + k] = (start_t)base; pos_s[4 * t + k] = base; base += v[k]; }     // (each thread its own four bins)
             if (t == 1023) start[4 * K2_NBUCK] = (start_t)base;
         }
         {
             int obase = 0;
-            for (int w = 0; w < 16; w++) { const int c = wown[w]; n_own += c; obase += w < wid ? c : 0; }
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) {
+                const int4 ws = *(const int4 *)&wown[4 * w4];
+                n_own += ws.x + ws.y + ws.z + ws.w;
+                obase += (4 * w4 < wid ? ws.x : 0) + (4 * w4 + 1 < wid ? ws.y : 0) + (4 * w4 + 2 < wid ? ws.z : 0) + (4 * w4 + 3 < wid ? ws.w : 0);
+            }
 #pragma unroll
             for (int k = 0; k < RPT; k++) {
-                if ((ownb[k] >> lane_) & 1ull)
-                    own_s[obase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ownb[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ownb[k], 0u))] = (unsigned short)(t + k * 1024);
+                if ((ownb[k] >> lane_) & 1ull) {
+                    const int i = t + k * 1024, pos = obase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ownb[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ownb[k], 0u));
+                    own_s[pos] = (unsigned short)i; ownpos[k] = pos;
+                    if (n_own <= K2_OWN_CAP) { k2_rayA w = ownrec[k]; w.flags |= i << 16; ownA_s[pos] = w; ownC_s[pos] = recC_s[i]; }
+                }
                 obase += (int)__popcll(ownb[k]);
             }
         }
         __syncthreads();
+        K2_FINE(4)
 #pragma unroll
         for (int it = 0; it < RPT; it++)
-            if (bkt[it] >= 0) order_s[atomicAdd(&pos_s[bkt[it]], 1)] = (unsigned short)bray[it];
+            if (bkt[it] >= 0) {
+                const int pos = atomicAdd(&pos_s[bkt[it]], 1);
+                const k2_rayA e = recA_s[bray[it]];                 // (this thread's own store)
+                order_s[pos] = (unsigned short)bray[it];
+                slope_s[pos] = e.dxc > 0 ? (float)e.sdyc / (float)e.dxc : 0.0f;
+            }
+        }
         R = s_R; x1 = sh_f2i(q.x); y1 = sh_f2i(q.y);
         if (blockIdx.x == 0 && t == 0) {                           // what the host reads: reach, blended pixels, the robot's pixel (workgroup 0 holds every ray)
             counters[0] = R; counters[2] = s_total; counters[3] = x1; counters[4] = y1;
@@ -1110,6 +1138,32 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
             }
         }
         __syncthreads();
+        // From which step on is an own ray ALONE on its pixels?  Two rays of a class share a pixel at major offset a only if their
+        // slopes differ by at most 1 / a (both minor offsets lie within 1/2 of slope * a): the ray's thread looks at the slopes of
+        // the eleven buckets either side of its own, takes the smallest difference g, and from step 1 / (g - 4e-7) + 2 on the ray's
+        // step lanes need no range lookup -- candidate ranges are whole buckets, and at 600 pixels nearly half the lanes used to find
+        // company there that never draws their pixel, which sent almost every item down the slow part.  No neighbour in sight:
+        // g >= 10 buckets.  (Diagonal pixels -- the other class of the quadrant draws there -- never take the shortcut.)
+        if (n_own > 0 && n_own <= K2_OWN_CAP) {                     // (uniform)
+#pragma unroll
+            for (int k = 0; k < RPT; k++) if (ownpos[k] >= 0) {
+                const k2_rayA e = ownrec[k];
+                const int bk = k2_ray_bucket(e), cb = bk & ~(K2_NBUCK - 1);
+                const int w0 = (int)start[max(bk - 11, cb)], w1 = (int)start[min(bk + 11, cb + K2_NBUCK - 1) + 1];
+                const float sl = e.dxc > 0 ? (float)e.sdyc / (float)e.dxc : 0.0f;
+                float g = 10.0f * (2.0f / (float)K2_NBUCK);
+                int same = 0;                                       // (entries with the ray's very slope: its own, and any other -> never alone)
+                for (int ci = w0; ci < w1; ci++) {
+                    const float d = fabsf(slope_s[ci] - sl);
+                    same += d == 0.0f ? 1 : 0;
+                    g = d > 0.0f && d < g ? d : g;
+                }
+                const int xa = same == 1 && g > 1.0e-6f ? min((int)(__builtin_amdgcn_rcpf(g - 4.0e-7f) * 1.0001f) + 2, 2047) : 2047;
+                ownA_s[ownpos[k]].flags |= xa << 5;                 // (bits 5 .. 15 were zero: "not known yet" = no shortcut)
+            }
+            // (no barrier: a step item fetched before its ray's thread got here reads zero there and takes the range lookup -- slower,
+            // never wrong; the word is written once, by one thread)
+        }
         if (x1 < 0 || x1 >= size || y1 < 0 || y1 >= size) {         // robot outside the map: nothing is drawn (:509-512)
             if (ride.on) { k3_ride rd = ride; if (sc.win_key) rd.d_pose = s_wpose; k2_ride_tail(rd, ride_cells, ride_ray, ride_cell, ride_r, ride_nw, ride_h, ride_nh, ride_v, ride_p); }   // (the ObstacleMap has its own test, at its own scale :557-560)
             return;
@@ -1139,7 +1193,7 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     // (the dealing: a core workgroup's items are the central ones, a sector workgroup's its octant's; without arcs everything goes round)
     const int zone_first = !arcs ? (int)blockIdx.x : is_core ? wg_in_xcd * 8 + xcd : wg_in_xcd - sc.ncore;
     const int zone_step = !arcs ? n_pix_wgs : is_core ? sc.ncore * 8 : wgs_in_xcd - sc.ncore;
-    const int zone_items = !arcs ? nA + nL : is_core ? nA : nLo;
+    const int zone_items = !arcs ? nA + nL : is_core ? 0 : nLo;          // (a core workgroup's central pixels: by counting, below)
     // T3: one lane per (ray, step) beyond the zone, ray = an entry of the sorted table, steps in blocks of 64.  Software
     // pipeline: an item's pixel is requested when the item is fetched, TWO iterations before its turn -- the map sits in HBM /
     // Infinity Cache, a microsecond away, and the phase is bound by that latency, not by its instructions (an item took 1.15 us with
@@ -1158,39 +1212,112 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     const int t3_first = arcs ? wg_in_xcd - sc.ncore : wg_in_xcd, t3_step = arcs ? wgs_in_xcd - sc.ncore : wgs_in_xcd;
     const int n_t3 = (K2_EXP == 6 || K2_EXP == 7) ? 0 : nblk * n_sec;      // (K2_EXP 5 / 6 / 7: no zone items / no step items / tables only)
     const float rcp_nv = __builtin_amdgcn_rcpf((float)(n_sec > 0 ? n_sec : 1));
+    // The step lanes are bound by their instruction count (2.8 M vector instructions of a launch's 5 M were theirs: 5 us of issue
+    // time on the sector workgroups' SIMDs): an item whose block lies beyond its ray's end leaves at once (a third of them), a lane
+    // beyond the step from which its ray is alone (xalone, table phase) neither looks up a range nor tests anything, and only the
+    // blocks near the robot, where neighbouring rays are less than a pixel apart, take the slow part.
+    const bool own_direct = BUILD && n_own <= K2_OWN_CAP;
 #define K2_FETCH(it, more_)                                                                              \
     {                                                                                                   \
         int k_;                                                                                         \
         SH_WAVE_FETCH(k_, atomicAdd(&s_nextB, 1))                                                       \
         const int item_ = t3_first + k_ * t3_step;                                                      \
-        (it).ptr = -1;                                                                                  \
         more_ = item_ < n_t3;                                                                           \
+        (it).valid = false;                                                                             \
         if (more_) {                                                                                    \
             int blk_ = (int)((float)item_ * rcp_nv);       /* item / n_sec (item < 2^24: settled exactly below) */ \
             int ri_ = item_ - blk_ * n_sec;                                                             \
             if (ri_ < 0) { blk_--; ri_ += n_sec; } else if (ri_ >= n_sec) { blk_++; ri_ -= n_sec; }     \
-            ri_ = BUILD ? (int)own_s[ri_] : ri_ + c0;                                                   \
-            const k2_rayA me_ = recA[ri_];                 /* (uniform: an LDS broadcast) */             \
-            const int x_ = K2_ZONE + blk_ * 64 + lane;                                                  \
-            if ((me_.flags & K2_F_VALID) && x_ <= me_.dxc) {                                            \
-                const int smaj_ = ((me_.flags >> 2) & 3) - 1;                                           \
-                const int dyc_ = me_.sdyc < 0 ? -me_.sdyc : me_.sdyc;                                   \
-                const int m_ = k2_minor_step<T>(x_, me_.dxc, dyc_, recC[ri_]);                          \
-                const int b_ = me_.sdyc < 0 ? -m_ : m_, a_ = smaj_ < 0 ? -x_ : x_;                      \
-                const int dx_ = (me_.flags & K2_F_MAJX) ? a_ : b_, dy_ = (me_.flags & K2_F_MAJX) ? b_ : a_; \
-                (it).x = x_; (it).b = b_; (it).ray = ri_; (it).lim2 = me_.lim2; (it).flags = me_.flags;  \
-                (it).ptr = (y1 + dy_) * size + (x1 + dx_);                 /* (step pixels of a clipped ray lie inside the map) */ \
-                (it).pix = K2_EXP_LOAD(map, (it).ptr);                                                  \
+            k2_rayA me_; int ray_;                         /* (uniform: LDS broadcasts) */               \
+            if (own_direct) { me_ = ownA_s[ri_]; ray_ = (int)((unsigned)me_.flags >> 16); }              \
+            else { ray_ = BUILD ? (int)own_s[ri_] : ri_ + c0; me_ = recA[ray_]; }                        \
+            const int x0_ = K2_ZONE + blk_ * 64;                                                        \
+            if ((me_.flags & K2_F_VALID) && x0_ <= me_.dxc) {              /* (uniform: the block holds steps of the ray) */ \
+                const double rc_ = own_direct ? ownC_s[ri_] : recC[ray_];                               \
+                const int x_ = x0_ + lane;                                                              \
+                if (x_ <= me_.dxc) {                                                                    \
+                    const int smaj_ = ((me_.flags >> 2) & 3) - 1;                                       \
+                    const int dyc_ = me_.sdyc < 0 ? -me_.sdyc : me_.sdyc;                               \
+                    const int m_ = k2_minor_step<T>(x_, me_.dxc, dyc_, rc_);                            \
+                    const int b_ = me_.sdyc < 0 ? -m_ : m_, a_ = smaj_ < 0 ? -x_ : x_;                  \
+                    const int dx_ = (me_.flags & K2_F_MAJX) ? a_ : b_, dy_ = (me_.flags & K2_F_MAJX) ? b_ : a_; \
+                    /* (from which step on the ray is alone on its pixels: bits 5 .. 15 of an own record's flags, 2047: never) */ \
+                    const int xa_ = own_direct ? (me_.flags >> 5) & 2047 : 2047;       /* (0: not known yet) */ \
+                    (it).x = x_; (it).b = b_; (it).ray = ray_; (it).lim2 = me_.lim2; (it).flags = me_.flags & 31; (it).valid = true; \
+                    (it).xalone = (xa_ == 2047 || xa_ == 0) ? 0x7fffffff : xa_;                         \
+                    (it).ptr = (y1 + dy_) * size + (x1 + dx_);         /* (step pixels of a clipped ray lie inside the map) */ \
+                    (it).pix = K2_EXP_LOAD(map, (it).ptr);                                              \
+                }                                                                                       \
             }                                                                                           \
         }                                                                                               \
     }
-    // (the first two items' pixels are requested before the zone is drawn: disjoint pixels -- steps below K2_ZONE there, from
+    // (the first item's pixels are requested before the zone is drawn: disjoint pixels -- steps below K2_ZONE there, from
     // K2_ZONE on here -- and the zone's dependent chains hide the map's latency)
-    k2_t3 cur, nxt, nx2;
-    cur.ptr = -1; cur.x = cur.b = cur.ray = cur.lim2 = cur.flags = 0; cur.pix = 0; nxt = cur; nx2 = cur;
-    bool more0 = false, more1 = false, more2 = false;
+    k2_t3 cur, nxt;
+    cur.ptr = 0; cur.x = K2_ZONE; cur.b = cur.ray = cur.lim2 = cur.flags = 0; cur.xalone = 0x7fffffff; cur.pix = 0; cur.valid = false; nxt = cur;
+    bool more0 = false, more1 = false;
     if (n_t3 > 0) K2_FETCH(cur, more0)
-    if (more0) K2_FETCH(nxt, more1)
+    // A core workgroup (arcs) draws its octant's CENTRAL pixels -- the rings below rB, where a pixel's window spans up to the whole
+    // circle -- by COUNTING, ray-centrically: every step x < rB of every ray that points into the octant or one next to it (a step's
+    // pixel lies in the ray's own octant or an adjacent one) adds one to its pixel's counter in LDS; blends of one value commute, and
+    // below a ray's V (x <= lim2) the value is TS_NO_OBSTACLE, so a pixel's counter is all it needs.  A step inside a V marks its
+    // pixel instead, and marked pixels (an obstacle within rB pixels plus the hole's half width of the robot) are drawn in the
+    // ordered way, one wavefront each scanning the rays by index.  529 wavefront items of 3 - 7 us (the launch's critical chain,
+    // behind a full sort) became 13 000 lane steps: no sorted table in a core workgroup at all.
+    if (core_count && K2_EXP != 5 && K2_EXP != 7) {
+        const int t = threadIdx.x;
+        int *cnt = pos_s;                                          // (zero since the launch's first barrier: a core workgroup makes no histogram)
+        int *cq = pos_s + 2048;                                    // marked pixels
+        const int rc_max = rB - 1 < Z ? rB - 1 : Z;                 // central rings 1 .. rc_max
+        int nv = 0, mix0 = 0;
+#pragma unroll
+        for (int k = 0; k < K2_RPT; k++) {
+            const int i = t + k * 1024;
+            if (i < n_rays) {
+                const k2_rayA e = recA[i];
+                if (e.flags & K2_F_VALID) {
+                    nv++; mix0 |= e.lim2 < 0 ? 1 : 0;
+                    const int d8 = (k2_ray_octant(e) - xcd) & 7;
+                    if (d8 == 0 || d8 == 1 || d8 == 7) {
+                        const int smaj = ((e.flags >> 2) & 3) - 1, dyc = e.sdyc < 0 ? -e.sdyc : e.sdyc;
+                        const double rc = recC[i];
+                        const int xe = rc_max < e.dxc ? rc_max : e.dxc;
+                        for (int x = 1; x <= xe; x++) {
+                            const int m = k2_minor_step<T>(x, e.dxc, dyc, rc);
+                            const int bq = e.sdyc < 0 ? -m : m, aq = smaj < 0 ? -x : x;
+                            int num;
+                            if (k2_pixel_octant((e.flags & K2_F_MAJX) ? aq : bq, (e.flags & K2_F_MAJX) ? bq : aq, num) == xcd) {
+                                if (x <= e.lim2) atomicAdd(&cnt[num], 1); else atomicOr(&cnt[num], 1 << 30);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (xcd == 0) {                                            // the robot's own pixel: step 0 of every ray
+            const int lane_ = t & 63;
+            const int tot = sh_wave_scan_incl(nv);
+            const unsigned long long mb = __ballot(mix0 != 0);
+            if (lane_ == 63) { atomicAdd(&cnt[2047], tot); if (mb) atomicOr(&cnt[2047], 1 << 30); }
+        }
+        __syncthreads();
+        const int npc = (rc_max * (rc_max + 1)) / 2 + (xcd == 0 ? 1 : 0);
+        for (int j = t; j < npc; j += 1024) {
+            int ddx = 0, ddy = 0;
+            const bool robot = j == (rc_max * (rc_max + 1)) / 2;
+            if (!robot) k2_octant_pixel(xcd, j, 1, ddx, ddy);
+            const int X = x1 + ddx, Y = y1 + ddy, c = cnt[robot ? 2047 : j];
+            if (c != 0 && X >= 0 && X < size && Y >= 0 && Y < size) {
+                const int ptr = Y * size + X;
+                if (c >> 30) cq[atomicAdd(&s_nmix, 1)] = ptr;
+                else {
+                    uint16_t pix = map[ptr];
+                    for (int k = 0; k < c; k++) { const uint16_t np = k2_blend(pix, TS_NO_OBSTACLE, alpha); if (np == pix) break; pix = np; }
+                    map[ptr] = pix;
+                }
+            }
+        }
+    }
     for (;;) {
         int k;
         SH_WAVE_FETCH(k, atomicAdd(&s_nextA, 1))
@@ -1215,68 +1342,63 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     // T3 (see above: its first two items were fetched before the zone)
     while (more0) {
         K2_ITEM_T0
-        more2 = false; nx2.ptr = -1;
-        if (more1) K2_FETCH(nx2, more2)
-        if (cur.ptr >= 0) {
-            // Out here rays are more than a pixel apart: nearly every pixel's candidate range holds its own ray and nothing else
-            // -- then it is blended at once (no hit test, no ordering).  A diagonal pixel (the quadrant's other class draws there
-            // too) or a range with company goes through the full lookup.  (The lane knows its pixel in its ray's own frame --
-            // class, major offset x, minor offset b: the range needs no classification.)
+        K2_FETCH(nxt, more1)
+        if (cur.valid && K2_EXP != 9) {                               // (K2_EXP 9: the items are fetched and dropped; 10: every lane takes the lone-ray path; 11: no shortcut by xalone)
             const int smaj = ((cur.flags >> 2) & 3) - 1, ab = cur.b < 0 ? -cur.b : cur.b;
-            int lo = 0, hi = 2;
-            if (ab != cur.x) rs_range(start, (cur.flags & K2_F_MAJX) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3), cur.x, cur.b, 0.0f, lo, hi);
-            const int v = cur.x <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(cur.lim2, cur.flags, recB[cur.ray], cur.x);
-            if (hi - lo == 1) {
-                K2_EXP_STORE(map, cur.ptr, k2_blend(cur.pix, v, alpha));
-            } else if (ab != cur.x && hi - lo <= K2_MAXHIT) {
-                // Company in the range (up to step ~170 the neighbouring rays are less than a pixel away): the OTHER rays of the
-                // range are tested -- this lane's own ray draws the pixel by construction.  A hit of a lower ray index ends the
-                // matter (that ray's lane owns the pixel); hits of higher indices are blended after this lane's value, in index
-                // order (at most K2_MAXHIT - 1 of them: kept sorted in registers).
-                int oidx[K2_MAXHIT - 1], oval[K2_MAXHIT - 1], no = 0;
-                bool owner = true;
-                for (int ci = lo; ci < hi && owner; ci++) {
-                    const int ray = (int)order[ci];
-                    if (ray == cur.ray) continue;
-                    const k2_rayA e = recA[ray];
-                    k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
-                    if (!k2_hit<T>(c, cur.x, cur.b)) continue;
-                    if (ray < cur.ray) { owner = false; break; }
-                    const int ov = cur.x <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(e.lim2, e.flags, recB[ray], cur.x);
-                    int posn = 0;
-#pragma unroll
-                    for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 < no && oidx[s2] < ray) posn++;
-#pragma unroll
-                    for (int s2 = K2_MAXHIT - 2; s2 >= 1; s2--) if (s2 > posn && s2 <= no) { oidx[s2] = oidx[s2 - 1]; oval[s2] = oval[s2 - 1]; }
-#pragma unroll
-                    for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 == posn) { oidx[s2] = ray; oval[s2] = ov; }
-                    no++;
-                }
-                if (owner) {
-                    uint16_t pix = k2_blend(cur.pix, v, alpha);
-#pragma unroll
-                    for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 < no) pix = k2_blend(pix, oval[s2], alpha);
-                    K2_EXP_STORE(map, cur.ptr, pix);
-                }
+            if (K2_EXP == 10 || (K2_EXP != 11 && cur.x >= cur.xalone && ab != cur.x)) {
+                // the ray shares no pixel from xalone on (diagonal pixels -- the quadrant's other class draws there too -- excepted)
+                K2_EXP_STORE(map, cur.ptr, k2_blend(cur.pix, cur.x <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(cur.lim2, 0, recB[cur.ray], cur.x), alpha));
             } else {
-                int hidx[K2_MAXHIT], hval[K2_MAXHIT], nh, min_ray;
-                bool overflow;
-                const int a_s = smaj < 0 ? -cur.x : cur.x;
-                const int cdx = (cur.flags & K2_F_MAJX) ? a_s : cur.b, cdy = (cur.flags & K2_F_MAJX) ? cur.b : a_s;
-                k2_lookup<T, K2_MAXHIT>(recA, recB, order, start, cdx, cdy, hidx, hval, nh, overflow, min_ray);
-                if (min_ray == cur.ray) {                          // the owner
-                    if (overflow) {
-                        K2_EXP_STORE(map, cur.ptr, k2_lane_draw_ordered<T>(recA, recB, order, start, cdx, cdy, cur.pix, alpha));
-                    } else {
-                        uint16_t pix = cur.pix;
+                // Nearer the robot neighbouring rays are less than a pixel apart: which rays can draw the pixel is one contiguous
+                // range of the slope-sorted table (the lane knows its pixel in its ray's own frame -- class, major offset x, minor
+                // offset b: the range needs no classification).  Its own ray alone in it: blended at once.  A diagonal pixel or a
+                // range with company goes on.
+                int lo = 0, hi = 2;
+                if (ab != cur.x) rs_range(start, (cur.flags & K2_F_MAJX) ? (smaj >= 0 ? 0 : 1) : (smaj >= 0 ? 2 : 3), cur.x, cur.b, 0.0f, lo, hi);
+                const int v = cur.x <= cur.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(cur.lim2, cur.flags, recB[cur.ray], cur.x);
+                if (hi - lo == 1) {
+                    K2_EXP_STORE(map, cur.ptr, k2_blend(cur.pix, v, alpha));
+                } else if (ab != cur.x && hi - lo <= K2_MAXHIT) {
+                    // Company in the range: the OTHER rays of the range are tested -- this lane's own ray draws the pixel by
+                    // construction.  A hit of a lower ray index ends the matter (that ray's lane owns the pixel); hits of higher
+                    // indices are blended after this lane's value, in index order (at most K2_MAXHIT - 1 of them: kept sorted in
+                    // registers).
+                    int oidx[K2_MAXHIT - 1], oval[K2_MAXHIT - 1], no = 0;
+                    bool owner = true;
+                    for (int ci = lo; ci < hi && owner; ci++) {
+                        const int ray = (int)order[ci];
+                        if (ray == cur.ray) continue;
+                        const k2_rayA e = recA[ray];
+                        k2_cand c; c.dxc = e.dxc; c.sdyc = e.sdyc; c.lim2 = e.lim2; c.ray = ray;
+                        if (!k2_hit<T>(c, cur.x, cur.b)) continue;
+                        if (ray < cur.ray) { owner = false; break; }
+                        const int ov = cur.x <= e.lim2 ? TS_NO_OBSTACLE : k2_pixval_fast(e.lim2, e.flags, recB[ray], cur.x);
+                        int posn = 0;
 #pragma unroll
-                        for (int s2 = 0; s2 < K2_MAXHIT; s2++) if (s2 < nh) pix = k2_blend(pix, hval[s2], alpha);
+                        for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 < no && oidx[s2] < ray) posn++;
+#pragma unroll
+                        for (int s2 = K2_MAXHIT - 2; s2 >= 1; s2--) if (s2 > posn && s2 <= no) { oidx[s2] = oidx[s2 - 1]; oval[s2] = oval[s2 - 1]; }
+#pragma unroll
+                        for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 == posn) { oidx[s2] = ray; oval[s2] = ov; }
+                        no++;
+                    }
+                    if (owner) {
+                        uint16_t pix = k2_blend(cur.pix, v, alpha);
+#pragma unroll
+                        for (int s2 = 0; s2 < K2_MAXHIT - 1; s2++) if (s2 < no) pix = k2_blend(pix, oval[s2], alpha);
                         K2_EXP_STORE(map, cur.ptr, pix);
                     }
+                } else {
+                    // a diagonal pixel, or more company than a lane orders in registers: all hits in ray order, by the lane of the lowest
+                    const int a_s = smaj < 0 ? -cur.x : cur.x;
+                    const int cdx = (cur.flags & K2_F_MAJX) ? a_s : cur.b, cdy = (cur.flags & K2_F_MAJX) ? cur.b : a_s;
+                    bool owner;
+                    const uint16_t pix = k2_lane_draw_ordered<T>(recA, recB, order, start, cdx, cdy, cur.pix, alpha, cur.ray, owner);
+                    if (owner) K2_EXP_STORE(map, cur.ptr, pix);
                 }
             }
         }
-        cur = nxt; nxt = nx2; more0 = more1; more1 = more2;
+        cur = nxt; more0 = more1;
         K2_ITEM_T1(2, 0)
     }
 #undef K2_FETCH
@@ -1286,6 +1408,16 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     __syncthreads();
     K2_STAMP(4)
     // the zone pixels with hits inside a V that the one-lane items queued: the ordered way, four pixels to a wavefront
+    if (core_count) {                                              // (a core workgroup's marked pixels: every ray by index, no sorted table)
+        const int ncq = s_nmix;
+        for (int item = wv; item < ncq; item += 16) {
+            const int ptr = pos_s[2048 + item];
+            const int py = ptr / size, px = ptr - py * size;
+            k2_wave_pixel<T>(px, py, x1, y1, size, recA, recB, n_rays, order, start, map, alpha, sval[wv], true);
+        }
+        K2_STAMP(5)
+        return;
+    }
     const int nq = s_nmix < K2_MIXQ ? s_nmix : K2_MIXQ;
     for (int item = wv; item * 4 < nq; item += 16) {
         const int qi = item * 4 + (lane >> 4);
@@ -1359,7 +1491,7 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         sc.win_key = (const unsigned long long *)win->d_key; sc.win_offs = win->d_offs_flat; sc.win_n_offs = win->n_offs; sc.win_bx = win->bx; sc.win_by = win->by; sc.win_bth = win->bth;
         sc.win_pose_out = const_cast<float *>(d_pose); sc.win_mail = win->mail; sc.win_seq = win->seq;
     }
-    static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, ncore_env = getenv("SLAMHIP_K2_NCORE") ? atoi(getenv("SLAMHIP_K2_NCORE")) : 4;
+    static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, ncore_env = getenv("SLAMHIP_K2_NCORE") ? atoi(getenv("SLAMHIP_K2_NCORE")) : 1;
     sc.rb_num = rb_env < 1 ? 1 : rb_env;                           // (radius, per 1080 rays, from which a zone pixel is one lane's)
     sc.ncore = 0;                                                  // (set below, once the grid is known)
     {
@@ -1384,18 +1516,18 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
         {
             const float hw_px = hole_width * cs->hscale * 0.5f;
             const bool hw_ok = hw_px >= 0.0f && hw_px < 8000.0f;
-            const int nc = ncore_env < 0 ? 0 : ncore_env;
+            const int nc = ncore_env <= 0 ? 0 : 1;                       // (one core workgroup per XCD: it draws its octant's central pixels by counting; SLAMHIP_K2_NCORE=0: no arcs)
             if (build && nc > 0 && !sc.span && hw_ok && cs->hs <= 16384 && grid % 8 == 0 && grid / 8 >= nc + 1) sc.ncore = nc;
         }
-#define K2_PIXELS(B, T) {                                                                                                   \
+#define K2_PIXELS(B, T, A) {                                                                                                \
             static std::atomic<unsigned long long> attr_set{0};              /* one bit per device (the attribute is the device's) */   \
-            if (!((attr_set.load(std::memory_order_acquire) >> (ctx->device & 63)) & 1ull)) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); attr_set.fetch_or(1ull << (ctx->device & 63), std::memory_order_release); } \
-            hipLaunchKernelGGL((k2_pixels<B, T>), dim3(grid), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_rayA *)cs->d_rays, \
+            if (!((attr_set.load(std::memory_order_acquire) >> (ctx->device & 63)) & 1ull)) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_pixels<B, T, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(B, B ? K2_LDS_RAYS : 0)); attr_set.fetch_or(1ull << (ctx->device & 63), std::memory_order_release); } \
+            hipLaunchKernelGGL((k2_pixels<B, T, A>), dim3(grid), dim3(1024), k2_lds_bytes(B, n), ctx->stream, sc, (const k2_rayA *)cs->d_rays, \
                                (const k2_rayB *)cs->d_k2_vprof, (const double *)cs->d_k2_cand, (const int *)((const double *)cs->d_k2_cand + cs->cap_rays), \
                                n, (const int *)cs->d_k2_start, cs->d_k2_counters, \
                                cs->hs, cs->d_hole, quality, grid, ride); }
-        if (build) { if (cs->hs <= 16384) K2_PIXELS(true, int) else K2_PIXELS(true, long long) }
-        else       { if (cs->hs <= 16384) K2_PIXELS(false, int) else K2_PIXELS(false, long long) }
+        if (build) { if (cs->hs <= 16384) { if (sc.ncore > 0) K2_PIXELS(true, int, true) else K2_PIXELS(true, int, false) } else K2_PIXELS(true, long long, false) }
+        else       { if (cs->hs <= 16384) K2_PIXELS(false, int, false) else K2_PIXELS(false, long long, false) }
 #undef K2_PIXELS
     }
     SH_HIP(hipGetLastError());
@@ -1426,6 +1558,31 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
                     a6 += (double)(h[i * 8 + 6] - h[i * 8]) * 0.01; a7 += (double)(h[i * 8 + 7] - h[i * 8 + 6]) * 0.01; a1 += (double)(h[i * 8 + 1] - h[i * 8 + 7]) * 0.01; c++;
                 }
                 if (c) fprintf(stderr, "[k2 times] inside the table phase, mean: start .. first barrier %.2f | rays .. second barrier %.2f | prefix, scatter, third + fourth barrier %.2f\n", a6 / c, a7 / c, a1 / c);
+            }
+            {
+                std::vector<unsigned long long> f(512 * 8);
+                (void)hipMemcpyFromSymbol(f.data(), HIP_SYMBOL(g_k2_fine), sizeof(unsigned long long) * f.size());
+                for (int role = 0; role < 2; role++) {
+                    static const int nce = getenv("SLAMHIP_K2_NCORE") ? atoi(getenv("SLAMHIP_K2_NCORE")) : 1;
+                    double a[6] = { 0 }; int c = 0;
+                    for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8] && h[i * 8 + 6] && f[i * 8] && ((i < 8 * nce) == (role == 0))) {
+                        a[0] += (double)(f[i * 8] - h[i * 8 + 6]) * 0.01; a[1] += (double)(f[i * 8 + 1] - f[i * 8]) * 0.01; a[2] += (double)(f[i * 8 + 2] - f[i * 8 + 1]) * 0.01;
+                        a[3] += (double)(h[i * 8 + 7] - f[i * 8 + 2]) * 0.01; a[4] += (double)(f[i * 8 + 3] - h[i * 8 + 7]) * 0.01; a[5] += (double)(f[i * 8 + 4] - f[i * 8 + 3]) * 0.01; c++;
+                    }
+                    if (c) fprintf(stderr, "[k2 times] %s, first thread: points + selection %.2f | rays %.2f | wave reductions %.2f | barrier %.2f | bins read, scan, barrier %.2f | lists, barrier %.2f\n",
+                                   role == 0 ? "core" : "sector", a[0] / c, a[1] / c, a[2] / c, a[3] / c, a[4] / c, a[5] / c);
+                }
+            }
+            for (int role = 0; role < 2; role++) {       // core workgroups (the first `ncore` of every XCD: blocks 0 .. 8 * ncore - 1) and sector workgroups apart
+                static const int ncore_env = getenv("SLAMHIP_K2_NCORE") ? atoi(getenv("SLAMHIP_K2_NCORE")) : 1;
+                double a[8] = { 0 }, e5 = 0, m5 = 0; int c = 0;
+                for (int i = 0; i < 512; i++) if (h[i * 8] && h[i * 8 + 5] >= h[i * 8] && h[i * 8 + 6] && ((i < 8 * ncore_env) == (role == 0))) {
+                    a[0] += (double)(h[i * 8 + 6] - h[i * 8]) * 0.01; a[1] += (double)(h[i * 8 + 7] - h[i * 8 + 6]) * 0.01; a[2] += (double)(h[i * 8 + 1] - h[i * 8 + 7]) * 0.01;
+                    a[3] += (double)(h[i * 8 + 2] - h[i * 8 + 1]) * 0.01; a[4] += (double)(h[i * 8 + 3] - h[i * 8 + 2]) * 0.01; a[5] += (double)(h[i * 8 + 4] - h[i * 8 + 3]) * 0.01; a[6] += (double)(h[i * 8 + 5] - h[i * 8 + 4]) * 0.01;
+                    const double e = (double)(h[i * 8 + 5] - t0) * 0.01; e5 += e; m5 = std::max(m5, e); c++;
+                }
+                if (c) fprintf(stderr, "[k2 times] %s workgroups (%d): first barrier %.2f | selection + rays %.2f | prefix, lists, scatter %.2f | zone %.2f | steps %.2f | wait for the workgroup %.2f | queue %.2f | end at %.2f (max %.2f) us after the launch's first stamp\n",
+                               role == 0 ? "core" : "sector", c, a[0] / c, a[1] / c, a[2] / c, a[3] / c, a[4] / c, a[5] / c, a[6] / c, e5 / c, m5);
             }
             fprintf(stderr, "[k2 times] %d workgroups, span %.2f us; first thread of each workgroup, mean (max):", nb, (double)(t1 - t0) * 0.01);
             for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f (%.2f) |", nm[k], acc[k] / std::max(nb, 1), mx[k]);
