@@ -36,7 +36,18 @@
 #define TS_NO_OBSTACLE 65500
 #define TS_OBSTACLE 0
 #define K2_NBUCK RS_NBUCK
-#define K2_ZONE 48                     // Chebyshev radius around the robot handled one wavefront per pixel
+// The zone: the Chebyshev radius round the robot inside which pixels are drawn pixel-centrically (beyond it: one lane per ray and
+// step).  Where neighbouring rays lie less than a pixel apart a pixel-centric lane is several times cheaper than the ray-centric
+// ones -- one lookup per pixel instead of one per crossing ray, no ownership to settle -- and a ring of radius a has 8a pixels, so
+// rays overlap out to about a = rays / 8: the zone's radius follows the ray count (48 .. 192; 1080 rays: 135).  Measured at 1080
+// rays on one box: radius 48 19.6 us, 96 16.9, 128 16.7, 160 16.5 (stand-alone updates, rocprofv3).
+#define K2_ZONE_MIN 48
+#define K2_ZONE_MAX 192
+static inline __host__ __device__ int k2_zone_radius(int n_rays)
+{
+    const int z = n_rays / 8;
+    return z < K2_ZONE_MIN ? K2_ZONE_MIN : z > K2_ZONE_MAX ? K2_ZONE_MAX : z;
+}
 #define K2_MAXHIT 4                    // hits a lane-per-pixel thread orders in registers
 #define K2_MIXQ 192                    // zone pixels with hits inside a V that a workgroup queues in LDS for its ordered one-pixel path
 
@@ -475,11 +486,11 @@ __device__ static __noinline__ void k2_wave_pixel(int X, int Y, int x1, int y1, 
 // Work is proportional to what is DRAWN, not to the scan's bounding square (round 2 visited every pixel of the square: ~4 M
 // lanes for ~0.64 M blended pixels at 2048^2).  Two tiers around the robot, by Chebyshev distance r (step x of a ray lies at
 // r = x exactly: the walk takes at most one minor step per major step):
-//   T1  r < K2_ZONE (48)   pixel-centric, wavefronts: tens to a thousand rays cross a pixel near the robot, a handful at r = 47.
+//   T1  r < zone           pixel-centric, wavefronts: tens to a thousand rays cross a pixel near the robot, a handful at r = 47.
 //                          Pixels are numbered from the centre outwards (k2_ring_pixel); a wavefront takes one pixel (r < rB), two
 //                          (rB <= r < rC: 32 lanes test the candidate rays of each) or four (16 lanes each): lanes test the candidates,
 //                          hits are rank-sorted by ray index through LDS and blended in that order by the group's first lane.
-//   T3  r >= K2_ZONE       one lane per (ray, step): the lane computes its pixel from the closed form of the walk and asks, like a
+//   T3  r >= zone          one lane per (ray, step): the lane computes its pixel from the closed form of the walk and asks, like a
 //                          pixel-centric lane would, which rays can draw that pixel -- one contiguous range of the slope-sorted
 //                          table.  Out here rays are more than a pixel apart: nearly always the range holds the lane's own ray and
 //                          nothing else, and the pixel is blended at once.  Otherwise (and on the diagonals, where the two classes
@@ -737,9 +748,12 @@ __device__ static __forceinline__ void k2_lane_pixels(int ddx, int ddy, bool exi
         }
     }
     if (mixed) {
-        const int slot = atomicAdd(n_mixq, 1);
+        // (out from radius 48 a pixel has a handful of candidates: the lane orders them itself -- hits x candidates tests; nearer the
+        // robot, a dozen or two, the pixel goes to the workgroup's queue; a full queue: drawn here all the same, slowly)
+        const int amax = max(ddx < 0 ? -ddx : ddx, ddy < 0 ? -ddy : ddy);
+        const int slot = amax >= K2_ZONE_MIN ? cap_mixq : atomicAdd(n_mixq, 1);
         if (slot < cap_mixq) mixq[slot] = ptr;
-        else { bool ow; map[ptr] = k2_lane_draw_ordered<T>(recA, recB, order, start, ddx, ddy, pix, alpha, -1, ow); }     // (queue full: drawn here, slowly)
+        else { bool ow; map[ptr] = k2_lane_draw_ordered<T>(recA, recB, order, start, ddx, ddy, pix, alpha, -1, ow); }
     } else if (nh > 0) {
         for (int k = 0; k < nh; k++) {
             const uint16_t np = k2_blend(pix, TS_NO_OBSTACLE, alpha);
@@ -793,7 +807,7 @@ static inline size_t k2_lds_bytes(bool build, int n_rays)
 struct k2_t3 { int ptr, x, b, ray, lim2, flags, xalone; uint16_t pix; bool valid; };
 
 // what the kernel needs of the scan when it makes the tables itself
-struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, ncore; int2 *span;
+struct k2_scan { const float2 *pts; float scale, hole_width; const float *d_pose; float4 h_pxcs; int *total_out; int *dirty; int rb_num, ncore, zone; int2 *span;
                  // the fused scan's form: the pose is not in memory yet -- the search (result-ring form: no final arriver, no chain)
                  // left only its key; every workgroup decodes the winner itself, the first one also stores the pose for later
                  // readers and delivers key + pose to the host's mailbox (k2_winner_pose)
@@ -965,7 +979,8 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     const bool is_core = !arcs || wg_in_xcd < sc.ncore;
     const bool core_count = arcs && is_core;                        // this workgroup draws its octant's central pixels by counting (below)
     int rB = (sc.rb_num * n_rays + 1079) / 1080;                    // (the radius from which a zone pixel is one lane's: by the ray COUNT, so that every workgroup agrees)
-    rB = rB < 1 ? 1 : rB > K2_ZONE ? K2_ZONE : rB;
+    const int zone = sc.zone > 0 ? sc.zone : k2_zone_radius(n_rays);   // (steps below `zone`: pixel-centric; from `zone` on: the step lanes)
+    rB = rB < 1 ? 1 : rB > K2_ZONE_MIN ? K2_ZONE_MIN : rB;
     int R, x1, y1, n_own = 0;
     if (BUILD) {
         const int t = threadIdx.x, lane_ = t & 63, wid = t >> 6;
@@ -1026,6 +1041,9 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
         int my_R = 0, my_total = 0;
 #pragma unroll
         for (int k = 0; k < RPT; k++) { bkt[k] = -1; bray[k] = 0; }
+#ifdef K2_TIMES
+        const unsigned long long tm0_ = wall_clock64();
+#endif
 #pragma unroll 1
         for (int it = 0; it * 64 < n_sel; it++) {                   // (rolled: k2_make_ray is kilobytes of code, fetched once per launch)
             const int j = lane_ + it * 64;
@@ -1046,6 +1064,9 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
             for (int k = 0; k < RPT; k++) if (k == it) { bkt[k] = bb; bray[k] = ri; }
         }
         K2_FINE(1)
+#ifdef K2_TIMES
+        if (lane_ == 0 && blockIdx.x < 512) { unsigned long long *p_ = g_k2_sub + ((size_t)blockIdx.x * 16 + wid) * 8; p_[2] = wall_clock64() - tm0_; p_[3] = (unsigned long long)n_sel; }
+#endif
         my_R = sh_wave_max_to_lane63(my_R);                         // one LDS atomic per wave, not per ray (same address)
         my_total = sh_wave_scan_incl(my_total);
         if (lane_ == 63) { atomicMax(&s_R, my_R); atomicAdd(&s_total, my_total); }
@@ -1071,7 +1092,7 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
                 k2_rayA e; e.dxc = 0; e.sdyc = 0; e.lim2 = 0; e.flags = 0;
                 if (i < n_rays && !(arcs && is_core)) {
                     e = recA_s[i];
-                    own = (e.flags & K2_F_VALID) && e.dxc >= K2_ZONE && (arcs ? k2_ray_octant(e) == xcd : (i >= c0 && i < c1));
+                    own = (e.flags & K2_F_VALID) && e.dxc >= zone && (arcs ? k2_ray_octant(e) == xcd : (i >= c0 && i < c1));
                 }
                 ownrec[k] = e;
                 ownb[k] = __ballot(own);
@@ -1185,7 +1206,7 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     // counter): an item costs what its pixels' hit lists cost, and a workgroup is only as fast as its slowest wavefront.
     // The zone: the central pixels (Chebyshev radius < rB, numbered from the robot's pixel outwards -- the closer, the more rays cross
     // a pixel: the longest items start first) are one wavefront's each; from rB on one lane's (k2_lane_pixels).
-    const int Z = K2_ZONE - 1 < R ? K2_ZONE - 1 : R, n_pix = (2 * Z + 1) * (2 * Z + 1);
+    const int Z = zone - 1 < R ? zone - 1 : R, n_pix = (2 * Z + 1) * (2 * Z + 1);
     const int pA = min((2 * rB - 1) * (2 * rB - 1), n_pix);
     const int nA = pA;                                              // central pixels: one item each
     const int nL = (n_pix - pA + 63) / 64;                          // no arcs: the rest of the zone in ring order, 64 pixels an item
@@ -1206,7 +1227,7 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
     // Rays are dealt BY INDEX (a scan's rays come in order of their angle: neighbours in index are neighbours in direction), and to
     // the XCDs by sector -- XCD s (workgroup b runs on XCD b % 8) draws the s-th eighth of the scan: a ray's pixels share their
     // 128-byte lines with its neighbours' (at r = 600 px adjacent rays are 3.5 px apart), and a line should meet one L2.
-    const int nblk = R >= K2_ZONE ? (R - K2_ZONE) / 64 + 1 : 0;      // steps K2_ZONE .. R
+    const int nblk = R >= zone ? (R - zone) / 64 + 1 : 0;            // steps zone .. R
     const int c0 = (int)(((long long)n_rays * xcd) >> 3);            // (!BUILD: the XCD's eighth of the scan by index; BUILD: the list own_s)
     const int n_sec = BUILD ? n_own : (int)(((long long)n_rays * (xcd + 1)) >> 3) - c0;
     const int t3_first = arcs ? wg_in_xcd - sc.ncore : wg_in_xcd, t3_step = arcs ? wgs_in_xcd - sc.ncore : wgs_in_xcd;
@@ -1231,7 +1252,7 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
             k2_rayA me_; int ray_;                         /* (uniform: LDS broadcasts) */               \
             if (own_direct) { me_ = ownA_s[ri_]; ray_ = (int)((unsigned)me_.flags >> 16); }              \
             else { ray_ = BUILD ? (int)own_s[ri_] : ri_ + c0; me_ = recA[ray_]; }                        \
-            const int x0_ = K2_ZONE + blk_ * 64;                                                        \
+            const int x0_ = zone + blk_ * 64;                                                           \
             if ((me_.flags & K2_F_VALID) && x0_ <= me_.dxc) {              /* (uniform: the block holds steps of the ray) */ \
                 const double rc_ = own_direct ? ownC_s[ri_] : recC[ray_];                               \
                 const int x_ = x0_ + lane;                                                              \
@@ -1251,10 +1272,10 @@ k2_pixels(const k2_scan sc, const k2_rayA *__restrict__ recA_g, const k2_rayB *_
             }                                                                                           \
         }                                                                                               \
     }
-    // (the first item's pixels are requested before the zone is drawn: disjoint pixels -- steps below K2_ZONE there, from
-    // K2_ZONE on here -- and the zone's dependent chains hide the map's latency)
+    // (the first item's pixels are requested before the zone is drawn: disjoint pixels -- steps below `zone` there, from
+    // `zone` on here -- and the zone's dependent chains hide the map's latency)
     k2_t3 cur, nxt;
-    cur.ptr = 0; cur.x = K2_ZONE; cur.b = cur.ray = cur.lim2 = cur.flags = 0; cur.xalone = 0x7fffffff; cur.pix = 0; cur.valid = false; nxt = cur;
+    cur.ptr = 0; cur.x = K2_ZONE_MIN; cur.b = cur.ray = cur.lim2 = cur.flags = 0; cur.xalone = 0x7fffffff; cur.pix = 0; cur.valid = false; nxt = cur;
     bool more0 = false, more1 = false;
     if (n_t3 > 0) K2_FETCH(cur, more0)
     // A core workgroup (arcs) draws its octant's CENTRAL pixels -- the rings below rB, where a pixel's window spans up to the whole
@@ -1494,6 +1515,8 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
     static const int rb_env = getenv("SLAMHIP_K2_RB") ? atoi(getenv("SLAMHIP_K2_RB")) : 12, ncore_env = getenv("SLAMHIP_K2_NCORE") ? atoi(getenv("SLAMHIP_K2_NCORE")) : 1;
     sc.rb_num = rb_env < 1 ? 1 : rb_env;                           // (radius, per 1080 rays, from which a zone pixel is one lane's)
     sc.ncore = 0;                                                  // (set below, once the grid is known)
+    static const int zone_env = getenv("SLAMHIP_K2_ZONE") ? atoi(getenv("SLAMHIP_K2_ZONE")) : 0;
+    sc.zone = zone_env >= 1 ? zone_env : 0;                        // (developer override of the zone's radius; 0: by the ray count)
     {
         sh_timer t(ctx, SLAMHIP_K_CS_HOLEMAP);
         if (!build)
@@ -1601,6 +1624,12 @@ int32_t cs_launch_holemap_update(slamhip_cs *cs, const float *d_pose, float4 h_p
             }
             std::vector<unsigned long long> sb(512 * 16 * 8);
             (void)hipMemcpyFromSymbol(sb.data(), HIP_SYMBOL(g_k2_sub), sizeof(unsigned long long) * sb.size());
+            {   // the making of the rays, per wavefront, by how many rays it made
+                double acc[5] = { 0 }; int cn[5] = { 0 };
+                for (int w = 0; w < 512 * 16; w++) if (sb[w * 8 + 2]) { const int ns = (int)sb[w * 8 + 3], c = ns == 0 ? 0 : ns < 16 ? 1 : ns < 48 ? 2 : ns <= 64 ? 3 : 4; acc[c] += (double)sb[w * 8 + 2] * 0.01; cn[c]++; }
+                fprintf(stderr, "[k2 times] a wavefront's ray loop, mean us by rays made: none %.2f (%d) | 1-15 %.2f (%d) | 16-47 %.2f (%d) | 48-64 %.2f (%d) | more %.2f (%d)\n",
+                        acc[0] / std::max(cn[0], 1), cn[0], acc[1] / std::max(cn[1], 1), cn[1], acc[2] / std::max(cn[2], 1), cn[2], acc[3] / std::max(cn[3], 1), cn[3], acc[4] / std::max(cn[4], 1), cn[4]);
+            }
             double tt[3] = { 0, 0, 0 }, cn[3] = { 0, 0, 0 }, wmax[3] = { 0, 0, 0 };
             struct top { double d; int kind, idx, wg, wv; };
             std::vector<top> tops;
