@@ -1527,7 +1527,7 @@ extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose
     // this call than in the headline loop -- and every workgroup of the HoleMap update, which must start with the pose anyway,
     // decodes it from the key (two loads in a row where it had one, under the 1.3 us its sixteen wavefronts take to start); its
     // first workgroup stores the pose for later readers and delivers key + pose to the mailbox.  One-launch updates only
-    // (scans of up to 2400 rays); SLAMHIP_FUSED_K1_DELIVERS=1 keeps the search's own delivery.
+    // (scans of up to 2048 rays); SLAMHIP_FUSED_K1_DELIVERS=1 keeps the search's own delivery.
     static const bool k1_delivers = getenv("SLAMHIP_FUSED_K1_DELIVERS") != nullptr;
     const bool decode = early && !k1_delivers && cs_holemap_one_launch(cs) && cs->n_points > 0;
     if (decode) {

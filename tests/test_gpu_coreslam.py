@@ -542,6 +542,55 @@ def test_holemap_unordered_dense_scan(cs_mod, ctx, det):
     dev.close()
 
 
+@pytest.mark.parametrize("size,R,fov,shuffle,rmin,rmax,hw", [
+    (2048, 1080, 360.0, False, 0.3, 1.2, 0.6),     # every obstacle INSIDE the zone: central and zone pixels inside the rays' V (marked pixels, the workgroups' queues, the lanes' own ordered draws)
+    (2048, 1080, 360.0, True, 2.0, 19.0, 0.6),     # a full scan in random ray order: index order is not angular order (the selection is by direction, the blend order by index)
+    (1024, 720, 180.0, False, 1.0, 15.0, 0.6),     # half a circle: four octants hold no ray at all
+    (2048, 1000, 45.0, False, 3.0, 18.0, 0.6),     # one octant holds every ray: its rays' far steps are one XCD's, the own-ray records overflow nothing
+    (2048, 2040, 30.0, True, 3.0, 18.0, 0.6),      # ... and more own rays than records fit side by side (the indirect own list), shuffled
+    (512, 64, 360.0, False, 0.2, 19.0, 2.5),       # a handful of rays, wide holes
+    (2048, 1080, 360.0, False, 2.0, 19.0, -0.6),   # a NEGATIVE hole width turns the extension round: no arcs (every workgroup holds every ray)
+])
+def test_holemap_arcs_inputs(cs_mod, ctx, det, size, R, fov, shuffle, rmin, rmax, hw):
+    """Round 5's HoleMap update gives every workgroup the rays of its octant and a margin, chosen by the direction of the float end
+    point (k2_arc_member, holemap.hip).  Scans that stress that choice -- against the oracle, pixel for pixel, three updates each from
+    poses that turn and move (the octants' borders sweep over the rays)."""
+    oc = det
+    dev = make_dev(cs_mod, ctx, size)
+    ref = np.full(size * size, 32750, np.uint16)
+    rng = np.random.default_rng(size + R)
+    for it in range(3):
+        ang = np.radians(np.linspace(0.0, fov, R, endpoint=False) + rng.uniform(-0.02, 0.02, R) + 17.0 * it)
+        rad = rng.uniform(rmin, rmax, R)
+        xy = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1).astype(np.float32)
+        if shuffle:
+            xy = xy[rng.permutation(R)]
+        pose = [20.0 + 0.4 * it, 19.5 - 0.3 * it, 0.7 * it - 0.4]
+        dev.set_scan(xy)
+        dev.update_holemap(pose, hw, 60)
+        n = oc.update_holemap(ref, size, dev.hole_scale, xy, pose, hw, 60)
+        assert dev.last_holemap_pixels == n
+        got = dev.holemap_download()
+        bad = np.flatnonzero(got != ref)
+        assert bad.size == 0, (it, bad.size, bad[:8], got[bad[:8]], ref[bad[:8]])
+    dev.close()
+
+
+@pytest.mark.parametrize("env", [{"SLAMHIP_K2_NCORE": "0"}, {"SLAMHIP_K2_ZONE": "48", "SLAMHIP_K2_RB": "5"}, {"SLAMHIP_K2_ZONE": "200", "SLAMHIP_K2_RB": "30"},
+                                 {"SLAMHIP_K2_GRID": "64"}])
+def test_holemap_variants(env):
+    """The HoleMap update's other forms on the ordinary test scans: without arcs (every workgroup holds every ray: what a kept host
+    mirror, a developer grid or an absurd hole width select), other zone radii and central radii, a grid of 64 workgroups (seven
+    sector workgroups per XCD: several zone items each, full queues)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_coreslam.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "holemap_golden or holemap_vs_oracle or holemap_unordered or holemap_degenerate or holemap_arcs_inputs or search_and_update_fused or fused_scans"],
+                       env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, (env, r.stdout.decode(errors="replace")[-3000:])
+
+
 def test_holemap_degenerate_inputs(cs_mod, ctx, det):
     oc = det
     size = 128
@@ -982,7 +1031,7 @@ def test_maps_checksum_and_replica_checks(cs_mod, ctx, det, sim, checksum_np):
 
 
 def test_holemap_large_scan_path():
-    """The HoleMap update of scans too large for the in-kernel tables (more than 2400 rays: k2_prepare + the pixel kernel reading
+    """The HoleMap update of scans too large for the in-kernel tables (more than 2048 rays: k2_prepare + the pixel kernel reading
     its tables from memory, the ObstacleMap update in launches of its own), forced on the ordinary test scans with
     SLAMHIP_K2_TWO_LAUNCHES=1: same maps, same fused results.  (Natively the path runs in the 3000- and 4097-ray cases below and
     in the soak.)"""
