@@ -364,6 +364,12 @@ template <bool MAX> __device__ static inline float k1_wave_redf(float x)      //
     return x;
 }
 
+// developer experiments (SLAMHIP_K1_EXP=n at build time, WRONG RESULTS): parts of k1_search_tiled left out, so that the counters say
+// what each costs (tools/k1_budget.sh) -- 1: the candidates' trigonometry (the jitters stand in for px, py, c, s), 2: the gather loops,
+// 3: the tiles' staging (loads and LDS writes) as well, 4: the epilogue's accumulator adds and everything behind them
+#ifndef K1_EXP
+#define K1_EXP 0
+#endif
 typedef unsigned int k1_u32x4 __attribute__((ext_vector_type(4)));   // a staging register quad (native vector: stays in VGPRs)
 
 // LAT: the candidates of a lane share their heading, bit for bit (a heading lattice: slamhip_cs_generate_offsets_lattice) -- the
@@ -529,6 +535,9 @@ k1_search_tiled(const k1_args a)
                 *(float4 *)&bnd[4] = make_float4(clo, chi, slo, shi);
             }
         }
+        // (Round 5, measured and rejected: the OTHER wavefronts making their candidates here, where they wait for the bounds, instead of
+        // under the first tile's loads -- the K1_EXP = 1 build says the trigonometry, 107 binary64-heavy instructions of a wavefront's
+        // 1472 that all sixteen resident wavefronts run in the same phase, costs the launch 1.7 us -- 17.2 - 17.4 us either way.)
         __syncthreads();
         K1_STAMP(2)
     } else
@@ -730,7 +739,7 @@ k1_search_tiled(const k1_args a)
             const int lstep = rstep * pitchb;                                                       \
             _Pragma("unroll") for (int k_ = 0; k_ < PF; k_++) {                                     \
                 const bool live = colok & (row0 + k_ * rstep < h_);                                 \
-                if (live) R[k_] = *(const k1_u32x4 *)((const char *)map + vofs);   /* (see above) */ \
+                if (live && K1_EXP != 3) R[k_] = *(const k1_u32x4 *)((const char *)map + vofs);   /* (see above) */ \
                 dst[k_] = live ? ldsd : -1;                                                         \
                 vofs += vstep; ldsd += lstep;                                                       \
             }                                                                                       \
@@ -738,7 +747,7 @@ k1_search_tiled(const k1_args a)
         K1_PREFETCH(0, true)
         if (MODE != 0 && pre) {                                    // (the first tile's loads are in flight)
 #pragma unroll
-            for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
+            for (int k = 0; k < CPL; k++) { if (K1_EXP == 1) q[k] = make_float4(a.bx * a.scale + c3[k][0], a.by * a.scale + c3[k][1], a.scale, c3[k][2]); else q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale); }
             if (LAT) {
 #pragma unroll
                 for (int k = 1; k < CPL; k++)
@@ -760,7 +769,7 @@ k1_search_tiled(const k1_args a)
 #pragma unroll
             for (int k = 0; k < PF; k++) asm volatile("" : "+v"(R[k]));
 #pragma unroll
-            for (int k = 0; k < PF; k++) if (dst[k] >= 0) *(k1_u32x4 *)(smem + dst[k]) = R[k];
+            for (int k = 0; k < PF; k++) if (dst[k] >= 0 && K1_EXP != 3) *(k1_u32x4 *)(smem + dst[k]) = R[k];
             __syncthreads();
             if (s == 0) K1_STAMP(6)
 #ifdef K1_TIMES
@@ -798,6 +807,7 @@ k1_search_tiled(const k1_args a)
                 asm volatile("v_mov_b32 %0, %1" : "=v"(p2d_v) : "s"(p2d_s));
                 asm volatile("v_mov_b32 %0, %1" : "=v"(cd_v) : "s"(cd_s));
             }
+            if (K1_EXP == 2 || K1_EXP == 3) { sum[0] += (uint32_t)nr; continue; }
             if (kind != K1_KIND_GLOBAL) {
                 // SHARED: every end point of every candidate lies in the tile (the box is rigorous).  BAND: the band
                 // holds rows [y0, y0+h) x columns [x0a, x0a+w8) of the map; an end point outside it (another band's,
@@ -1001,6 +1011,7 @@ k1_search_tiled(const k1_args a)
     // performs atomics a line at a time: with a lane's candidates adjacent -- every CPL-th word per instruction, 8 lines at two
     // candidates per lane, 16 at four -- the adds took twice / four times as long, and spaced 64 bytes apart, one line each, a
     // 16 384-candidate launch went from 25 to 38 us; measured)
+    if (K1_EXP == 4) { if (sum[0] == 0x12345u && cnt[0] == 77u) a.verify[0] = 1u; return; }
     u64 *acc = a.acc + (size_t)g * GROUP + (size_t)t;
     u64 tot[CPL];
 #pragma unroll
