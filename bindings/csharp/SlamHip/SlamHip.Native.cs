@@ -23,6 +23,8 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_ctx_create(int deviceOrdinal, out IntPtr ctx);
         [DllImport(Lib)] internal static extern int slamhip_ctx_destroy(IntPtr ctx);
         [DllImport(Lib)] internal static extern int slamhip_ctx_synchronize(IntPtr ctx);
+        [DllImport(Lib)] internal static extern int slamhip_ctx_set_wait_timeout(IntPtr ctx, long timeoutMs);
+        [DllImport(Lib)] internal static extern int slamhip_ctx_poisoned(IntPtr ctx, out int poisoned);
 
         // ---- CoreSLAM operator level --------------------------------------------------------------------------------
         [DllImport(Lib)] internal static extern int slamhip_cs_create(IntPtr ctx, float physicalMapSize, int holeMapSize, int obstacleMapSize, out IntPtr cs);
@@ -52,6 +54,10 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_cs_update_obstaclemap_pxcs(IntPtr cs, in Vector4 pxcs, int maxObstacleHits);
         [DllImport(Lib)] internal static extern int slamhip_cs_search_and_update(IntPtr cs, in Vector3 searchPose, float holeWidth, int quality, int maxObstacleHits,
                                                                                  out Vector3 pose, out int dist, out int index);
+        [DllImport(Lib)] internal static extern int slamhip_cs_search_and_update_pxcs(IntPtr cs, Vector4* pxcsSearch, Vector4* pxcsUpdateHole, Vector4* pxcsUpdateObstacle, int k,
+                                                                                      float holeWidth, int quality, int maxObstacleHits, out int index, out int dist);
+        [DllImport(Lib)] internal static extern int slamhip_cs_update_maps_pxcs(IntPtr cs, in Vector4 pxcsHole, in Vector4 pxcsObstacle, float holeWidth, int quality, int maxObstacleHits);
+        [DllImport(Lib)] internal static extern int slamhip_cs_offsets_download(IntPtr cs, Vector3* offs, int n);
 
         // ---- HectorSLAM operator level ------------------------------------------------------------------------------
         [DllImport(Lib)] internal static extern int slamhip_hs_create(IntPtr ctx, float cellLength, int width, int height, int levels, out IntPtr hs);
@@ -78,14 +84,23 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_group_reset(IntPtr group, int unmappedObstacleHits);
         [DllImport(Lib)] internal static extern int slamhip_group_set_scan(IntPtr group, Vector2* points, int nPoints);
         [DllImport(Lib)] internal static extern int slamhip_group_set_offsets(IntPtr group, Vector3* offs, int n);
+        [DllImport(Lib)] internal static extern int slamhip_group_generate_offsets(IntPtr group, int n, float sigmaXY, float sigmaTheta, ulong seed, ulong stream);
+        [DllImport(Lib)] internal static extern int slamhip_group_size(IntPtr group, out int n);
+        [DllImport(Lib)] internal static extern int slamhip_group_holemap_upload(IntPtr group, ushort* pixels, nuint n);
+        [DllImport(Lib)] internal static extern int slamhip_group_search_and_update(IntPtr group, in Vector3 searchPose, float holeWidth, int quality, int maxObstacleHits,
+                                                                                    out Vector3 pose, out int dist, out int index);
         [DllImport(Lib)] internal static extern int slamhip_group_search(IntPtr group, in Vector3 searchPose, out Vector3 pose, out int dist, out int index);
         [DllImport(Lib)] internal static extern int slamhip_group_update_maps(IntPtr group, in Vector3 pose, float holeWidth, int quality, int maxObstacleHits);
         [DllImport(Lib)] internal static extern int slamhip_group_replicas_equal(IntPtr group, out int equal);
         [DllImport(Lib)] internal static extern int slamhip_cs_maps_checksum(IntPtr cs, ulong* holeAndObstacleWords);
         [DllImport(Lib)] internal static extern int slamhip_hs_checksum(IntPtr hs, int level, ulong* valueAndUpdateIndexWords);
 
+        internal const int ErrTimeout = -6;                              // SLAMHIP_ERR_TIMEOUT: a blocking wait passed its bound; the context is poisoned
+
         internal static void Check(int status)
         {
+            if (status == ErrTimeout)
+                throw new TimeoutException($"slamhip: {Marshal.PtrToStringAnsi(slamhip_last_error())} (the device context is poisoned: dispose the objects on it)");
             if (status != 0)
                 throw new InvalidOperationException($"slamhip error {status}: {Marshal.PtrToStringAnsi(slamhip_last_error())}");
         }
@@ -129,6 +144,21 @@ namespace SlamHip
         }
 
         public void Synchronize() => Native.Check(Native.slamhip_ctx_synchronize(Ctx.Ptr));
+
+        /// <summary>Bound on every blocking wait on this device, in milliseconds (default 10 000, or SLAMHIP_WAIT_TIMEOUT_MS; 0: none).
+        /// The reference's ParallelWorker.Work waits for its threads without a bound; here a kernel that never ends surfaces as a
+        /// TimeoutException, after which the device context is poisoned: every later call fails at once, nothing is re-executed, and
+        /// the objects on it are to be disposed.</summary>
+        public long WaitTimeoutMs
+        {
+            set => Native.Check(Native.slamhip_ctx_set_wait_timeout(Ctx.Ptr, value));
+        }
+
+        /// <summary>True once a blocking wait on this device has timed out.</summary>
+        public bool Poisoned
+        {
+            get { Native.Check(Native.slamhip_ctx_poisoned(Ctx.Ptr, out int p)); return p != 0; }
+        }
 
         public void Dispose() => Ctx.Dispose();
     }

@@ -265,6 +265,29 @@ int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out_failures);
 int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float search_pose[3], float hole_width,
                                      int32_t quality, int32_t max_obstacle_hits, float out_pose[3],
                                      int32_t *out_dist, int32_t *out_index);
+/* The same scan with the CALLER's trigonometry, end to end: the reference forms c = MathF.Cos(theta) * Scale, s = MathF.Sin(theta) * Scale
+ * with the platform CRT, in CalculateDistanceSISD (:232-235) and again for the two map updates of the winner (:499-502 at the
+ * HoleMap's scale, :545-548 at the ObstacleMap's -- from the pose AFTER NormalizeAngle :746, whose float arithmetic moves theta by
+ * up to an ulp of 2 pi even inside (-pi, pi]), and a .NET host that wants results IDENTICAL to its own MathF -- not to this
+ * library's deterministic routine -- hands in what it computed.  Two forms:
+ *   slamhip_cs_search_and_update_pxcs: the K candidates as K x 4 (px, py, c, s) at the HoleMap's scale for the search (flat order:
+ *     index 0 is the un-jittered search pose, then MonteCarloSearch's draws thread by thread, :626-649), and the K candidates'
+ *     rows for the updates -- from the NORMALISED pose -- at the HoleMap's and the ObstacleMap's scale (NULL: no ObstacleMap update).
+ *     The call evaluates every candidate, keeps the first strict minimum in flat order (:644-648, :698-705; index 0 when no point
+ *     of any candidate lies in the map, :257), and draws both updates from row `index` of the caller's update arrays (only that
+ *     row is read: the arrays stay on the host);
+ *   slamhip_cs_distance_pxcs, then slamhip_cs_update_maps_pxcs with the winner's two rows: for a host that would rather form the
+ *     update rows of ONE pose after the search than of all K before it (what the C# shim's TrigMode.Host does).
+ * The pose itself never crosses the boundary: the caller knows candidate `index`.  Blocking; every integer output -- distances,
+ * index, both maps -- is bit-exact with the C# on any platform BY CONSTRUCTION. */
+int32_t slamhip_cs_search_and_update_pxcs(slamhip_cs *cs, const float *pxcs_search, const float *pxcs_update_hole,
+                                          const float *pxcs_update_obstacle, int32_t K,
+                                          float hole_width, int32_t quality, int32_t max_obstacle_hits,
+                                          int32_t *out_index, int32_t *out_dist);
+/* UpdateHoleMap (:750) and UpdateObstacleMap (:751) of one pose given as its (px, py, c, s) at either scale (pxcs_obstacle NULL:
+ * the HoleMap only): both enqueued, one wait. */
+int32_t slamhip_cs_update_maps_pxcs(slamhip_cs *cs, const float pxcs_hole[4], const float pxcs_obstacle[4], float hole_width,
+                                    int32_t quality, int32_t max_obstacle_hits);
 
 /* ------------------------------------------------------------------------------------------------
  * CoreSLAM, processor level (host-side orchestration in C++, mirrors the public C# class)
@@ -387,6 +410,8 @@ int32_t slamhip_group_reset(slamhip_group *g, int32_t unmapped_obstacle_hits);
 int32_t slamhip_group_holemap_upload(slamhip_group *g, const uint16_t *pixels, size_t n_pixels);
 int32_t slamhip_group_set_scan(slamhip_group *g, const float *xy, int32_t n_points);
 int32_t slamhip_group_set_offsets(slamhip_group *g, const float *offs, int32_t n);
+/* ... or generated on every GPU of the group (slamhip_cs_generate_offsets: the same list everywhere, keyed by seed, stream and index) */
+int32_t slamhip_group_generate_offsets(slamhip_group *g, int32_t n, float sigma_xy, float sigma_theta, uint64_t seed, uint64_t stream);
 /* Candidates block-sharded over the GPUs, one ncclAllReduce(min, uint64, count 1) of the packed key
  * over xGMI, winner pose recomputed locally. */
 int32_t slamhip_group_search(slamhip_group *g, const float search_pose[3], float out_pose[3],

@@ -101,6 +101,8 @@ def _declare(L):
         "slamhip_cs_last_holemap_pixels": (i32, [vp, P(i64)]),
         "slamhip_cs_maps_checksum": (i32, [vp, P(u64)]),
         "slamhip_cs_search_and_update": (i32, [vp, fp, f, i32, i32, fp, ip, ip]),
+        "slamhip_cs_search_and_update_pxcs": (i32, [vp, fp, fp, fp, i32, f, i32, i32, ip, ip]),
+        "slamhip_cs_update_maps_pxcs": (i32, [vp, fp, fp, f, i32, i32]),
         "slamhip_cs_selfcheck_failures": (i32, [vp, P(C.c_uint32)]),
         "slamhip_cs_prepared_lists": (i32, [vp, P(C.c_uint64), P(C.c_uint64)]),
         "slamhip_csproc_create": (i32, [vp, f, i32, i32, fp, f, f, i32, i32, vpp]),
@@ -146,6 +148,7 @@ def _declare(L):
         "slamhip_group_holemap_upload": (i32, [vp, u16p, sz]),
         "slamhip_group_set_scan": (i32, [vp, fp, i32]),
         "slamhip_group_set_offsets": (i32, [vp, fp, i32]),
+        "slamhip_group_generate_offsets": (i32, [vp, i32, f, f, u64, u64]),
         "slamhip_group_search": (i32, [vp, fp, fp, ip, ip]),
         "slamhip_group_update_maps": (i32, [vp, fp, f, i32, i32]),
         "slamhip_group_search_and_update": (i32, [vp, fp, f, i32, i32, fp, ip, ip]),

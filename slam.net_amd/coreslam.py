@@ -264,6 +264,24 @@ class CoreSlamDevice:
         return pose, d.value, i.value
 
 
+    def search_and_update_pxcs(self, pxcs_search, pxcs_update_hole, pxcs_update_obst=None, hole_width=0.6, quality=50, max_hits=10):
+        """The fused scan with the caller's own (px, py, c, s) (slamhip_cs_search_and_update_pxcs): the candidates for the search,
+        and their rows -- of the normalised pose -- at both map scales for the updates.  Returns (index, distance) of the first strict
+        minimum; both maps are updated from row `index` of the update arrays."""
+        ps = np.ascontiguousarray(pxcs_search, np.float32).reshape(-1, 4)
+        ph = np.ascontiguousarray(pxcs_update_hole, np.float32).reshape(-1, 4)
+        po = None if pxcs_update_obst is None else np.ascontiguousarray(pxcs_update_obst, np.float32).reshape(-1, 4)
+        assert ph.shape == ps.shape and (po is None or po.shape == ps.shape)
+        d, i = C.c_int32(), C.c_int32()
+        capi.call("slamhip_cs_search_and_update_pxcs", self._h, capi.fptr(ps), capi.fptr(ph), capi.fptr(po) if po is not None else None, int(ps.shape[0]),
+                  C.c_float(hole_width), int(quality), int(max_hits), C.byref(i), C.byref(d))
+        return i.value, d.value
+
+    def update_maps_pxcs(self, pxcs_hole, pxcs_obst=None, hole_width=0.6, quality=50, max_hits=10):
+        ph = capi.f32(pxcs_hole); po = None if pxcs_obst is None else capi.f32(pxcs_obst)
+        capi.call("slamhip_cs_update_maps_pxcs", self._h, capi.fptr(ph), capi.fptr(po) if po is not None else None, C.c_float(hole_width), int(quality), int(max_hits))
+
+
 class HoleMap:
     """CoreSLAM/HoleMap.cs: Pixels / Size / Scale / GetPackedPixels(), backed by the device map."""
 

@@ -1505,6 +1505,40 @@ extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
     return SLAMHIP_OK;
 }
 
+// Both map updates of one pose from the caller's (px, py, c, s) at either scale (slamhip.h): enqueued back to back, one wait.
+extern "C" int32_t slamhip_cs_update_maps_pxcs(slamhip_cs *cs, const float pxcs_hole[4], const float pxcs_obstacle[4], float hole_width,
+                                               int32_t quality, int32_t max_obstacle_hits)
+{
+    SH_CHECK_ARG(cs && pxcs_hole && quality >= 0 && quality <= 256 && max_obstacle_hits >= -128 && max_obstacle_hits <= 127);
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    cs->last_hole_pixels = 0; cs->hole_pixels_pending = false;
+    if (cs->n_points <= 0) return SLAMHIP_OK;
+    SH_TRY(cs_launch_holemap_update(cs, nullptr, make_float4(pxcs_hole[0], pxcs_hole[1], pxcs_hole[2], pxcs_hole[3]), make_float4(0, 0, 0, 0), hole_width, quality));   // :750
+    if (pxcs_obstacle)
+        SH_TRY(cs_launch_obstacle_update(cs, nullptr, make_float4(pxcs_obstacle[0], pxcs_obstacle[1], pxcs_obstacle[2], pxcs_obstacle[3]), max_obstacle_hits));     // :751
+    return finish_holemap(cs);
+}
+
+// The fused scan with the caller's (px, py, c, s): slamhip.h.  A composition of the _pxcs operators -- what it adds is the contract
+// (one call, the winner's rows taken from the caller's own arrays, the update rows being those of the NORMALISED pose), not speed:
+// the candidates cross PCIe.
+extern "C" int32_t slamhip_cs_search_and_update_pxcs(slamhip_cs *cs, const float *pxcs_search, const float *pxcs_update_hole,
+                                                     const float *pxcs_update_obstacle, int32_t K,
+                                                     float hole_width, int32_t quality, int32_t max_obstacle_hits,
+                                                     int32_t *out_index, int32_t *out_dist)
+{
+    SH_CHECK_ARG(cs && pxcs_search && pxcs_update_hole && K > 0);
+    SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_obstacle_hits >= -128 && max_obstacle_hits <= 127);
+    int32_t bi = 0, bd = 0;
+    SH_TRY(slamhip_cs_distance_pxcs(cs, pxcs_search, K, nullptr, &bi, &bd));        // (:732; the packed key's minimum IS the first strict minimum in flat order)
+    if (bi < 0 || bi >= K) SH_FAIL(SLAMHIP_ERR_STATE, "the search returned candidate %d of %d", (int)bi, (int)K);
+    SH_TRY(slamhip_cs_update_maps_pxcs(cs, pxcs_update_hole + 4 * (size_t)bi, pxcs_update_obstacle ? pxcs_update_obstacle + 4 * (size_t)bi : nullptr,
+                                       hole_width, quality, max_obstacle_hits));    // (:750-751)
+    if (out_index) *out_index = bi;
+    if (out_dist) *out_dist = bd;
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality,
                                                 int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index)
 {

@@ -237,6 +237,16 @@ extern "C" int32_t slamhip_group_set_offsets(slamhip_group *g, const float *offs
     return SLAMHIP_OK;
 }
 
+// the generator is keyed by (seed, stream, index): every replica makes the very same list, and a rank's block of it is the same
+// candidates whatever the number of ranks -- no list crosses the host
+extern "C" int32_t slamhip_group_generate_offsets(slamhip_group *g, int32_t n, float sigma_xy, float sigma_theta, uint64_t seed, uint64_t stream)
+{
+    SH_CHECK_ARG(g && n >= 0);
+    for (int r = 0; r < g->n; r++) SH_TRY(slamhip_cs_generate_offsets(g->cs[r], n, sigma_xy, sigma_theta, seed, stream));
+    g->n_offs = n;
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_group_search(slamhip_group *g, const float pose[3], float out_pose[3], int32_t *out_dist, int32_t *out_index)
 {
     SH_CHECK_ARG(g && pose);

@@ -11,8 +11,16 @@
  *   abi_harness <libslamhip.so> <dir>
  *     <dir>/k1.meta  "size physical R K"             k1_pixels.u16 k1_xy.f32 k1_pxcs.f32 k1_base.f32 k1_offs.f32 k1_dist.i32
  *     <dir>/k2.meta  "size physical R scans hw q"     k2_xy.f32 k2_pxcs.f32 k2_after1.u16 k2_after_all.u16 k2_counts.i64
+ *     <dir>/k3.meta  "obst_size physical R scans max_hits"  k3_xy.f32 k3_pxcs.f32 k3_after1.i8 k3_after_all.i8
  *     <dir>/k5.meta  "side cell_bits R scans"         k5_xy.f32 k5_poses.f32 k5_value.f32 k5_upd.i32
- *   exit code 0 = every comparison bit-exact; otherwise the first failure is printed.
+ *     <dir>/k4.meta  "R"   k4_xy.f32 k4_hint.f32 k4_pose.f32   (a match on the grid the k5 scans built; the expected pose within 1e-4)
+ *   exit code 0 = every comparison bit-exact (the match: within its tolerance); otherwise the first failure is printed.
+ *
+ *   abi_harness <libslamhip.so> --group <dir>
+ *     the multi-GPU entry points (slamhip_group_*) on a group of ONE GPU, from the k1 fixture: maps uploaded to the group, scan and
+ *     jitters set on it, slamhip_group_search against the golden winner, slamhip_group_search_and_update against the same scan
+ *     through a plain slamhip_cs (pose, distance, index and the HoleMap afterwards), slamhip_group_replicas_equal -- the path the
+ *     driver's 8-GPU box runs first, driven by a caller that is not Python.
  *
  *   abi_harness <libslamhip.so> --bench-proc <hole_size> <rays> <candidates> <scans>
  *     times slamhip_csproc_update (CoreSLAMProcessor.Update, CoreSLAMProcessor.cs:717-752) from a native caller: what a P/Invoke
@@ -196,6 +204,151 @@ static int replay_k5(slamhip_ctx *ctx, const char *dir)
     return 0;
 }
 
+/* K3: UpdateObstacleMap, ten scans in sequence (CoreSLAMProcessor.cs:540-593,:456-490) */
+static int32_t (*p_cs_update_obstaclemap_pxcs)(slamhip_cs *, const float *, int32_t);
+static int32_t (*p_cs_obstaclemap_download)(slamhip_cs *, int8_t *, size_t);
+static int32_t (*p_cs_reset)(slamhip_cs *, int32_t);
+static int replay_k3(slamhip_ctx *ctx, const char *dir)
+{
+    double m[5];
+    if (!read_meta(dir, "k3.meta", m, 5)) FAIL("k3.meta missing");
+    const int os = (int)m[0], R = (int)m[2], scans = (int)m[3], max_hits = (int)m[4];
+    const float physical = (float)m[1];
+    const size_t n = (size_t)os * os;
+    float *xy = slurp(dir, "k3_xy.f32", sizeof(float) * 2 * (size_t)R * scans);
+    float *pxcs = slurp(dir, "k3_pxcs.f32", sizeof(float) * 4 * (size_t)scans);
+    int8_t *after1 = slurp(dir, "k3_after1.i8", n), *after_all = slurp(dir, "k3_after_all.i8", n);
+    slamhip_cs *cs = NULL;
+    CALL(p_cs_create(ctx, physical, 4 * os, os, &cs));
+    CALL(p_cs_reset(cs, -5));                                     /* UnmappedObstacleHits (:96): the fixture's start value */
+    int8_t *got = malloc(n);
+    for (int i = 0; i < scans; i++) {
+        CALL(p_cs_set_scan(cs, xy + 2 * (size_t)R * i, R));
+        CALL(p_cs_update_obstaclemap_pxcs(cs, pxcs + 4 * i, max_hits));
+        if (i == 0) {
+            CALL(p_cs_obstaclemap_download(cs, got, n));
+            if (memcmp(got, after1, n) != 0) FAIL("k3: ObstacleMap after the first scan differs from the golden image");
+        }
+    }
+    CALL(p_cs_obstaclemap_download(cs, got, n));
+    for (size_t i = 0; i < n; i++)
+        if (got[i] != after_all[i]) FAIL("k3: cell %zu is %d, golden %d", i, (int)got[i], (int)after_all[i]);
+    CALL(p_cs_destroy(cs));
+    free(xy); free(pxcs); free(after1); free(after_all); free(got);
+    printf("k3 ok: %d scans x %d rays on %d^2\n", scans, R, os);
+    return 0;
+}
+
+/* K4: ScanMatcher.MatchData on the grid the K5 scans built (HectorSLAM/Matcher/ScanMatcher.cs:64-125); pose within 1e-4 m / rad */
+static int32_t (*p_hs_match)(slamhip_hs *, const float *, float *);
+static int replay_k4(slamhip_ctx *ctx, const char *dir)
+{
+    double m[4], m4[1];
+    if (!read_meta(dir, "k5.meta", m, 4) || !read_meta(dir, "k4.meta", m4, 1)) FAIL("k4.meta / k5.meta missing");
+    const int side = (int)m[0], R = (int)m[2], scans = (int)m[3], R4 = (int)m4[0];
+    const uint32_t cell_bits = (uint32_t)m[1];
+    float cell;
+    memcpy(&cell, &cell_bits, 4);
+    float *xy = slurp(dir, "k5_xy.f32", sizeof(float) * 2 * (size_t)R * scans);
+    float *poses = slurp(dir, "k5_poses.f32", sizeof(float) * 3 * (size_t)scans);
+    float *mxy = slurp(dir, "k4_xy.f32", sizeof(float) * 2 * (size_t)R4);
+    float *hint = slurp(dir, "k4_hint.f32", sizeof(float) * 3), *want = slurp(dir, "k4_pose.f32", sizeof(float) * 3);
+    slamhip_hs *hs = NULL;
+    CALL(p_hs_create(ctx, cell, side, side, 1, &hs));
+    const float origin[2] = { 0.0f, 0.0f };
+    for (int i = 0; i < scans; i++) {
+        CALL(p_hs_set_scan(hs, xy + 2 * (size_t)R * i, R, origin));
+        CALL(p_hs_update_by_scan(hs, poses + 3 * i));
+    }
+    float pose[3] = { 0, 0, 0 };
+    CALL(p_hs_set_scan(hs, mxy, R4, origin));
+    CALL(p_hs_match(hs, hint, pose));
+    for (int c = 0; c < 3; c++)
+        if (!(fabsf(pose[c] - want[c]) <= 1.0e-4f)) FAIL("k4: matched pose component %d is %.7g, expected %.7g", c, pose[c], want[c]);
+    CALL(p_hs_destroy(hs));
+    free(xy); free(poses); free(mxy); free(hint); free(want);
+    printf("k4 ok: match of %d rays on %d^2 -> %.5f %.5f %.5f\n", R4, side, pose[0], pose[1], pose[2]);
+    return 0;
+}
+
+/* the multi-GPU entry points on a group of one GPU (the k1 fixture) */
+typedef struct slamhip_group slamhip_group;
+static int32_t (*p_group_create)(const int32_t *, int32_t, float, int32_t, int32_t, slamhip_group **);
+static int32_t (*p_group_destroy)(slamhip_group *);
+static int32_t (*p_group_size)(slamhip_group *, int32_t *);
+static int32_t (*p_group_cs)(slamhip_group *, int32_t, slamhip_cs **);
+static int32_t (*p_group_reset)(slamhip_group *, int32_t);
+static int32_t (*p_group_holemap_upload)(slamhip_group *, const uint16_t *, size_t);
+static int32_t (*p_group_set_scan)(slamhip_group *, const float *, int32_t);
+static int32_t (*p_group_set_offsets)(slamhip_group *, const float *, int32_t);
+static int32_t (*p_group_search)(slamhip_group *, const float *, float *, int32_t *, int32_t *);
+static int32_t (*p_group_search_and_update)(slamhip_group *, const float *, float, int32_t, int32_t, float *, int32_t *, int32_t *);
+static int32_t (*p_group_replicas_equal)(slamhip_group *, int32_t *);
+static int32_t (*p_cs_search_and_update)(slamhip_cs *, const float *, float, int32_t, int32_t, float *, int32_t *, int32_t *);
+static int run_group(void *h, const char *dir)
+{
+    RESOLVE(p_group_create, "slamhip_group_create"); RESOLVE(p_group_destroy, "slamhip_group_destroy"); RESOLVE(p_group_size, "slamhip_group_size");
+    RESOLVE(p_group_cs, "slamhip_group_cs"); RESOLVE(p_group_reset, "slamhip_group_reset"); RESOLVE(p_group_holemap_upload, "slamhip_group_holemap_upload");
+    RESOLVE(p_group_set_scan, "slamhip_group_set_scan"); RESOLVE(p_group_set_offsets, "slamhip_group_set_offsets"); RESOLVE(p_group_search, "slamhip_group_search");
+    RESOLVE(p_group_search_and_update, "slamhip_group_search_and_update"); RESOLVE(p_group_replicas_equal, "slamhip_group_replicas_equal");
+    RESOLVE(p_cs_search_and_update, "slamhip_cs_search_and_update"); RESOLVE(p_cs_reset, "slamhip_cs_reset");
+    double m[4];
+    if (!read_meta(dir, "k1.meta", m, 4)) FAIL("k1.meta missing");
+    const int size = (int)m[0], R = (int)m[2], K = (int)m[3];
+    const float physical = (float)m[1];
+    const size_t n = (size_t)size * size;
+    uint16_t *pixels = slurp(dir, "k1_pixels.u16", sizeof(uint16_t) * n);
+    float *xy = slurp(dir, "k1_xy.f32", sizeof(float) * 2 * (size_t)R);
+    float *base = slurp(dir, "k1_base.f32", sizeof(float) * 3);
+    float *offs = slurp(dir, "k1_offs.f32", sizeof(float) * 3 * (size_t)(K - 1));
+    int32_t *want = slurp(dir, "k1_dist.i32", sizeof(int32_t) * (size_t)K);
+    int wbi = 0;
+    for (int k = 0; k < K; k++) if (want[k] < want[wbi]) wbi = k;
+    const int32_t dev0 = 0;
+    slamhip_group *g = NULL;
+    CALL(p_group_create(&dev0, 1, physical, size, size / 4 > 0 ? size / 4 : 1, &g));
+    int32_t ng = 0;
+    CALL(p_group_size(g, &ng));
+    if (ng != 1) FAIL("group: size %d", (int)ng);
+    CALL(p_group_reset(g, -5));
+    CALL(p_group_holemap_upload(g, pixels, n));
+    CALL(p_group_set_scan(g, xy, R));
+    CALL(p_group_set_offsets(g, offs, K - 1));
+    float pose[3] = { 0, 0, 0 }, fpose[3] = { 0, 0, 0 }, cpose[3] = { 0, 0, 0 };
+    int32_t d = -1, i = -1;
+    CALL(p_group_search(g, base, pose, &d, &i));                  /* block-sharded search + the exchange of the packed keys */
+    if (i != wbi || d != want[wbi]) FAIL("group: search winner (%d, %d), golden (%d, %d)", (int)i, (int)d, wbi, (int)want[wbi]);
+    CALL(p_group_search_and_update(g, base, 0.6f, 50, 10, fpose, &d, &i));   /* the whole scan on every GPU of the group */
+    if (i != wbi || d != want[wbi]) FAIL("group: fused winner (%d, %d), golden (%d, %d)", (int)i, (int)d, wbi, (int)want[wbi]);
+    /* the same scan through a plain handle on its own context */
+    slamhip_ctx *ctx = NULL;
+    slamhip_cs *cs = NULL, *cs0 = NULL;
+    CALL(p_ctx_create(0, &ctx));
+    CALL(p_cs_create(ctx, physical, size, size / 4 > 0 ? size / 4 : 1, &cs));
+    CALL(p_cs_reset(cs, -5));
+    CALL(p_cs_holemap_upload(cs, pixels, n));
+    CALL(p_cs_set_scan(cs, xy, R));
+    CALL(p_cs_set_offsets(cs, offs, K - 1));
+    int32_t d2 = -1, i2 = -1;
+    CALL(p_cs_search_and_update(cs, base, 0.6f, 50, 10, cpose, &d2, &i2));
+    if (i2 != i || d2 != d || memcmp(cpose, fpose, sizeof cpose) != 0) FAIL("group: fused scan differs from the single handle's (%d %d | %d %d)", (int)i, (int)d, (int)i2, (int)d2);
+    uint16_t *a = malloc(sizeof(uint16_t) * n), *b = malloc(sizeof(uint16_t) * n);
+    CALL(p_group_cs(g, 0, &cs0));
+    CALL(p_cs_holemap_download(cs0, a, n));
+    CALL(p_cs_holemap_download(cs, b, n));
+    if (memcmp(a, b, sizeof(uint16_t) * n) != 0) FAIL("group: the replica's HoleMap differs from the single handle's after the fused scan");
+    if (memcmp(a, pixels, sizeof(uint16_t) * n) == 0) FAIL("group: the fused scan did not draw");
+    int32_t eq = 0;
+    CALL(p_group_replicas_equal(g, &eq));
+    if (eq != 1) FAIL("group: replicas_equal says %d", (int)eq);
+    CALL(p_cs_destroy(cs));
+    CALL(p_ctx_destroy(ctx));
+    CALL(p_group_destroy(g));
+    free(pixels); free(xy); free(base); free(offs); free(want); free(a); free(b);
+    printf("group ok: 1 GPU, winner %d distance %d, replica equals the single handle\n", (int)i, (int)d);
+    return 0;
+}
+
 typedef struct slamhip_csproc slamhip_csproc;
 static int32_t (*p_csproc_create)(slamhip_ctx *, float, int32_t, int32_t, const float *, float, float, int32_t, int32_t, slamhip_csproc **);
 static int32_t (*p_csproc_destroy)(slamhip_csproc *);
@@ -276,7 +429,17 @@ int main(int argc, char **argv)
         RESOLVE(p_ctx_destroy, "slamhip_ctx_destroy");
         return bench_proc(h, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
     }
-    if (argc != 3) { fprintf(stderr, "usage: abi_harness <libslamhip.so> <fixture dir>\n"); return 1; }
+    if (argc == 4 && strcmp(argv[2], "--group") == 0) {
+        void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "abi_harness: dlopen failed: %s\n", dlerror()); return 2; }
+        RESOLVE(p_last_error, "slamhip_last_error");
+        RESOLVE(p_ctx_create, "slamhip_ctx_create"); RESOLVE(p_ctx_destroy, "slamhip_ctx_destroy");
+        RESOLVE(p_cs_create, "slamhip_cs_create"); RESOLVE(p_cs_destroy, "slamhip_cs_destroy");
+        RESOLVE(p_cs_holemap_upload, "slamhip_cs_holemap_upload"); RESOLVE(p_cs_holemap_download, "slamhip_cs_holemap_download");
+        RESOLVE(p_cs_set_scan, "slamhip_cs_set_scan"); RESOLVE(p_cs_set_offsets, "slamhip_cs_set_offsets");
+        return run_group(h, argv[3]);
+    }
+    if (argc != 3) { fprintf(stderr, "usage: abi_harness <libslamhip.so> <fixture dir> | --group <fixture dir> | --bench-proc <size> <rays> <candidates> <scans>\n"); return 1; }
     void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "abi_harness: dlopen failed: %s\n", dlerror()); return 2; }
     RESOLVE(p_last_error, "slamhip_last_error");
@@ -298,12 +461,18 @@ int main(int argc, char **argv)
     RESOLVE(p_hs_set_scan, "slamhip_hs_set_scan");
     RESOLVE(p_hs_update_by_scan, "slamhip_hs_update_by_scan");
     RESOLVE(p_hs_cells_download, "slamhip_hs_cells_download");
+    RESOLVE(p_cs_update_obstaclemap_pxcs, "slamhip_cs_update_obstaclemap_pxcs");
+    RESOLVE(p_cs_obstaclemap_download, "slamhip_cs_obstaclemap_download");
+    RESOLVE(p_cs_reset, "slamhip_cs_reset");
+    RESOLVE(p_hs_match, "slamhip_hs_match");
     if (strcmp(argv[2], "--symbols-only") == 0) { printf("symbols ok\n"); return 0; }   /* (the CPU suite: no GPU, no compute) */
     slamhip_ctx *ctx = NULL;
     CALL(p_ctx_create(0, &ctx));
     int rc = replay_k1(ctx, argv[2]);
     if (rc == 0) rc = replay_k2(ctx, argv[2]);
+    if (rc == 0) rc = replay_k3(ctx, argv[2]);
     if (rc == 0) rc = replay_k5(ctx, argv[2]);
+    if (rc == 0) rc = replay_k4(ctx, argv[2]);
     CALL(p_ctx_destroy(ctx));
     if (rc == 0) printf("abi_harness: all golden replays bit-exact\n");
     return rc;

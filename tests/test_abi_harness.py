@@ -1,6 +1,7 @@
 """The C-ABI driven by a caller that is not Python: tests/abi_harness.c is compiled with gcc, dlopen()s libslamhip.so the way
 a P/Invoke binding does (entry points by name, prototypes restated on the caller's side, caller-owned malloc buffers) and
-replays one golden fixture each for K1 (distance batch + search), K2 (HoleMap update, ten scans) and K5 (Hector grid update).
+replays one golden fixture each for K1 (distance batch + search), K2 (HoleMap update, ten scans), K3 (ObstacleMap update), K5 (Hector
+grid update) and K4 (a match on that grid), and drives the multi-GPU entry points on a group of one GPU.
 SURVEY.md sec.8b / H9: the C# shim, the ctypes harness and a native harness all go through the same extern "C" symbols."""
 import os
 import shutil
@@ -62,6 +63,16 @@ def write_fixtures(d):
     g["after_all"].astype("<u2").tofile(os.path.join(d, "k2_after_all.u16"))
     g["counts"].astype("<i8").tofile(os.path.join(d, "k2_counts.i64"))
 
+    g = np.load(os.path.join(GOLD, "cs_obstacle_64_r360.npz"))
+    osize = int(g["size"])
+    with open(os.path.join(d, "k3.meta"), "w") as f:      # (the ObstacleMap's scale is obst_size / physical: 64 cells over 40 m)
+        f.write("%d %r %d %d %d\n" % (osize, 40.0, g["xy"].shape[1], g["xy"].shape[0], int(g["max_hits"])))
+    assert np.float32(osize) / np.float32(40.0) == g["scale"]
+    g["xy"].astype("<f4").tofile(os.path.join(d, "k3_xy.f32"))
+    g["pxcs"].astype("<f4").tofile(os.path.join(d, "k3_pxcs.f32"))
+    g["after1"].astype("i1").tofile(os.path.join(d, "k3_after1.i8"))
+    g["after_all"].astype("i1").tofile(os.path.join(d, "k3_after_all.i8"))
+
     g = np.load(os.path.join(GOLD, "hs_grid_200_r180.npz"))
     with open(os.path.join(d, "k5.meta"), "w") as f:      # (the cell length as its binary32 bit pattern: exact through a text file)
         f.write("%d %d %d %d\n" % (int(g["side"]), int(np.float32(g["cell"]).view(np.uint32)), g["xy"].shape[1], g["xy"].shape[0]))
@@ -69,6 +80,22 @@ def write_fixtures(d):
     g["poses"].astype("<f4").tofile(os.path.join(d, "k5_poses.f32"))
     g["value"].astype("<f4").tofile(os.path.join(d, "k5_value.f32"))
     g["upd"].astype("<i4").tofile(os.path.join(d, "k5_upd.i32"))
+    # K4: a match on the grid those scans built -- the expected pose from the CPU checker (test infrastructure), run here
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    oc.set_trig_mode(oc.TRIG_DET)
+    side, cell = int(g["side"]), float(g["cell"])
+    grid = oc.Grid(cell, side, side)
+    for xy, pose in zip(g["xy"], g["poses"]):
+        grid.update_by_scan(xy, pose)
+    hint = (g["poses"][-1] + np.array([0.06, -0.05, 0.02], np.float32)).astype(np.float32)
+    want = grid.match(g["match_xy"], hint, iterations=3, n_threads=1)
+    with open(os.path.join(d, "k4.meta"), "w") as f:
+        f.write("%d\n" % g["match_xy"].shape[0])
+    g["match_xy"].astype("<f4").tofile(os.path.join(d, "k4_xy.f32"))
+    hint.astype("<f4").tofile(os.path.join(d, "k4_hint.f32"))
+    np.asarray(want, "<f4").tofile(os.path.join(d, "k4_pose.f32"))
 
 
 @pytest.mark.gpu
@@ -80,7 +107,21 @@ def test_native_caller_replays_golden_fixtures(tmp_path):
     r = subprocess.run([exe, lib_path(), d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out
-    assert "k1 ok" in out and "k2 ok" in out and "k5 ok" in out and "all golden replays bit-exact" in out
+    assert "k1 ok" in out and "k2 ok" in out and "k3 ok" in out and "k4 ok" in out and "k5 ok" in out and "all golden replays bit-exact" in out
+
+
+@pytest.mark.gpu
+def test_native_caller_drives_a_group_of_one_gpu(tmp_path):
+    """--group: the multi-GPU entry points (slamhip_group_*: block-sharded search, the exchange of the packed keys, the fused scan on
+    every GPU, the replica check) on a group of ONE GPU, from a caller that is not Python -- the path the driver's 8-GPU box runs
+    first (CoreSLAMProcessor.cs:674-710 across devices instead of threads)."""
+    exe = build_harness(str(tmp_path))
+    d = str(tmp_path / "fx")
+    os.makedirs(d)
+    write_fixtures(d)
+    r = subprocess.run([exe, lib_path(), "--group", d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "group ok" in out, out
 
 
 @pytest.mark.gpu

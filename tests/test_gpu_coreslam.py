@@ -901,6 +901,20 @@ def test_group_single_gpu(cs_mod, ctx, det, sim):
         got = np.empty(size * size, np.uint16)
         capi.call("slamhip_cs_holemap_download", cs0, got.ctypes.data_as(C.POINTER(C.c_uint16)), got.size)
         assert (got == ref).all()
+        # a list GENERATED on every GPU of the group (what the C# shim's multi-GPU constructor asks for per scan): the same scan once more
+        capi.call("slamhip_group_generate_offsets", g, K - 1, C.c_float(0.1), C.c_float(0.17), C.c_uint64(9), C.c_uint64(3))
+        gen = np.empty((K - 1, 3), np.float32)
+        capi.call("slamhip_cs_offsets_download", cs0, capi.fptr(gen), K - 1)
+        capi.call("slamhip_group_search_and_update", g, capi.fptr(base), C.c_float(0.6), 50, 60, capi.fptr(fp), C.byref(dist), C.byref(idx))
+        rbi, rpose, rbd, _ = oc.search(ref, size, scale, xy, base, gen)
+        wp = np.array([rpose[0], rpose[1], oc.normalize_angle(float(rpose[2]))], np.float32)
+        assert idx.value == rbi and dist.value == rbd and (fp == wp).all()
+        oc.update_holemap(ref, size, scale, xy, wp, 0.6, 50)
+        capi.call("slamhip_cs_holemap_download", cs0, got.ctypes.data_as(C.POINTER(C.c_uint16)), got.size)
+        assert (got == ref).all()
+        eq = C.c_int32()
+        capi.call("slamhip_group_replicas_equal", g, C.byref(eq))
+        assert eq.value == 1
     finally:
         capi.call("slamhip_group_destroy", g)
 
@@ -1028,6 +1042,56 @@ def test_maps_checksum_and_replica_checks(cs_mod, ctx, det, sim, checksum_np):
         assert eq.value == 1
     finally:
         capi.call("slamhip_group_destroy", g)
+
+
+@pytest.mark.parametrize("size,K", [(1024, 16384), (2048, 16384), (400, 4001)])
+def test_search_and_update_host_trig(cs_mod, ctx, oc, sim, size, K):
+    """slamhip_cs_search_and_update_pxcs: the fused scan with the CALLER's trigonometry at both map scales -- the only form in which a
+    .NET host is identical to CoreSLAMProcessor.cs:232-235, :499-502, :545-548 rather than to this library's deterministic routine.
+    The oracle runs in TRIG_LIBM mode (glibc's cosf / sinf standing in for the host's MathF), the candidates' (px, py, c, s) come from
+    its libm path, and distances' arg-min, index and BOTH maps must be bit-exact over several scans (configurations C2 and C3 sizes,
+    and the simulator's)."""
+    oc.set_trig_mode(oc.TRIG_LIBM)
+    try:
+        osize = size // 4
+        R = 1080 if size >= 1024 else 360
+        dev = cs_mod.CoreSlamDevice(ctx, 40.0, size, osize)
+        segs = sim.default_field()
+        rng = sim.PCG32(size + K)
+        ref_h = np.full(size * size, 32750, np.uint16)
+        ref_o = np.full((osize, osize), -5, np.int8)
+        traj = sim.trajectory(9)
+        for p in traj[:5]:                                            # (mapping updates from the host's own trigonometry)
+            _, xy = sim.make_scan(segs, p, R, rng)
+            dev.set_scan(xy)
+            dev.update_holemap_pxcs(oc.pose_to_pxcs(p, dev.hole_scale)); dev.update_obstaclemap_pxcs(oc.pose_to_pxcs(p, dev.obst_scale))
+            oc.update_holemap(ref_h, size, dev.hole_scale, xy, p); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, p)
+        assert (dev.holemap_download() == ref_h).all() and (dev.obstaclemap_download() == ref_o).all()
+        for it, p in enumerate(traj[5:]):
+            _, xy = sim.make_scan(segs, p, R, rng)
+            base = (p + np.array([0.03, -0.02, math.radians(1.0)], np.float32)).astype(np.float32)
+            offs = sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=100 + it)
+            poses = np.vstack([base[None], (base[None] + offs).astype(np.float32)]).astype(np.float32)      # (:635-637: search + jitter, binary32 adds)
+            ps = oc.poses_to_pxcs(poses, dev.hole_scale)
+            norm = poses.copy()
+            norm[:, 2] = [oc.normalize_angle(a) for a in poses[:, 2]]                                          # (:746: the updates' pose)
+            dev.set_scan(xy)
+            rbi, rpose, rbd, _ = oc.search(ref_h, size, dev.hole_scale, xy, base, offs)
+            if it % 2 == 0:                                              # the one-call form: update rows of every candidate
+                ph, po = oc.poses_to_pxcs(norm, dev.hole_scale), oc.poses_to_pxcs(norm, dev.obst_scale)
+                idx, dist = dev.search_and_update_pxcs(ps, ph, po, 0.6, 50, 10)
+            else:                                                        # the two-call form: the winner's rows formed after the search
+                _, idx, dist = dev.distance_pxcs(ps, want_all=False)
+                dev.update_maps_pxcs(oc.pose_to_pxcs(norm[idx], dev.hole_scale), oc.pose_to_pxcs(norm[idx], dev.obst_scale), 0.6, 50, 10)
+            assert (idx, dist) == (rbi, rbd), (it, idx, dist, rbi, rbd)
+            assert (poses[idx] == rpose).all()
+            rpose[2] = oc.normalize_angle(rpose[2])
+            oc.update_holemap(ref_h, size, dev.hole_scale, xy, rpose); oc.update_obstaclemap(ref_o, osize, dev.obst_scale, xy, rpose)
+            assert (dev.holemap_download() == ref_h).all(), it
+            assert (dev.obstaclemap_download() == ref_o).all(), it
+        dev.close()
+    finally:
+        oc.set_trig_mode(oc.TRIG_DET)
 
 
 def test_holemap_large_scan_path():
