@@ -30,6 +30,16 @@ class Context:
     def synchronize(self):
         capi.call("slamhip_ctx_synchronize", self._h)
 
+    def set_wait_timeout(self, timeout_ms):
+        """Bound on every blocking wait of the context (slamhip_ctx_set_wait_timeout; <= 0: none)."""
+        capi.call("slamhip_ctx_set_wait_timeout", self._h, int(timeout_ms))
+
+    @property
+    def poisoned(self):
+        v = C.c_int32()
+        capi.call("slamhip_ctx_poisoned", self._h, C.byref(v))
+        return bool(v.value)
+
     def timing_enable(self, mask=-1):
         """mask: bit k enables kernel class k (capi.K_*); 0 = off; -1 = all."""
         capi.call("slamhip_ctx_timing_enable", self._h, int(mask))

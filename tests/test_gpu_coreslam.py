@@ -4,6 +4,7 @@ bit-exact; poses must be identical floats (same IEEE adds on both sides)."""
 import glob
 import math
 import os
+import time
 
 import numpy as np
 import pytest
@@ -1092,6 +1093,40 @@ def test_search_and_update_host_trig(cs_mod, ctx, oc, sim, size, K):
         dev.close()
     finally:
         oc.set_trig_mode(oc.TRIG_DET)
+
+
+def test_blocking_wait_times_out_and_poisons_the_context(cs_mod, sim):
+    """A blocking call whose completion word does not arrive within the context's bound (slamhip_ctx_set_wait_timeout) returns
+    SLAMHIP_ERR_TIMEOUT and poisons the context: every later blocking call on it fails with the same code at once, nothing is
+    re-executed, and the handles are still destroyed cleanly.  (The 'kernel that never ends' is a queue of eighty one-million-
+    candidate searches in front of a blocking one, against a bound of 2 ms.)"""
+    import slam.net_amd.capi as capi
+    ctx2 = cs_mod.Context(0)
+    dev = cs_mod.CoreSlamDevice(ctx2, 40.0, 1024, 256)
+    try:
+        segs = sim.default_field()
+        rng = sim.PCG32(5)
+        p = sim.trajectory(2)[-1]
+        _, xy = sim.make_scan(segs, p, 1080, rng)
+        dev.set_scan(xy); dev.update_holemap(p)
+        dev.generate_offsets((1 << 20) - 1, 0.1, 0.17, seed=3, stream=1)
+        pose, dist, idx = dev.search(p)                              # (a sound call first: the bound is generous by default)
+        assert not ctx2.poisoned
+        ctx2.set_wait_timeout(2)
+        for _ in range(80):
+            dev.search_shard_enqueue(p, 0, 1 << 20)
+        t0 = time.perf_counter()
+        with pytest.raises(capi.SlamhipError) as e:
+            dev.search(p)
+        assert e.value.code == capi.ERR_TIMEOUT and time.perf_counter() - t0 < 1.0
+        assert ctx2.poisoned
+        for _ in range(3):                                           # poisoned: fails at once, with the same code
+            t1 = time.perf_counter()
+            with pytest.raises(capi.SlamhipError) as e2:
+                dev.search(p)
+            assert e2.value.code == capi.ERR_TIMEOUT and time.perf_counter() - t1 < 0.05
+    finally:
+        dev.close(); ctx2.close()                                    # (destroy waits for the queue to drain: no bound there)
 
 
 def test_holemap_large_scan_path():
