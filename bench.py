@@ -704,6 +704,61 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
     dtb = (time.perf_counter() - t0) / 5
     out["c4_hector_match_3_level_2048_pyramid"] = {"us_per_match_blocking": dt * 1e6, "batched_hints": B,
                                                     "batched_matches_per_s_incl_transfers": B / dtb}
+    # Per-kernel roofline fractions of the secondary kernels (SURVEY.md sec.8d's algorithmic bytes / the kernel's own launch time,
+    # HIP events on the library's stream: slamhip_ctx_timing_*), so that the line shows them instead of leaving them to be derived:
+    #   K2 4 B per blended pixel | K4 24 B per point-iteration (3 levels x 3 iterations x rays) | K5 16 B per touched cell + 4 B for
+    #   its cached probability (touched = cells whose update index moved, counted on the host from two downloads).
+    try:
+        sec = {}
+        PEAK = 8.0e12
+        dk = cs.CoreSlamDevice(ctx, 40.0, 2048, 512)
+        rngk = sim.PCG32(1234)
+        trajk = sim.trajectory(40)
+        scank = [sim.make_scan(segs, p, 1080, rngk)[1] for p in trajk]
+        for i in range(8):
+            dk.set_scan(scank[i]); dk.update_holemap(trajk[i])
+        ctx.timing_reset(); ctx.timing_enable(1 << capi.K_CS_HOLEMAP)
+        px = 0
+        for i in range(8, 40):
+            dk.set_scan(scank[i]); dk.update_holemap(trajk[i]); px += dk.last_holemap_pixels
+        ms2, n2 = ctx.timing_get(capi.K_CS_HOLEMAP)
+        ctx.timing_enable(0)
+        us2 = ms2 / max(n2, 1) * 1e3
+        sec["k2_holemap_update_2048_1080_rays"] = {"us_per_launch_hip_events": us2, "blended_pixels_per_update": px // max(n2, 1), "algorithmic_bytes_per_update": 4 * (px // max(n2, 1)),
+                                                   "achieved_GBps": 4.0 * px / max(n2, 1) / (us2 * 1e-6) / 1e9, "roofline_frac": 4.0 * px / max(n2, 1) / (us2 * 1e-6) / PEAK,
+                                                   "note": "a latency / instruction-bound kernel, not a bandwidth one (DESIGN.md sec.4 K2); stand-alone updates with host work between them: idle clocks"}
+        dk.close()
+        # K5: every scan updating the three grids
+        ctx.timing_reset(); ctx.timing_enable(1 << capi.K_HS_UPDATE)
+        for s5, p5 in scans:
+            rep.UpdateByScan(hs.ScanCloud(s5), p5)
+        ms5, n5 = ctx.timing_get(capi.K_HS_UPDATE)
+        ctx.timing_enable(0)
+        before = [mm.GetCells()["update_index"].copy() for mm in rep.Maps]
+        rep.UpdateByScan(hs.ScanCloud(scans[0][0]), scans[0][1])
+        touched = int(sum(int((mm.GetCells()["update_index"] != b).sum()) for mm, b in zip(rep.Maps, before)))
+        us5 = ms5 / max(n5, 1) * 1e3
+        sec["k5_hector_grid_update_3_level_2048"] = {"us_per_launch_hip_events": us5, "touched_cells_per_update": touched, "algorithmic_bytes_per_update": 20 * touched,
+                                                     "achieved_GBps": 20.0 * touched / (us5 * 1e-6) / 1e9, "roofline_frac": 20.0 * touched / (us5 * 1e-6) / PEAK}
+        # K4: the batched matcher (throughput form) and the single match (a latency chain), kernel time only
+        ctx.timing_reset(); ctx.timing_enable(1 << capi.K_HS_MATCH)
+        for _ in range(3):
+            m.MatchDataBatch(rep, scan, hints)
+        msb, nb = ctx.timing_get(capi.K_HS_MATCH)
+        ctx.timing_reset()
+        for _ in range(30):
+            m.MatchData(rep, scan, hint)
+        ms1, n1 = ctx.timing_get(capi.K_HS_MATCH)
+        ctx.timing_enable(0)
+        bytes_match = 3 * 3 * 1080 * 24
+        usb, us1 = msb / max(nb, 1) * 1e3, ms1 / max(n1, 1) * 1e3
+        sec["k4_hector_match_batched_4096_hints"] = {"us_per_launch_hip_events": usb, "matches_per_s_kernel_only": B / (usb * 1e-6), "algorithmic_bytes_per_match": bytes_match,
+                                                     "achieved_GBps": B * bytes_match / (usb * 1e-6) / 1e9, "roofline_frac": B * bytes_match / (usb * 1e-6) / PEAK}
+        sec["k4_hector_match_single"] = {"us_per_launch_hip_events": us1, "algorithmic_bytes_per_match": bytes_match, "roofline_frac": bytes_match / (us1 * 1e-6) / PEAK,
+                                         "note": "nine dependent Gauss-Newton iterations: a latency chain by construction"}
+        out["secondary_kernels_roofline"] = sec
+    except Exception as e:                                         # noqa: BLE001
+        out["secondary_kernels_roofline"] = {"error": repr(e)}
     # the headline list is restored for the CPU baseline's parity spot-check
     dev.set_offsets(sim.gaussian_offsets(a.cands - 1, 0.1, math.radians(10.0), seed=42))
     gc.enable()

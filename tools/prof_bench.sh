@@ -34,7 +34,29 @@ run k2write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/k2writ
 run k2tcc     --kernel-trace --pmc TCC_HIT TCC_MISS --output-format csv -d $out/k2tcc -o p -- $k2
 run k2sq1     --kernel-trace --pmc $SQ1 --output-format csv -d $out/k2sq1 -o p -- $k2
 run k2sq2     --kernel-trace --pmc $SQ2 --output-format csv -d $out/k2sq2 -o p -- $k2
+# the Hector kernels: the grid update (30 updates of the 3-level 2048^2 pyramid), the single match (a latency chain) and the batched one
+k5="python3 $root/tools/prof_k5.py"
+k4="python3 $root/tools/prof_k4.py single"
+k4b="python3 $root/tools/prof_k4.py batch"
+run k5stats   --kernel-trace --stats --output-format csv -d $out/k5stats -o stats -- $k5
+run k5fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/k5fetch -o p -- $k5
+run k5write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/k5write -o p -- $k5
+run k5sq1     --kernel-trace --pmc $SQ1 --output-format csv -d $out/k5sq1 -o p -- $k5
+run k5sq2     --kernel-trace --pmc $SQ2 --output-format csv -d $out/k5sq2 -o p -- $k5
+run k4stats   --kernel-trace --stats --output-format csv -d $out/k4stats -o stats -- $k4
+run k4fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/k4fetch -o p -- $k4
+run k4write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/k4write -o p -- $k4
+run k4sq1     --kernel-trace --pmc $SQ1 --output-format csv -d $out/k4sq1 -o p -- $k4
+run k4sq2     --kernel-trace --pmc $SQ2 --output-format csv -d $out/k4sq2 -o p -- $k4
+run k4bstats  --kernel-trace --stats --output-format csv -d $out/k4bstats -o stats -- $k4b
+# the fused scan back to back (C3) and CoreSLAMProcessor.Update from the native caller: kernel timelines (tools/trace_gaps.py)
+run c3trace   --kernel-trace --output-format csv -d $out/c3trace -o t -- python3 $root/tools/prof_c3.py 300
+gcc -O1 -o /tmp/abi_harness $root/tests/abi_harness.c -ldl -lm
+run proctrace --kernel-trace --output-format csv -d $out/proctrace -o t -- /tmp/abi_harness $root/slam.net_amd/libslamhip.so --bench-proc 2048 1080 16385 300
 cd $root
+python3 tools/trace_gaps.py $out/c3trace > $out/timeline_c3.txt 2>&1
+python3 tools/trace_gaps.py $out/proctrace > $out/timeline_csproc.txt 2>&1
+python3 tools/kernels_bench.py > $out/kernels_bench.json 2> $out/kernels_bench.err
 timeout 600 python3 bench.py > $out/bench.json 2> $out/bench.err
 # keep what travels back small: the per-dispatch counter CSVs are summarised here, the raw files stay on the box
 python3 tools/prof_summary.py $tag --collect

@@ -56,9 +56,19 @@ def bench_line(name):
 
 
 if "--collect" in sys.argv:
-    out = {"stats": stats("stats"), "stats262k": stats("stats262k"), "k2stats": stats("k2stats")}
-    for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2"):
+    out = {"stats": stats("stats"), "stats262k": stats("stats262k"), "k2stats": stats("k2stats"), "k5stats": stats("k5stats"), "k4stats": stats("k4stats"),
+           "k4bstats": stats("k4bstats")}
+    for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2",
+                "k5fetch", "k5write", "k5sq1", "k5sq2", "k4fetch", "k4write", "k4sq1", "k4sq2"):
         out[sub] = pmc(sub)
+    for name in ("timeline_c3.txt", "timeline_csproc.txt"):
+        pth = os.path.join(src, name)
+        out[name] = open(pth).read() if os.path.exists(pth) else None
+    pth = os.path.join(src, "kernels_bench.json")
+    try:
+        out["kernels_bench"] = json.load(open(pth))
+    except Exception:                                              # noqa: BLE001
+        out["kernels_bench"] = None
     for name in ("bench.json", "stats.out", "stats262k.out", "fetch.out", "sq1.out"):
         out["line_" + name] = bench_line(name)
     json.dump(out, open(os.path.join(src, "collected.json"), "w"))
@@ -167,6 +177,31 @@ if k2:
         "sq": sq_summary(c["k2sq1"], c["k2sq2"], k2, float(k2row["AverageNs"]) if k2row else None),
     }, open(os.path.join(dst, tag + "_k2_counters.json"), "w"), indent=1)
 
-json.dump({k: c[k] for k in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2")},
+# 6. the secondary kernels: event-bracketed timings (tools/kernels_bench.py) and the rocprofv3 passes over the Hector kernels
+sec = {"kernels_bench_hip_events": c.get("kernels_bench")}
+for nm, pat, st, f_, w_, s1, s2, alg in (("k5_hector_grid_update", "k5_cells", "k5stats", "k5fetch", "k5write", "k5sq1", "k5sq2", "16 B per touched cell + 4 B for its cached probability"),
+                                          ("k4_hector_match_single", "k4_match", "k4stats", "k4fetch", "k4write", "k4sq1", "k4sq2", "24 B per point-iteration: 3 levels x 3 iterations x 1080 rays = 233 KB per match")):
+    kn = next((k for k in c.get(s1, {}) if pat in k), None)
+    row = next((r for r in c.get(st, []) if pat in r["Name"]), None)
+    if kn:
+        fs = c.get(f_, {}).get(kn, {}).get("FETCH_SIZE", 0.0); ws = c.get(w_, {}).get(kn, {}).get("WRITE_SIZE", 0.0)
+        sec[nm] = {"kernel": kn, "avg_launch_ns_rocprof_stats": float(row["AverageNs"]) if row else None, "calls": int(row["Calls"]) if row else None,
+                   "algorithmic_bytes": alg, "FETCH_SIZE_KB_per_launch": fs, "WRITE_SIZE_KB_per_launch": ws,
+                   "hbm_bytes_per_launch_raw": (fs + ws) * 1024.0, "hbm_bytes_per_launch_gfx950_corrected_upper": (2.0 * fs + ws) * 1024.0,
+                   "sq": sq_summary(c[s1], c.get(s2), kn, float(row["AverageNs"]) if row else None)}
+rowb = next((r for r in c.get("k4bstats", []) if "k4_match" in r["Name"]), None)
+if rowb:
+    sec["k4_hector_match_batched_4096"] = {"avg_launch_ns_rocprof_stats": float(rowb["AverageNs"]), "calls": int(rowb["Calls"]),
+                                           "matches_per_s": 4096 / (float(rowb["AverageNs"]) * 1e-9), "algorithmic_TBps": 4096 * 233280 / (float(rowb["AverageNs"]) * 1e-9) / 1e12}
+for r in c.get("k2stats", []):
+    if "k3_" in r["Name"] or "k2_" in r["Name"]:
+        sec.setdefault("k2_k3_rocprof_stats", []).append({"kernel": short(r["Name"]), "avg_ns": float(r["AverageNs"]), "calls": int(r["Calls"])})
+json.dump(sec, open(os.path.join(dst, tag + "_secondary_kernels.json"), "w"), indent=1)
+for name, outn in (("timeline_c3.txt", "_timeline_c3.txt"), ("timeline_csproc.txt", "_timeline_csproc.txt")):
+    if c.get(name):
+        open(os.path.join(dst, tag + outn), "w").write(c[name])
+
+json.dump({k: c.get(k) for k in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2",
+                                 "k5fetch", "k5write", "k5sq1", "k5sq2", "k4fetch", "k4write", "k4sq1", "k4sq2")},
           open(os.path.join(dst, tag + "_bench_pmc_per_kernel.json"), "w"), indent=1)
 print("wrote profiles/%s_*; K1 rocprof avg %s ns (262144 candidates: %s ns)" % (tag, k1row["AverageNs"] if k1row else "?", k1row262["AverageNs"] if k1row262 else "?"))
