@@ -157,43 +157,100 @@ __device__ unsigned long long g_k4_times[16];
 #define K4_STAMP_BEGIN
 #endif
 
-// GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) broadcast in sums[].
+// GetCompleteHessianDerivs (:135-204) for the whole workgroup; result (9 sums) in sums[], uniform in every wavefront.
 // order: dTr.x, dTr.y, dTr.z, H11, H22, H33, H12, H13, H23
+//
+// Round 5: a single match is nine dependent iterations on ONE compute unit, and with 16 wavefronts (four per SIMD) it was
+// bound by VALU issue, not by latency (profiles/r05_secondary_kernels.json: 475 VALU instructions per wavefront and iteration,
+// 0.22 of a wavefront's cycles issuing VALU x 4 wavefronts per SIMD): every wavefront repeats the uniform part of an
+// iteration -- Matrix3x2.CreateRotation's IEEERemainder, two binary64 sin/cos evaluations, the 3 x 3 inverse -- and three
+// barriers.  Now
+//  * FEW wavefronts with several points per lane (the single match runs 256 lanes x 5 points: one wavefront per SIMD, the
+//    uniform part once per SIMD), the points of the scan in LDS, the taps of a lane's points requested together by a
+//    branch-free interpolation (outside the grid: taps of cell 0, result selected to zero -- ScanMatcher.cs:216-219);
+//  * ONE barrier per iteration: the wave partials go to one of two alternating LDS blocks, and after the barrier every
+//    wavefront adds the partials itself -- lane k * NW + w loads partial w of sum k, a DPP row tree in binary64 (the same tree
+//    and order as before), nine v_readlane;
+//  * the rotation's sin/cos is the one the derivative needs (:145-146) whenever |angle| < pi (IEEERemainder returns its
+//    argument there, exactly), so it is evaluated once.
 // (Round 4, measured and rejected: a 4 x 4 window of probabilities per point kept in registers across a level's iterations, so
 // that iterations 2 .. n read no memory -- 34.0 -> 37.1 us per match: the first iteration's 64 bytes per point in four unaligned
-// 16-byte loads cost more than the later iterations' taps, which hit the L2 anyway; and the compiler folds a select between
-// struct members into one indexed load, i.e. puts the window into scratch memory, unless the values pass through an opaque asm.)
-// PRE: the thread's (at most HS_PRE) points are already in registers (pre[]): the scan does not change between the
-// iterations of a match, and the point load heads a chain of two dependent memory round trips (point -> four taps).
-#define HS_PRE 2
-template <bool PRE, int BDIM>
-__device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__restrict__ pts, int n, const float pose[3],
-                                        double *red /* [16*9 + 9] LDS */, float sums[9], const float2 *pre = nullptr)
+// 16-byte loads cost more than the later iterations' taps, which hit the L2 anyway.)
+#define HS_LDS_PTS 2048                    // scan points kept in LDS (16 KB); longer scans are read from global memory
+
+// Matrix3x2.CreateRotation (m3x2.h) given sin/cos of the SAME angle: valid for |radians| < pi, where IEEERemainder(radians,
+// 2 pi) == radians
+__device__ static inline sh_m3x2 hs_rotation_sc(float radians, float s_in, float c_in)
 {
-    const sh_m3x2 t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]),
-                                              sh_m3x2_translation(pose[0] * L.cell, pose[1] * L.cell)),
-                                  sh_m3x2_scale(L.stm));                   // :139-142
+    const float pi = 3.14159274f;
+    if (!(fabsf(radians) < pi)) return sh_m3x2_rotation(radians);
+    const float epsilon = 0.001f * pi / 180.0f;
+    float c = c_in, s = s_in;
+    if (radians > -epsilon && radians < epsilon) { c = 1; s = 0; }
+    else if (radians > pi / 2 - epsilon && radians < pi / 2 + epsilon) { c = 0; s = 1; }
+    else if (radians < -pi + epsilon || radians > pi - epsilon) { c = -1; s = 0; }
+    else if (radians > -pi / 2 - epsilon && radians < -pi / 2 + epsilon) { c = 0; s = -1; }
+    sh_m3x2 r = { c, s, -s, c, 0.0f, 0.0f };
+    return r;
+}
+
+template <int BDIM> struct hs_shape {
+    static constexpr int NW = BDIM >> 6;                                   // wavefronts
+    static constexpr int PU = BDIM >= 1024 ? 2 : BDIM >= 512 ? 3 : 5;      // points per lane and pass (1080 rays: one pass)
+    static constexpr int RED = 9 * NW;                                     // doubles per reduction block
+};
+
+template <int BDIM, bool LDSP>
+__device__ static __forceinline__ void hs_hessian_block(const hs_level_dev &L, const float2 *pts, int n, const float pose[3],
+                                                        double *red /* [hs_shape::RED]: this iteration's block */, float sums[9])
+{
+    constexpr int NW = hs_shape<BDIM>::NW, PU = hs_shape<BDIM>::PU;
     K4_STAMP_BEGIN
     float s, c;
     sh_det_sincosf(pose[2], &s, &c);
+    const sh_m3x2 t = sh_m3x2_mul(sh_m3x2_mul(hs_rotation_sc(pose[2], s, c),
+                                              sh_m3x2_translation(pose[0] * L.cell, pose[1] * L.cell)),
+                                  sh_m3x2_scale(L.stm));                   // :139-142
     const float sinRot = s * L.stm, cosRot = c * L.stm;                    // :145-146
+    const float limx = (float)L.w - 2.0f, limy = (float)L.h - 2.0f;       // MapProperties.cs:42
     K4_STAMP(0)                                                            // transform + trigonometry
     float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int base = 0; base < n; base += BDIM * PU) {
+        float2 p[PU], r0[PU], r1[PU];
+        float fx[PU], fy[PU];
+        bool ok[PU];
 #pragma unroll
-    for (int u = 0; u < (PRE ? HS_PRE : 1); u++)
-    for (int i = threadIdx.x + (PRE ? u * BDIM : 0); i < n; i += PRE ? n : BDIM) {
-        const float2 p = PRE ? pre[u] : pts[i];
-        float mx, my, P, gx, gy;
-        sh_v2_transform(p.x, p.y, t, &mx, &my);                            // :161
-        hs_interp(L, mx, my, P, gx, gy);                                   // :162
-        const float fun = 1.0f - P;                                        // :164
-        const float rot = ((-sinRot * p.x - cosRot * p.y) * gx + (cosRot * p.x - sinRot * p.y) * gy);   // :169-170
-        acc[0] += gx * fun;  acc[1] += gy * fun;  acc[2] += rot * fun;     // :166,:167,:172
-        acc[3] += gx * gx;   acc[4] += gy * gy;   acc[5] += rot * rot;     // :174-176
-        acc[6] += gx * gy;   acc[7] += gx * rot;  acc[8] += gy * rot;      // :178-180
+        for (int u = 0; u < PU; u++) {
+            const int i = base + (int)threadIdx.x + u * BDIM;
+            p[u] = i < n ? pts[i] : make_float2(0.f, 0.f);
+            float cx, cy;
+            sh_v2_transform(p[u].x, p[u].y, t, &cx, &cy);                  // :161
+            // InterpMapValueWithDerivatives (:211-249), MapProperties.cs:83-87
+            ok[u] = i < n && !(!(cx == cx) || !(cy == cy) || cx < 0.0f || cx > limx || cy < 0.0f || cy > limy);
+            const float fxx = floorf(cx), fyy = floorf(cy);                // :222
+            const int ix = ok[u] ? (int)fxx : 0, iy = ok[u] ? (int)fyy : 0;
+            fx[u] = cx - fxx; fy[u] = cy - fyy;                            // :225
+            const int idx = iy * L.w + ix;                                 // :227
+            __builtin_memcpy(&r0[u], L.prob + idx, sizeof(float2));        // (two adjacent taps: one 8-byte load)
+            __builtin_memcpy(&r1[u], L.prob + idx + L.w, sizeof(float2));
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const float i0 = r0[u].x, i1 = r0[u].y, i2 = r1[u].x, i3 = r1[u].y;            // :230-233
+            const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;        // :235-239
+            const float xi = 1.0f - fx[u], yi = 1.0f - fy[u];              // :241-242
+            float P = ((i0 * xi + i1 * fx[u]) * yi) + ((i2 * xi + i3 * fx[u]) * fy[u]);   // :245-246
+            float gx = -((dx1 * xi) + (dx2 * fx[u]));                      // :247
+            float gy = -((dy1 * yi) + (dy2 * fy[u]));                      // :248
+            if (!ok[u]) { P = 0.0f; gx = 0.0f; gy = 0.0f; }                // :216-219
+            const float fun = 1.0f - P;                                    // :164
+            const float rot = ((-sinRot * p[u].x - cosRot * p[u].y) * gx + (cosRot * p[u].x - sinRot * p[u].y) * gy);   // :169-170
+            acc[0] += gx * fun;  acc[1] += gy * fun;  acc[2] += rot * fun; // :166,:167,:172
+            acc[3] += gx * gx;   acc[4] += gy * gy;   acc[5] += rot * rot; // :174-176
+            acc[6] += gx * gy;   acc[7] += gx * rot;  acc[8] += gy * rot;  // :178-180
+        }
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    constexpr int nw = BDIM >> 6;           // (the block size is a template parameter: read from the dispatch packet it was re-loaded from memory in every iteration)
     K4_STAMP(1)                                                            // points: taps, interpolation, products
     // the nine trees step by step side by side (independent adds between the steps of one tree), then one store block
 #pragma unroll
@@ -210,27 +267,32 @@ __device__ static void hs_hessian_block(const hs_level_dev &L, const float2 *__r
     for (int k = 0; k < 9; k++) acc[k] += hs_dpp_f32<0x143, 0xc>(acc[k]);         // row_bcast:31 -> rows 2, 3
     if (lane == 63) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) red[k * 16 + wid] = (double)acc[k];
+        for (int k = 0; k < 9; k++) red[k * NW + wid] = (double)acc[k];
     }
     K4_STAMP(2)                                                            // wave sums + store
     __syncthreads();
-    K4_STAMP(3)                                                            // barrier 1
-    // nine sums over (up to) 16 wave partials: lane k*16 + w holds partial w of sum k, so each sum is one DPP row
-    if (threadIdx.x < 9 * 16) {
-        const int w = threadIdx.x & 15;
-        double v = w < nw ? red[threadIdx.x] : 0.0;
-        v += hs_dpp_f64<0xB1, 0xf>(v);
-        v += hs_dpp_f64<0x4E, 0xf>(v);
-        v += hs_dpp_f64<0x124, 0xf>(v);
-        v += hs_dpp_f64<0x128, 0xf>(v);
-        if (w == 0) red[9 * 16 + (threadIdx.x >> 4)] = v;
+    K4_STAMP(3)                                                            // the barrier
+    // every wavefront: nine sums over the NW wave partials; value v = k * NW + w sits in lane v & 63 of register v >> 6, so a
+    // sum is one aligned group of NW lanes of a DPP row; after the tree the group's first lane holds it
+    constexpr int NV = 9 * NW, NR = (NV + 63) >> 6;
+    double d[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) d[r] = lane + 64 * r < NV ? red[lane + 64 * r] : 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (NW >= 2) d[r] += hs_dpp_f64<0xB1, 0xf>(d[r]);
+        if (NW >= 4) d[r] += hs_dpp_f64<0x4E, 0xf>(d[r]);
+        if (NW == 8) d[r] += hs_dpp_f64<0x141, 0xf>(d[r]);             // row_half_mirror: the other quad of the group of 8
+        if (NW >= 16) d[r] += hs_dpp_f64<0x124, 0xf>(d[r]);
+        if (NW >= 16) d[r] += hs_dpp_f64<0x128, 0xf>(d[r]);
     }
-    K4_STAMP(4)                                                            // partial sums
-    __syncthreads();
-    K4_STAMP(5)                                                            // barrier 2
-    for (int k = 0; k < 9; k++) sums[k] = (float)red[9 * 16 + k];
-    __syncthreads();
-    K4_STAMP(6)                                                            // read totals + barrier 3
+    float f[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) f[r] = (float)d[r];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        sums[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f[(k * NW) >> 6]), (k * NW) & 63));
+    K4_STAMP(4)                                                            // totals
 }
 
 // EstimateTransformationLogLh (:93-125) applied by every thread identically (uniform registers)
@@ -258,35 +320,32 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
          float *__restrict__ out, int only_level, int iters_override, uint32_t *mail, uint32_t mail_seq,
          const float2 *up_src, float2 *up_dst, uint32_t *up_flag, uint32_t up_seq)
 {
-    __shared__ double red[16 * 9 + 9];
+    __shared__ double red[2 * hs_shape<BDIM>::RED];
+    __shared__ float2 pts_s[HS_LDS_PTS];
     const int b = blockIdx.x;
     float est_w[3] = { hint1.x, hint1.y, hint1.z };                         // :43 (a single hint travels in the launch arguments)
     if (hints) { est_w[0] = hints[3 * b]; est_w[1] = hints[3 * b + 1]; est_w[2] = hints[3 * b + 2]; }
-    const bool pre_ok = n <= HS_PRE * BDIM;
-    float2 pre[HS_PRE];
+    const bool in_lds = n <= HS_LDS_PTS;
     if (up_src) {
-        // A single match on a freshly set scan (one workgroup, n <= HS_PRE * BDIM): the points come straight from the pinned
-        // staging block -- this launch IS the scan upload.  Every lane keeps its points in registers for the iterations and
-        // stores them to the device copy for the launches that follow (grid update); the stores depend on the loads, so after
+        // A single match on a freshly set scan (one workgroup, n <= HS_LDS_PTS): the points come straight from the pinned
+        // staging block -- this launch IS the scan upload.  The lanes keep the points in LDS for the iterations and store
+        // them to the device copy for the launches that follow (grid update); the stores depend on the loads, so after
         // the barrier the staging block has been read and the host may refill it.
-#pragma unroll
-        for (int u = 0; u < HS_PRE; u++) {
-            const int i = threadIdx.x + u * BDIM;
-            pre[u] = i < n ? up_src[i] : make_float2(0.f, 0.f);
-            if (i < n) up_dst[i] = pre[u];
+        for (int i = threadIdx.x; i < n; i += BDIM) {
+            const float2 v = up_src[i];
+            pts_s[i] = v;
+            up_dst[i] = v;
         }
         __syncthreads();
         if (threadIdx.x < SH_UPLOAD_PARTS) __hip_atomic_store(up_flag + threadIdx.x, up_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the words of sh_upload: common.h)
-    } else {
-#pragma unroll
-        for (int u = 0; u < HS_PRE; u++) {
-            const int i = threadIdx.x + u * BDIM;
-            pre[u] = (pre_ok && i < n) ? pts[i] : make_float2(0.f, 0.f);
-        }
+    } else if (in_lds) {
+        for (int i = threadIdx.x; i < n; i += BDIM) pts_s[i] = pts[i];
+        __syncthreads();
     }
     if (n > 0) {                                                           // :66 (else: hint returned, :83)
         const int l_hi = only_level >= 0 ? only_level : A.n - 1;
         const int l_lo = only_level >= 0 ? only_level : 0;
+        int par = 0;
         for (int l = l_hi; l >= l_lo; l--) {                               // :47
             const hs_level_dev &L = A.lv[l];
             float est[3];
@@ -295,8 +354,9 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
             const int iters = only_level >= 0 ? iters_override : L.iterations;
             for (int it = 0; it < iters; it++) {                           // :70-73
                 float sums[9];
-                if (pre_ok) hs_hessian_block<true, BDIM>(L, pts, n, est, red, sums, pre);
-                else hs_hessian_block<false, BDIM>(L, pts, n, est, red, sums);
+                if (in_lds) hs_hessian_block<BDIM, true>(L, pts_s, n, est, red + par, sums);
+                else hs_hessian_block<BDIM, false>(L, pts, n, est, red + par, sums);
+                par ^= hs_shape<BDIM>::RED;                                // (a block is written again two barriers after it was read)
                 hs_step(sums, est);
             }
             est[2] = sh_normalize_angle(est[2]);                           // :76
@@ -317,10 +377,10 @@ __global__ void __launch_bounds__(256)
 k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, const float *__restrict__ pose_in,
            float *__restrict__ out12)
 {
-    __shared__ double red[16 * 9 + 9];
+    __shared__ double red[hs_shape<256>::RED];
     float pose[3] = { pose_in[0], pose_in[1], pose_in[2] };
     float sums[9];
-    hs_hessian_block<false, 256>(A.lv[level], pts, n, pose, red, sums);
+    hs_hessian_block<256, false>(A.lv[level], pts, n, pose, red, sums);
     if (threadIdx.x == 0) {
         out12[0] = sums[3]; out12[1] = sums[6]; out12[2] = sums[7];
         out12[3] = sums[6]; out12[4] = sums[4]; out12[5] = sums[8];
@@ -1218,7 +1278,7 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     float *d_in = hs->d_io, *d_out = hs->d_io + 3 * (size_t)B;
     const bool mail1 = B == 1 && !ctx->mail_off;                          // one match: the kernel itself delivers the pose to the host
     // ... and pulls a freshly set scan from the staging block itself (k4_match): no upload launch in the per-scan chain
-    const bool pull = B == 1 && hs->upload_pending && hs->n_points > 0 && hs->n_points <= HS_PRE * 1024;
+    const bool pull = B == 1 && hs->upload_pending && hs->n_points > 0 && hs->n_points <= HS_LDS_PTS;
     const float2 *up_src = nullptr; float2 *up_dst = nullptr; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
     if (pull) {                                                           // (committed below, once the launch is in the stream)
         up_src = (const float2 *)hs->h_pts; up_dst = hs->d_pts; up_flag = (uint32_t *)(hs->h_pts + 2 * (size_t)hs->cap_points);
@@ -1234,16 +1294,20 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     if (defer_seq && !mail1) SH_FAIL(SLAMHIP_ERR_STATE, "a deferred match is a single match through the mailbox");
     {
         sh_timer t(ctx, SLAMHIP_K_HS_MATCH);
-        // a single match is a latency chain (levels x iterations): 1024 lanes leave one or two scan points per lane;
-        // batches keep 256 lanes per hint (throughput: many workgroups per CU)
-        if (B <= 64)
-            hipLaunchKernelGGL(k4_match<1024>, dim3(B), dim3(1024), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
-                               B > 1 ? (const float *)d_in : (const float *)nullptr, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters,
-                               mail1 ? ctx->mailbox : (uint32_t *)nullptr, mail1 ? (mail_seq = sh_mail_seq_next(ctx)) : 0u, up_src, up_dst, up_flag, up_seq);
-        else
-            hipLaunchKernelGGL(k4_match<256>, dim3(B), dim3(256), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points,
-                               (const float *)d_in, make_float3(hints[0], hints[1], hints[2]), d_out, only_level, iters, (uint32_t *)nullptr, 0u,
-                               (const float2 *)nullptr, (float2 *)nullptr, (uint32_t *)nullptr, 0u);
+        // a single match is a latency chain on one compute unit, bound by VALU issue: 256 lanes (one wavefront per SIMD, five
+        // scan points per lane at 1080 rays; hs_hessian_block); batches keep 256 lanes per hint too (many workgroups per CU)
+        static const int lanes1 = [] { const char *e = getenv("SLAMHIP_K4_LANES"); const int v = e ? atoi(e) : 0; return v == 512 || v == 1024 ? v : 256; }();
+        const float *d_hints = B > 1 ? (const float *)d_in : (const float *)nullptr;
+        const float3 h1 = make_float3(hints[0], hints[1], hints[2]);
+        uint32_t *mb = mail1 ? ctx->mailbox : (uint32_t *)nullptr;
+        if (mail1) mail_seq = sh_mail_seq_next(ctx);
+        const int lanes = B <= 8 ? lanes1 : 256;
+#define K4_LAUNCH(BD) hipLaunchKernelGGL(k4_match<BD>, dim3(B), dim3(BD), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points, d_hints, h1, d_out, \
+                                         only_level, iters, mb, mail_seq, up_src, up_dst, up_flag, up_seq)
+        if (lanes == 1024) K4_LAUNCH(1024);
+        else if (lanes == 512) K4_LAUNCH(512);
+        else K4_LAUNCH(256);
+#undef K4_LAUNCH
     }
     SH_HIP(hipGetLastError());
     if (pull) { hs->upload_pending = false; hs->upload_seq = up_seq; hs->pts_in_flight = true; }
@@ -1254,7 +1318,7 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
             (void)hipStreamSynchronize(ctx->stream);
             unsigned long long h[16];
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k4_times), sizeof(h));
-            static const char *nm[7] = { "transform+trig", "points", "wave sums", "barrier 1", "partials", "barrier 2", "totals+barrier 3" };
+            static const char *nm[7] = { "transform+trig", "points", "wave sums", "barrier", "totals", "-", "-" };
             double tot = 0;
             for (int k = 0; k < 7; k++) tot += (double)h[k];
             fprintf(stderr, "[k4 times] %d matches, thread 0 of the workgroup, us per match:", calls);
