@@ -35,6 +35,8 @@ def extra_defs():
         d.append("-DK5_TIMES=1")
     if os.environ.get("SLAMHIP_K1_EXP"):        # developer experiment (wrong results): parts of the search kernel left out, for its instruction budget
         d.append("-DK1_EXP=%s" % os.environ["SLAMHIP_K1_EXP"])
+    if os.environ.get("SLAMHIP_K1_DMA0"):       # developer A/B: 0 = the first tile through staging registers like the later ones
+        d.append("-DK1_DMA0=%s" % os.environ["SLAMHIP_K1_DMA0"])
     if os.environ.get("SLAMHIP_K2_EXP"):        # developer experiment (wrong results): which memory traffic bounds K2's step lanes
         d.append("-DK2_EXP=%s" % os.environ["SLAMHIP_K2_EXP"])
     if os.environ.get("SLAMHIP_K2_LDS_RAYS"):   # developer experiment: rays of the K2 pixel kernel's LDS table

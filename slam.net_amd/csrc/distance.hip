@@ -367,6 +367,9 @@ template <bool MAX> __device__ static inline float k1_wave_redf(float x)      //
 // developer experiments (SLAMHIP_K1_EXP=n at build time, WRONG RESULTS): parts of k1_search_tiled left out, so that the counters say
 // what each costs (tools/k1_budget.sh) -- 1: the candidates' trigonometry (the jitters stand in for px, py, c, s), 2: the gather loops,
 // 3: the tiles' staging (loads and LDS writes) as well, 4: the epilogue's accumulator adds and everything behind them
+#ifndef K1_DMA0
+#define K1_DMA0 1                      // the first tile of a workgroup by LDS-DMA (see the steps)
+#endif
 #ifndef K1_EXP
 #define K1_EXP 0
 #endif
@@ -744,7 +747,37 @@ k1_search_tiled(const k1_args a)
                 vofs += vstep; ldsd += lstep;                                                       \
             }                                                                                       \
         }
+#if K1_DMA0
+        {
+            // The FIRST tile by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes straight into 1 KiB of LDS, the base in M0):
+            // nobody reads a previous tile, so the tile area itself can be the landing zone -- no staging registers, no
+            // ds_write pass and one barrier less in front of the first gather.  A wave-wide load lands contiguously, so the tile's
+            // 16-byte units are dealt in row-major order (unit e = row * ncols + col; the pitch stays w8 * 2).  Later tiles keep
+            // the register form: their loads are in flight while the current tile is read, and the registers ARE the second buffer.
+            const int4 pa_ = *(const int4 *)&stepbuf[0];
+            const int w8_ = __builtin_amdgcn_readfirstlane(pa_.z), h_ = __builtin_amdgcn_readfirstlane(pa_.w);
+            const int ncols = w8_ >> 3, nunits = ncols * h_;
+            const unsigned S2_ = (unsigned)S * 2u;
+            const unsigned gofs = ((unsigned)__builtin_amdgcn_readfirstlane(pa_.y) * (unsigned)S + (unsigned)__builtin_amdgcn_readfirstlane(pa_.x)) * 2u;
+            const float rn = 1.0f / (float)ncols;
+#pragma unroll
+            for (int k_ = 0; k_ < PF; k_++) {
+                const int e0 = (k_ * NW + wv) * 64;
+                if (e0 < nunits && K1_EXP != 3) {
+                    const int e = e0 + lane;
+                    const int row = (int)(((float)e + 0.5f) * rn);      // e < 4096, ncols <= 64: (e + 0.5) / ncols is at least 1/128 away from an integer
+                    const int col = e - row * ncols;
+                    if (e < nunits)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)map + (gofs + (unsigned)row * S2_ + ((unsigned)col << 4))),
+                                                         (__attribute__((address_space(3))) void *)(smem + K1_TILE_OFS + (e0 << 4)), 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int k_ = 0; k_ < PF; k_++) dst[k_] = -1;
+        }
+#else
         K1_PREFETCH(0, true)
+#endif
         if (MODE != 0 && pre) {                                    // (the first tile's loads are in flight)
 #pragma unroll
             for (int k = 0; k < CPL; k++) { if (K1_EXP == 1) q[k] = make_float4(a.bx * a.scale + c3[k][0], a.by * a.scale + c3[k][1], a.scale, c3[k][2]); else q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale); }
@@ -762,6 +795,8 @@ k1_search_tiled(const k1_args a)
 #ifdef K1_TIMES
             const unsigned long long ts0 = wall_clock64();
 #endif
+            if (K1_DMA0 && s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's part of the first tile has landed
+            else {
             __syncthreads();                                       // the previous tile is no longer read
             // (every staging register is claimed here, outside any branch: the loads that filled them sit under exec masks,
             // where the compiler cannot count them, and without this it guards the NEXT prefetch's address temporaries --
@@ -770,6 +805,7 @@ k1_search_tiled(const k1_args a)
             for (int k = 0; k < PF; k++) asm volatile("" : "+v"(R[k]));
 #pragma unroll
             for (int k = 0; k < PF; k++) if (dst[k] >= 0 && K1_EXP != 3) *(k1_u32x4 *)(smem + dst[k]) = R[k];
+            }
             __syncthreads();
             if (s == 0) K1_STAMP(6)
 #ifdef K1_TIMES
