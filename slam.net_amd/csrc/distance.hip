@@ -368,7 +368,7 @@ template <bool MAX> __device__ static inline float k1_wave_redf(float x)      //
 // what each costs (tools/k1_budget.sh) -- 1: the candidates' trigonometry (the jitters stand in for px, py, c, s), 2: the gather loops,
 // 3: the tiles' staging (loads and LDS writes) as well, 4: the epilogue's accumulator adds and everything behind them
 #ifndef K1_DMA0
-#define K1_DMA0 1                      // the first tile of a workgroup by LDS-DMA (see the steps)
+#define K1_DMA0 0                      // 1: the first tile of a workgroup by LDS-DMA (see the steps; measured, no gain: DESIGN.md Appendix A)
 #endif
 #ifndef K1_EXP
 #define K1_EXP 0

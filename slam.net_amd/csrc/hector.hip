@@ -151,7 +151,10 @@ __device__ static inline float hs_wave_sum_f32(float v)
 // accumulated by thread 0 of workgroup 0
 __device__ unsigned long long g_k4_times[16];
 #define K4_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = wall_clock64(); g_k4_times[k] += t_ - k4_last; k4_last = t_; } }
-#define K4_STAMP_BEGIN unsigned long long k4_last = wall_clock64();
+__device__ unsigned long long g_k4_last;
+__device__ unsigned long long g_k4_pts[16];      // the points' phase per iteration of a match (coarse level first)
+__device__ int g_k4_iter;
+#define K4_STAMP_BEGIN unsigned long long k4_last = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) { if (g_k4_last) g_k4_times[5] += k4_last - g_k4_last; }
 #else
 #define K4_STAMP(k) {}
 #define K4_STAMP_BEGIN
@@ -251,6 +254,9 @@ __device__ static __forceinline__ void hs_hessian_block(const hs_level_dev &L, c
         }
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#ifdef K4_TIMES
+    if (threadIdx.x == 0 && blockIdx.x == 0) { g_k4_pts[g_k4_iter & 15] += wall_clock64() - k4_last; g_k4_iter++; }
+#endif
     K4_STAMP(1)                                                            // points: taps, interpolation, products
     // the nine trees step by step side by side (independent adds between the steps of one tree), then one store block
 #pragma unroll
@@ -293,6 +299,9 @@ __device__ static __forceinline__ void hs_hessian_block(const hs_level_dev &L, c
     for (int k = 0; k < 9; k++)
         sums[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f[(k * NW) >> 6]), (k * NW) & 63));
     K4_STAMP(4)                                                            // totals
+#ifdef K4_TIMES
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_k4_last = k4_last;          // (stamp 5: from here to the next iteration's start: the step, the level change)
+#endif
 }
 
 // EstimateTransformationLogLh (:93-125) applied by every thread identically (uniform registers)
@@ -325,23 +334,36 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
     const int b = blockIdx.x;
     float est_w[3] = { hint1.x, hint1.y, hint1.z };                         // :43 (a single hint travels in the launch arguments)
     if (hints) { est_w[0] = hints[3 * b]; est_w[1] = hints[3 * b + 1]; est_w[2] = hints[3 * b + 2]; }
+#ifdef K4_TIMES
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_k4_iter = 0;
+#endif
     const bool in_lds = n <= HS_LDS_PTS;
-    if (up_src) {
-        // A single match on a freshly set scan (one workgroup, n <= HS_LDS_PTS): the points come straight from the pinned
-        // staging block -- this launch IS the scan upload.  The lanes keep the points in LDS for the iterations and store
-        // them to the device copy for the launches that follow (grid update); the stores depend on the loads, so after
-        // the barrier the staging block has been read and the host may refill it.
-        for (int i = threadIdx.x; i < n; i += BDIM) {
-            const float2 v = up_src[i];
-            pts_s[i] = v;
-            up_dst[i] = v;
+    if (up_src || in_lds) {
+        // The scan's points into LDS, every lane's loads requested together (one memory round trip, not one per point).
+        // up_src: a single match on a freshly set scan (one workgroup, n <= HS_LDS_PTS) reads them straight from the pinned
+        // staging block -- this launch IS the scan upload -- and stores them to the device copy for the launches that follow
+        // (grid update); the stores depend on the loads, so after the barrier the staging block has been read and the host may
+        // refill it.
+        constexpr int FU = HS_LDS_PTS / BDIM;
+        const float2 *src = up_src ? up_src : pts;
+        float2 v[FU];
+#pragma unroll
+        for (int u = 0; u < FU; u++) { const int i = threadIdx.x + u * BDIM; if (i < n) v[u] = src[i]; }
+#pragma unroll
+        for (int u = 0; u < FU; u++) {
+            const int i = threadIdx.x + u * BDIM;
+            if (i < n) { pts_s[i] = v[u]; if (up_src) up_dst[i] = v[u]; }
         }
         __syncthreads();
-        if (threadIdx.x < SH_UPLOAD_PARTS) __hip_atomic_store(up_flag + threadIdx.x, up_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the words of sh_upload: common.h)
-    } else if (in_lds) {
-        for (int i = threadIdx.x; i < n; i += BDIM) pts_s[i] = pts[i];
-        __syncthreads();
+        if (up_src && threadIdx.x < SH_UPLOAD_PARTS) __hip_atomic_store(up_flag + threadIdx.x, up_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the words of sh_upload: common.h)
     }
+    // (Round 5, measured and rejected: the finer levels' taps requested early -- one LDS-DMA word per point and row at the hint
+    // pose, into a dump nobody reads, issued inside the first iteration so that their lines arrive while the coarse level
+    // iterates.  In the per-scan flow the grid update has just rewritten the cached probabilities from every XCD and the points'
+    // phase takes 14.0 us per match instead of 8.9 on a resting pyramid, but the requests cost more than the misses they avoid:
+    // 23.6 -> 25.5 us per match stand-alone, 30.7 -> 34.0 us inside HectorSLAMProcessor.Update -- vector memory returns in
+    // order, so the coarse level's own taps queue behind them, and twelve scattered 4-byte requests per lane are as much work
+    // for the address unit as two iterations' taps.)
     if (n > 0) {                                                           // :66 (else: hint returned, :83)
         const int l_hi = only_level >= 0 ? only_level : A.n - 1;
         const int l_lo = only_level >= 0 ? only_level : 0;
@@ -1294,9 +1316,10 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
     if (defer_seq && !mail1) SH_FAIL(SLAMHIP_ERR_STATE, "a deferred match is a single match through the mailbox");
     {
         sh_timer t(ctx, SLAMHIP_K_HS_MATCH);
-        // a single match is a latency chain on one compute unit, bound by VALU issue: 256 lanes (one wavefront per SIMD, five
-        // scan points per lane at 1080 rays; hs_hessian_block); batches keep 256 lanes per hint too (many workgroups per CU)
-        static const int lanes1 = [] { const char *e = getenv("SLAMHIP_K4_LANES"); const int v = e ? atoi(e) : 0; return v == 512 || v == 1024 ? v : 256; }();
+        // a single match is a latency chain on one compute unit, bound by VALU issue: 512 lanes (two wavefronts per SIMD, three
+        // scan points per lane at 1080 rays; hs_hessian_block -- rocprofv3, 1080 rays, 3 levels: 1024 lanes 33.7 us, 512 23.9,
+        // 256 25.9); batches run 256 lanes per hint (many workgroups per CU)
+        static const int lanes1 = [] { const char *e = getenv("SLAMHIP_K4_LANES"); const int v = e ? atoi(e) : 0; return v == 256 || v == 1024 ? v : 512; }();
         const float *d_hints = B > 1 ? (const float *)d_in : (const float *)nullptr;
         const float3 h1 = make_float3(hints[0], hints[1], hints[2]);
         uint32_t *mb = mail1 ? ctx->mailbox : (uint32_t *)nullptr;
@@ -1318,12 +1341,17 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
             (void)hipStreamSynchronize(ctx->stream);
             unsigned long long h[16];
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k4_times), sizeof(h));
-            static const char *nm[7] = { "transform+trig", "points", "wave sums", "barrier", "totals", "-", "-" };
+            static const char *nm[7] = { "transform+trig", "points", "wave sums", "barrier", "totals", "step..next (and the gap between matches)", "-" };
             double tot = 0;
             for (int k = 0; k < 7; k++) tot += (double)h[k];
             fprintf(stderr, "[k4 times] %d matches, thread 0 of the workgroup, us per match:", calls);
             for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.2f |", nm[k], (double)h[k] * 0.01 / calls);
             fprintf(stderr, " sum %.2f\n", tot * 0.01 / calls);
+            unsigned long long hp[16];
+            (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_k4_pts), sizeof(hp));
+            fprintf(stderr, "[k4 times] the points' phase per iteration, us:");
+            for (int k = 0; k < 12; k++) fprintf(stderr, " %.2f", (double)hp[k] * 0.01 / calls);
+            fprintf(stderr, "\n");
         }
     }
 #endif
