@@ -34,8 +34,9 @@
 struct hs_level {
     int w, h; float cell, stm;             // MapProperties: Dimensions, CellLength, ScaleToMap (MapProperties.cs:22-32)
     sh_m3x2 map_t_world, world_t_map;      // GridMap.cs:46-47
-    float *d_value; int32_t *d_upd;        // LogOddsCell SoA (GridMap.cs:13)
-    float *d_prob;                         // GetCachedProbability of every cell (OccGridMap.cs:97-107), kept current by every writer of d_value
+    slamhip_cell *d_cells;                 // mapArray (GridMap.cs:13) in the reference's own layout, LogOddsCell {UpdateIndex, Value} (LogOddsCell.cs:16-21): the grid
+                                           // update reads and writes a cell with ONE 8-byte access (two arrays: 30.8 -> 26.9 us per update with the second one left out)
+    float *d_prob;                         // GetCachedProbability of every cell (OccGridMap.cs:97-107), kept current by every writer of d_cells
     int curr_update_index;                 // OccGridMap.cs:20
     int iterations;                        // EstimateIterations (OccGridMap.cs:53)
 };
@@ -43,7 +44,6 @@ struct hs_level {
 struct hs_level_dev {                      // what the kernels need, by value
     int w, h; float cell, stm;
     sh_m3x2 map_t_world, world_t_map;
-    const float *value;
     const float *prob;                     // what the matcher's taps read: exp and divide happen when a cell changes, not per tap
     int iterations;
 };
@@ -69,12 +69,6 @@ struct hs_levels_arg { hs_level_dev lv[HS_MAX_LEVELS]; int n; };
 
 // ---- K4 device code ------------------------------------------------------------------------------------------
 // OccGridMap.GetCachedProbability (:97-107)
-__device__ static inline float hs_prob(const float *__restrict__ value, int idx)
-{
-    const float odds = expf(value[idx]);                                   // :101
-    return odds / (odds + 1.0f);                                           // :102
-}
-
 __device__ static inline float hs_prob_v(float v)
 {
     const float odds = expf(v);                                            // :101
@@ -419,7 +413,10 @@ k4_hessian(hs_levels_arg A, int level, const float2 *__restrict__ pts, int n, co
 // processed in index order by the reference, and a cell changes at most twice per update (BresenhamCellFree marks it,
 // BresenhamCellOcc overrides the mark), so all a cell needs is the smallest index of a line that crosses it as "free",
 // the smallest index of a line that ends in it, and their order -- no atomics, no per-cell scratch, coalesced rows.
-struct k5_level { int w, h; sh_m3x2 t; float *value; int32_t *upd; float *prob; int mark_free, mark_occ; int wg0, wgn; };
+struct k5_level { int w, h; sh_m3x2 t; slamhip_cell *cells; float *prob; int mark_free, mark_occ; int wg0, wgn; };
+// a cell as one 8-byte word: update_index in the low half, the value's bits in the high half (slamhip_cell, include/slamhip.h)
+__device__ static __forceinline__ void k5_load_cell(const slamhip_cell *c, float &v, int &u) { const int2 w = *(const int2 *)c; u = w.x; v = __int_as_float(w.y); }
+__device__ static __forceinline__ void k5_store_cell(slamhip_cell *c, float v, int u) { *(int2 *)c = make_int2(u, __float_as_int(v)); }
 struct k5_arg { k5_level lv[HS_MAX_LEVELS]; int n; };
 // The update gated on the device (HectorSLAMProcessor's per-scan flow, slamhip_hsproc_update): the launch is enqueued right
 // behind the match, before the host has the pose -- the kernel reads the matched pose the match left in device memory, applies
@@ -547,11 +544,10 @@ __device__ static inline void k5_transition(const k5_level &L, float &v, int &u,
 }
 __device__ static inline void k5_apply(const k5_level &L, int cell, int first_free, int first_occ, float lo_free, float lo_occ)
 {
-    float v = L.value[cell];
-    int u = L.upd[cell];
+    float v; int u;
+    k5_load_cell(L.cells + cell, v, u);
     k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
-    L.value[cell] = v;
-    L.upd[cell] = u;
+    k5_store_cell(L.cells + cell, v, u);
     L.prob[cell] = hs_prob_v(v);
 }
 
@@ -571,6 +567,9 @@ __device__ static inline int k5_wave_min(int x)
 // the lines inside a bucket then differs from workgroup to workgroup (LDS atomics), so the work that is shared out between
 // workgroups goes by LINE INDEX (byidx), never by table position.
 #define K5_LDS_FIXED ((4 * RS_NBUCK + 4) * 4)
+#ifndef K5_EXP
+#define K5_EXP 0
+#endif
 #ifdef K5_TIMES
 // developer instrumentation (build with SLAMHIP_K5_TIMES=1): 100 MHz wall-clock stamps per workgroup: start, tables, zone, end
 __device__ unsigned long long g_k5_times[1024 * 4];
@@ -656,7 +655,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     const int n4 = (n_pts + 3) & ~3;
     k5_line *cand_s = (k5_line *)(pos_s + (BUILD ? 4 * RS_NBUCK : 0));
     k5_line *byidx_s = cand_s + (BUILD ? n4 : 0);
-    __shared__ int wsum[16];
+    __shared__ __attribute__((aligned(16))) int wsum[16];
     __shared__ int s_R, s_nv, s_first;
     __shared__ int s_bound[9], s_rec[10], s_wsum_all, s_wtot[((K5_LDS_LINES + 1023) / 1024) * 16];   // BUILD: the sectors of phase 2 (below)
     // workgroups are shared out over the levels (host: wg0, wgn)
@@ -720,10 +719,10 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
 #pragma unroll
             for (int k = 0; k < RPT; k++) if (k == it) bkt[k] = bb;
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            my_R = max(my_R, __shfl_down(my_R, off, 64)); my_nv += __shfl_down(my_nv, off, 64); my_first = min(my_first, __shfl_down(my_first, off, 64));
-        }
-        if (lane_ == 0) { atomicMax(&s_R, my_R); atomicAdd(&s_nv, my_nv); atomicMin(&s_first, my_first); }
+        // (wave reductions by DPP, common.h: eighteen shuffles -- ds_bpermute, ~100 cycles each, on an LDS pipe that 32 wavefronts
+        // of the compute unit use at once in this phase -- were a microsecond of it)
+        my_R = sh_wave_max_to_lane63(my_R); my_nv = sh_wave_scan_incl(my_nv); my_first = sh_wave_min_all(my_first);
+        if (lane_ == 63) { atomicMax(&s_R, my_R); atomicAdd(&s_nv, my_nv); atomicMin(&s_first, my_first); }
         if (t < 10) s_rec[t] = rec_v;
         __syncthreads();
         // Phase 2's sectors: the lines go to the XCDs in eight ranges of consecutive indices (locality: see phase 2) that hold EQUAL
@@ -736,15 +735,18 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             int v[4], sum = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = start[4 * t + k]; sum += v[k]; }
-            int incl = sum;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane_ >= off) incl += o;
-            }
+            const int incl = sh_wave_scan_incl(sum);
             if (lane_ == 63) wsum[wid] = incl;
             __syncthreads();                                               // (every thread has read its bins)
             int base = incl - sum;
-            for (int w = 0; w < wid; w++) base += wsum[w];
+            {   // the wave totals in front of this one: four 16-byte reads, not up to fifteen dependent ones
+                const int4 *w4 = (const int4 *)wsum;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int4 x = w4[q];
+                    base += (4 * q + 0 < wid ? x.x : 0) + (4 * q + 1 < wid ? x.y : 0) + (4 * q + 2 < wid ? x.z : 0) + (4 * q + 3 < wid ? x.w : 0);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) { start[4 * t + k] = base; pos_s[4 * t + k] = base; base += v[k]; }
             if (t == 1023) start[4 * RS_NBUCK] = base;
@@ -761,6 +763,41 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             if (sec_out && (int)blockIdx.x == L.wg0 && t == 0) sec_out[lvl * K5_SEC] = -1;      // (no record for the next update)
             return;
         }
+        // From which step on is a line ALONE on its cells (round 5; K2's finding, holemap.hip)?  Step a of a line lies at minor offset
+        // floor(a * slope + h), h = (da / 2) / da in [1/2 - 1/(2 da), 1/2] (:228-235), so two lines of a class -- signed slopes: a
+        // cell of minor offset 0 is shared across the sign -- meet at major offset a only if a * |slope difference| < 1 + 1/(2 da):
+        // beyond the zone (da >= 16) never from a = 1.0625 / g + 2 on, g the smallest slope difference to any other line of the class.
+        // A thread per line looks at the twelve buckets either side of the line's own (no line in sight: g >= 10 bucket widths) and leaves
+        // the step in bits 5 .. 17 of the line's flags; from there on the line's step lanes of phase 2 look nothing up (a cell on
+        // the diagonal, which the quadrant's other class touches too, excepted).  No barrier: a lane that reads the word before it
+        // is written finds zero = "not known" and takes the lookup -- slower, never wrong.
+        // Only the lines of this workgroup's own sector (phase 2 below) are asked about.
+        {
+            const int wg_l_ = (int)blockIdx.x - L.wg0, xcd_ = wg_l_ & 7;
+            const bool rec_ok_ = s_rec[0] == n_pts;
+            const int c0_ = xcd_ == 0 ? 0 : rec_ok_ ? s_rec[1 + xcd_] : (int)(((long long)n_pts * xcd_) >> 3);
+            const int c1_ = xcd_ == 7 ? n_pts : rec_ok_ ? s_rec[2 + xcd_] : (int)(((long long)n_pts * (xcd_ + 1)) >> 3);
+            for (int i = c0_ + t; i < c1_; i += 1024) {
+                const k5_line e = byidx_s[i];
+                if (!(e.flags & 1) || e.da < K5_ZONE) continue;
+                const float sl = (float)e.sdb * __builtin_amdgcn_rcpf((float)e.da);
+                const int smaj = ((e.flags >> 2) & 3) - 1;
+                const int cb = rs_class((e.flags & 2) != 0, smaj) * RS_NBUCK, bk = cb + rs_bucket(sl);
+                const int w0 = start[max(bk - 12, cb)], w1 = start[min(bk + 12, cb + RS_NBUCK - 1) + 1];    // (the table's buckets come from the exact quotient: one bucket of slack)
+                float g = 10.0f * (2.0f / (float)RS_NBUCK);
+                int same = 0;                                              // (lines with this very slope: its own, and any other -> never alone)
+                for (int ci = w0; ci < w1; ci++) {
+                    const k5_line c = cand_s[ci];
+                    const float d = fabsf((float)c.sdb * __builtin_amdgcn_rcpf((float)c.da) - sl);
+                    same += d == 0.0f ? 1 : 0;
+                    g = d > 0.0f && d < g ? d : g;
+                }
+                // (slopes by the hardware reciprocal: each within 2.5e-7 of the quotient; equal quotients that come out an ulp apart
+                // make g tiny, i.e. "never alone")
+                const int xa = same == 1 && g > 4.0e-6f ? min((int)(1.0625f * __builtin_amdgcn_rcpf(g - 1.0e-6f) * 1.0001f) + 2, 8191) : 8191;
+                byidx_s[i].flags = e.flags | (xa << 5);
+            }
+        }
     } else {
         const int *start_g = start_all + (size_t)lvl * (4 * RS_NBUCK + 1), *hdr = hdr_all + lvl * K5_HDR;
         bx = hdr[0]; by = hdr[1]; R = hdr[2]; nv = hdr[3]; first_line = hdr[4];
@@ -769,6 +806,9 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         __syncthreads();
     }
     K5_STAMP(1)
+#if K5_EXP == 1                          // developer experiment (wrong results): the launch with its table phase alone
+    return;
+#endif
     const k5_line *cand = BUILD ? cand_s : cand_all + (size_t)lvl * cap;
     const k5_line *byidx = BUILD ? byidx_s : byidx_all + (size_t)lvl * cap;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -782,8 +822,8 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         if (X < 0 || X >= L.w || Y < 0 || Y >= L.h) continue;              // wave-uniform
         const int dx = X - bx, dy = Y - by;
         const int cell = Y * L.w + X;
-        float v = L.value[cell];                                           // (requested now, needed after the search)
-        int u = L.upd[cell];
+        float v; int u;
+        k5_load_cell(L.cells + cell, v, u);                                // (requested now, needed after the search)
         int first_free = 0x7fffffff, first_occ = 0x7fffffff;
         if (dx == 0 && dy == 0) first_free = first_line;
         else {
@@ -804,8 +844,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         }
         if (lane == 63 && (first_free != 0x7fffffff || first_occ != 0x7fffffff)) {
             k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
-            L.value[cell] = v;
-            L.upd[cell] = u;
+            k5_store_cell(L.cells + cell, v, u);
             L.prob[cell] = hs_prob_v(v);
         }
     }
@@ -820,6 +859,9 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     //     Lines are dealt by index (a scan's points come in order of their angle), to the XCDs by sector: a line's cells share
     //     their 128-byte rows with its neighbours'.
     K5_STAMP(2)
+#if K5_EXP == 2                          // developer experiment (wrong results): tables and the zone, no lines beyond it
+    return;
+#endif
     if (R < K5_ZONE) {
         if (BUILD && sec_out && (int)blockIdx.x == L.wg0 && threadIdx.x == 0) sec_out[lvl * K5_SEC] = -1;
         return;
@@ -835,7 +877,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     // (software pipeline: a cell's value and update index are requested when its item is fetched, two iterations before its
     // turn -- the three arrays of a 2048^2 level are 48 MB, a microsecond or two away; two ahead against one: 32.6 -> 32.2 us,
     // and the kernel's 64 VGPRs leave no room for a third)
-    struct k5_item { int cell, dx, dy, ray, end; float v; int u; };
+    struct k5_item { int cell, dx, dy, ray, end, xalone; float v; int u; };
 #define K5_FETCH(it, item_)                                                                         \
     {                                                                                               \
         (it).cell = -1;                                                                             \
@@ -856,13 +898,14 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
                 const int am_ = smaj_ < 0 ? -i_ : i_, bm_ = me_.sdb < 0 ? -m_ : m_;                 \
                 (it).dx = (me_.flags & 2) ? am_ : bm_; (it).dy = (me_.flags & 2) ? bm_ : am_;       \
                 (it).ray = me_.ray; (it).end = i_ == me_.da;                                        \
+                { const int xa_ = (me_.flags >> 5) & 8191; (it).xalone = (xa_ == 0 || xa_ == 8191) ? 0x7fffffff : xa_; } \
                 (it).cell = (by + (it).dy) * L.w + (bx + (it).dx);                                  \
-                (it).v = L.value[(it).cell]; (it).u = L.upd[(it).cell];                             \
+                k5_load_cell(L.cells + (it).cell, (it).v, (it).u);                                  \
             }                                                                                       \
         }                                                                                           \
     }
     k5_item cur, nxt, nx2;
-    cur.cell = -1; cur.dx = cur.dy = cur.ray = cur.end = cur.u = 0; cur.v = 0.f; nxt = cur; nx2 = cur;
+    cur.cell = -1; cur.dx = cur.dy = cur.ray = cur.end = cur.u = 0; cur.xalone = 0x7fffffff; cur.v = 0.f; nxt = cur; nx2 = cur;
     int item = wg_x * 16 + wv;
     K5_FETCH(cur, item)
     K5_FETCH(nxt, item + wgs_x * 16)
@@ -873,12 +916,14 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
             int first_free = 0x7fffffff, first_occ = 0x7fffffff;
             int lo = 0, hi = 2;
-            if (adx != ady) {                                              // (a diagonal cell: the quadrant's other class touches it too)
+            const bool lone = K5_EXP == 3 || (K5_EXP != 4 && adx != ady && (adx > ady ? adx : ady) >= cur.xalone);     // (K5_EXP 3: every lane takes the lone path -- wrong results; 4: none does)
+                // (beyond the step from which the line shares no cell: the table phase)
+            if (adx != ady && !lone) {                                     // (a diagonal cell: the quadrant's other class touches it too)
                 const bool xm = adx > ady;
                 rs_range(start, xm ? (dx > 0 ? 0 : 1) : (dy > 0 ? 2 : 3), xm ? adx : ady, xm ? dy : dx, 0.5f, lo, hi);
             }
             bool mine = true;
-            if (hi - lo == 1) { if (cur.end) first_occ = cur.ray; else first_free = cur.ray; }
+            if (lone || hi - lo == 1) { if (cur.end) first_occ = cur.ray; else first_free = cur.ray; }
             else {
                 int cls[2], a[2], b[2];
                 const int ncls = rs_classes(dx, dy, cls, a, b);
@@ -897,8 +942,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
                 float v = cur.v;
                 int u = cur.u;
                 k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
-                L.value[cur.cell] = v;
-                L.upd[cur.cell] = u;
+                k5_store_cell(L.cells + cur.cell, v, u);
                 L.prob[cur.cell] = hs_prob_v(v);
             }
         }
@@ -915,30 +959,26 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
 #endif
 }
 
-__global__ void k5_fill_cells(float *value, int32_t *upd, float *prob, size_t n)
+__global__ void k5_fill_cells(slamhip_cell *cells, float *prob, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const float p0 = hs_prob_v(0.0f);
-    for (; i < n; i += stride) { value[i] = 0.0f; upd[i] = -1; prob[i] = p0; }   // LogOddsCell.Reset :38-42
+    for (; i < n; i += stride) { cells[i].value = 0.0f; cells[i].update_index = -1; prob[i] = p0; }   // LogOddsCell.Reset :38-42
 }
 
-__global__ void k5_pack_cells(const float *value, const int32_t *upd, slamhip_cell *out, size_t n)
+// the cached probabilities of an uploaded mapArray
+__global__ void k5_refresh_prob(const slamhip_cell *cells, float *prob, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { out[i].update_index = upd[i]; out[i].value = value[i]; }
-}
-__global__ void k5_unpack_cells(const slamhip_cell *in, float *value, int32_t *upd, float *prob, size_t n)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { upd[i] = in[i].update_index; value[i] = in[i].value; prob[i] = hs_prob_v(in[i].value); }
+    if (i < n) prob[i] = hs_prob_v(cells[i].value);
 }
 // GridMap.GetBitmapData (GridMap.cs:104-115)
-__global__ void k5_bitmap(const float *value, uint8_t *out, size_t n)
+__global__ void k5_bitmap(const slamhip_cell *cells, uint8_t *out, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = value[i];
+    const float v = cells[i].value;
     const int sgn = (v > 0.0f) - (v < 0.0f);
     out[i] = (uint8_t)(127 - sgn * 127);                                   // :111
 }
@@ -948,13 +988,13 @@ __global__ void k5_extends_init(int32_t *ext)
 {
     if (threadIdx.x < 4) ext[threadIdx.x] = threadIdx.x < 2 ? -1 : 10000;
 }
-__global__ __launch_bounds__(256) void k5_extends(const float *value, int w, int h, int32_t *ext)
+__global__ __launch_bounds__(256) void k5_extends(const slamhip_cell *cells, int w, int h, int32_t *ext)
 {
     int xmax = -1, ymax = -1, xmin = 10000, ymin = 10000;
     for (int y = blockIdx.x; y < h; y += gridDim.x) {                      // one row per workgroup pass: coalesced reads
-        const float *row = value + (size_t)y * w;
+        const slamhip_cell *row = cells + (size_t)y * w;
         for (int x = threadIdx.x; x < w; x += 256)
-            if (row[x] != 0.0f) {                                          // :161 (a NaN cell counts, as in the reference)
+            if (row[x].value != 0.0f) {                                          // :161 (a NaN cell counts, as in the reference)
                 xmax = max(xmax, x); xmin = min(xmin, x);
                 ymax = max(ymax, y); ymin = min(ymin, y);
             }
@@ -968,10 +1008,24 @@ __global__ __launch_bounds__(256) void k5_extends(const float *value, int w, int
         atomicMin(ext + 2, xmin); atomicMin(ext + 3, ymin);
     }
 }
-__global__ void k5_probability(const float *value, const int32_t *idx, int n, float *out)
+__global__ void k5_probability(const slamhip_cell *cells, const int32_t *idx, int n, float *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = hs_prob(value, idx[i]);
+    if (i < n) out[i] = hs_prob_v(cells[idx[i]].value);                   // OccGridMap.GetCachedProbability (:97-107)
+}
+
+// the two words of slamhip_hs_checksum (common.h: k_checksum's definition, per member of the cell): out[0] over the values' bit
+// patterns, out[1] over the update indices
+__global__ void __launch_bounds__(256) k5_checksum_cells(const slamhip_cell *__restrict__ cells, size_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long av = 0, au = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const slamhip_cell c = cells[i];
+        av += sh_mix64(((unsigned long long)i << 32) | (unsigned long long)__float_as_uint(c.value));
+        au += sh_mix64(((unsigned long long)i << 32) | (unsigned long long)(uint32_t)c.update_index);
+    }
+    for (int off = 32; off > 0; off >>= 1) { av += __shfl_down(av, off, 64); au += __shfl_down(au, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, av); atomicAdd(out + 1, au); }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -986,7 +1040,7 @@ static hs_levels_arg levels_arg(slamhip_hs *hs)
         const hs_level &L = hs->lv[l];
         A.lv[l].w = L.w; A.lv[l].h = L.h; A.lv[l].cell = L.cell; A.lv[l].stm = L.stm;
         A.lv[l].map_t_world = L.map_t_world; A.lv[l].world_t_map = L.world_t_map;
-        A.lv[l].value = L.d_value; A.lv[l].prob = L.d_prob; A.lv[l].iterations = L.iterations;
+        A.lv[l].prob = L.d_prob; A.lv[l].iterations = L.iterations;
     }
     return A;
 }
@@ -997,7 +1051,7 @@ extern "C" int32_t slamhip_hs_destroy(slamhip_hs *hs)
     (void)hipSetDevice(hs->ctx->device);
     (void)hipStreamSynchronize(hs->ctx->stream);
     for (int l = 0; l < hs->n_levels; l++) {
-        (void)hipFree(hs->lv[l].d_value); (void)hipFree(hs->lv[l].d_upd); (void)hipFree(hs->lv[l].d_prob);
+        (void)hipFree(hs->lv[l].d_cells); (void)hipFree(hs->lv[l].d_prob);
     }
     (void)hipFree(hs->d_pts_base); (void)hipFree(hs->d_io);
     if (hs->h_pts) (void)hipHostFree(hs->h_pts);
@@ -1015,7 +1069,7 @@ extern "C" int32_t slamhip_hs_reset(slamhip_hs *hs)
     SH_HIP(hipSetDevice(hs->ctx->device));
     for (int l = 0; l < hs->n_levels; l++) {
         hs_level &L = hs->lv[l];
-        hipLaunchKernelGGL(k5_fill_cells, dim3(1024), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, L.d_prob, (size_t)L.w * L.h);                   // GridMap.Reset :56-62
+        hipLaunchKernelGGL(k5_fill_cells, dim3(1024), dim3(256), 0, hs->ctx->stream, L.d_cells, L.d_prob, (size_t)L.w * L.h);                   // GridMap.Reset :56-62
         L.curr_update_index = 0;                                           // OccGridMap.Reset :244-252
     }
     SH_HIP(hipStreamSynchronize(hs->ctx->stream));
@@ -1043,8 +1097,7 @@ extern "C" int32_t slamhip_hs_create(slamhip_ctx *ctx, float cell_length, int32_
         L.map_t_world = sh_m3x2_mul(sh_m3x2_scale(L.stm), sh_m3x2_translation(0.0f, 0.0f));   // GridMap.cs:46 (offset = 0)
         if (!sh_m3x2_invert(L.map_t_world, &L.world_t_map)) { slamhip_set_error("Map to world matrix is not invertible"); rc = SLAMHIP_ERR_INVALID; break; }  // :47-50
         const size_t n = (size_t)w * h;
-        if (hipMalloc(&L.d_value, sizeof(float) * n) != hipSuccess || hipMalloc(&L.d_upd, sizeof(int32_t) * n) != hipSuccess ||
-            hipMalloc(&L.d_prob, sizeof(float) * n) != hipSuccess) {
+        if (hipMalloc(&L.d_cells, sizeof(slamhip_cell) * n) != hipSuccess || hipMalloc(&L.d_prob, sizeof(float) * n) != hipSuccess) {
             slamhip_set_error("device allocation failed (level %d)", l); rc = SLAMHIP_ERR_NOMEM; break;
         }
         w /= 2; h /= 2;                                                   // :55
@@ -1092,15 +1145,10 @@ extern "C" int32_t slamhip_hs_cells_upload(slamhip_hs *hs, int32_t level, const 
     hs_level &L = hs->lv[level];
     SH_CHECK_ARG(n == (size_t)L.w * L.h);
     SH_HIP(hipSetDevice(hs->ctx->device));
-    slamhip_cell *d = nullptr;
-    SH_HIP(hipMalloc(&d, sizeof(slamhip_cell) * n));
-    hipError_t e = hipMemcpyAsync(d, cells, sizeof(slamhip_cell) * n, hipMemcpyHostToDevice, hs->ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k5_unpack_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, d, L.d_value, L.d_upd, L.d_prob, n);
-        e = hipStreamSynchronize(hs->ctx->stream);
-    }
-    (void)hipFree(d);
-    SH_HIP(e);
+    // (the device holds the reference's own layout: a plain copy, then the cached probabilities)
+    SH_HIP(hipMemcpyAsync(L.d_cells, cells, sizeof(slamhip_cell) * n, hipMemcpyHostToDevice, hs->ctx->stream));
+    hipLaunchKernelGGL(k5_refresh_prob, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, (const slamhip_cell *)L.d_cells, L.d_prob, n);
+    SH_HIP(hipStreamSynchronize(hs->ctx->stream));
     // keep the once-per-scan guards meaningful: the next scan's marks must exceed every stored index
     int mx = -1;
     for (size_t i = 0; i < n; i++) if (cells[i].update_index > mx) mx = cells[i].update_index;
@@ -1117,13 +1165,8 @@ extern "C" int32_t slamhip_hs_cells_download(slamhip_hs *hs, int32_t level, slam
     hs_level &L = hs->lv[level];
     SH_CHECK_ARG(n == (size_t)L.w * L.h);
     SH_HIP(hipSetDevice(hs->ctx->device));
-    slamhip_cell *d = nullptr;
-    SH_HIP(hipMalloc(&d, sizeof(slamhip_cell) * n));
-    hipLaunchKernelGGL(k5_pack_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, L.d_value, L.d_upd, d, n);
-    hipError_t e = hipMemcpyAsync(cells, d, sizeof(slamhip_cell) * n, hipMemcpyDeviceToHost, hs->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
-    (void)hipFree(d);
-    SH_HIP(e);
+    SH_HIP(hipMemcpyAsync(cells, L.d_cells, sizeof(slamhip_cell) * n, hipMemcpyDeviceToHost, hs->ctx->stream));
+    SH_HIP(hipStreamSynchronize(hs->ctx->stream));
     return SLAMHIP_OK;
 }
 
@@ -1135,7 +1178,7 @@ extern "C" int32_t slamhip_hs_bitmap_download(slamhip_hs *hs, int32_t level, uin
     SH_HIP(hipSetDevice(hs->ctx->device));
     uint8_t *d = nullptr;
     SH_HIP(hipMalloc(&d, n));
-    hipLaunchKernelGGL(k5_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, L.d_value, d, n);
+    hipLaunchKernelGGL(k5_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs->ctx->stream, (const slamhip_cell *)L.d_cells, d, n);
     hipError_t e = hipMemcpyAsync(out, d, n, hipMemcpyDeviceToHost, hs->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
     (void)hipFree(d);
@@ -1151,7 +1194,7 @@ extern "C" int32_t slamhip_hs_map_extends(slamhip_hs *hs, int32_t level, int32_t
     int32_t *d = nullptr;
     SH_HIP(hipMalloc(&d, 4 * sizeof(int32_t)));
     hipLaunchKernelGGL(k5_extends_init, dim3(1), dim3(64), 0, hs->ctx->stream, d);
-    hipLaunchKernelGGL(k5_extends, dim3(L.h < 2048 ? L.h : 2048), dim3(256), 0, hs->ctx->stream, L.d_value, L.w, L.h, d);
+    hipLaunchKernelGGL(k5_extends, dim3(L.h < 2048 ? L.h : 2048), dim3(256), 0, hs->ctx->stream, (const slamhip_cell *)L.d_cells, L.w, L.h, d);
     int32_t e4[4] = {0, 0, 0, 0};
     hipError_t e = hipMemcpyAsync(e4, d, sizeof(e4), hipMemcpyDeviceToHost, hs->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
@@ -1176,8 +1219,8 @@ extern "C" int32_t slamhip_hs_checksum(slamhip_hs *hs, int32_t level, uint64_t o
     SH_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
     hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
-        sh_checksum_launch<uint32_t>(ctx, L.d_value, (size_t)L.w * L.h, d);
-        sh_checksum_launch<uint32_t>(ctx, L.d_upd, (size_t)L.w * L.h, d + 1);
+        const size_t n = (size_t)L.w * L.h, want = (n + 2047) / 2048;
+        hipLaunchKernelGGL(k5_checksum_cells, dim3((unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want)), dim3(256), 0, ctx->stream, (const slamhip_cell *)L.d_cells, n, d);
         e = hipMemcpyAsync(out, d, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1197,7 +1240,7 @@ extern "C" int32_t slamhip_hs_probability(slamhip_hs *hs, int32_t level, const i
     hipError_t e = hipMalloc(&dout, sizeof(float) * n);
     if (e == hipSuccess) e = hipMemcpyAsync(di, indices, sizeof(int32_t) * n, hipMemcpyHostToDevice, hs->ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k5_probability, dim3(sh_div_up(n, 256)), dim3(256), 0, hs->ctx->stream, L.d_value, di, n, dout);
+        hipLaunchKernelGGL(k5_probability, dim3(sh_div_up(n, 256)), dim3(256), 0, hs->ctx->stream, (const slamhip_cell *)L.d_cells, di, n, dout);
         e = hipMemcpyAsync(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost, hs->ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(hs->ctx->stream);
@@ -1430,7 +1473,7 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3], const k5_g
         A.lv[l].w = L.w; A.lv[l].h = L.h;
         A.lv[l].t = sh_m3x2_mul(sh_m3x2_mul(sh_m3x2_rotation(pose[2]), sh_m3x2_translation(pose[0], pose[1])),
                                 sh_m3x2_scale(L.stm));                    // OccGridMap.cs:120-123
-        A.lv[l].value = L.d_value; A.lv[l].upd = L.d_upd; A.lv[l].prob = L.d_prob;
+        A.lv[l].cells = L.d_cells; A.lv[l].prob = L.d_prob;
         A.lv[l].mark_free = L.curr_update_index + 1;                      // :116
         A.lv[l].mark_occ = L.curr_update_index + 2;                       // :117
     }
