@@ -574,8 +574,11 @@ __device__ static inline int k5_wave_min(int x)
 // developer instrumentation (build with SLAMHIP_K5_TIMES=1): 100 MHz wall-clock stamps per workgroup: start, tables, zone, end
 __device__ unsigned long long g_k5_times[1024 * 4];
 #define K5_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 1024) g_k5_times[blockIdx.x * 4 + (k)] = wall_clock64(); }
+__device__ unsigned long long g_k5_sub[1024 * 8];    // table phase, thread 0: behind the 1st barrier, the lines, the bins' prefix (2 stamps), the scatter
+#define K5_SUB(k) { if (threadIdx.x == 0 && blockIdx.x < 1024) g_k5_sub[blockIdx.x * 8 + (k)] = wall_clock64(); }
 #else
 #define K5_STAMP(k) {}
+#define K5_SUB(k) {}
 #endif
 #define K5_SEC 16                      // ints per level of the sector record: [0] the scan's line count, [1..9] the bounds of the eight sectors
 // The sector bounds for the NEXT update, by the level's first workgroup when it has drawn its last cell (its tables still stand
@@ -680,6 +683,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         int rec_v = -1;                                                     // (the sectors the level's first workgroup left last time: below;
         if (t < 10 && sec_in) rec_v = sec_in[lvl * K5_SEC + t];            //  requested here, stored behind the lines loop: no wait of its own)
         __syncthreads();
+        K5_SUB(0)
         float bxf, byf;
         sh_v2_transform(ox, oy, T, &bxf, &byf);                            // :126
         bx = sh_f2i(rintf(bxf)); by = sh_f2i(rintf(byf));                  // :127 ToRoundPoint (banker's, VectorEx.cs:183-186)
@@ -725,6 +729,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         if (lane_ == 63) { atomicMax(&s_R, my_R); atomicAdd(&s_nv, my_nv); atomicMin(&s_first, my_first); }
         if (t < 10) s_rec[t] = rec_v;
         __syncthreads();
+        K5_SUB(1)
         // Phase 2's sectors: the lines go to the XCDs in eight ranges of consecutive indices (locality: see phase 2) that hold EQUAL
         // WORK, not equal counts -- with equal counts the sectors of the benchmark scan took 3.9 .. 13.6 us on level 0 (the long
         // corridor against the near wall; SLAMHIP_K5_TIMES) and the launch waited for the slowest.  The bounds are those the level's
@@ -738,6 +743,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             const int incl = sh_wave_scan_incl(sum);
             if (lane_ == 63) wsum[wid] = incl;
             __syncthreads();                                               // (every thread has read its bins)
+        K5_SUB(2)
             int base = incl - sum;
             {   // the wave totals in front of this one: four 16-byte reads, not up to fifteen dependent ones
                 const int4 *w4 = (const int4 *)wsum;
@@ -752,6 +758,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
             if (t == 1023) start[4 * RS_NBUCK] = base;
         }
         __syncthreads();
+        K5_SUB(3)
 #pragma unroll
         for (int it = 0; it < RPT; it++) {
             const int i = t + it * 1024;
@@ -759,6 +766,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         }
         R = s_R; nv = s_nv; first_line = s_first;
         __syncthreads();
+        K5_SUB(4)
         if (nv == 0) {
             if (sec_out && (int)blockIdx.x == L.wg0 && t == 0) sec_out[lvl * K5_SEC] = -1;      // (no record for the next update)
             return;
@@ -1557,7 +1565,19 @@ static int32_t hs_update_enqueue(slamhip_hs *hs, const float pose[3], const k5_g
             unsigned long long t0 = ~0ull, t1 = 0;
             for (int i = 0; i < 1024; i++) if (h[i * 4] && h[i * 4 + 3] >= h[i * 4]) { t0 = std::min(t0, h[i * 4]); t1 = std::max(t1, h[i * 4 + 3]); }
             fprintf(stderr, "[k5 times] span %.2f us; per level, first thread of each workgroup, mean (max) us:\n", (double)(t1 - t0) * 0.01);
+            std::vector<unsigned long long> hsub(1024 * 8);
+            (void)hipMemcpyFromSymbol(hsub.data(), HIP_SYMBOL(g_k5_sub), sizeof(unsigned long long) * hsub.size());
             for (int l = 0; l < hs->n_levels; l++) {
+                {   // the table phase in parts, mean over the level's workgroups: start -> barrier 1 -> lines -> prefix a -> prefix b -> scatter -> tables done
+                    double part[6] = { 0, 0, 0, 0, 0, 0 }; int cc = 0;
+                    for (int i = A.lv[l].wg0; i < A.lv[l].wg0 + A.lv[l].wgn && i < 1024; i++) if (h[i * 4] && hsub[i * 8 + 4] >= h[i * 4]) {
+                        unsigned long long prev = h[i * 4];
+                        for (int k = 0; k < 5; k++) { part[k] += (double)(hsub[i * 8 + k] - prev) * 0.01; prev = hsub[i * 8 + k]; }
+                        part[5] += (double)(h[i * 4 + 1] - prev) * 0.01; cc++;
+                    }
+                    if (cc) fprintf(stderr, "   level %d table phase: zero+barrier %.2f | lines+reductions+barrier %.2f | prefix a %.2f | prefix b %.2f | scatter+barrier %.2f | alone pass + rest %.2f\n",
+                                    l, part[0] / cc, part[1] / cc, part[2] / cc, part[3] / cc, part[4] / cc, part[5] / cc);
+                }
                 double acc[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 }, end = 0, endmx = 0, st = 0; int c = 0;
                 for (int i = A.lv[l].wg0; i < A.lv[l].wg0 + A.lv[l].wgn && i < 1024; i++) if (h[i * 4] && h[i * 4 + 3] >= h[i * 4]) {
                     for (int k = 0; k < 3; k++) { const double d = (double)(h[i * 4 + k + 1] - h[i * 4 + k]) * 0.01; acc[k] += d; mx[k] = std::max(mx[k], d); }

@@ -199,16 +199,44 @@ def test_match_vs_oracle(hs_mod, ctx, det, sim, side, cell, levels, R, iters):
     got = matcher.MatchData(rep.Maps[1], scan, hints[1])
     want = ref[1].match(xy, hints[1], iters[1], 1)
     assert np.allclose(got[:2], want[:2], atol=POS_TOL) and abs(got[2] - want[2]) < ANG_TOL
-    # batched hints == single-hint launches (same kernel, one workgroup per hint)
+    # batched hints against single-hint launches: up to 8 hints run the single match's kernel (512 lanes per hint) -- the same
+    # floats; larger batches run 256 lanes per hint, whose wave partials are summed in another order -- the same pose within the
+    # noise of a binary32 sum (1e-5 of a cell)
+    singles = [matcher.MatchData(rep, scan, hint) for hint in hints]
+    small = matcher.MatchDataBatch(rep, scan, np.stack(hints))
+    for i in range(len(hints)):
+        assert (small[i] == singles[i]).all()
     batch = matcher.MatchDataBatch(rep, scan, np.stack(hints * 8))
-    for i, hint in enumerate(hints * 8):
-        assert (batch[i] == matcher.MatchData(rep, scan, hint)).all()
+    for i in range(len(hints) * 8):
+        assert np.abs(np.asarray(batch[i]) - np.asarray(singles[i % len(hints)])).max() < 2e-5, (i, batch[i], singles[i % len(hints)])
     # empty scan returns the hint (:82-83); a hint far outside the map leaves the estimate unchanged (:97,:124)
     assert (matcher.MatchData(rep, hs_mod.ScanCloud(np.zeros((0, 2), np.float32)), hints[1]) == hints[1]).all()
     far = np.array([500.0, 500.0, 0.3], np.float32)
     got = matcher.MatchData(rep, scan, far)
     want = oc.match_pyramid(ref, xy, far, iters, 1)
     assert (np.asarray(got) == np.asarray(want)).all()                 # (no iteration moves it: the same float transforms there and back)
+    rep.close()
+
+
+def test_match_long_scan_vs_oracle(hs_mod, ctx, det, sim):
+    """Scans beyond the 2048 points the matcher keeps in LDS are read from global memory (hs_hessian_block<.., false>): single
+    match and a batch, against the oracle (ScanMatcher.cs:41-125)."""
+    oc = det
+    rep, ref, segs, rng = build_pair(hs_mod, ctx, oc, sim, 400, 0.1, 3, 400, 10)
+    true_pose = np.array([20.6, 20.25, 0.12], np.float32)
+    rays, xy = sim.make_scan(segs, true_pose, 2500, rng)
+    scan = hs_mod.ScanCloud(xy)
+    matcher = hs_mod.ScanMatcher(4)
+    hints = [true_pose + np.array(d, np.float32) for d in ((0.1, -0.08, 0.03), (-0.15, 0.1, -0.05))]
+    for hint in hints:
+        got = matcher.MatchData(rep, scan, hint)
+        want = oc.match_pyramid(ref, xy, hint, [3, 3, 3], n_threads=1)
+        assert abs(got[0] - want[0]) < POS_TOL and abs(got[1] - want[1]) < POS_TOL, (hint, got, want)
+        assert abs(math.remainder(float(got[2]) - float(want[2]), 2 * math.pi)) < ANG_TOL, (hint, got, want)
+    batch = matcher.MatchDataBatch(rep, scan, np.stack(hints * 6))
+    for i in range(12):
+        want = oc.match_pyramid(ref, xy, hints[i % 2], [3, 3, 3], n_threads=1)
+        assert np.abs(np.asarray(batch[i][:2]) - np.asarray(want[:2])).max() < POS_TOL and abs(batch[i][2] - want[2]) < ANG_TOL
     rep.close()
 
 
