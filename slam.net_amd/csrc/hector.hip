@@ -883,7 +883,7 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
     const int n_sec = (xcd == 7 ? n_pts : rec_ok ? s_rec[2 + xcd] : (int)(((long long)n_pts * (xcd + 1)) >> 3)) - c0;
     const int items = nblk * n_sec;
     // (software pipeline: a cell's value and update index are requested when its item is fetched, two iterations before its
-    // turn -- the three arrays of a 2048^2 level are 48 MB, a microsecond or two away; two ahead against one: 32.6 -> 32.2 us,
+    // turn -- the cells and probabilities of a 2048^2 level are 48 MB, a microsecond or two away; two ahead against one: 32.6 -> 32.2 us,
     // and the kernel's 64 VGPRs leave no room for a third)
     struct k5_item { int cell, dx, dy, ray, end, xalone; float v; int u; };
 #define K5_FETCH(it, item_)                                                                         \

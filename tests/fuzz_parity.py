@@ -239,6 +239,11 @@ def main():
                 ok = ok and rep.Maps[l].GetMapExtends() == ref[l].map_extends()
             hint = (p + np.array([0.05, -0.04, 0.02], np.float32)).astype(np.float32)
             m = hs.ScanMatcher(4).MatchData(rep, hs.ScanCloud(xy), hint)
+            # the batched form: up to 8 hints run the single match's kernel (the same floats), larger batches 256 lanes per hint
+            mb3 = hs.ScanMatcher(4).MatchDataBatch(rep, hs.ScanCloud(xy), np.stack([hint] * 3))
+            batch_same = bool(all((np.asarray(mb3[i]) == np.asarray(m)).all() or (np.isnan(np.asarray(m)).any() and np.isnan(np.asarray(mb3[i])).any()) for i in range(3)))
+            mb12 = np.asarray(hs.ScanMatcher(4).MatchDataBatch(rep, hs.ScanCloud(xy), np.stack([hint] * 12)))
+            batch_same = batch_same and bool((mb12 == mb12[0][None]).all() or np.isnan(mb12).any())
             w = oc.match_pyramid(ref, xy, hint, [3] * levels, 4)
             cells_ok = ok
             # (a handful of rays gives a near-singular Hessian: the 1e-7 differences between summation orders -- the
@@ -248,6 +253,7 @@ def main():
             # count; that spread (oracle at 1 and 4 threads) is the floor of any comparison and is added to the tolerance.
             # A match that runs away from its hint (coarse grids, few iterations) amplifies those differences from
             # iteration to iteration and is not compared either.
+            near0 = n_near
             if R >= 180 and math.hypot(w[0] - hint[0], w[1] - hint[1]) < 0.5 and abs(w[2] - hint[2]) < 0.1:
                 w1 = oc.match_pyramid(ref, xy, hint, [3] * levels, 1)
                 tol = 1e-4 + 10.0 * np.abs(w1 - w)
@@ -276,9 +282,12 @@ def main():
                             bool(np.all(np.asarray(m) > outs.min(0) - pad) and np.all(np.asarray(m) < outs.max(0) + pad))
                     n_near += 1
                 ok = ok and close
+                if close and n_near == near0:                        # (a well-conditioned match: the other summation order of the large batch agrees as well)
+                    ok = ok and bool(np.all(np.abs(mb12[0] - w) < 2.0 * tol))
+            ok = ok and batch_same
             desc = "hector side %d levels %d rays %d pose %s" % (side, levels, R, np.round(pose, 2))
             if not ok:
-                desc += " | cells equal: %s, match %s vs oracle %s (hint %s)" % (cells_ok, np.asarray(m), w, hint)
+                desc += " | cells equal: %s, match %s vs oracle %s (hint %s), batches consistent: %s, batch of 12: %s" % (cells_ok, np.asarray(m), w, hint, batch_same, mb12[0])
                 if a.dump:
                     np.savez(a.dump, side=side, side_h=side_h, ff=ff, fo=fo, levels=levels, cell=cell, hint=hint, m=np.asarray(m), w=w, n_updates=len(htrace),
                              **{"xy%d" % i: t[0] for i, t in enumerate(htrace)}, **{"p%d" % i: t[1] for i, t in enumerate(htrace)})
