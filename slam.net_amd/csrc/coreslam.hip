@@ -685,13 +685,13 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
 #define SH_MAXF(a, b) ((a) > (b) ? (a) : (b))
     bool sane = true;
     std::vector<uint64_t> &keys = cs->h_sort_keys;                 // (kept between scans: no allocation per scan)
-    keys.resize((size_t)n);
     const float icell = cs->hscale / 64.0f;         // 64-pixel cells per metre (ordering only: any monotone map of the coordinates does)
     // cell coordinates of every point (a branch-free loop over the 2 n floats: vectorised), their minima, and the sanity flag
     std::vector<int> &cellxy = cs->h_cell_xy;
     cellxy.resize((size_t)n * 2);
+    int dmax = 0;                                   // (the largest distance of a cell coordinate from 32768: the codes' compression, below)
     {
-        int bad = 0;
+        int bad = 0, cmin = 65535, cmax = 0;         // (min / max: reductions the loop vectorises with; the distance is V-shaped in the coordinate)
         int *cu = cellxy.data();
         for (int i = 0; i < 2 * n; i++) {
             const float v = xy[i];
@@ -699,9 +699,14 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
             float g = v * icell + 32768.0f;
             g = g > 0.0f ? g : 0.0f;                 // (NaN -> 0)
             g = g < 65535.0f ? g : 65535.0f;
-            cu[i] = (int)g;
+            const int c = (int)g;
+            cu[i] = c;
+            cmin = c < cmin ? c : cmin;
+            cmax = c > cmax ? c : cmax;
         }
         sane = !bad;
+        const int dlo = cmin >= 32768 ? cmin - 32768 : 32767 - cmin, dhi = cmax >= 32768 ? cmax - 32768 : 32767 - cmax;
+        dmax = dlo > dhi ? dlo : dhi;
     }
     // Morton codes of the cell coordinates.  The order is that of the ABSOLUTE codes -- the scan frame's origin, the robot, is the
     // curve's major boundary: the scan splits into its four quadrants first, then recursively; measured at the headline size against
@@ -710,19 +715,48 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     // bit 15, so subtracting 32768 - 2^m keeps every comparison and leaves 2 (m + 1) bits: two 8-bit passes for scans up to
     // 128 cells (160 m at 2048^2 / 40 m) instead of three 11-bit ones with their 2048-bin prefix sums.
     g_sst.lap(1);
-    int dmax = 0;
-    for (int i = 0; i < 2 * n; i++) { const int d = cellxy[(size_t)i] >= 32768 ? cellxy[(size_t)i] - 32768 : 32767 - cellxy[(size_t)i]; dmax = d > dmax ? d : dmax; }
     int mbits = 0;
     while ((1 << mbits) <= dmax) mbits++;                         // every cell in [32768 - 2^m, 32768 + 2^m)
     const bool compressed = mbits <= 10;
     const int shift_c = compressed ? 32768 - (1 << mbits) : 0;
     const int code_bits = compressed ? 2 * (mbits + 1) : 32;
-    for (int i = 0; i < n; i++) {
-        const uint32_t code = part1by1((uint32_t)(cellxy[2 * (size_t)i] - shift_c)) | (part1by1((uint32_t)(cellxy[2 * (size_t)i + 1] - shift_c)) << 1);
-        keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
-    }
-    g_sst.lap(2);
-    {   // LSD radix sort on the code (stable 8-bit passes over the bits in use; ties keep ray order)
+    // The order is that of (code, ray index): unique keys, so any sorting algorithm gives the same permutation.  Scans of up to 2048
+    // rays whose compressed code takes at most 21 bits (every scan within 1280 m at the headline scale) sort 32-bit keys -- half
+    // the bytes of the general form; this loop is the largest single piece of the host's chain between two scans.
+    const bool small = n <= 2048 && code_bits <= 21;
+    std::vector<uint32_t> &order = cs->h_sort_order;               // ray index by sorted position
+    order.resize((size_t)n);
+    if (small) {
+        std::vector<uint32_t> &k32 = cs->h_sort_k32;
+        k32.resize(2 * (size_t)n);
+        uint32_t *src = k32.data(), *dst = k32.data() + n;
+        for (int i = 0; i < n; i++) {
+            const uint32_t code = part1by1((uint32_t)(cellxy[2 * (size_t)i] - shift_c)) | (part1by1((uint32_t)(cellxy[2 * (size_t)i + 1] - shift_c)) << 1);
+            src[i] = (code << 11) | (uint32_t)i;
+        }
+        g_sst.lap(2);
+        // LSD radix sort on the code (stable 8-bit passes over the bits in use; ties keep ray order); the digits' histograms are
+        // counted in ONE pass over the keys (three independent increments per key instead of one dependent chain per pass)
+        unsigned cnt[3][256];
+        memset(cnt, 0, sizeof(cnt));
+        for (int i = 0; i < n; i++) { const uint32_t k = src[i] >> 11; cnt[0][k & 255u]++; cnt[1][(k >> 8) & 255u]++; cnt[2][(k >> 16) & 255u]++; }
+        for (int dgt = 0; dgt * 8 < code_bits; dgt++) {
+            const int shift = 11 + dgt * 8;
+            unsigned *c = cnt[dgt];
+            if (c[(src[0] >> shift) & 255u] == (unsigned)n) continue;        // every key has the same digit
+            unsigned sum = 0;
+            for (int k = 0; k < 256; k++) { const unsigned v = c[k]; c[k] = sum; sum += v; }
+            for (int i = 0; i < n; i++) dst[c[(src[i] >> shift) & 255u]++] = src[i];
+            uint32_t *t = src; src = dst; dst = t;
+        }
+        for (int j = 0; j < n; j++) order[(size_t)j] = src[j] & 2047u;
+    } else {
+        keys.resize((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const uint32_t code = part1by1((uint32_t)(cellxy[2 * (size_t)i] - shift_c)) | (part1by1((uint32_t)(cellxy[2 * (size_t)i + 1] - shift_c)) << 1);
+            keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
+        }
+        g_sst.lap(2);
         std::vector<uint64_t> &tmp = cs->h_sort_tmp;
         tmp.resize((size_t)n);
         uint64_t *src = keys.data(), *dst = tmp.data();
@@ -737,7 +771,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
             for (int i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 255u]++] = src[i];
             uint64_t *t = src; src = dst; dst = t;
         }
-        if (src != keys.data()) memcpy(keys.data(), src, sizeof(uint64_t) * (size_t)n);
+        for (int j = 0; j < n; j++) order[(size_t)j] = (uint32_t)src[j];
     }
     g_sst.lap(3);
     std::vector<int> &rb = cs->h_rb_start;
@@ -772,7 +806,7 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     const float marg = (spread_px + 40.0f) / cs->hscale;       // metres: translation spread + a nominal arc
     const float amax = area_f > 0.0f ? area_f * (60.0f * 1024.0f / 2.0f) / (cs->hscale * cs->hscale) : 3.0e38f;   // square metres
     for (int j = 0; j < n; j++) {
-        const int i = (int)(uint32_t)keys[j];
+        const int i = (int)order[(size_t)j];
         const float X = xy[2 * i], Y = xy[2 * i + 1];
         sorted[2 * j] = X; sorted[2 * j + 1] = Y;
         const float Xr = rc * X - rs * Y, Yr = rs * X + rc * Y;

@@ -50,6 +50,7 @@ struct slamhip_cs {
     float2 *d_pts_sorted;         // spatially sorted copy for K1 (integer sum: any order is exact)
     int4 *d_ray_blk;              // per sorted ray: (first ray of its block, one past its last, block index, 0)
     std::vector<uint64_t> h_sort_keys, h_sort_tmp;   // set_scan's sort buffers
+    std::vector<uint32_t> h_sort_k32, h_sort_order;   // ... the 32-bit form's, and the resulting order (ray index by sorted position)
     std::vector<int> h_cell_xy;                      // ... and the points' 64-pixel cell coordinates
     std::vector<int> h_rb_start;  // host copy of the block table
     std::vector<float> h_rb_ex, h_rb_ey, h_rb_mx, h_rb_my;   // per ray block, scan frame, pixels: bounding box size and centre
