@@ -4,7 +4,8 @@
 // InterpMapValueWithDerivatives (HectorSLAM/Matcher/ScanMatcher.cs:41-249): all pyramid levels and all
 // iterations of one match run in ONE persistent workgroup (the reference fans out to ParallelWorker
 // threads once per iteration, :154); the nine sums are accumulated per lane in fp32, reduced across the
-// workgroup in fp64 and the 3x3 system is solved on the device with the BCL's cofactor formulas.
+// workgroup in fp64 and the 3x3 system is solved on the device with the BCL's cofactor formulas.  A single match is 512
+// lanes with the scan's points in LDS, one barrier and one sine / cosine per iteration (hs_hessian_block: round 5).
 // Occupancy probabilities exp(v)/(exp(v)+1) (OccGridMap.GetCachedProbability, OccGridMap.cs:97-107) are READ from a dense
 // per-level grid `prob` that every writer of the log-odds grid keeps current (K5 for the cells it touches, upload and
 // reset for all of them) -- the device's form of the reference's per-cell cache, without its epochs: the value always is
@@ -20,6 +21,7 @@
 // cell near the begin cell, or beyond that the lane of the lowest line index among the lines that touch it (one lane
 // per (line, step), closed-form Bresenham position) -- which finds the first "free" line and the first line that ends
 // in the cell and replays the at most two state transitions literally: bit-exact fp32 cell values and update indices.
+// The cells are stored as the reference stores them, LogOddsCell {UpdateIndex, Value} (LogOddsCell.cs:16-21): one 8-byte access.
 #include "common.h"
 #include "m3x2.h"
 #include "raster.h"
@@ -75,69 +77,23 @@ __device__ static inline float hs_prob_v(float v)
     return odds / (odds + 1.0f);                                           // :102
 }
 
-// InterpMapValueWithDerivatives (ScanMatcher.cs:211-249)
-__device__ static inline void hs_interp(const hs_level_dev &L, float cx, float cy, float &P, float &gx, float &gy)
-{
-    const float limx = (float)L.w - 2.0f, limy = (float)L.h - 2.0f;       // MapProperties.cs:42
-    if (!(cx == cx) || !(cy == cy) || cx < 0.0f || cx > limx || cy < 0.0f || cy > limy) {   // MapProperties.cs:83-87
-        P = gx = gy = 0.0f;                                                // :216-219
-        return;
-    }
-    const int ix = (int)floorf(cx), iy = (int)floorf(cy);                  // :222
-    const float fx = cx - (float)ix, fy = cy - (float)iy;                  // :225
-    const int idx = iy * L.w + ix;                                         // :227
-    // the two taps of a row are adjacent: one 8-byte load each (4-byte aligned is enough for global dwordx2), from the
-    // grid of cached probabilities (:97-107 -- the reference caches them per cell and map-update epoch as well)
-    float2 r0, r1;
-    __builtin_memcpy(&r0, L.prob + idx, sizeof(float2));
-    __builtin_memcpy(&r1, L.prob + idx + L.w, sizeof(float2));
-    const float i0 = r0.x, i1 = r0.y;                                      // :230-231
-    const float i2 = r1.x, i3 = r1.y;                                      // :232-233
-    const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;            // :235-239
-    const float xi = 1.0f - fx, yi = 1.0f - fy;                            // :241-242
-    P = ((i0 * xi + i1 * fx) * yi) + ((i2 * xi + i3 * fx) * fy);           // :245-246
-    gx = -((dx1 * xi) + (dx2 * fx));                                       // :247
-    gy = -((dy1 * yi) + (dy2 * fy));                                       // :248
-}
-
-// wave-wide sum of a double in six DPP steps (no LDS permutes: a ds_bpermute costs ~100 cycles of latency, and nine
-// sums x six steps of them dominated an iteration): butterfly inside each row of 16 lanes, then row_bcast:15 into
-// rows 1 and 3 and row_bcast:31 into rows 2 and 3 -- the total is valid in lane 63.  Lanes a step's row mask excludes
-// add zero (update_dpp's `old`).
+// one DPP step of a binary64 value (the wave partials' tree in hs_hessian_block; no LDS permutes: a ds_bpermute costs ~100
+// cycles of latency).  Lanes a step's row mask excludes receive zero (update_dpp's `old`).
 template <int CTRL, int ROWS> __device__ static inline double hs_dpp_f64(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xf, false),
                             __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xf, false));
 }
-__device__ static inline double hs_wave_sum(double v)
-{
-    v += hs_dpp_f64<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
-    v += hs_dpp_f64<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
-    v += hs_dpp_f64<0x124, 0xf>(v);         // row_ror:4
-    v += hs_dpp_f64<0x128, 0xf>(v);         // row_ror:8
-    v += hs_dpp_f64<0x142, 0xa>(v);         // row_bcast:15 -> rows 1, 3
-    v += hs_dpp_f64<0x143, 0xc>(v);         // row_bcast:31 -> rows 2, 3
-    return v;
-}
 
-// the same tree in binary32: one DPP-modified add per step.  (The nine binary64 wave sums of an iteration -- two DPP moves
-// and a double add per step, in dependent chains -- were half of the matcher's run time; the reference itself sums these
-// terms in binary32, sequentially per thread chunk, ScanMatcher.cs:166-180, so a binary32 tree over 64 lanes is at least
-// as accurate as what it is compared with.  The 16 wave partials are still added in binary64.)
+// one DPP step in binary32: the wave trees of the nine sums (butterfly inside each row of 16 lanes, then row_bcast:15 into rows
+// 1 and 3 and row_bcast:31 into rows 2 and 3 -- the total is valid in lane 63).  (Nine binary64 wave sums per iteration -- two DPP
+// moves and a double add per step, in dependent chains -- were half of the first matcher's run time; the reference itself sums
+// these terms in binary32, sequentially per thread chunk, ScanMatcher.cs:166-180, so a binary32 tree over 64 lanes is at least
+// as accurate as what it is compared with.  The wave partials are still added in binary64.)
 template <int CTRL, int ROWS> __device__ static inline float hs_dpp_f32(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
-}
-__device__ static inline float hs_wave_sum_f32(float v)
-{
-    v += hs_dpp_f32<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
-    v += hs_dpp_f32<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
-    v += hs_dpp_f32<0x124, 0xf>(v);         // row_ror:4
-    v += hs_dpp_f32<0x128, 0xf>(v);         // row_ror:8
-    v += hs_dpp_f32<0x142, 0xa>(v);         // row_bcast:15 -> rows 1, 3
-    v += hs_dpp_f32<0x143, 0xc>(v);         // row_bcast:31 -> rows 2, 3
-    return v;
 }
 
 #ifdef K4_TIMES
@@ -541,14 +497,6 @@ __device__ static inline void k5_transition(const k5_level &L, float &v, int &u,
         if (v < 50.0f) v += lo_occ;                                        // :211-214
         u = L.mark_occ;                                                    // :216
     }
-}
-__device__ static inline void k5_apply(const k5_level &L, int cell, int first_free, int first_occ, float lo_free, float lo_occ)
-{
-    float v; int u;
-    k5_load_cell(L.cells + cell, v, u);
-    k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
-    k5_store_cell(L.cells + cell, v, u);
-    L.prob[cell] = hs_prob_v(v);
 }
 
 // wave-wide minimum by DPP (butterfly in rows of 16, row_bcast:15 / :31): valid in lane 63
