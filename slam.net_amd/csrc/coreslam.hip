@@ -685,7 +685,8 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
 #define SH_MAXF(a, b) ((a) > (b) ? (a) : (b))
     bool sane = true;
     std::vector<uint64_t> &keys = cs->h_sort_keys;                 // (kept between scans: no allocation per scan)
-    const float icell = cs->hscale / 64.0f;         // 64-pixel cells per metre (ordering only: any monotone map of the coordinates does)
+    static const float cell_px = getenv("SLAMHIP_RB_CELL") ? (float)atof(getenv("SLAMHIP_RB_CELL")) : 64.0f;   // (tuning override: the Z-order's cell, pixels)
+    const float icell = cs->hscale / (cell_px >= 8.0f ? cell_px : 64.0f);         // 64-pixel cells per metre (ordering only: any monotone map of the coordinates does)
     // cell coordinates of every point (a branch-free loop over the 2 n floats: vectorised), their minima, and the sanity flag
     std::vector<int> &cellxy = cs->h_cell_xy;
     cellxy.resize((size_t)n * 2);
