@@ -18,6 +18,10 @@ m = hs.ScanMatcher(4)
 xy, p = scans[-1]; scan = hs.ScanCloud(xy); hint = p + np.array([0.1, -0.08, 0.03], np.float32)
 if mode == "single":
     for _ in range(60): m.MatchData(rep, scan, hint)
+elif mode == "fresh":       # every match on a freshly set scan (the per-scan flow's form: the match pulls the scan from the staging block), scans and hints alternating
+    for k in range(60):
+        xy2, p2 = scans[-1 - (k % 4)]
+        m.MatchData(rep, hs.ScanCloud(xy2.copy()), p2 + np.array([0.1, -0.08, 0.03], np.float32))
 else:
     B = 4096
     hints = np.tile(hint, (B, 1)) + np.random.default_rng(0).normal(0, 0.05, (B, 3)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
