@@ -47,6 +47,7 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_cs_generate_offsets(IntPtr cs, int n, float sigmaXY, float sigmaTheta, ulong seed, ulong stream);
         [DllImport(Lib)] internal static extern int slamhip_cs_generate_offsets_lattice(IntPtr cs, int n, float sigmaXY, float sigmaTheta, ulong seed, ulong stream);
         [DllImport(Lib)] internal static extern int slamhip_cs_prepared_lists(IntPtr cs, out ulong served, out ulong prepared);
+        [DllImport(Lib)] internal static extern int slamhip_cs_prelaunch_stats(IntPtr cs, [Out] ulong[] four);
         [DllImport(Lib)] internal static extern int slamhip_cs_search(IntPtr cs, in Vector3 searchPose, out Vector3 pose, out int dist, out int index);
         [DllImport(Lib)] internal static extern int slamhip_cs_update_holemap(IntPtr cs, in Vector3 pose, float holeWidth, int quality);
         [DllImport(Lib)] internal static extern int slamhip_cs_update_holemap_pxcs(IntPtr cs, in Vector4 pxcs, float holeWidth, int quality);

@@ -255,6 +255,13 @@ int32_t slamhip_cs_maps_checksum(slamhip_cs *cs, uint64_t out[2]);
  * the box reasoning holds; the parity tests assert it).  Returns the count accumulated so far. */
 int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out_failures);
 
+/* Diagnostics of slamhip_csproc_update's scan flow (CoreSLAMProcessor.cs:717-752): since round 5 the search launch of a scan goes
+ * into the stream BEFORE the scan's tables are made and waits for them on the device (DESIGN.md sec.4 "The per-scan flow").
+ * out[0] scans searched that way, out[1] such launches abandoned (the last scan's launch layout did not serve the new scan: searched
+ * again in the ordinary order), out[2] scans whose layout had to be remade first, out[3] scans refused (first scans, a changed ray
+ * count, a new candidate list, SLAMHIP_PRELAUNCH=0 ...).  The results do not depend on the path taken. */
+int32_t slamhip_cs_prelaunch_stats(slamhip_cs *cs, uint64_t out[4]);
+
 /* Fused configuration C3 (device boundary at CoreSLAMProcessor.cs:732,:750,:751): search, NormalizeAngle
  * (:746) and both map updates in one call; the winning pose never leaves the device between them.
  * Completion: the call returns when the winning pose is back on the host.  The two map updates are enqueued

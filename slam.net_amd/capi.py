@@ -104,6 +104,7 @@ def _declare(L):
         "slamhip_cs_search_and_update_pxcs": (i32, [vp, fp, fp, fp, i32, f, i32, i32, ip, ip]),
         "slamhip_cs_update_maps_pxcs": (i32, [vp, fp, fp, f, i32, i32]),
         "slamhip_cs_selfcheck_failures": (i32, [vp, P(C.c_uint32)]),
+        "slamhip_cs_prelaunch_stats": (i32, [vp, P(C.c_uint64)]),
         "slamhip_cs_prepared_lists": (i32, [vp, P(C.c_uint64), P(C.c_uint64)]),
         "slamhip_csproc_create": (i32, [vp, f, i32, i32, fp, f, f, i32, i32, vpp]),
         "slamhip_csproc_destroy": (i32, [vp]),

@@ -261,6 +261,13 @@ class CoreSlamDevice:
         return a.value, b.value
 
     @property
+    def prelaunch_stats(self):
+        """(searched ahead of the scan's tables, abandoned, layout remade first, refused): slamhip_cs_prelaunch_stats"""
+        v = (C.c_uint64 * 4)()
+        capi.call("slamhip_cs_prelaunch_stats", self._h, v)
+        return tuple(int(x) for x in v)
+
+    @property
     def selfcheck_failures(self):
         v = C.c_uint32()
         capi.call("slamhip_cs_selfcheck_failures", self._h, C.byref(v))

@@ -185,6 +185,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipStreamSynchronize(cs->ctx->stream);
     (void)hipFree(cs->d_hole); (void)hipFree(cs->d_obst);
     (void)hipFree(cs->d_scan_blob); if (cs->h_scan_blob) (void)hipHostFree(cs->h_scan_blob);
+    (void)hipFree(cs->d_scan_flag);
     if (cs->ev_scan) (void)hipEventDestroy(cs->ev_scan);
     (void)hipFree(cs->d_offs_flat); (void)hipFree(cs->d_ev_off); (void)hipFree(cs->d_ev_idx);
     (void)hipFree(cs->d_pxcs); (void)hipFree(cs->d_partial); (void)hipFree(cs->d_dist);
@@ -627,14 +628,13 @@ static inline uint32_t part1by1(uint32_t x)
     return x;
 }
 
-extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t n)
+// slamhip_cs_set_scan in two parts: the blocks a scan lives in (capacity, which of the two device blocks, the staging block free
+// again) and the scan's tables.  cs_search_and_update_prelaunched puts the search launch between them.
+static int32_t cs_set_scan_begin(slamhip_cs *cs, int32_t n)
 {
-    SH_CHECK_ARG(cs && n >= 0 && (xy || n == 0));
-    SH_HIP(hipSetDevice(cs->ctx->device));
     g_sst.start();
     cs->n_points = 0;                                  // (stays "no scan" if anything below fails)
     cs->n_rb = 0;
-    if (n == 0) return SLAMHIP_OK;
     if (n > cs->cap_points) {
         // one device block and one pinned staging block for everything a scan uploads: rays (original order: K2/K3 are
         // ray-order dependent), rays sorted for K1, K1's per-ray block table, the block starts -- one copy per scan
@@ -669,12 +669,21 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
         else SH_HIP(hipEventSynchronize(cs->ev_scan));
         cs->scan_in_flight = false;
     }
+    cs->k1_scan_dirty = true;
+    cs->scan_gen++;
+    g_sst.lap(0);
+    return SLAMHIP_OK;
+}
+
+// force_bar: the search launch that reads this scan's tables is already in the stream (it waits on the device for cs->d_scan_flag):
+// the tables are stored through the BAR whatever blob_use says -- the caller has made sure that nothing older reads the block
+static int32_t cs_set_scan_finish(slamhip_cs *cs, const float *xy, int32_t n, bool force_bar)
+{
     const int cap_ = cs->cap_points;
     int *h_rayblk = (int *)cs->h_scan_blob;
     float *h_pts = (float *)((char *)cs->h_scan_blob + (size_t)cap_ * 16);
     float *sorted = (float *)((char *)cs->h_scan_blob + (size_t)cap_ * 24);
     int *h_rb = (int *)((char *)cs->h_scan_blob + (size_t)cap_ * 32);
-    g_sst.lap(0);
     memcpy(h_pts, xy, sizeof(float) * 2 * (size_t)n);
     // K1 sums integers, so it may visit the rays in any order: sort them along a Z-order curve at
     // 64-pixel granularity so that a ray block's end points stay close together in the map (the rigid
@@ -842,14 +851,12 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     }
 #undef SH_MINF
 #undef SH_MAXF
-    cs->k1_scan_dirty = true;
-    cs->scan_gen++;
     memcpy(h_rb, rb.data(), sizeof(int) * rb.size());
     g_sst.lap(5);
     const size_t used = (size_t)cap_ * 32 + sizeof(int) * rb.size();
     // (a blocking call that returned through the mailbox leaves a stream the runtime has not yet seen finish; the copy takes
     // its immediate path only on a stream the runtime knows to be idle: one query lets it find out)
-    if (cs->ctx->large_bar && cs->blob_use[cs->scan_buf] <= cs->launch_done) {
+    if (cs->ctx->large_bar && (force_bar || cs->blob_use[cs->scan_buf] <= cs->launch_done)) {
         // The device block of this scan is idle (nothing that read it is still running: see launch_done) and the host can store
         // into device memory: the upload is a copy by the CPU through the PCIe aperture -- write-combined, 32 KB in ~1 us,
         // tools/ubench_bar.hip -- and the launches that follow find the data in memory (their doorbell is ordered behind the
@@ -877,6 +884,15 @@ extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t 
     cs->n_points = n;
     g_sst.lap(6); g_sst.done();
     return SLAMHIP_OK;
+}
+
+extern "C" int32_t slamhip_cs_set_scan(slamhip_cs *cs, const float *xy, int32_t n)
+{
+    SH_CHECK_ARG(cs && n >= 0 && (xy || n == 0));
+    SH_HIP(hipSetDevice(cs->ctx->device));
+    if (n == 0) { cs->n_points = 0; cs->n_rb = 0; return SLAMHIP_OK; }
+    SH_TRY(cs_set_scan_begin(cs, n));
+    return cs_set_scan_finish(cs, xy, n, false);
 }
 
 // The search may be put into the operator's stream once the side stream's launch (ensure_shard) has COMPLETED: the host watches
@@ -1526,6 +1542,13 @@ extern "C" int32_t slamhip_cs_maps_checksum(slamhip_cs *cs, uint64_t out[2])
     return SLAMHIP_OK;
 }
 
+extern "C" int32_t slamhip_cs_prelaunch_stats(slamhip_cs *cs, uint64_t out[4])
+{
+    SH_CHECK_ARG(cs && out);
+    for (int k = 0; k < 4; k++) out[k] = cs->pl_stats[k];
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
 {
     SH_CHECK_ARG(cs && out);
@@ -1572,6 +1595,107 @@ extern "C" int32_t slamhip_cs_search_and_update_pxcs(slamhip_cs *cs, const float
     if (out_index) *out_index = bi;
     if (out_dist) *out_dist = bd;
     return SLAMHIP_OK;
+}
+
+// CoreSLAMProcessor.Update's scan (:723 set_scan, :732 search, :746-751 updates) with the SEARCH LAUNCH FIRST.  Between two scans the
+// host's chain -- the pose comes back, the next scan is converted, sorted, cut into blocks and stored, the search is launched -- is a
+// few microseconds longer than the map update the device is still busy with, and a launch that arrives when the queue has just run
+// dry starts 5 us late (profiles/r05_timeline_csproc.txt).  The search's launch parameters do not depend on the new scan's tables
+// -- the layout is the last scan's (cs_launch_distance), the buffers alternate, the ray count is known -- only its DATA does: so the
+// launch goes into the stream first, behind the running map update, the host makes the tables while that update finishes, and the
+// launch waits ON THE DEVICE for the word the host stores behind the tables (k1_search_tiled: a.scan_flag).  Afterwards the host
+// tests what the launch assumed -- the layout legal for the new blocks, the points sane -- and otherwise tells the launch to leave
+// (the word with bit 31 set) and searches again in the ordinary order.  *took = false: nothing was done.
+int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_t n, const float pose[3], float hole_width, int32_t quality,
+                                         int32_t max_hits, float out_pose[3], bool *took)
+{
+    *took = false;
+    static const bool on = getenv("SLAMHIP_PRELAUNCH") ? atoi(getenv("SLAMHIP_PRELAUNCH")) != 0 : true;
+    static const bool wait_updates = getenv("SLAMHIP_FUSED_WAIT_UPDATES") != nullptr, k1_delivers = getenv("SLAMHIP_FUSED_K1_DELIVERS") != nullptr;
+    slamhip_ctx *ctx = cs->ctx;
+    if (g_cst.on) {                                               // (developer aid: why scans take the ordinary order)
+        static thread_local unsigned why[8], calls;
+        why[0] += n != cs->n_points; why[1] += cs->k1_layout_dirty; why[2] += !cs->pts_sane; why[3] += cs->upload_pending; why[4] += cs->scan_in_flight;
+        why[5] += !(cs->blob_use[cs->scan_buf ^ 1] <= cs->launch_done); why[6] += !cs_holemap_one_launch(cs);
+        if ((++calls & 255u) == 0) fprintf(stderr, "[slamhip] prelaunch refused in %u calls: ray count %u, layout dirty %u, points %u, upload pending %u, scan in flight %u, block busy %u, two-launch update %u\n",
+                                           calls, why[0], why[1], why[2], why[3], why[4], why[5], why[6]);
+    }
+    if (!on || !xy || n <= 0 || n != cs->n_points || n > cs->cap_points || !ctx->large_bar || ctx->mail_off || ctx->timing != 0 || wait_updates || k1_delivers ||
+        cs->k1_layout_dirty || !cs->pts_sane || cs->n_offs <= 0 || cs->upload_pending || cs->scan_in_flight || !cs_holemap_one_launch(cs)) { cs->pl_stats[3]++; return SLAMHIP_OK; }
+    SH_CHECK_ARG(quality >= 0 && quality <= 256 && max_hits >= -128 && max_hits <= 127);
+    SH_HIP(hipSetDevice(ctx->device));
+    // the device block the new scan goes into must be idle BEFORE the search that reads it is launched (the launch marks it in use)
+    if (!(cs->blob_use[cs->scan_buf ^ 1] <= cs->launch_done)) { cs->pl_stats[3]++; return SLAMHIP_OK; }
+    if (!cs->d_scan_flag) {
+        // (fine-grained device memory: the word is polled by a running launch while the host stores it through the BAR -- in an ordinary
+        // allocation the poll is served from the L2 for tens of microseconds after the store has landed)
+        SH_HIP(hipExtMallocWithFlags((void **)&cs->d_scan_flag, 64, hipDeviceMallocFinegrained));
+        SH_HIP(hipMemsetAsync(cs->d_scan_flag, 0, 64, ctx->stream));
+        SH_HIP(hipStreamSynchronize(ctx->stream));
+        cs->scan_flag_seq = 0;
+    }
+    *took = true;
+    SH_TRY(cs_set_scan_begin(cs, n));
+    cs->n_points = n;                                              // (the launch's ray count; the tables follow)
+    cs->scan_flag_seq = (cs->scan_flag_seq + 1) & 0x7fffffffu;
+    if (cs->scan_flag_seq == 0) cs->scan_flag_seq = 1;
+    // (the word through the BAR, fenced on both sides: behind the tables' stores, in front of whatever the host does next)
+    auto answer = [cs](uint32_t v) { __builtin_ia32_sfence(); *(volatile uint32_t *)cs->d_scan_flag = v; __builtin_ia32_sfence(); };
+    int32_t rc_f = SLAMHIP_OK;
+    bool abandoned = false;
+    {
+        sh_mail_guard lock(ctx);
+        const uint32_t seq = sh_mail_seq_next(ctx);
+        cs->k1_ring_request = true; cs->k1_prelaunch = true;
+        const int32_t rc_r = search_enqueue(cs, pose, 0, cs->n_offs + 1, cs->d_key);
+        cs->k1_prelaunch = false;
+        if (g_cst.on && rc_r == CS_RC_NO_PRELAUNCH) { static thread_local unsigned nn; if ((++nn & 15u) == 0) fprintf(stderr, "[slamhip] prelaunch: %u launches needed a new layout\n", nn); }
+        if (rc_r != CS_RC_NO_PRELAUNCH) {
+            cs->k1_ring_request = false;
+            if (rc_r != SLAMHIP_OK) { cs->n_points = 0; return rc_r; }   // (nothing was launched)
+            g_cst.lap(3);
+            rc_f = cs_set_scan_finish(cs, xy, n, true);
+            if (rc_f != SLAMHIP_OK || !cs->pts_sane || !cs_k1_layout_legal(cs)) {
+                answer(cs->scan_flag_seq | 0x80000000u);           // the launch leaves; its result word stays rested
+                abandoned = true;
+                cs->pl_stats[1]++;
+            }
+            if (!abandoned) {
+            answer(cs->scan_flag_seq);
+            cs->pl_stats[0]++;
+            if (g_cst.on && (cs->scan_flag_seq & 63u) == 0) fprintf(stderr, "[slamhip] prelaunched searches: spins of the first workgroup, last %u, sum %u\n", ((volatile uint32_t *)cs->d_scan_flag)[8], ((volatile uint32_t *)cs->d_scan_flag)[9]);
+            cs->k1_scan_dirty = false;                             // (the launch is out; the layout for this scan is made in the idle refresh below)
+            cs_k2_winner win;
+            win.d_key = cs->k1_ring_last; win.d_offs_flat = cs->d_offs_flat; win.n_offs = cs->n_offs; win.bx = pose[0]; win.by = pose[1]; win.bth = pose[2];
+            win.mail = ctx->mailbox; win.seq = seq;
+            const int32_t rc_u = cs_launch_holemap_update(cs, cs->d_best_pose, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), hole_width, quality, true, max_hits, &win);
+            g_cst.lap(4);
+            cs_layout_idle_refresh(cs);
+            g_cst.lap(5);
+            SH_TRY(rc_u);
+            const int32_t rc_p = cs_speculate_next(cs);
+            g_cst.lap(7);
+            SH_TRY(sh_flag_wait(ctx, ctx->mailbox + 15, seq));
+            g_cst.lap(6); g_cst.done();
+            SH_TRY(rc_p);
+            cs->hole_pixels_pending = true;
+            cs->launch_done = cs->k1_launch_no;
+            const float *hp = (const float *)(ctx->mailbox + 2);
+            if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
+            return SLAMHIP_OK;
+            }
+        }
+        cs->k1_ring_request = false;
+    }
+    if (abandoned) {                                               // (the tables stand: the ordinary search over them; its layout is made first)
+        SH_TRY(rc_f);
+        return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, nullptr, nullptr);
+    }
+    cs->pl_stats[2]++;
+    // the layout has to be remade for the new scan: the ordinary order (nothing was launched -- the block was found idle above, whatever
+    // the refused launch has noted in blob_use since)
+    SH_TRY(cs_set_scan_finish(cs, xy, n, true));
+    return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, nullptr, nullptr);
 }
 
 extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality,

@@ -94,6 +94,9 @@ struct slamhip_cs {
     std::vector<float> h_grp_prev; int k1_group_prev;   // the groups' figures before the last ensure_shard (layout kept when unchanged)
     bool k1_layout_dirty, k1_layout_spread; int k1_layout_budget, k1_layout_groups; float k1_layout_theta;
     bool k1_scan_dirty;                         // a new scan since the layout was made (set_scan): it is kept if still legal, see cs_launch_distance
+    bool k1_prelaunch;                          // the search launch now being made precedes its scan's tables (cs_search_and_update_prelaunched, coreslam.hip): the layout is the last scan's, unchecked
+    uint64_t pl_stats[4];                       // slamhip_cs_prelaunch_stats: launched ahead of the tables | abandoned | a new layout was needed | refused (ordinary order)
+    uint32_t *d_scan_flag; uint32_t scan_flag_seq;   // ... and waits on the device for this word: the host stores the scan's number there when the tables have landed (or the number | 2^31: abandon the launch)
     bool k1_layout_stale;                       // ... and the one for the scan now set is made in the host's next idle wait (cs_layout_idle_refresh)
     int k1_layout_target, k1_layout_band_parts;
     float gen_sigma_xy, gen_sigma_theta;        // offsets generated on the device: their distribution
@@ -154,10 +157,14 @@ int32_t cs_alloc_candidates(slamhip_cs *cs, int count);
 int32_t cs_flush_scan(slamhip_cs *cs);
 int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int count, bool want_dist, bool cand_sane,
                            uint64_t *key_dst);
+bool cs_k1_layout_legal(const slamhip_cs *cs);   // distance.hip: are the layout's counts of ray ranges legal for the scan now set?
 void cs_layout_idle_refresh(slamhip_cs *cs);   // host only: call between a search's enqueue and the wait for its result
 // coreslam.hip: produces a device-generated jitter list that is still pending (slamhip_cs_generate_offsets)
 int32_t cs_flush_generate(slamhip_cs *cs);
 int32_t cs_side_join(slamhip_cs *cs);
+#define CS_RC_NO_PRELAUNCH 77                   // cs_launch_distance, internal: a prelaunch would need a new layout -- nothing was launched
+int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_t n, const float pose[3], float hole_width, int32_t quality,
+                                         int32_t max_hits, float out_pose[3], bool *took);   // coreslam.hip; *took = false: nothing done, the caller takes the ordinary order
 // developer switch SLAMHIP_FUSED_TIMES=1: host clock between the stages of the per-scan calls (mean over 64 calls, stderr)
 struct cs_stage_times {
     bool on; double acc[12]; int n; timespec t; const char *what;

@@ -196,7 +196,7 @@ k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_poin
 static_assert(K1_MAXBANDS == 4, "the step threads split t into (piece, band) with shifts");
 #define K1_TABLE_G 64                  // groups with their own chunk count (the rest: one uniform count)
 #define K1_TABLE_WGS 2048
-#define K1_MAXCUT 640                  // entries of the cut table in the kernel arguments (ray ranges cut by cost: k1_balanced_cuts)
+#define K1_MAXCUT 624                  // entries of the cut table in the kernel arguments (ray ranges cut by cost: k1_balanced_cuts)
 #define K1_ACC_INMAP 36                // accumulator fields: pixel sum below (R < 2^20 rays x 65535), workgroups with an in-map end point,
 #define K1_ACC_ARRIVED 50              // workgroups arrived (chunks per group < 2^14)
 #define K1_ZERO_OFS 0                  // dynamic LDS: a zero word (16 bytes), then the tile
@@ -235,6 +235,7 @@ struct k1_args {
     // starts -- the workgroups that finish candidates min their keys straight into it (no return, no count, no last finisher: the
     // END OF THE LAUNCH is the completion) -- and this launch leaves the NEXT slot all ones for the next one.  Null: key_out + the chain.
     unsigned long long *ring_slot, *ring_reset;
+    const uint32_t *scan_flag; uint32_t scan_seq;   // a launch that precedes its scan's tables (cs_search_and_update_prelaunched): wait here for scan_seq; bit 31 set: leave
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
     // rays at the same time: their tiles overlap almost completely, L2 reuse)
@@ -456,6 +457,28 @@ k1_search_tiled(const k1_args a)
         rlo = (int)(((unsigned)rc * (unsigned)a.n_rays) / (unsigned)nrc); rhi = (int)(((unsigned)(rc + 1) * (unsigned)a.n_rays) / (unsigned)nrc);
     } else { rlo = (int)(((long long)rc * a.n_rays) / nrc); rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc); }
     const int nrays = rhi - rlo;
+    if (a.scan_flag) {
+        // The launch was put into the stream before its scan's tables existed (coreslam.hip, cs_search_and_update_prelaunched): the
+        // host stores the scan's number behind the tables (through the BAR, fenced), and nothing of the scan is read before the
+        // number is seen -- by every wavefront for itself.  The word lives in fine-grained memory and is loaded at system scope: never
+        // from a cache.  The tables need no invalidate of their own -- the launch started with clean caches and no wavefront touches
+        // a line of the scan before it has seen the number (an ACQUIRE here is a buffer_inv in every one of the launch's 4096
+        // wavefronts as they start, one after the other, each emptying the L2 under the workgroups already at work: the search
+        // took 50 us instead of 23).  The loads behind the loop depend on its exit.  Normally the word is there long before the
+        // launch starts (it starts behind the previous scan's map update): one load.  Bit 31: the host found that the launch's assumptions do not hold for this scan -- leave without a trace (the
+        // result word stays rested: the map update that decodes it falls back to the search pose, holemap.hip; the host searches
+        // again).  A host that never answers: the same after ~10 s, with the self-check counter raised.
+        uint32_t v = 0;
+        int spins = 0;
+        for (;;) {
+            v = __hip_atomic_load(a.scan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((v & 0x7fffffffu) == a.scan_seq) break;
+            if (++spins > (1 << 23)) { if (t == 0) atomicAdd(a.verify, 1u); v = 0x80000000u; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (blockIdx.x == 0 && t == 0) { ((uint32_t *)a.scan_flag)[8] = (uint32_t)spins; ((uint32_t *)a.scan_flag)[9] += (uint32_t)spins; }   // (developer aid: how long the first workgroup waited, SLAMHIP_FUSED_TIMES)
+        if (__builtin_amdgcn_readfirstlane(v) & 0x80000000u) return;
+    }
     // (the two block numbers are uniform, and the compiler would wait for them -- to move them into SGPRs -- before it issues
     // the loads below: a memory round trip at the head of every workgroup.  Loaded through an address that looks
     // lane-dependent they stay in VGPRs and are waited for where they are used)
@@ -1601,6 +1624,8 @@ static bool k1_layout_legal(const slamhip_cs *cs)
 
 // The layout for the scan now set, made while the host has nothing else to do (it waits for a search's result): the launch that
 // just left used the previous scan's (cs_launch_distance).  Touches host state only.
+bool cs_k1_layout_legal(const slamhip_cs *cs) { return k1_layout_legal(cs); }
+
 void cs_layout_idle_refresh(slamhip_cs *cs)
 {
     if (!cs->k1_layout_stale || cs->k1_layout_dirty || cs->k1_scan_dirty || cs->n_points <= 0) return;
@@ -1628,6 +1653,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     static const int no_table = env_int("SLAMHIP_K1_NOTABLE", 0);
     const bool sane = cs->pts_sane && cand_sane;
     const bool tiled = sane && (cs->hs % 8 == 0) && !force_global;
+    if (cs->k1_prelaunch && !tiled) return CS_RC_NO_PRELAUNCH;      // (the fallback kernels read the scan's blocks on the host)
     const int n_rb = cs->n_rb;
     int32_t *dist = want_dist ? cs->d_dist : nullptr;
     unsigned long long *key = (unsigned long long *)key_dst;
@@ -1674,6 +1700,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.sig = cs->k1_sig; a.sig_val = cs->k1_sig_val;
         cs->k1_sig_armed = a.sig != nullptr;
         a.ring_slot = ring_slot; a.ring_reset = ring_reset;
+        a.scan_flag = cs->k1_prelaunch ? cs->d_scan_flag : nullptr; a.scan_seq = cs->scan_flag_seq;
         if (ring && (a.best_pose || a.done_flag || a.sig)) SH_FAIL(SLAMHIP_ERR_STATE, "a ring search delivers nothing but its key");
 
         // launch layout
@@ -1686,6 +1713,13 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         g_cst.lap(8);
         bool remake = cs->k1_layout_dirty || cs->k1_layout_groups != n_groups || cs->k1_layout_budget != budget || cs->k1_layout_spread != have_spread ||
                       cs->k1_layout_target != target || (have_spread && !(fabsf(bth - cs->k1_layout_theta) < 0.1f));
+        if (cs->k1_prelaunch) {
+            // The launch precedes its scan's tables (cs_search_and_update_prelaunched): it keeps the last scan's layout, whose legality
+            // for the new ray blocks the caller tests when they exist (and abandons the launch if it fails); a layout that has to be
+            // remade for another reason needs the new blocks: no prelaunch.
+            if (remake) { cs->k1_ring_request = ring; return CS_RC_NO_PRELAUNCH; }
+            cs->k1_layout_stale = true;
+        } else
         if (!remake && cs->k1_scan_dirty) {
             // A new scan under an unchanged candidate list (the per-scan flow): the layout made for the last scan serves this one
             // if its counts of ray ranges are legal for the new ray blocks -- only the balance of the launch depends on the layout,

@@ -161,13 +161,12 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
         }
     }
     g_pt.lap(0);
-    SH_TRY(slamhip_cs_set_scan(p->cs, p->cloud.data(), n));               // :723
-    g_pt.lap(1);
 
     float new_pose[3];
     if (p->scan_count >= p->search_beginning && n > 0) {                  // :726
         float search[3];
         for (int i = 0; i < 3; i++) search[i] = p->pose[i] + (odo[i] - p->last_odo[i]);   // :728
+        // (the candidates first: they do not depend on the scan, and the search launch may precede the scan's tables -- below)
         if (!p->pinned) {
             const int nj = (p->threads > 0 ? p->threads : 1) * p->iters;  // :143-160, :662-665
             if (p->lattice) SH_TRY(slamhip_cs_generate_offsets_lattice(p->cs, nj, p->sigma_xy, p->sigma_theta, p->seed, p->scan_no));
@@ -176,12 +175,24 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
         p->scan_no++;
         memcpy(p->last_odo, odo, sizeof(odo));                            // :745
         g_pt.lap(2);
+        // set_scan (:723), search (:732), NormalizeAngle (:746) and both map updates (:750-751): the search launch first where it can
+        bool took = false;
+        SH_TRY(cs_search_and_update_prelaunched(p->cs, p->cloud.data(), n, search, p->hole_width, p->quality, p->max_hits, new_pose, &took));
+        if (took) {
+            memcpy(p->pose, new_pose, sizeof(new_pose));                  // :747
+            g_pt.lap(3); g_pt.done();
+            return SLAMHIP_OK;
+        }
+        SH_TRY(slamhip_cs_set_scan(p->cs, p->cloud.data(), n));           // :723
+        g_pt.lap(1);
         // search (:732), NormalizeAngle (:746) and both map updates (:750-751) fused on the device
         SH_TRY(slamhip_cs_search_and_update(p->cs, search, p->hole_width, p->quality, p->max_hits, new_pose, nullptr, nullptr));
         memcpy(p->pose, new_pose, sizeof(new_pose));                      // :747
         g_pt.lap(3); g_pt.done();
         return SLAMHIP_OK;
     }
+    SH_TRY(slamhip_cs_set_scan(p->cs, p->cloud.data(), n));               // :723
+    g_pt.lap(1);
     if (p->scan_count < p->search_beginning) p->scan_count++;             // :741
     else if (n == 0) {
         // searching scan with an empty cloud: every distance is int.MaxValue, the base pose wins (:257,:626-628)

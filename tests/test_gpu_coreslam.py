@@ -826,6 +826,50 @@ def test_processor_vs_oracle(cs_mod, ctx, det, sim):
     proc2.Dispose(); proc.Dispose()
 
 
+def test_processor_search_launched_ahead_of_the_scan(cs_mod, ctx, det, sim):
+    """CoreSLAMProcessor.Update (CoreSLAMProcessor.cs:717-752) with the search launch put into the stream before the scan's tables
+    (cs_search_and_update_prelaunched): one candidate list kept over many scans of one ray count, so that the launch-ahead path is
+    taken; in between scans whose ray blocks the last layout does not serve (every ray far from the next: one block per ray) and a
+    scan with a NaN point (the search then runs on the bounds-checked kernels) -- those launches are abandoned on the device and the
+    scan is searched again in the ordinary order.  Pose and both maps equal the oracle state machine after every scan; the
+    library's counters say that every path was taken."""
+    oc = det
+    segs = sim.default_field()
+    start = np.array([20.0, 20.0, 0.0], np.float32)
+    proc = cs_mod.CoreSLAMProcessor(40.0, 1024, 128, start, 0.1, math.radians(10), 500, 4, ctx=ctx)
+    proc.HoleWidth = 2.0
+    ref = oc.CSProc(40.0, 1024, 128, start)
+    ref.set_params(hole_width=2.0)
+    rng = sim.PCG32(33)
+    R = 720
+    offs = sim.gaussian_offsets(4000, seed=77)
+    proc.SetOffsets(offs)
+    true_traj = sim.trajectory(40, step=(0.05, 0.02, math.radians(0.4)))
+    nprng = np.random.default_rng(5)
+    for i, tp in enumerate(true_traj):
+        rays, _ = sim.make_scan(segs, tp, R, rng)
+        if i in (17, 18, 29):                                           # a scan scattered all over the room: every ray its own block
+            rays = rays.copy()
+            rays[:, 0] = nprng.uniform(-math.pi, math.pi, R).astype(np.float32)
+            rays[:, 1] = nprng.uniform(0.5, 18.0, R).astype(np.float32)
+        if i == 24:
+            rays = rays.copy(); rays[5, 1] = np.nan
+        est = proc.Pose.copy()
+        assert (est == ref.pose).all()
+        seg_pose = (est + np.array([0.05, 0.02, math.radians(0.4)], np.float32)).astype(np.float32) if i else est
+        proc.Update([cs_mod.ScanSegment(rays, seg_pose)])
+        ref.update(seg_pose[None], [0, rays.shape[0]], rays, offs)
+        assert (proc.Pose == ref.pose).all() or (np.isnan(proc.Pose).any() and np.isnan(ref.pose).any()), (i, proc.Pose, ref.pose)
+        if i % 4 == 3 or i in (17, 18, 19, 24, 25, 29, 30):
+            assert (proc.HoleMap.Pixels == ref.holemap).all(), i
+            assert (proc.ObstacleMap.Pixels == ref.obstaclemap).all(), i
+    ahead, abandoned, remade, refused = proc.device.prelaunch_stats
+    if os.environ.get("SLAMHIP_PRELAUNCH", "1") != "0" and not os.environ.get("SLAMHIP_NO_HOSTWAIT"):
+        assert ahead >= 10 and abandoned >= 1 and refused >= 1, (ahead, abandoned, remade, refused)
+    assert proc.device.selfcheck_failures == 0
+    proc.Dispose()
+
+
 def test_processor_long_run_vs_oracle(cs_mod, ctx, det, sim):
     """The simulator's loop (Simulation/MainWindow.xaml.cs:136-210) headless for 160 scans around the inner obstacle: the
     estimate after every Update and both maps along the way must equal the oracle state machine's bit for bit -- any
