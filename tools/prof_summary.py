@@ -61,7 +61,7 @@ if "--collect" in sys.argv:
     for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2",
                 "k5fetch", "k5write", "k5sq1", "k5sq2", "k4fetch", "k4write", "k4sq1", "k4sq2"):
         out[sub] = pmc(sub)
-    for name in ("timeline_c3.txt", "timeline_csproc.txt", "timeline_hsproc.txt"):
+    for name in ("timeline_c3.txt", "timeline_csproc.txt", "timeline_csproc_launch_ahead.txt", "timeline_hsproc.txt"):
         pth = os.path.join(src, name)
         out[name] = open(pth).read() if os.path.exists(pth) else None
     pth = os.path.join(src, "kernels_bench.json")
@@ -197,7 +197,7 @@ for r in c.get("k2stats", []):
     if "k3_" in r["Name"] or "k2_" in r["Name"]:
         sec.setdefault("k2_k3_rocprof_stats", []).append({"kernel": short(r["Name"]), "avg_ns": float(r["AverageNs"]), "calls": int(r["Calls"])})
 json.dump(sec, open(os.path.join(dst, tag + "_secondary_kernels.json"), "w"), indent=1)
-for name, outn in (("timeline_c3.txt", "_timeline_c3.txt"), ("timeline_csproc.txt", "_timeline_csproc.txt"), ("timeline_hsproc.txt", "_timeline_hsproc.txt")):
+for name, outn in (("timeline_c3.txt", "_timeline_c3.txt"), ("timeline_csproc.txt", "_timeline_csproc.txt"), ("timeline_csproc_launch_ahead.txt", "_timeline_csproc_launch_ahead.txt"), ("timeline_hsproc.txt", "_timeline_hsproc.txt")):
     if c.get(name):
         open(os.path.join(dst, tag + outn), "w").write(c[name])
 
