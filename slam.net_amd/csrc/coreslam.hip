@@ -1688,6 +1688,7 @@ int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_
         cs->k1_ring_request = false;
     }
     if (abandoned) {                                               // (the tables stand: the ordinary search over them; its layout is made first)
+        if (rc_f != SLAMHIP_OK) cs->n_points = 0;                  // (... unless making them failed: no scan)
         SH_TRY(rc_f);
         return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, nullptr, nullptr);
     }
