@@ -225,13 +225,19 @@ namespace CoreSLAM
             Vector3 odometry = segments[segments.Count - 1].Pose;                  // :719
             SegmentsToCloud(segments, odometry);                                    // :723 (:187-207)
             if (group != null && TrigMode == TrigMode.Host) throw new NotSupportedException("TrigMode.Host runs on one GPU");
-            fixed (Vector2* p = CollectionsMarshal.AsSpan(cloud))
-            {
-                if (group != null) Native.Check(Native.slamhip_group_set_scan(group.Ptr, p, cloud.Count));
-                else Native.Check(Native.slamhip_cs_set_scan(cs.Ptr, p, cloud.Count));
-            }
+            bool searching = scanCount >= PositionSearchBeginning && cloud.Count > 0;   // :726
+            // One GPU, the library's trigonometry: set_scan (:723), the search (:732) and the updates (:746-751) are ONE call below --
+            // slamhip_cs_scan_search_and_update, which may put the search launch into the stream before the scan's tables are made
+            // (the candidates are generated first: they do not depend on the scan).  Every other path sets the scan here.
+            bool oneCall = searching && group == null && TrigMode != TrigMode.Host;
+            if (!oneCall)
+                fixed (Vector2* p = CollectionsMarshal.AsSpan(cloud))
+                {
+                    if (group != null) Native.Check(Native.slamhip_group_set_scan(group.Ptr, p, cloud.Count));
+                    else Native.Check(Native.slamhip_cs_set_scan(cs.Ptr, p, cloud.Count));
+                }
 
-            if (scanCount >= PositionSearchBeginning && cloud.Count > 0)            // :726
+            if (searching)
             {
                 Vector3 search = Pose + (odometry - lastOdometryPose);              // :728
                 if (!pinnedOffsets)
@@ -260,11 +266,13 @@ namespace CoreSLAM
                     MapsChanged();
                     return;
                 }
-                // search (:732), NormalizeAngle (:746) and both map updates (:750-751): one call.  It returns when the pose is
-                // on the host; the map updates are enqueued behind the search and finish ~40 us later -- every later call that
+                // the scan (:723), search (:732), NormalizeAngle (:746) and both map updates (:750-751): one call.  It returns when the
+                // pose is on the host; the map updates are enqueued behind the search and finish ~40 us later -- every later call that
                 // touches the maps (the next search, the mirrors' downloads below) is ordered behind them on the device
-                Native.Check(Native.slamhip_cs_search_and_update(cs.Ptr, search, HoleWidth, Quality, MaxObstacleHits,
-                                                                 out Vector3 found, out _, out _));
+                Vector3 found;
+                fixed (Vector2* p = CollectionsMarshal.AsSpan(cloud))
+                    Native.Check(Native.slamhip_cs_scan_search_and_update(cs.Ptr, p, cloud.Count, search, HoleWidth, Quality, MaxObstacleHits,
+                                                                          out found, out _, out _));
                 Pose = found;
             }
             else

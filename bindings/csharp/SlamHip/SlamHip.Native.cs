@@ -55,6 +55,8 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_cs_update_obstaclemap_pxcs(IntPtr cs, in Vector4 pxcs, int maxObstacleHits);
         [DllImport(Lib)] internal static extern int slamhip_cs_search_and_update(IntPtr cs, in Vector3 searchPose, float holeWidth, int quality, int maxObstacleHits,
                                                                                  out Vector3 pose, out int dist, out int index);
+        [DllImport(Lib)] internal static extern int slamhip_cs_scan_search_and_update(IntPtr cs, Vector2* xy, int nPoints, in Vector3 searchPose, float holeWidth, int quality, int maxObstacleHits,
+                                                                                      out Vector3 pose, out int dist, out int index);
         [DllImport(Lib)] internal static extern int slamhip_cs_search_and_update_pxcs(IntPtr cs, Vector4* pxcsSearch, Vector4* pxcsUpdateHole, Vector4* pxcsUpdateObstacle, int k,
                                                                                       float holeWidth, int quality, int maxObstacleHits, out int index, out int dist);
         [DllImport(Lib)] internal static extern int slamhip_cs_update_maps_pxcs(IntPtr cs, in Vector4 pxcsHole, in Vector4 pxcsObstacle, float holeWidth, int quality, int maxObstacleHits);

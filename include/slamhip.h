@@ -255,7 +255,7 @@ int32_t slamhip_cs_maps_checksum(slamhip_cs *cs, uint64_t out[2]);
  * the box reasoning holds; the parity tests assert it).  Returns the count accumulated so far. */
 int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out_failures);
 
-/* Diagnostics of slamhip_csproc_update's scan flow (CoreSLAMProcessor.cs:717-752): since round 5 the search launch of a scan goes
+/* Diagnostics of slamhip_cs_scan_search_and_update / slamhip_csproc_update (CoreSLAMProcessor.cs:717-752): the search launch of a scan goes
  * into the stream BEFORE the scan's tables are made and waits for them on the device (DESIGN.md sec.4 "The per-scan flow").
  * out[0] scans searched that way, out[1] such launches abandoned (the last scan's launch layout did not serve the new scan: searched
  * again in the ordinary order), out[2] scans whose layout had to be remade first, out[3] scans refused (first scans, a changed ray
@@ -272,6 +272,15 @@ int32_t slamhip_cs_prelaunch_stats(slamhip_cs *cs, uint64_t out[4]);
 int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float search_pose[3], float hole_width,
                                      int32_t quality, int32_t max_obstacle_hits, float out_pose[3],
                                      int32_t *out_dist, int32_t *out_index);
+/* slamhip_cs_set_scan + slamhip_cs_search_and_update in ONE call -- a scan of CoreSLAMProcessor.Update from :723 to :751 (the candidate list
+ * is set or generated before it: it does not depend on the scan).  Same results as the two calls.  What the one call can do that the
+ * two cannot: put the search launch into the stream BEFORE the scan's tables are made (the launch's parameters do not depend on
+ * them) and let it wait for them on the device, so that the device does not idle between the previous scan's map update and this
+ * search while the host sorts (DESIGN.md sec.4 "The per-scan flow" 5; slamhip_cs_prelaunch_stats counts how often; SLAMHIP_PRELAUNCH=0:
+ * never).  slamhip_csproc_update is built on it.  xy: n_points (x, y) pairs in the robot frame, valid during the call. */
+int32_t slamhip_cs_scan_search_and_update(slamhip_cs *cs, const float *xy, int32_t n_points, const float search_pose[3], float hole_width,
+                                          int32_t quality, int32_t max_obstacle_hits, float out_pose[3], int32_t *out_dist,
+                                          int32_t *out_index);
 /* The same scan with the CALLER's trigonometry, end to end: the reference forms c = MathF.Cos(theta) * Scale, s = MathF.Sin(theta) * Scale
  * with the platform CRT, in CalculateDistanceSISD (:232-235) and again for the two map updates of the winner (:499-502 at the
  * HoleMap's scale, :545-548 at the ObstacleMap's -- from the pose AFTER NormalizeAngle :746, whose float arithmetic moves theta by

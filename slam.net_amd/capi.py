@@ -101,6 +101,7 @@ def _declare(L):
         "slamhip_cs_last_holemap_pixels": (i32, [vp, P(i64)]),
         "slamhip_cs_maps_checksum": (i32, [vp, P(u64)]),
         "slamhip_cs_search_and_update": (i32, [vp, fp, f, i32, i32, fp, ip, ip]),
+        "slamhip_cs_scan_search_and_update": (i32, [vp, fp, i32, fp, f, i32, i32, fp, ip, ip]),
         "slamhip_cs_search_and_update_pxcs": (i32, [vp, fp, fp, fp, i32, f, i32, i32, ip, ip]),
         "slamhip_cs_update_maps_pxcs": (i32, [vp, fp, fp, f, i32, i32]),
         "slamhip_cs_selfcheck_failures": (i32, [vp, P(C.c_uint32)]),

@@ -281,6 +281,15 @@ class CoreSlamDevice:
         return pose, d.value, i.value
 
 
+    def scan_search_and_update(self, xy, search_pose, hole_width=0.6, quality=50, max_hits=10):
+        """set_scan + search_and_update in one call (slamhip_cs_scan_search_and_update): the search launch may precede the scan's tables"""
+        pts = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        sp = capi.f32(search_pose)
+        pose = np.empty(3, np.float32); d, i = C.c_int32(), C.c_int32()
+        capi.call("slamhip_cs_scan_search_and_update", self._h, capi.fptr(pts), int(pts.shape[0]), capi.fptr(sp), C.c_float(hole_width), int(quality),
+                  int(max_hits), capi.fptr(pose), C.byref(d), C.byref(i))
+        return pose, d.value, i.value
+
     def search_and_update_pxcs(self, pxcs_search, pxcs_update_hole, pxcs_update_obst=None, hole_width=0.6, quality=50, max_hits=10):
         """The fused scan with the caller's own (px, py, c, s) (slamhip_cs_search_and_update_pxcs): the candidates for the search,
         and their rows -- of the normalised pose -- at both map scales for the updates.  Returns (index, distance) of the first strict

@@ -1607,7 +1607,7 @@ extern "C" int32_t slamhip_cs_search_and_update_pxcs(slamhip_cs *cs, const float
 // tests what the launch assumed -- the layout legal for the new blocks, the points sane -- and otherwise tells the launch to leave
 // (the word with bit 31 set) and searches again in the ordinary order.  *took = false: nothing was done.
 int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_t n, const float pose[3], float hole_width, int32_t quality,
-                                         int32_t max_hits, float out_pose[3], bool *took)
+                                         int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index, bool *took)
 {
     *took = false;
     static const bool on = getenv("SLAMHIP_PRELAUNCH") ? atoi(getenv("SLAMHIP_PRELAUNCH")) != 0 : true;
@@ -1680,8 +1680,12 @@ int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_
             SH_TRY(rc_p);
             cs->hole_pixels_pending = true;
             cs->launch_done = cs->k1_launch_no;
+            const volatile uint64_t *hk = (const volatile uint64_t *)ctx->mailbox;
             const float *hp = (const float *)(ctx->mailbox + 2);
+            const uint64_t key = hk[0];
             if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
+            if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);
+            if (out_index) *out_index = (int32_t)(uint32_t)key;
             return SLAMHIP_OK;
             }
         }
@@ -1690,13 +1694,24 @@ int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_
     if (abandoned) {                                               // (the tables stand: the ordinary search over them; its layout is made first)
         if (rc_f != SLAMHIP_OK) cs->n_points = 0;                  // (... unless making them failed: no scan)
         SH_TRY(rc_f);
-        return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, nullptr, nullptr);
+        return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, out_dist, out_index);
     }
     cs->pl_stats[2]++;
     // the layout has to be remade for the new scan: the ordinary order (nothing was launched -- the block was found idle above, whatever
     // the refused launch has noted in blob_use since)
     SH_TRY(cs_set_scan_finish(cs, xy, n, true));
-    return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, nullptr, nullptr);
+    return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, out_dist, out_index);
+}
+
+extern "C" int32_t slamhip_cs_scan_search_and_update(slamhip_cs *cs, const float *xy, int32_t n, const float pose[3], float hole_width, int32_t quality,
+                                                     int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index)
+{
+    SH_CHECK_ARG(cs && pose && n >= 0 && (xy || n == 0));
+    bool took = false;
+    SH_TRY(cs_search_and_update_prelaunched(cs, xy, n, pose, hole_width, quality, max_hits, out_pose, out_dist, out_index, &took));
+    if (took) return SLAMHIP_OK;
+    SH_TRY(slamhip_cs_set_scan(cs, xy, n));                            // :723
+    return slamhip_cs_search_and_update(cs, pose, hole_width, quality, max_hits, out_pose, out_dist, out_index);   // :732, :746-751
 }
 
 extern "C" int32_t slamhip_cs_search_and_update(slamhip_cs *cs, const float pose[3], float hole_width, int32_t quality,

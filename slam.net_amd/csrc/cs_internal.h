@@ -164,7 +164,7 @@ int32_t cs_flush_generate(slamhip_cs *cs);
 int32_t cs_side_join(slamhip_cs *cs);
 #define CS_RC_NO_PRELAUNCH 77                   // cs_launch_distance, internal: a prelaunch would need a new layout -- nothing was launched
 int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_t n, const float pose[3], float hole_width, int32_t quality,
-                                         int32_t max_hits, float out_pose[3], bool *took);   // coreslam.hip; *took = false: nothing done, the caller takes the ordinary order
+                                         int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index, bool *took);   // coreslam.hip; *took = false: nothing done, the caller takes the ordinary order
 // developer switch SLAMHIP_FUSED_TIMES=1: host clock between the stages of the per-scan calls (mean over 64 calls, stderr)
 struct cs_stage_times {
     bool on; double acc[12]; int n; timespec t; const char *what;

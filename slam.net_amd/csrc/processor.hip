@@ -176,17 +176,7 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
         memcpy(p->last_odo, odo, sizeof(odo));                            // :745
         g_pt.lap(2);
         // set_scan (:723), search (:732), NormalizeAngle (:746) and both map updates (:750-751): the search launch first where it can
-        bool took = false;
-        SH_TRY(cs_search_and_update_prelaunched(p->cs, p->cloud.data(), n, search, p->hole_width, p->quality, p->max_hits, new_pose, &took));
-        if (took) {
-            memcpy(p->pose, new_pose, sizeof(new_pose));                  // :747
-            g_pt.lap(3); g_pt.done();
-            return SLAMHIP_OK;
-        }
-        SH_TRY(slamhip_cs_set_scan(p->cs, p->cloud.data(), n));           // :723
-        g_pt.lap(1);
-        // search (:732), NormalizeAngle (:746) and both map updates (:750-751) fused on the device
-        SH_TRY(slamhip_cs_search_and_update(p->cs, search, p->hole_width, p->quality, p->max_hits, new_pose, nullptr, nullptr));
+        SH_TRY(slamhip_cs_scan_search_and_update(p->cs, p->cloud.data(), n, search, p->hole_width, p->quality, p->max_hits, new_pose, nullptr, nullptr));
         memcpy(p->pose, new_pose, sizeof(new_pose));                      // :747
         g_pt.lap(3); g_pt.done();
         return SLAMHIP_OK;

@@ -870,6 +870,40 @@ def test_processor_search_launched_ahead_of_the_scan(cs_mod, ctx, det, sim):
     proc.Dispose()
 
 
+def test_scan_search_and_update_equals_the_two_calls(cs_mod, ctx, sim):
+    """slamhip_cs_scan_search_and_update == slamhip_cs_set_scan + slamhip_cs_search_and_update (CoreSLAMProcessor.cs:723, :732,
+    :746-751): two operators fed the same scans and the same candidate list, one through the two calls, one through the one call
+    (whose search launch precedes the scan's tables from the second scan on): pose, distance, index and both maps equal after
+    every scan, and the counters say the launch-ahead path was taken."""
+    segs = sim.default_field()
+    a = cs_mod.CoreSlamDevice(ctx, 40.0, 1024, 256)
+    b = cs_mod.CoreSlamDevice(ctx, 40.0, 1024, 256)
+    rng = sim.PCG32(91)
+    traj = sim.trajectory(16, step=(0.06, 0.02, math.radians(0.5)))
+    offs = sim.gaussian_offsets(8191, 0.1, math.radians(8.0), seed=5)
+    for d in (a, b):
+        d.set_offsets(offs)
+    for i, p in enumerate(traj):
+        _, xy = sim.make_scan(segs, p, 900, rng)
+        if i < 4:                                                          # (mapping first)
+            for d in (a, b):
+                d.set_scan(xy); d.update_holemap(p, 0.6, 50); d.update_obstaclemap(p, 10)
+            continue
+        search = (p + np.array([0.03, -0.02, math.radians(0.8)], np.float32)).astype(np.float32)
+        a.set_scan(xy)
+        pa, da, ia = a.search_and_update(search, 0.6, 50, 10)
+        pb, db, ib = b.scan_search_and_update(xy, search, 0.6, 50, 10)
+        assert (pa == pb).all() and da == db and ia == ib, (i, pa, pb, da, db, ia, ib)
+        if i % 3 == 0 or i == len(traj) - 1:
+            assert (a.holemap_download() == b.holemap_download()).all(), i
+            assert (a.obstaclemap_download() == b.obstaclemap_download()).all(), i
+    ahead, abandoned, remade, refused = b.prelaunch_stats
+    if os.environ.get("SLAMHIP_PRELAUNCH", "1") != "0" and not os.environ.get("SLAMHIP_NO_HOSTWAIT"):
+        assert ahead >= 6, (ahead, abandoned, remade, refused)
+    assert a.prelaunch_stats[0] == 0
+    a.close(); b.close()
+
+
 def test_processor_long_run_vs_oracle(cs_mod, ctx, det, sim):
     """The simulator's loop (Simulation/MainWindow.xaml.cs:136-210) headless for 160 scans around the inner obstacle: the
     estimate after every Update and both maps along the way must equal the oracle state machine's bit for bit -- any
