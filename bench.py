@@ -674,6 +674,16 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
                         "caller": "tests/abi_harness.c --bench-proc (C, dlopen): a rectangular room; 300 scans timed after 1800 untimed ones (sustained clocks)"}
                 else:
                     out["coreslam_processor_update_native_caller_2048_map_1080_rays_16385_candidates"] = {"error": txt[-400:]}
+                # HectorSLAMProcessor.Update the same way (--bench-hsproc: 2048^2 x 3 levels, 1080 rays, every scan updating the grids)
+                r = subprocess.run([exe, capi.SO_PATH, "--bench-hsproc", "2048", "3", "1080", "300"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+                txt = r.stdout.decode(errors="replace")
+                if r.returncode == 0 and "hsproc_us_per_scan" in txt:
+                    us = float(txt.split("hsproc_us_per_scan")[1].split()[0])
+                    out["hector_processor_update_native_caller_2048_pyramid_3_levels_1080_rays"] = {
+                        "us_per_scan": us, "scans_per_s": 1e6 / us,
+                        "caller": "tests/abi_harness.c --bench-hsproc (C, dlopen): the same room, every scan matched and the grids updated; 300 scans timed after 1800 untimed ones"}
+                else:
+                    out["hector_processor_update_native_caller_2048_pyramid_3_levels_1080_rays"] = {"error": txt[-400:]}
     except Exception as e:                                         # noqa: BLE001
         out["coreslam_processor_update_native_caller_2048_map_1080_rays_16385_candidates"] = {"error": repr(e)}
     # C4: Hector Gauss-Newton match, 3-level 2048^2 pyramid, 1080 rays

@@ -23,6 +23,7 @@
  *     driver's 8-GPU box runs first, driven by a caller that is not Python.
  *
  *   abi_harness <libslamhip.so> --bench-proc <hole_size> <rays> <candidates> <scans>
+ *   abi_harness <libslamhip.so> --bench-hsproc <side> <levels> <rays> <scans>      HectorSLAMProcessor.Update, every scan updating the grids
  *     times slamhip_csproc_update (CoreSLAMProcessor.Update, CoreSLAMProcessor.cs:717-752) from a native caller: what a P/Invoke
  *     caller pays per scan, without an interpreter in the loop (bench.py's own figure goes through Python / ctypes).  The scans are
  *     a rectangular room seen from a slowly moving robot (ranges by ray / wall intersection, made here); prints one line
@@ -419,6 +420,70 @@ static int bench_proc(void *h, int size, int R, int K, int scans)
     return 0;
 }
 
+/* HectorSLAMProcessor.Update (Main/HectorSLAMProcessor.cs:86-126) from a native caller: the same room, a hint = the last match,
+ * thresholds at zero so that every scan updates the grids (the configuration of tools/exp.py hsproc ... 0). */
+typedef struct slamhip_hsproc slamhip_hsproc;
+static int32_t (*p_hsproc_create)(slamhip_ctx *, float, int32_t, int32_t, const float *, int32_t, slamhip_hsproc **);
+static int32_t (*p_hsproc_destroy)(slamhip_hsproc *);
+static int32_t (*p_hsproc_update)(slamhip_hsproc *, const float *, int32_t, const float *, const float *, int32_t, int32_t *);
+static int32_t (*p_hsproc_get)(slamhip_hsproc *, float *, float *, float *, float *);
+static int32_t (*p_hsproc_set_thresholds)(slamhip_hsproc *, float, float);
+static int bench_hsproc(void *h, int side, int levels, int R, int scans)
+{
+    RESOLVE(p_hsproc_create, "slamhip_hsproc_create");
+    RESOLVE(p_hsproc_destroy, "slamhip_hsproc_destroy");
+    RESOLVE(p_hsproc_update, "slamhip_hsproc_update");
+    RESOLVE(p_hsproc_get, "slamhip_hsproc_get");
+    RESOLVE(p_hsproc_set_thresholds, "slamhip_hsproc_set_thresholds");
+    RESOLVE(p_ctx_synchronize, "slamhip_ctx_synchronize");
+    slamhip_ctx *ctx = NULL;
+    CALL(p_ctx_create(0, &ctx));
+    const float start[3] = { 20.0f, 20.0f, 0.0f }, origin[2] = { 0.0f, 0.0f };
+    slamhip_hsproc *p = NULL;
+    CALL(p_hsproc_create(ctx, 40.0f / (float)side, side, side, start, levels, &p));
+    CALL(p_hsproc_set_thresholds(p, 0.0f, 0.0f));
+    const int n_distinct = 64, warm = 12;
+    float *xy = malloc(sizeof(float) * 2 * (size_t)R * n_distinct), *poses = malloc(sizeof(float) * 3 * n_distinct);
+    for (int k = 0; k < n_distinct; k++) {
+        const double x = 20.0 + 0.04 * k, y = 20.0 + 0.015 * k, th = 0.004 * k;
+        poses[3 * k] = (float)x; poses[3 * k + 1] = (float)y; poses[3 * k + 2] = (float)th;
+        for (int i = 0; i < R; i++) {                               /* the cloud in the robot frame (ScanCloud.Points) */
+            const double a = (double)i * 6.283185307179586 / R;
+            const double r = room_range(x, y, a + th) + 0.002 * (double)((i * 7 + k * 3) % 11 - 5);
+            xy[2 * ((size_t)k * R + i)] = (float)(r * cos(a)); xy[2 * ((size_t)k * R + i) + 1] = (float)(r * sin(a));
+        }
+    }
+    int32_t upd = 0, n_upd = 0;
+    for (int k = 0; k < warm; k++) CALL(p_hsproc_update(p, xy + 2 * (size_t)k * R, R, origin, poses + 3 * k, 1, &upd));     /* (:179: the first loops map without matching) */
+    CALL(p_ctx_synchronize(ctx));
+    struct timespec t0, t1;
+    double us[2] = { 0.0, 0.0 };
+    float hint[3] = { poses[3 * (warm - 1)], poses[3 * (warm - 1) + 1], poses[3 * (warm - 1) + 2] };
+    int kk = 0;
+    for (int pass = 0; pass < 3; pass++) {
+        const int n = pass == 1 ? 5 * scans : scans;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int k = 0; k < n; k++, kk++) {
+            const int j = warm + kk % (n_distinct - warm);
+            /* (the hint: the scan's true pose perturbed a little -- the lap jumps back every 52 scans, which a hint from the last match would not survive) */
+            hint[0] = poses[3 * j] + 0.03f; hint[1] = poses[3 * j + 1] - 0.02f; hint[2] = poses[3 * j + 2] + 0.01f;
+            CALL(p_hsproc_update(p, xy + 2 * (size_t)j * R, R, origin, hint, 0, &upd));
+            n_upd += upd;
+        }
+        if (pass != 1) CALL(p_ctx_synchronize(ctx));
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (pass != 1) us[pass / 2] = ((double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3) / n;
+    }
+    float mp[3], lp[3], tm = 0, tu = 0;
+    CALL(p_hsproc_get(p, mp, lp, &tm, &tu));
+    printf("hsproc_us_per_scan %.3f  (sustained clocks; the first %d scans, from idle clocks: %.3f; %d^2 x %d levels, %d rays, %d of %d scans updated the grids; last match %.3f %.3f %.4f)\n",
+           us[1], scans, us[0], side, levels, R, n_upd, 7 * scans, mp[0], mp[1], mp[2]);
+    CALL(p_hsproc_destroy(p));
+    CALL(p_ctx_destroy(ctx));
+    free(xy); free(poses);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc == 7 && strcmp(argv[2], "--bench-proc") == 0) {
@@ -428,6 +493,14 @@ int main(int argc, char **argv)
         RESOLVE(p_ctx_create, "slamhip_ctx_create");
         RESOLVE(p_ctx_destroy, "slamhip_ctx_destroy");
         return bench_proc(h, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+    }
+    if (argc == 7 && strcmp(argv[2], "--bench-hsproc") == 0) {
+        void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "abi_harness: dlopen failed: %s\n", dlerror()); return 2; }
+        RESOLVE(p_last_error, "slamhip_last_error");
+        RESOLVE(p_ctx_create, "slamhip_ctx_create");
+        RESOLVE(p_ctx_destroy, "slamhip_ctx_destroy");
+        return bench_hsproc(h, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
     }
     if (argc == 4 && strcmp(argv[2], "--group") == 0) {
         void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);

@@ -133,3 +133,20 @@ def test_native_caller_times_processor_update(tmp_path):
     assert r.returncode == 0 and "proc_us_per_scan" in out, out
     us = float(out.split("proc_us_per_scan")[1].split()[0])
     assert 1.0 < us < 5000.0, out
+
+
+@pytest.mark.gpu
+def test_native_caller_times_hector_processor_update(tmp_path):
+    """--bench-hsproc: HectorSLAMProcessor.Update from the native caller (a short run: the mode works, every scan updates the
+    grids and the match tracks the room: the last match lies where the lap's last scan was taken)."""
+    exe = build_harness(str(tmp_path))
+    r = subprocess.run([exe, lib_path(), "--bench-hsproc", "512", "3", "360", "40"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "hsproc_us_per_scan" in out, out
+    us = float(out.split("hsproc_us_per_scan")[1].split()[0])
+    assert 1.0 < us < 5000.0, out
+    assert "280 of 280 scans updated the grids" in out, out
+    mx, my, mth = [float(v) for v in out.split("last match")[1].replace(")", " ").split()[:3]]
+    # the timed loop ends with scan kk = 7 * 40 - 1 of the lap: j = 12 + kk % 52
+    j = 12 + (7 * 40 - 1) % 52
+    assert abs(mx - (20.0 + 0.04 * j)) < 0.08 and abs(my - (20.0 + 0.015 * j)) < 0.08 and abs(mth - 0.004 * j) < 0.02, out
