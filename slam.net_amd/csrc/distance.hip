@@ -849,6 +849,8 @@ k1_search_tiled(const k1_args a)
             const int nr = __builtin_amdgcn_readfirstlane(cb.z) >> 16;         // <= CS_RB_MAX = 64
 #ifdef K1_TIMES
             if (t == 0 && blockIdx.x < 4096) g_k1_times[blockIdx.x * 16 + 10 + kind] += (unsigned long long)nr;
+            if (t == 0 && blockIdx.x < 4096 && s < 3)            // (the first three steps' shapes: kind | tile width << 4 | tile rows << 16 | rays << 32)
+                g_k1_sub[blockIdx.x * 8 + 5 + s] = (unsigned long long)kind | ((unsigned long long)__builtin_amdgcn_readfirstlane(ca.z) << 4) | ((unsigned long long)__builtin_amdgcn_readfirstlane(ca.w) << 16) | ((unsigned long long)nr << 32);
 #endif
             const unsigned pbase = cpts_lds + (unsigned)zv + (unsigned)(__builtin_amdgcn_readfirstlane(cb.z) & 0xffff) * 8u;
             const int x0a = __builtin_amdgcn_readfirstlane(ca.x), y0 = __builtin_amdgcn_readfirstlane(ca.y);
@@ -1956,10 +1958,17 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
                     const int i = order[(size_t)oi];
                     fprintf(stderr, "  wg %4d: start +%6.2f |", i, (double)(h[i * 16] - t0) * 0.01);
                     for (int k = 0; k < 8; k++) fprintf(stderr, " %s %5.2f", nm[k], (double)(h[i * 16 + k + 1] - h[i * 16 + k]) * 0.01);
-                    fprintf(stderr, " tail %5.2f | end +%6.2f | g %2d nc %2d rays shared %d global %d band %d\n",
+                    fprintf(stderr, " tail %5.2f | end +%6.2f | g %2d nc %2d rays shared %d global %d band %d",
                             h[i * 16 + 9] > h[i * 16 + 8] ? (double)(h[i * 16 + 9] - h[i * 16 + 8]) * 0.01 : 0.0,
                             (double)(endof(i) - t0) * 0.01, (int)h[i * 16 + 14], (int)h[i * 16 + 15], (int)h[i * 16 + 11],
                             (int)h[i * 16 + 12], (int)h[i * 16 + 13]);
+                    {
+                        unsigned long long sbx[8];
+                        (void)hipMemcpyFromSymbol(sbx, HIP_SYMBOL(g_k1_sub), sizeof(sbx), sizeof(unsigned long long) * (size_t)i * 8);
+                        fprintf(stderr, " | steps");
+                        for (int k = 5; k < 8; k++) if (sbx[k]) fprintf(stderr, " [kind %d tile %d x %d, %d rays]", (int)(sbx[k] & 15), (int)((sbx[k] >> 4) & 0xfff), (int)((sbx[k] >> 16) & 0xffff), (int)(sbx[k] >> 32));
+                        fprintf(stderr, "\n");
+                    }
                 }
                 {   // per CU: workgroups hosted and the time the last of them ends
                     std::vector<unsigned long long> ws((size_t)nw * 16);
