@@ -228,8 +228,17 @@ def main():
     if two_events:
         ev0.record(ext)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        final_key = step()
+    if os.environ.get("SLAMHIP_BENCH_STEP_TIMES"):                 # developer aid: the host's time per step inside the timed region (stderr)
+        ts = [t0]
+        for _ in range(a.steps):
+            final_key = step()
+            ts.append(time.perf_counter())
+        dts = np.diff(ts) * 1e6
+        print("bench.py host us per step: mean %.2f p50 %.2f p90 %.2f max %.2f; the ten longest: %s at %s" %
+              (dts.mean(), np.median(dts), np.percentile(dts, 90), dts.max(), np.round(np.sort(dts)[-10:], 1), np.argsort(dts)[-10:]), file=sys.stderr)
+    else:
+        for _ in range(a.steps):
+            final_key = step()
     if two_events:
         ev1.record(ext)
     torch.cuda.synchronize()                # (the whole device: the library's streams included)
@@ -377,6 +386,7 @@ def main():
                        "cold_clocks": None if cold is None else {
                            "ms_per_step": cold * 1e3, "value": K_total / cold,
                            "note": "the same K steps behind the same W warm-up steps, measured before the clock warm-up: a burst on an idle chip"},
+                       "search_plan": dict(zip(("searches_with_a_plan_launch", "without", "host_waits_for_a_plan_slot", "plans_skipped_inputs_in_flight"), dev.plan_stats)),
                        "best_index": final_key & 0xFFFFFFFF, "best_distance": final_key >> 32},
             "roofline": roof,
         }

@@ -25,6 +25,7 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_ctx_synchronize(IntPtr ctx);
         [DllImport(Lib)] internal static extern int slamhip_ctx_set_wait_timeout(IntPtr ctx, long timeoutMs);
         [DllImport(Lib)] internal static extern int slamhip_ctx_poisoned(IntPtr ctx, out int poisoned);
+        [DllImport(Lib)] internal static extern int slamhip_ctx_philox4x32_10(IntPtr ctx, uint[] counter4, uint[] key2, [Out] uint[] out4);
 
         // ---- CoreSLAM operator level --------------------------------------------------------------------------------
         [DllImport(Lib)] internal static extern int slamhip_cs_create(IntPtr ctx, float physicalMapSize, int holeMapSize, int obstacleMapSize, out IntPtr cs);
@@ -48,6 +49,7 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_cs_generate_offsets_lattice(IntPtr cs, int n, float sigmaXY, float sigmaTheta, ulong seed, ulong stream);
         [DllImport(Lib)] internal static extern int slamhip_cs_prepared_lists(IntPtr cs, out ulong served, out ulong prepared);
         [DllImport(Lib)] internal static extern int slamhip_cs_prelaunch_stats(IntPtr cs, [Out] ulong[] four);
+        [DllImport(Lib)] internal static extern int slamhip_cs_plan_stats(IntPtr cs, [Out] ulong[] four);
         [DllImport(Lib)] internal static extern int slamhip_cs_search(IntPtr cs, in Vector3 searchPose, out Vector3 pose, out int dist, out int index);
         [DllImport(Lib)] internal static extern int slamhip_cs_update_holemap(IntPtr cs, in Vector3 pose, float holeWidth, int quality);
         [DllImport(Lib)] internal static extern int slamhip_cs_update_holemap_pxcs(IntPtr cs, in Vector4 pxcs, float holeWidth, int quality);

@@ -203,6 +203,12 @@ int32_t slamhip_cs_prepared_lists(slamhip_cs *cs, uint64_t *out_served, uint64_t
 int32_t slamhip_cs_generate_offsets_lattice(slamhip_cs *cs, int32_t n, float sigma_xy, float sigma_theta,
                                             uint64_t seed, uint64_t stream);
 int32_t slamhip_cs_offsets_download(slamhip_cs *cs, float *offs, int32_t n);
+/* Known-answer access to the generator's integer stream (what FillRandomQueues' Redzen samplers, CoreSLAMProcessor.cs:599-612, are
+ * replaced by has no reference vectors of its own, so it is pinned to its published specification instead): ONE Philox4x32-10 block
+ * computed on the device -- counter[4], key[2] -> out[4] -- to be compared with Random123's kat_vectors (tests/test_gpu_coreslam.py;
+ * the same vectors pin the NumPy restatement, oracle/np_oracle.py: philox4x32_10, philox_jitters).  Jitter i of a generated list uses
+ * counter (i, 0, stream low, stream high) and key (seed low, seed high). */
+int32_t slamhip_ctx_philox4x32_10(slamhip_ctx *ctx, const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 
 /* ParallelMonteCarloSearch / SingleMonteCarloSearch (CoreSLAMProcessor.cs:624-710) over the flat
  * candidate list: candidate 0 = search_pose itself (:626-628), candidate k = search_pose + offs[k-1].
@@ -225,7 +231,11 @@ int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float search_pose[3]
  * that keeps a word across such calls copies it first (slamhip_cs_key_read).  No caller memory is involved, so the kernel needs no final arriver: the workgroups that complete
  * candidates min their keys straight into the word (the previous call's launch left it all ones), and the end of the launch is
  * the completion (the cross-thread arg-min of :695-705 as fire-and-forget atomics).  slamhip_cs_key_read waits for the handle's
- * stream and copies one such word to the host. */
+ * stream and copies one such word to the host.
+ * Backpressure (round 6): every search launch is accompanied by its plan (slamhip_cs_plan_stats), whose buffers exist four times, so
+ * a caller that enqueues searches faster than the device runs them is held in this call until the search three launches back has
+ * started (the device still has two searches queued: nothing idles) -- at most 20 ms or the context's wait bound, whichever is
+ * shorter; past that the search is launched without a plan. */
 int32_t slamhip_cs_search_shard_enqueue(slamhip_cs *cs, const float search_pose[3], int32_t first, int32_t count,
                                         const uint64_t **d_key);
 int32_t slamhip_cs_key_read(slamhip_cs *cs, const uint64_t *d_key, uint64_t *out_key);
@@ -261,6 +271,15 @@ int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out_failures);
  * again in the ordinary order), out[2] scans whose layout had to be remade first, out[3] scans refused (first scans, a changed ray
  * count, a new candidate list, SLAMHIP_PRELAUNCH=0 ...).  The results do not depend on the path taken. */
 int32_t slamhip_cs_prelaunch_stats(slamhip_cs *cs, uint64_t out[4]);
+
+/* Diagnostics of the search's PLAN (round 6; replaces nothing in the reference -- it is how CalculateDistanceSISD's candidate transform,
+ * CoreSLAMProcessor.cs:232-235, is made once per candidate instead of once per candidate and ray range): every search launch of the
+ * tiled kernel is accompanied by one small launch on a stream of its own that leaves each candidate's (px, py, c, s) and each
+ * workgroup's tile steps in device memory, stamped; the search kernel uses what carries its stamp and works out the rest itself.
+ * out[0] searches launched with a plan, out[1] without (explicit pose lists, lattice lists, prelaunched searches, SLAMHIP_K1_PLAN=0),
+ * out[2] times the host waited for a free plan slot (it was four searches ahead of the device), out[3] plans not launched because a
+ * launch that writes their inputs (candidate gather, scan upload) had not been seen to finish.  Results never depend on the path. */
+int32_t slamhip_cs_plan_stats(slamhip_cs *cs, uint64_t out[4]);
 
 /* Fused configuration C3 (device boundary at CoreSLAMProcessor.cs:732,:750,:751): search, NormalizeAngle
  * (:746) and both map updates in one call; the winning pose never leaves the device between them.

@@ -466,3 +466,66 @@ class NpGrid:
         dTr = tot[0:3]
         H = np.array([[tot[3], tot[6], tot[7]], [tot[6], tot[4], tot[8]], [tot[7], tot[8], tot[5]]], np.float32)
         return H, dTr
+
+
+# ---- the device candidate generator (what replaces FillRandomQueues, CoreSLAMProcessor.cs:599-612) -------------------------------
+# Philox4x32-10 as published (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 1.x
+# philox.h): multipliers 0xD2511F53 / 0xCD9E8D57, Weyl key increments 0x9E3779B9 / 0xBB67AE85, ten rounds.  The reference's
+# generator (Redzen's ziggurat, entropy-seeded) is not reproducible, so THIS is the specification of the library's own stream:
+# libslamhip's k_jitter (csrc/coreslam.hip) must produce the same integers, and -- through float logf / sqrtf / sincosf /
+# normcdfinvf, which are the device library's and a few ulp from exact -- floats within a few ulp of philox_jitters().
+PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+# known answers: Random123's kat_vectors for philox4x32, 10 rounds (counter[4], key[2] -> output[4])
+PHILOX4X32_10_KAT = (
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+)
+
+
+def philox4x32_10(ctr, key):
+    """ctr: (..., 4) uint32 counters, key: (k0, k1) -> (..., 4) uint32.  Vectorised over leading dimensions."""
+    c = np.asarray(ctr, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = c[..., 0], c[..., 1], c[..., 2], c[..., 3]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(PHILOX_M0) * c0
+        p1 = np.uint64(PHILOX_M1) * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
+        n1 = p1 & mask
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+        n3 = p0 & mask
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + PHILOX_W1) & 0xFFFFFFFF
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def philox_jitter_words(n, seed, stream):
+    """The three uniforms of jitter i = 0 .. n-1 as the kernel forms them: counter (i, 0, stream_lo, stream_hi), key (seed_lo, seed_hi);
+    u = ((float)(word >> 8) + 0.5f) * 2^-24 of words 0, 1, 2 IN BINARY32 -- from 2^23 on the sum is not representable and rounds to
+    even (so u can be exactly 1.0: its logarithm is 0, the jitter (0, 0)); the scaling is exact."""
+    i = np.arange(n, dtype=np.uint64)
+    ctr = np.stack([i, np.zeros(n, np.uint64), np.full(n, stream & 0xFFFFFFFF, np.uint64), np.full(n, (stream >> 32) & 0xFFFFFFFF, np.uint64)], axis=-1)
+    w = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    u = (((w[:, :3] >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)).astype(np.float64)
+    return w, u
+
+
+def philox_jitters(n, sigma_xy, sigma_theta, seed=0, stream=0):
+    """k_jitter restated in binary64 (csrc/coreslam.hip): dx, dy ~ N(0, sigma_xy) by Box-Muller from u1, u2; dtheta = the i-th of n
+    equal-probability strata of N(0, sigma_theta), at position u3 inside the stratum (quantile capped below 1).  Returns
+    float64 (n, 3): the exact values the device's float results are a few ulp from."""
+    from scipy.special import ndtri
+    _, u = philox_jitter_words(n, seed, stream)
+    u1, u2, u3 = u[:, 0], u[:, 1], u[:, 2]
+    with np.errstate(divide="ignore"):
+        rad = np.sqrt(np.float32(-2.0) * np.log(u1))
+    ang = (np.float32(6.28318530718) * u2.astype(np.float32)).astype(np.float64)      # (one binary32 rounding, as the kernel: sincosf's argument)
+    i = np.arange(n, dtype=np.float64)
+    qf = ((np.float32(1) * i.astype(np.float32) + u3.astype(np.float32)) / np.float32(n)).astype(np.float32)   # binary32, as the kernel
+    q = np.minimum(qf, np.float32(0.99999994)).astype(np.float64)
+    sxy, sth = np.float64(np.float32(sigma_xy)), np.float64(np.float32(sigma_theta))
+    return np.stack([sxy * rad * np.cos(ang), sxy * rad * np.sin(ang), sth * ndtri(q)], axis=-1)

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libslamhip.so")
 SOURCES = ["context.hip", "distance.hip", "holemap.hip", "obstacle.hip", "coreslam.hip", "processor.hip",
            "hector.hip", "group.hip"]
-HEADERS = ["common.h", "cs_internal.h", "det_trig.h", "m3x2.h", "raster.h", "obstacle_dev.h", os.path.join("..", "..", "include", "slamhip.h")]
+HEADERS = ["common.h", "cs_internal.h", "det_trig.h", "m3x2.h", "raster.h", "obstacle_dev.h", "k1_pieces.inc", os.path.join("..", "..", "include", "slamhip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fno-slp-vectorize",      # v_pk_*_f32 runs at half rate on CDNA4 and computed unused lanes in K1
 

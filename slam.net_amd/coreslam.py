@@ -40,6 +40,14 @@ class Context:
         capi.call("slamhip_ctx_poisoned", self._h, C.byref(v))
         return bool(v.value)
 
+    def philox4x32_10(self, counter, key):
+        """One Philox4x32-10 block on the device (slamhip_ctx_philox4x32_10): the candidate generator's integer stream, for known-answer tests."""
+        c = (C.c_uint32 * 4)(*[int(x) & 0xFFFFFFFF for x in counter])
+        k = (C.c_uint32 * 2)(*[int(x) & 0xFFFFFFFF for x in key])
+        o = (C.c_uint32 * 4)()
+        capi.call("slamhip_ctx_philox4x32_10", self._h, c, k, o)
+        return tuple(int(x) for x in o)
+
     def timing_enable(self, mask=-1):
         """mask: bit k enables kernel class k (capi.K_*); 0 = off; -1 = all."""
         capi.call("slamhip_ctx_timing_enable", self._h, int(mask))
@@ -265,6 +273,13 @@ class CoreSlamDevice:
         """(searched ahead of the scan's tables, abandoned, layout remade first, refused): slamhip_cs_prelaunch_stats"""
         v = (C.c_uint64 * 4)()
         capi.call("slamhip_cs_prelaunch_stats", self._h, v)
+        return tuple(int(x) for x in v)
+
+    @property
+    def plan_stats(self):
+        """(searches launched with a plan, without, host waits for a plan slot, plans skipped: inputs in flight): slamhip_cs_plan_stats"""
+        v = (C.c_uint64 * 4)()
+        capi.call("slamhip_cs_plan_stats", self._h, v)
         return tuple(int(x) for x in v)
 
     @property

@@ -166,6 +166,31 @@ k_gather_offsets(float *__restrict__ offs_flat, const int *__restrict__ ev_idx_i
     k_side_arrive(side_arrive, side_flag, side_seq);
 }
 
+// known-answer access to the generator's integer stream (slamhip_ctx_philox4x32_10): one Philox4x32-10 block on the device
+__global__ void k_philox_kat(uint32_t *io)
+{
+    uint32_t c[4] = { io[0], io[1], io[2], io[3] };
+    philox4x32_10(c, io[4], io[5]);
+    io[6] = c[0]; io[7] = c[1]; io[8] = c[2]; io[9] = c[3];
+}
+
+extern "C" int32_t slamhip_ctx_philox4x32_10(slamhip_ctx *ctx, const uint32_t counter[4], const uint32_t key[2], uint32_t out[4])
+{
+    SH_CHECK_ARG(ctx && counter && key && out);
+    SH_HIP(hipSetDevice(ctx->device));
+    uint32_t h[10] = { counter[0], counter[1], counter[2], counter[3], key[0], key[1], 0, 0, 0, 0 };
+    uint32_t *d = nullptr;
+    SH_HIP(hipMalloc(&d, sizeof(h)));
+    hipError_t e = hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_philox_kat, dim3(1), dim3(1), 0, ctx->stream, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    SH_HIP(e);
+    for (int k = 0; k < 4; k++) out[k] = h[6 + k];
+    return SLAMHIP_OK;
+}
+
 // winner pose from the packed key: search_pose + offs[index-1] (:635-637), theta normalised (:746)
 __global__ void k_best_pose(const unsigned long long *__restrict__ key, const float *__restrict__ offs_flat,
                             float bx, float by, float bth, float *__restrict__ out_pose)
@@ -183,6 +208,8 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     if (!cs) return SLAMHIP_OK;
     (void)hipSetDevice(cs->ctx->device);
     (void)hipStreamSynchronize(cs->ctx->stream);
+    cs_plan_free(cs);
+    if (cs->plan_stream) (void)hipStreamDestroy(cs->plan_stream);
     (void)hipFree(cs->d_hole); (void)hipFree(cs->d_obst);
     (void)hipFree(cs->d_scan_blob); if (cs->h_scan_blob) (void)hipHostFree(cs->h_scan_blob);
     (void)hipFree(cs->d_scan_flag);
@@ -639,6 +666,7 @@ static int32_t cs_set_scan_begin(slamhip_cs *cs, int32_t n)
         // one device block and one pinned staging block for everything a scan uploads: rays (original order: K2/K3 are
         // ray-order dependent), rays sorted for K1, K1's per-ray block table, the block starts -- one copy per scan
         SH_HIP(hipStreamSynchronize(cs->ctx->stream));
+        SH_TRY(cs_plan_drain(cs));
         (void)hipFree(cs->d_scan_blob); if (cs->h_scan_blob) (void)hipHostFree(cs->h_scan_blob);
         cs->d_scan_blob = nullptr; cs->h_scan_blob = nullptr; cs->cap_points = 0;
         const int cap = n + n / 4 + 64;
@@ -878,6 +906,7 @@ static int32_t cs_set_scan_finish(slamhip_cs *cs, const float *xy, int32_t n, bo
         cs->upload_bytes = (used + 15) & ~(size_t)15;
     } else {
         SH_HIP(hipMemcpyAsync(cs->d_scan_cur, cs->h_scan_blob, used, hipMemcpyHostToDevice, cs->ctx->stream));
+        cs_plan_inputs_pending(cs);
         SH_HIP(hipEventRecord(cs->ev_scan, cs->ctx->stream));
         cs->scan_in_flight = true;
     }
@@ -919,6 +948,7 @@ int32_t cs_flush_scan(slamhip_cs *cs)
     if (!cs->upload_pending) return SLAMHIP_OK;
     // (the upload state is committed once the launch that carries it is in the stream: on an error the scan stays pending)
     SH_TRY(sh_upload(cs->ctx, cs->h_scan_blob, cs->d_scan_cur, cs->upload_bytes, (uint32_t *)cs->h_key + 28, cs->upload_seq + 1));
+    cs_plan_inputs_pending(cs);
     cs->upload_pending = false;
     cs->upload_seq++;
     cs->scan_in_flight = true;
@@ -1109,6 +1139,7 @@ static int32_t cs_speculate_next(slamhip_cs *cs)
     }
     if (cs->spec_cap_offs != cs->cap_offs || cs->spec_cap_cand != cs->cap_cand || cs->spec_cap_grp != cs->cap_grp) {
         SH_HIP(hipStreamSynchronize(cs->side_stream));
+        SH_TRY(cs_plan_drain(cs));
         spec_free(cs);
         SH_HIP(hipMalloc(&cs->spec_offs_flat, sizeof(float) * 3 * (size_t)cs->cap_offs));
         SH_HIP(hipMalloc(&cs->spec_ev_off, sizeof(float) * 3 * (size_t)cs->cap_cand));
@@ -1236,6 +1267,7 @@ static int32_t ensure_shard(slamhip_cs *cs, int first, int count)
         return memcmp(p.data(), cs->h_grp_dth.data(), 4 * a) != 0 || memcmp(p.data() + a, cs->h_grp_dxy.data(), 4 * b) != 0 ||
                memcmp(p.data() + a + b, cs->h_grp_lohi.data(), 4 * c) != 0;
     };
+    cs_plan_inputs_pending(cs);                                    // (every branch below launches the gather in the operator's stream)
     // a pending scan upload rides on the gather launch as one more workgroup
     const int up_wg = cs->upload_pending ? SH_UPLOAD_PARTS : 0;
     const uint4 *up_src = nullptr; uint4 *up_dst = nullptr; int up_n16 = 0; uint32_t *up_flag = nullptr; uint32_t up_seq = 0;
@@ -1549,6 +1581,13 @@ extern "C" int32_t slamhip_cs_prelaunch_stats(slamhip_cs *cs, uint64_t out[4])
     return SLAMHIP_OK;
 }
 
+extern "C" int32_t slamhip_cs_plan_stats(slamhip_cs *cs, uint64_t out[4])
+{
+    SH_CHECK_ARG(cs && out);
+    for (int k = 0; k < 4; k++) out[k] = cs->plan_stats[k];
+    return SLAMHIP_OK;
+}
+
 extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
 {
     SH_CHECK_ARG(cs && out);
@@ -1558,8 +1597,8 @@ extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     *out = h[0];
     if (getenv("SLAMHIP_K1_STATS"))
-        fprintf(stderr, "[slamhip] K1 step kinds (ray x sub-batch units): group tile %u, sub-batch tiles %u, banded %u, global gathers %u\n",
-                h[1], h[2], h[4], h[3]);
+        fprintf(stderr, "[slamhip] K1 step kinds (ray x sub-batch units): group tile %u, sub-batch tiles %u, banded %u, global gathers %u; plan: workgroups with their record %u, without %u, wavefront slots with stamped candidates %u\n",
+                h[1], h[2], h[4], h[3], h[5], h[6], h[7]);
     return SLAMHIP_OK;
 }
 

@@ -16,6 +16,7 @@
 #define K1_GROUP_BIG 2048              // ... or 512 lanes x 4 for large searches,
 #define K1_RING_SLOTS 4                // result words of the enqueue-only search (valid until K1_RING_SLOTS - 1 further ring launches)
 #define K1_GROUP_SMALL 512             // 512 lanes x 1 for small ones (slamhip_cs::k1_group, ensure_shard)
+#define K1_PLAN_SLOTS 4                // plans of searches in flight (distance.hip: a slot is reused when the search that read it has finished)
 
 
 // k1_make_layout (distance.hip): a ray block's terms of the cost estimate that do not depend on the candidate group
@@ -117,6 +118,17 @@ struct slamhip_cs {
     uint64_t *d_k1_ring; unsigned k1_ring_pos;
     bool k1_ring_request;         // the next search launch is a ring launch ...
     uint64_t *k1_ring_last;       // ... and this is the slot it used
+    // the search's plan (distance.hip, k1_plan): K1_PLAN_SLOTS sets of buffers used in turn, filled on a stream of their own
+    hipStream_t plan_stream;
+    float4 *d_plan_px[K1_PLAN_SLOTS]; uint32_t *d_plan_pst[K1_PLAN_SLOTS]; uint2 *d_plan_rec[K1_PLAN_SLOTS];
+    int plan_cap_cand, plan_cap_wgs;
+    uint32_t plan_seq;            // stamps handed out (a stamp is never 0 and never reused while its slot holds it)
+    uint32_t plan_count;          // plans launched (slot = plan_count % K1_PLAN_SLOTS)
+    uint32_t k1_launches;         // tiled search launches so far: each stores its number into word 25 of h_key when it STARTS (k1_args::started)
+    uint32_t plan_slot_user[K1_PLAN_SLOTS];   // the number of the search launch that read the slot last
+    uint32_t plan_inputs_after;   // the plan kernel reads what launches in the operator's stream wrote (candidate gather, scan upload): it may only be
+                                  // launched once the search launch of this number has started (0: nothing pending)
+    uint64_t plan_stats[4];       // searches launched with a plan | without | host waits for a free slot | plans skipped because their inputs were still in flight
     uint32_t upload_seq;          // set_scan uploads issued (the upload's workgroups store it into words 28 .. 31 of h_key when they have read the staging block)
 
     // ---- K2 HoleMap update -----------------------------------------------------------------------------
@@ -153,6 +165,11 @@ struct slamhip_cs {
 
 // distance.hip
 int32_t cs_alloc_candidates(slamhip_cs *cs, int count);
+// waits for the plan stream (before anything a plan launch may still read is freed or rewritten by the host) / releases the plan buffers
+int32_t cs_plan_drain(slamhip_cs *cs);
+void    cs_plan_free(slamhip_cs *cs);
+// a launch in the operator's stream writes what the next plan launches read (candidate gather, scan upload): see plan_inputs_after
+static inline void cs_plan_inputs_pending(slamhip_cs *cs) { cs->plan_inputs_after = cs->k1_launches + 1; }
 // launches the scan upload that slamhip_cs_set_scan left pending (every launch that reads the scan calls it first)
 int32_t cs_flush_scan(slamhip_cs *cs);
 int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int count, bool want_dist, bool cand_sane,

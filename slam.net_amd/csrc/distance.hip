@@ -196,7 +196,7 @@ k1_reduce(const uint2 *__restrict__ partial, int n_chunks, int count, int n_poin
 static_assert(K1_MAXBANDS == 4, "the step threads split t into (piece, band) with shifts");
 #define K1_TABLE_G 64                  // groups with their own chunk count (the rest: one uniform count)
 #define K1_TABLE_WGS 2048
-#define K1_MAXCUT 624                  // entries of the cut table in the kernel arguments (ray ranges cut by cost: k1_balanced_cuts)
+#define K1_MAXCUT 596                  // entries of the cut table in the kernel arguments (ray ranges cut by cost: k1_balanced_cuts)
 #define K1_ACC_INMAP 36                // accumulator fields: pixel sum below (R < 2^20 rays x 65535), workgroups with an in-map end point,
 #define K1_ACC_ARRIVED 50              // workgroups arrived (chunks per group < 2^14)
 #define K1_ZERO_OFS 0                  // dynamic LDS: a zero word (16 bytes), then the tile
@@ -235,6 +235,17 @@ struct k1_args {
     // starts -- the workgroups that finish candidates min their keys straight into it (no return, no count, no last finisher: the
     // END OF THE LAUNCH is the completion) -- and this launch leaves the NEXT slot all ones for the next one.  Null: key_out + the chain.
     unsigned long long *ring_slot, *ring_reset;
+    // The PLAN of a search (k1_plan, launched beside the search on a stream of its own, round 6): what a workgroup's prologue used to
+    // work out before its first tile -- every candidate's (px, py, c, s) (the deterministic trigonometry, once per candidate instead of
+    // once per candidate and ray range) and every workgroup's step records (bounds -> boxes -> tile steps) -- left in device memory and
+    // STAMPED with the plan's number: a workgroup that finds its record stamped plan_seq takes its steps from it, a wavefront that
+    // finds its 64 candidates' stamp takes their (px, py, c, s) from plan_px, anything else is worked out as before (a plan that is
+    // late, or was never made, costs time, never a result).  plan_px: (px, py, c, s) per candidate in evaluation order; plan_pst: one
+    // stamp per 64 candidates, stored after its candidates were written back -- and plan_px is only READ by a wavefront that has
+    // seen the stamp (no line of it can be in a cache from before); plan_rec: K1_PLAN_REC_WORDS words per workgroup, every 8-word
+    // unit carrying its own stamp (see k1_plan).  Null: no plan.
+    float4 *plan_px; uint32_t *plan_pst; uint2 *plan_rec; uint32_t plan_seq;
+    uint32_t *started; uint32_t launch_no;          // workgroup 0 stores launch_no here when the launch starts (pinned host word): everything before it in the stream has finished
     const uint32_t *scan_flag; uint32_t scan_seq;   // a launch that precedes its scan's tables (cs_search_and_update_prelaunched): wait here for scan_seq; bit 31 set: leave
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
     // groups [uni_g0, uni_g0 + uni_ng) with uni_nc chunks each, chunk-major (neighbouring groups work on the same
@@ -258,6 +269,8 @@ struct k1_args {
 };
 static_assert(sizeof(k1_args) <= 4096, "kernel arguments are limited to 4 KB");
 static_assert(sizeof(k1_args::tab_rec) == 8 && offsetof(k1_args, tab) % 8 == 0, "table records are 8-byte aligned");
+#define K1_PLAN_STEPS 15               // step records a workgroup's plan record holds (a workgroup with more plans for itself)
+#define K1_PLAN_REC_WORDS 128          // a plan record: 16 x 8 words -- [0] header {stamp, steps (-1: too many), -, -, -, -, -, stamp}, [1 + i] step i {the step record's words 0 .. 6, stamp}
 
 #ifdef K1_TIMES
 // developer instrumentation (build with SLAMHIP_K1_TIMES=1): 100 MHz wall-clock stamps per workgroup and phase
@@ -365,6 +378,87 @@ template <bool MAX> __device__ static inline float k1_wave_redf(float x)      //
     return x;
 }
 
+// Which (candidate group, ray range) a workgroup of the search launch works on: the launch layout of k1_args (shared by the search
+// kernel and the plan kernel, which must agree).
+struct k1_wg_t { int g, nc, nbp, bp, rlo, rhi; };
+__device__ __forceinline__ k1_wg_t k1_wg_decode(const k1_args &a, const int bid)
+{
+    int g, chunk, nc, nbp = 1;
+    if ((int)bid < a.n_tab_wgs) {
+        // (a byte load from the kernel arguments is a VECTOR load on this target -- a full memory round trip at the head of the
+        // workgroup; the containing word is a scalar load)
+        const unsigned pw = ((const unsigned *)a.wg_pos)[bid >> 2];
+        const int p = (int)((pw >> ((bid & 3u) * 8u)) & 0xffu);
+        const k1_args::tab_rec rec = a.tab[p];
+        nc = rec.nc;
+        chunk = bid - (int)rec.first;
+        g = rec.group;
+        nbp = rec.nbp;
+    } else {
+        // the uniform part runs chunk-major: the workgroups in flight work on the SAME rays for neighbouring theta groups,
+        // whose tiles overlap almost completely (L2 reuse).  (Sending ray chunk c of every group to XCD c % 8 -- one
+        // fabric fetch per tile instead of one per XCD -- was measured 1.2x to 2x SLOWER.)
+        const int b = bid - a.n_tab_wgs;
+        nc = a.uni_nc;
+        chunk = b / (unsigned)a.uni_ng;
+        g = a.uni_g0 + (b - chunk * a.uni_ng);
+    }
+    // the chunk = rays [rlo, rhi) of the sorted scan, cut into pieces at ray block boundaries (host: <= K1_MAXR
+    // rays, <= K1_MAXP pieces)
+    // (theta-tail groups: nbp workgroups share a ray range and take every nbp-th band of its banded tiles -- their
+    // run time is the number of tile steps, which more ray ranges would not reduce)
+    const int rc = chunk / nbp, bp = chunk - rc * nbp, nrc = nc / nbp;
+    int rlo, rhi;
+#define K1_CUT(i) ((int)((((const unsigned *)a.cut)[(i) >> 1] >> (((i) & 1) * 16)) & 0xffffu))
+    if (a.uni_cut && (int)bid >= a.n_tab_wgs) {             // (uniform part: nbp = 1, rc = chunk)
+        rlo = K1_CUT(chunk); rhi = K1_CUT(chunk + 1);
+    } else if (a.tab_cut && (int)bid < a.n_tab_wgs) {
+        const int i0 = a.tab_cut + (int)bid;
+        rlo = K1_CUT(i0);
+        rhi = rc + 1 < nrc ? K1_CUT(i0 + nbp) : a.n_rays;
+    } else
+#undef K1_CUT
+    if (a.n_rays <= 46340) {                                       // (rc < nrc <= n_rays: the products fit 32 bits; the 64-bit division is a hundred scalar instructions)
+        rlo = (int)(((unsigned)rc * (unsigned)a.n_rays) / (unsigned)nrc); rhi = (int)(((unsigned)(rc + 1) * (unsigned)a.n_rays) / (unsigned)nrc);
+    } else { rlo = (int)(((long long)rc * a.n_rays) / nrc); rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc); }
+    k1_wg_t W; W.g = g; W.nc = nc; W.nbp = nbp; W.bp = bp; W.rlo = rlo; W.rhi = rhi;
+    return W;
+}
+
+// The bounds {pxmin, pxmax, pymin, pymax, cmin, cmax, smin, smax} of a group's candidates from the group's jitter bounds gb
+// (k_gather_offsets) and the search pose of the launch; every lane computes them, lane 0 stores them.
+__device__ __forceinline__ void k1_bounds_from_jitter(const k1_args &a, const float gb[6], float *bnd, const int lane)
+{
+    // px = (bx + dx) * scale + 0.5 and theta = btheta + dtheta are monotone in the jitter (every float operation
+    // rounds monotonically), so the extreme jitters give the extreme px, py and theta of the group.  cos and sin
+    // over [theta_lo, theta_hi] only need to be bounded, not reproduced: one reduction by a multiple of 2 pi in
+    // double, the hardware sine / cosine at the end points, +-1 where the interval (with a margin) holds a
+    // multiple of pi/2, and a pad of 1e-4 (a fifth of a pixel at 40 m) that covers the approximation.
+    const float scale = a.scale;
+    const float pxl = (a.bx + gb[0]) * scale + 0.5f, pxh = (a.bx + gb[1]) * scale + 0.5f;
+    const float pyl = (a.by + gb[2]) * scale + 0.5f, pyh = (a.by + gb[3]) * scale + 0.5f;
+    const float tlf = a.bth + gb[4], thf = a.bth + gb[5];
+    const double n2 = rint((double)tlf * 0.15915494309189535) * 6.283185307179586;
+    const float rl = (float)((double)tlf - n2), rh = (float)((double)thf - n2);      // rl in [-pi, pi], rh >= rl
+    const float as = scale, pad = as * 1.0e-4f;                 // (scale = pixels per metre > 0)
+    const float cl = __cosf(rl) * as, ch = __cosf(rh) * as, sl = __sinf(rl) * as, sh = __sinf(rh) * as;
+    float clo = fminf(cl, ch) - pad, chi = fmaxf(cl, ch) + pad, slo = fminf(sl, sh) - pad, shi = fmaxf(sl, sh) + pad;
+    const bool all = !(rh - rl < 6.2f);
+    {   // multiples k of pi/2 in [rl - 1e-3, rh + 1e-3]: k_lo .. k_hi; residue m is among them iff (m - k_lo) mod 4 <= k_hi - k_lo
+        // (this wave's arithmetic is on the critical path of the workgroup: a loop over the eleven possible k was 0.3 us)
+        const int k_lo = (int)ceilf((rl - 1.0e-3f) * 0.636619772f), span = (int)floorf((rh + 1.0e-3f) * 0.636619772f) - k_lo;
+        if (all || ((0 - k_lo) & 3) <= span) chi = as + pad;
+        if (all || ((1 - k_lo) & 3) <= span) shi = as + pad;
+        if (all || ((2 - k_lo) & 3) <= span) clo = -as - pad;
+        if (all || ((3 - k_lo) & 3) <= span) slo = -as - pad;
+    }
+    const float4 qlo = make_float4(pxl, pyl, 0.f, 0.f), qhi = make_float4(pxh, pyh, 0.f, 0.f);
+    if (lane == 0) {
+        *(float4 *)&bnd[0] = make_float4(qlo.x, qhi.x, qlo.y, qhi.y);
+        *(float4 *)&bnd[4] = make_float4(clo, chi, slo, shi);
+    }
+}
+
 // developer experiments (SLAMHIP_K1_EXP=n at build time, WRONG RESULTS): parts of k1_search_tiled left out, so that the counters say
 // what each costs (tools/k1_budget.sh) -- 1: the candidates' trigonometry (the jitters stand in for px, py, c, s), 2: the gather loops,
 // 3: the tiles' staging (loads and LDS writes) as well, 4: the epilogue's accumulator adds and everything behind them
@@ -380,8 +474,11 @@ typedef unsigned int k1_u32x4 __attribute__((ext_vector_type(4)));   // a stagin
 // four products c*X, s*Y, s*X, c*Y of a ray point are formed once per lane, from the lane's first candidate, and every candidate
 // adds them to its own px, py in the reference's order (:240-241): the same floats as k1_coords, 2 (CPL = 2) or 3 (CPL = 4) of the
 // ~12.75 VALU operations per candidate and ray less.
+#ifndef K1_VGPR_CAP
+#define K1_VGPR_CAP __attribute__((amdgpu_num_vgpr(104)))
+#endif
 template <int MODE, bool VERIFY, int CPL, int GROUP, bool LAT = false>
-__global__ void __launch_bounds__(GROUP / CPL, GROUP / CPL / 64 / 2)          // two workgroups per CU
+__global__ void __launch_bounds__(GROUP / CPL, GROUP / CPL / 64 / 2) K1_VGPR_CAP         // two workgroups per CU
 k1_search_tiled(const k1_args a)
 {
     constexpr int LANES = GROUP / CPL, NW = LANES / 64, PF = 65536 / (LANES * 16);      // PF staging vectors per lane: 64 KB per pass
@@ -396,6 +493,7 @@ k1_search_tiled(const k1_args a)
     __shared__ unsigned long long wkey[NW];
     __shared__ unsigned wfin[NW];
     __shared__ int s_nsteps;
+    __shared__ int s_plan_ok;
     const unsigned cpts_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cpts;
 
     const uint16_t *__restrict__ map = a.map;
@@ -404,28 +502,12 @@ k1_search_tiled(const k1_args a)
     int zv;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));                   // opaque zero (see k1_point_lds)
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);         // wave index in the workgroup
-    int g, chunk, nc, nbp = 1;
-    if ((int)blockIdx.x < a.n_tab_wgs) {
-        // (a byte load from the kernel arguments is a VECTOR load on this target -- a full memory round trip at the head of the
-        // workgroup; the containing word is a scalar load)
-        const unsigned pw = ((const unsigned *)a.wg_pos)[blockIdx.x >> 2];
-        const int p = (int)((pw >> ((blockIdx.x & 3u) * 8u)) & 0xffu);
-        const k1_args::tab_rec rec = a.tab[p];
-        nc = rec.nc;
-        chunk = blockIdx.x - (int)rec.first;
-        g = rec.group;
-        nbp = rec.nbp;
-    } else {
-        // the uniform part runs chunk-major: the workgroups in flight work on the SAME rays for neighbouring theta groups,
-        // whose tiles overlap almost completely (L2 reuse).  (Sending ray chunk c of every group to XCD c % 8 -- one
-        // fabric fetch per tile instead of one per XCD -- was measured 1.2x to 2x SLOWER.)
-        const int b = blockIdx.x - a.n_tab_wgs;
-        nc = a.uni_nc;
-        chunk = b / (unsigned)a.uni_ng;
-        g = a.uni_g0 + (b - chunk * a.uni_ng);
-    }
+    const k1_wg_t W = k1_wg_decode(a, (int)blockIdx.x);
+    const int g = W.g, nc = W.nc, nbp = W.nbp;
     if (a.ring_reset && blockIdx.x == 0 && t == 0)                 // (the slot of the NEXT ring launch; launches are ordered by the stream)
         __hip_atomic_store(a.ring_reset, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.started && blockIdx.x == 0 && t == 0)                    // (the host learns that everything before this launch in the stream has finished)
+        __hip_atomic_store(a.started, a.launch_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     K1_STAMP(0)
 #ifdef K1_TIMES
     if (t == 0 && blockIdx.x < 4096) { for (int k = 0; k < 8; k++) g_k1_sub[blockIdx.x * 8 + k] = 0; }
@@ -439,23 +521,8 @@ k1_search_tiled(const k1_args a)
     }
 #endif
     // the chunk = rays [rlo, rhi) of the sorted scan, cut into pieces at ray block boundaries (host: <= K1_MAXR
-    // rays, <= K1_MAXP pieces)
-    // (theta-tail groups: nbp workgroups share a ray range and take every nbp-th band of its banded tiles -- their
-    // run time is the number of tile steps, which more ray ranges would not reduce)
-    const int rc = chunk / nbp, bp = chunk - rc * nbp, nrc = nc / nbp;
-    int rlo, rhi;
-#define K1_CUT(i) ((int)((((const unsigned *)a.cut)[(i) >> 1] >> (((i) & 1) * 16)) & 0xffffu))
-    if (a.uni_cut && (int)blockIdx.x >= a.n_tab_wgs) {             // (uniform part: nbp = 1, rc = chunk)
-        rlo = K1_CUT(chunk); rhi = K1_CUT(chunk + 1);
-    } else if (a.tab_cut && (int)blockIdx.x < a.n_tab_wgs) {
-        const int i0 = a.tab_cut + (int)blockIdx.x;
-        rlo = K1_CUT(i0);
-        rhi = rc + 1 < nrc ? K1_CUT(i0 + nbp) : a.n_rays;
-    } else
-#undef K1_CUT
-    if (a.n_rays <= 46340) {                                       // (rc < nrc <= n_rays: the products fit 32 bits; the 64-bit division is a hundred scalar instructions)
-        rlo = (int)(((unsigned)rc * (unsigned)a.n_rays) / (unsigned)nrc); rhi = (int)(((unsigned)(rc + 1) * (unsigned)a.n_rays) / (unsigned)nrc);
-    } else { rlo = (int)(((long long)rc * a.n_rays) / nrc); rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc); }
+    // rays, <= K1_MAXP pieces): k1_wg_decode
+    const int bp = W.bp, rlo = W.rlo, rhi = W.rhi;
     const int nrays = rhi - rlo;
     if (a.scan_flag) {
         // The launch was put into the stream before its scan's tables existed (coreslam.hip, cs_search_and_update_prelaunched): the
@@ -497,6 +564,22 @@ k1_search_tiled(const k1_args a)
 #pragma unroll
         for (int k = 0; k < 6; k++) gb[k] = a.grp_bounds[8 * (size_t)g + k];
     }
+    // The plan (k1_args): the workgroup's record -- wave 0, one 8-byte load per lane -- and the stamps of the lanes' candidates come
+    // with the first round trip; a wavefront whose stamp is the plan's reads (px, py, c, s) under the first tile's loads instead of
+    // making them, and needs no jitters.
+    const bool planned = MODE == 1 && !LAT && pre && a.plan_rec != nullptr;
+    uint2 prw = make_uint2(0u, 0u);
+    uint32_t pst[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) pst[k] = 0u;
+    if (planned) {
+        if (wv == 0) prw = a.plan_rec[(size_t)blockIdx.x * (K1_PLAN_REC_WORDS / 2) + lane];
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int j = g * GROUP + k * LANES + t;
+            pst[k] = a.plan_pst[(j < count ? j : count - 1) >> 6];
+        }
+    }
     float4 q[CPL];
     float c3[CPL][3];
 #pragma unroll
@@ -504,7 +587,7 @@ k1_search_tiled(const k1_args a)
         const int j = g * GROUP + k * LANES + t;
         const int jc = j < count ? j : count - 1;
         if (MODE == 0) q[k] = a.pxcs[jc];
-        else { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
+        else if (!planned) { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
     }
     int4 rinfo[RU];
     float2 rpt[RU];
@@ -515,7 +598,7 @@ k1_search_tiled(const k1_args a)
         rinfo[u] = make_int4(0, 0, 0, 0); rpt[u] = make_float2(0.f, 0.f);
         if (i < nrays) { rinfo[u] = a.ray_blk[r]; rpt[u] = a.pts[r]; }   // (lanes beyond the chunk issue nothing)
     }
-    if (t == 0) { s_nsteps = 0; *(unsigned *)(smem + K1_ZERO_OFS) = 0u; }
+    if (t == 0) { s_nsteps = 0; s_plan_ok = 0; *(unsigned *)(smem + K1_ZERO_OFS) = 0u; }
     if (MODE != 0 && !pre) {
 #pragma unroll
         for (int k = 0; k < CPL; k++) q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale);
@@ -529,37 +612,25 @@ k1_search_tiled(const k1_args a)
                 pieces[rinfo[u].z - blk_first] = make_int2(i, (rinfo[u].y < rhi ? rinfo[u].y : rhi) - (rlo + i));
         }
     }
+    bool have_plan = false;
+    if (planned) {
+        if (wv == 0) {
+            // the record is good when every one of its 8-word units carries the plan's stamp (and the header says the steps fit)
+            const bool okl = ((lane & 3) != 3 || prw.y == a.plan_seq) && (lane != 0 || prw.x == a.plan_seq);
+            const int ns = __builtin_amdgcn_readfirstlane((int)prw.y);             // (lane 0: the header's step count)
+            const bool ok = __builtin_amdgcn_ballot_w64(okl) == ~0ull && ns >= 0 && ns <= K1_PLAN_STEPS;
+            if (lane >= 4) *(int2 *)&stepbuf[2 * lane - 8] = make_int2((int)prw.x, (int)prw.y);
+            if (lane == 0 && ok) { s_plan_ok = 1; s_nsteps = ns; }
+        }
+        __syncthreads();
+        have_plan = __builtin_amdgcn_readfirstlane(s_plan_ok) != 0;
+        if (VERIFY && t == 0) atomicAdd(a.verify + (have_plan ? 5 : 6), 1u);     // (self-check builds count the workgroups that found their record / did not)
+    }
     K1_STAMP(1)
+    if (!have_plan) {
     if (pre) {
         if (wv == 0) {
-            // px = (bx + dx) * scale + 0.5 and theta = btheta + dtheta are monotone in the jitter (every float operation
-            // rounds monotonically), so the extreme jitters give the extreme px, py and theta of the group.  cos and sin
-            // over [theta_lo, theta_hi] only need to be bounded, not reproduced: one reduction by a multiple of 2 pi in
-            // double, the hardware sine / cosine at the end points, +-1 where the interval (with a margin) holds a
-            // multiple of pi/2, and a pad of 1e-4 (a fifth of a pixel at 40 m) that covers the approximation.
-            const float scale = a.scale;
-            const float pxl = (a.bx + gb[0]) * scale + 0.5f, pxh = (a.bx + gb[1]) * scale + 0.5f;
-            const float pyl = (a.by + gb[2]) * scale + 0.5f, pyh = (a.by + gb[3]) * scale + 0.5f;
-            const float tlf = a.bth + gb[4], thf = a.bth + gb[5];
-            const double n2 = rint((double)tlf * 0.15915494309189535) * 6.283185307179586;
-            const float rl = (float)((double)tlf - n2), rh = (float)((double)thf - n2);      // rl in [-pi, pi], rh >= rl
-            const float as = scale, pad = as * 1.0e-4f;                 // (scale = pixels per metre > 0)
-            const float cl = __cosf(rl) * as, ch = __cosf(rh) * as, sl = __sinf(rl) * as, sh = __sinf(rh) * as;
-            float clo = fminf(cl, ch) - pad, chi = fmaxf(cl, ch) + pad, slo = fminf(sl, sh) - pad, shi = fmaxf(sl, sh) + pad;
-            const bool all = !(rh - rl < 6.2f);
-            {   // multiples k of pi/2 in [rl - 1e-3, rh + 1e-3]: k_lo .. k_hi; residue m is among them iff (m - k_lo) mod 4 <= k_hi - k_lo
-                // (this wave's arithmetic is on the critical path of the workgroup: a loop over the eleven possible k was 0.3 us)
-                const int k_lo = (int)ceilf((rl - 1.0e-3f) * 0.636619772f), span = (int)floorf((rh + 1.0e-3f) * 0.636619772f) - k_lo;
-                if (all || ((0 - k_lo) & 3) <= span) chi = as + pad;
-                if (all || ((1 - k_lo) & 3) <= span) shi = as + pad;
-                if (all || ((2 - k_lo) & 3) <= span) clo = -as - pad;
-                if (all || ((3 - k_lo) & 3) <= span) slo = -as - pad;
-            }
-            const float4 qlo = make_float4(pxl, pyl, 0.f, 0.f), qhi = make_float4(pxh, pyh, 0.f, 0.f);
-            if (lane == 0) {
-                *(float4 *)&bnd[0] = make_float4(qlo.x, qhi.x, qlo.y, qhi.y);
-                *(float4 *)&bnd[4] = make_float4(clo, chi, slo, shi);
-            }
+            k1_bounds_from_jitter(a, gb, bnd, lane);
         }
         // (Round 5, measured and rejected: the OTHER wavefronts making their candidates here, where they wait for the bounds, instead of
         // under the first tile's loads -- the K1_EXP = 1 build says the trigonometry, 107 binary64-heavy instructions of a wavefront's
@@ -597,127 +668,18 @@ k1_search_tiled(const k1_args a)
     }
     K1_STAMP(3)
     const int npieces = __builtin_amdgcn_readfirstlane(blk_last_v - blk_first + 1);
-    for (int p = wv; p < npieces; p += NW) {                       // one wave per piece, one lane per ray
-        const int2 pi = pieces[p];
-        const float2 pt = cpts[pi.x + (lane < pi.y ? lane : pi.y - 1)];
-        const float4 b0 = *(const float4 *)&bnd[0], b1 = *(const float4 *)&bnd[4];
-        const float bb8[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
-        int bx0, by0, bx1, by1;
-        k1_ray_box(bb8, pt, bx0, by0, bx1, by1);
-        bx0 = k1_wave_red<false>(bx0); by0 = k1_wave_red<false>(by0);
-        bx1 = k1_wave_red<true>(bx1);  by1 = k1_wave_red<true>(by1);
-        K1_STAMP(4)
-        // The last lanes of the wave (row 3 holds the reduced boxes) make the piece's steps, one lane per band; the lanes of a piece
-        // take the same decision from the same box.  Steps are appended in arrival order: any order gives the same integer sums.
-        // (The boxes used to go through the LDS and a barrier to one thread per (piece, band).)
-        // k1_plan: the box clipped to the map, cut into row bands that fit the tile budget (one band, not clipped: SHARED).
-        struct k1_plan_t { int nsteps, kind, x0a, y0, w8, h, shift; float cost; };
-        auto k1_plan = [&](const int4 bx, const int nr_, const int band) -> k1_plan_t {
-            k1_plan_t P; P.nsteps = 1; P.kind = K1_KIND_GLOBAL; P.x0a = 0; P.y0 = 0; P.w8 = 8; P.h = 0; P.shift = 0; P.cost = 4.5f * (float)nr_;
-            const int cx0 = max(bx.x, 0), cy0 = max(bx.y, 0), cx1 = min(bx.z, S - 1), cy1 = min(bx.w, S - 1);
-            if (cx1 < cx0 || cy1 < cy0) { P.nsteps = 0; P.cost = 0.0f; return P; }   // no candidate has an end point of this piece in the map
-            // The tile's width is its pitch in the LDS, and the gathers of a wavefront -- one ray, 64 candidates: end points a few dozen
-            // pixels apart in BOTH directions -- meet the LDS banks by (row * pitch / 4 + x / 2) mod 32.  A pitch that is a multiple of 16
-            // pixels moves a row by a multiple of 8 banks: the rows fall on 4, 2 or 1 distinct bank offsets (192 pixels: every row
-            // on the same banks).  Eight more columns make the row step an odd multiple of 4 banks -- 8 distinct offsets -- at the
-            // price of one more 16-byte vector per row to stage.
-            // (Only where the wider tile needs no more bands than the plain one: at 262 144 candidates, whose tiles fill the budget,
-            // padding everywhere cost 4 % -- more tiles banded -- where it gains 8 % at 65 536.)
-            int xa = cx0 & ~7, ww = ((cx1 - xa + 1) + 7) & ~7;
-            const int H = cy1 - cy0 + 1;
-            // (And only for groups of 1024 candidates or more: a tile of the 512-candidate groups of small searches serves too few
-            // gathers to pay for the extra vector -- 4001 candidates: 14.1 -> 14.9 us with it.)
-            if (GROUP >= 1024 && !(ww & 8) && !a.nopad && ww < 512 && (xa + ww + 8 <= S || xa >= 8)) {
-                const int wp = ww + 8, vp = wp >> 3, vu = ww >> 3;
-                const int shp = 32 - __clz(vp - 1), shu = vu <= 1 ? 0 : 32 - __clz(vu - 1);
-                const int hp = min(k1_div(a.budget, wp * 2), PF * NW * (64 >> (shp & 31))), hu = min(k1_div(a.budget, ww * 2), PF * NW * (64 >> (shu & 31)));
-                if (hp >= 1 && hu >= 1 && k1_div(H + hp - 1, hp) == k1_div(H + hu - 1, hu)) { if (xa + ww + 8 <= S) ww += 8; else { xa -= 8; ww += 8; } }
-            }
-            const int vpr = ww >> 3;
-            const int sh = vpr <= 1 ? 0 : 32 - __clz(vpr - 1);
-            const int hmax = min(k1_div(a.budget, ww * 2), PF * NW * (64 >> (sh & 31)));
-            // bands pay for themselves only when the rays of the piece amortise the staging of every band: a band costs about
-            // as much as K1_BAND_STAGE rays of gathers to stage, a range-tested gather 1.9 and a global gather 4.5 ray units
-            const int nb_ = hmax >= 1 ? k1_div(H + hmax - 1, hmax) : K1_MAXBANDS + 1;
-            const bool bands_pay = nb_ == 1 || (float)nb_ * (a.band_stage + 1.9f * (float)nr_) < 4.5f * (float)nr_;      // (the host's cost estimate mirrors this: k1_group_cost)
-            if (vpr <= 64 && hmax >= 1 && nb_ <= K1_MAXBANDS && bands_pay) {
-                P.nsteps = nb_;
-                const int hb = k1_div(H + nb_ - 1, nb_);
-                const bool whole = nb_ == 1 && cx0 == bx.x && cy0 == bx.y && cx1 == bx.z && cy1 == bx.w;
-                P.kind = whole ? K1_KIND_SHARED : K1_KIND_BAND;
-                P.x0a = xa; P.w8 = ww; P.shift = sh;
-                P.y0 = cy0 + band * hb;
-                P.h = min(hb, cy1 + 1 - P.y0);
-                // (cost in ray units, for the choice between a piece and its halves: a tile step has a fixed part -- barriers, the
-                // step's set-up -- plus a part per full budget of bytes staged (a step of a full 60 KB tile weighs ~26 rays of
-                // gathers at two candidates per lane: the cuts' calibration), a plain gather 1, a range-tested one 1.9 and it is
-                // made in every band)
-                const float stage = (float)nb_ * 6.0f + 20.0f * (float)(ww * 2) * (float)H / (float)a.budget;
-                P.cost = stage * (2.0f / (float)CPL) + (whole ? (float)nr_ : 1.9f * (float)nb_ * (float)nr_);
-                if (P.h <= 0 && band < nb_) P.h = 0;               // (rounding can leave the last band empty: see the emit test)
-            }
-            return P;
-        };
-        const int pc = p;
-        const int nr_all = pieces[pc].y, r_first = pieces[pc].x;
-        const bool planner = lane >= 64 - K1_MAXBANDS;
-        const int4 bx = make_int4(bx0, by0, bx1, by1);
-        k1_plan_t full = k1_plan(bx, nr_all, planner ? lane - (64 - K1_MAXBANDS) : 0);
-        // A BANDED piece -- its box does not fit one tile: every band walks ALL its rays with range-tested gathers -- is tried as two:
-        // the rays of a block are in Z order, so each half of them spans about half the box, and two plain tiles cost 2 stagings
-        // + 1 x the gathers where four bands cost 4 + 4 x (the slowest workgroups of a launch at the headline size were the ones
-        // holding such a piece: 14 us of compute against a mean of 8).  The halves' boxes are two more rounds of wave reductions,
-        // made only when a piece needs them; the halves are taken when their estimated cost is lower (in practice always: the
-        // decision did not move with the weights).  Measured, sustained clocks: 16 384 candidates 17.97 -> 17.02 us, 65 536:
-        // 39.2 -> 37.6, 262 144 / 1024^2 / 4096^2: unchanged.  Pieces too wide for any tile (global gathers) are left alone:
-        // splitting those gained nothing at 2048^2 and cost 3 % at 4096^2, 32 768 candidates.  SLAMHIP_K1_NOSPLIT=1 for the A/B.
-        // (Groups of 1024 candidates or more: with 512-candidate groups -- small searches, whose launch is mostly prologue -- the extra
-        // planning and steps cost more than the gathers they save: 4001 candidates 14.4 -> 15.4 us.)
-        const bool want = GROUP >= 1024 && planner && lane == 63 && !a.nosplit && nr_all >= 8 && full.nsteps != 0 && full.nsteps > 1;
-        bool split = false;
-        k1_plan_t half;
-        half.nsteps = 0; half.kind = K1_KIND_GLOBAL; half.x0a = 0; half.y0 = 0; half.w8 = 8; half.h = 0; half.shift = 0; half.cost = 0.0f;
-        int h_first = r_first, h_nr = nr_all;
-        if (__builtin_amdgcn_ballot_w64(want) != 0) {             // (uniform)
-            const int h1 = (nr_all / 2 + 1) & ~1;                  // (even: the gather loops take ray pairs)
-            int ax0, ay0, ax1, ay1;
-            k1_ray_box(bb8, pt, ax0, ay0, ax1, ay1);
-            const bool inA = lane < h1;
-            const int A0 = k1_wave_red<false>(inA ? ax0 : 0x7fffffff), A1 = k1_wave_red<false>(inA ? ay0 : 0x7fffffff);
-            const int A2 = k1_wave_red<true>(inA ? ax1 : (int)0x80000000), A3 = k1_wave_red<true>(inA ? ay1 : (int)0x80000000);
-            const int B0 = k1_wave_red<false>(inA ? 0x7fffffff : ax0), B1 = k1_wave_red<false>(inA ? 0x7fffffff : ay0);
-            const int B2 = k1_wave_red<true>(inA ? (int)0x80000000 : ax1), B3 = k1_wave_red<true>(inA ? (int)0x80000000 : ay1);
-            const int idx = lane - (64 - 2 * K1_MAXBANDS);         // lanes 56 .. 63: half = idx / K1_MAXBANDS, band = idx % K1_MAXBANDS
-            const int hb_ = idx >= K1_MAXBANDS ? 1 : 0, band_ = idx >= 0 ? idx - hb_ * K1_MAXBANDS : 0;
-            const k1_plan_t pa = k1_plan(make_int4(A0, A1, A2, A3), h1, hb_ == 0 ? band_ : 0);
-            const k1_plan_t pb = k1_plan(make_int4(B0, B1, B2, B3), nr_all - h1, hb_ == 1 ? band_ : 0);
-            split = pa.cost + pb.cost < full.cost;                 // (the same in every lane of row 3: same boxes)
-            half = hb_ ? pb : pa;
-            h_first = hb_ ? r_first + h1 : r_first; h_nr = hb_ ? nr_all - h1 : h1;
-            if (split) {
-                if (idx < 0) continue;
-                const int band = band_;
-                if (band < half.nsteps && (half.kind == K1_KIND_GLOBAL || half.h > 0) && (half.kind == K1_KIND_BAND ? (nbp == 2 ? (band & 1) == bp : band % nbp == bp) : bp == 0)) {
-                    int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
-                    dst[0] = make_int4(half.x0a, half.y0, half.w8, half.h);
-                    dst[1] = make_int4(half.shift, half.kind, h_first | (h_nr << 16), 0);
-                }
-                continue;
-            }
-        }
-        if (!planner) continue;
-        {
-            const int band = lane - (64 - K1_MAXBANDS);
-            const int prec = r_first | (nr_all << 16);
-            const bool live = full.kind == K1_KIND_GLOBAL ? true : full.h > 0;
-            if (band < full.nsteps && live && (full.kind == K1_KIND_BAND ? (nbp == 2 ? (band & 1) == bp : band % nbp == bp) : bp == 0)) {
-                int4 *dst = (int4 *)&stepbuf[atomicAdd(&s_nsteps, 1) * 8];
-                dst[0] = make_int4(full.x0a, full.y0, full.w8, full.h);
-                dst[1] = make_int4(full.shift, full.kind, prec, 0);
-            }
-        }
-    }
+    // the pieces' boxes and tile steps (k1_pieces.inc: the text is shared with the plan kernel -- as a FUNCTION the same statements
+    // cost the search kernel 24 more vector registers and, at four candidates per lane, spills)
+#define K1_PIECE_STAMP K1_STAMP(4)
+#define K1_STEP_SLOT(i) (i)
+#include "k1_pieces.inc"
+#undef K1_STEP_SLOT
+#undef K1_PIECE_STAMP
     __syncthreads();
+    }
+#ifdef K1_TIMES
+    else if (t == 0 && blockIdx.x < 4096) { const unsigned long long now_ = wall_clock64(); for (int k = 2; k <= 4; k++) g_k1_times[blockIdx.x * 16 + k] = now_; }
+#endif
     const int nsteps = s_nsteps;
     K1_STAMP(5)
 
@@ -802,8 +764,36 @@ k1_search_tiled(const k1_args a)
         K1_PREFETCH(0, true)
 #endif
         if (MODE != 0 && pre) {                                    // (the first tile's loads are in flight)
+            // With a plan, a wavefront whose candidates carry the plan's stamp (64 candidates of a slot share one: the choice is per
+            // wavefront, a scalar branch) reads (px, py, c, s); any other makes them as ever -- from jitters it loads now, a second
+            // round trip behind the tile's.  (ONE site for the trigonometry: a second, conditional copy of it cost the kernel 23
+            // vector registers.)
+            bool make = true;
+            if (planned) {
+                bool all_ok = true;
+#pragma unroll
+                for (int k = 0; k < CPL; k++) all_ok = all_ok && pst[k] == a.plan_seq;
+                if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {
+                    make = false;
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) {
+                        const int j = g * GROUP + k * LANES + t;
+                        q[k] = a.plan_px[j < count ? j : count - 1];
+                    }
+                    if (VERIFY && lane == 0) atomicAdd(a.verify + 7, (unsigned)CPL);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) {
+                        const int j = g * GROUP + k * LANES + t;
+                        const int jc = j < count ? j : count - 1;
+                        c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2];
+                    }
+                }
+            }
+            if (make) {
 #pragma unroll
             for (int k = 0; k < CPL; k++) { if (K1_EXP == 1) q[k] = make_float4(a.bx * a.scale + c3[k][0], a.by * a.scale + c3[k][1], a.scale, c3[k][2]); else q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale); }
+            }
             if (LAT) {
 #pragma unroll
                 for (int k = 1; k < CPL; k++)
@@ -1148,10 +1138,108 @@ k1_search_tiled(const k1_args a)
     K1_STAMP(9)
 }
 
+
+// ---- the plan kernel --------------------------------------------------------------------------------------------
+// One launch per search, on a stream of its own beside the search launch (cs_launch_distance): what every workgroup of k1_search_tiled
+// would otherwise work out in front of its first tile, made ONCE and left in device memory (k1_args: plan_px, plan_pst, plan_rec).
+//   blocks [0, n_wgs)       one wavefront per workgroup of the search launch: its ray range (k1_wg_decode -- the same layout), the group's
+//                           bounds from the jitter bounds, the boxes and step records of its pieces (k1_pieces.inc -- the same text), and
+//                           the record: 16 units of 8 words, [0] = {stamp, steps or -1, ...}, [1 + i] = step i, word 7 of every unit =
+//                           stamp, all 512 bytes in ONE store instruction (a unit never exists without its stamp);
+//   blocks [n_wgs, ...)     256 candidates each: (px, py, c, s) = k1_candidate (the deterministic trigonometry, bit for bit what the search
+//                           kernel's lanes compute), stored THROUGH the L2 to memory (agent-scope stores: the L2 is per XCD) and
+//                           waited for, THEN the stamps of the four 64-candidate runs.
+// The search kernel trusts nothing without its stamp, so the launch may be late or missing; a stamp is the search's number, never reused.
+__device__ static inline int k1_plan_slot(const int i) { return i <= K1_PLAN_STEPS ? i : K1_PLAN_STEPS + 1; }
+template <int GROUP, int CPL>
+__global__ void __launch_bounds__(64)
+k1_plan(const k1_args a, const int n_wgs)
+{
+    constexpr int NW = 1, PF = 64;                                  // (k1_pieces.inc: PF * NW = the search workgroup's 64 staging vectors per lane and wave)
+    const int lane = threadIdx.x, wv = 0;
+    const uint32_t seq = a.plan_seq;
+    if ((int)blockIdx.x >= n_wgs) {
+        const int j0 = ((int)blockIdx.x - n_wgs) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = j0 + 64 * k;
+            if (j < a.count) {
+                const float c3[3] = { a.src3[3 * j], a.src3[3 * j + 1], a.src3[3 * j + 2] };
+                const float4 q = k1_candidate<1, true>(c3, a.bx, a.by, a.bth, a.scale);
+                // (agent-scope stores go THROUGH this XCD's L2 to memory; a release fence instead -- a write-back of the whole L2, once
+                // per block, under the running search whose accumulators live there -- cost the search launch beside it more than a microsecond)
+                unsigned long long *dst = (unsigned long long *)(a.plan_px + j);
+                __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(q.y) << 32) | __float_as_uint(q.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(q.w) << 32) | __float_as_uint(q.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every store above has been performed at the memory side
+        if (lane < 4 && j0 - lane + 64 * lane < a.count)
+            __hip_atomic_store(a.plan_pst + (((int)blockIdx.x - n_wgs) * 4 + lane), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // (little LDS and few registers: these wavefronts share the compute units with the search launch before this one, which leaves
+    // ~23 KB of LDS and 96 registers per lane free -- the rays are read from memory where the search kernel keeps a copy in LDS,
+    // and only the records that fit a plan record are kept)
+    __shared__ __attribute__((aligned(16))) int stepbuf[(K1_PLAN_STEPS + 2) * 8];
+    __shared__ int2 pieces[K1_MAXP];
+    __shared__ __attribute__((aligned(16))) float bnd[8];
+    __shared__ int s_nsteps;
+    const int S = a.S;
+    const k1_wg_t W = k1_wg_decode(a, (int)blockIdx.x);
+    const int g = W.g, nbp = W.nbp, bp = W.bp, rlo = W.rlo, rhi = W.rhi, nrays = rhi - rlo;
+    float gb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) gb[k] = a.grp_bounds[8 * (size_t)g + k];
+    const int blk_first = a.ray_blk[rlo].z, blk_last = a.ray_blk[rhi - 1].z;
+    if (lane == 0) s_nsteps = 0;
+    for (int i = lane; i < nrays; i += 64) {
+        const int4 ri = a.ray_blk[rlo + i];
+        if (i == 0 || ri.x == rlo + i) pieces[ri.z - blk_first] = make_int2(i, (ri.y < rhi ? ri.y : rhi) - (rlo + i));
+    }
+    const float2 *cpts = a.pts + rlo;
+    k1_bounds_from_jitter(a, gb, bnd, lane);
+    __syncthreads();
+    const int npieces = min(blk_last - blk_first + 1, K1_MAXP);   // (a plan that lags so far behind that its scan's block is being rewritten must still end)
+#define K1_PIECE_STAMP
+#define K1_STEP_SLOT(i) k1_plan_slot(i)                        /* (a function: the argument is an atomicAdd) */
+#include "k1_pieces.inc"
+#undef K1_STEP_SLOT
+#undef K1_PIECE_STAMP
+    __syncthreads();
+    const int nsteps = s_nsteps;
+    const bool fits = nsteps <= K1_PLAN_STEPS;
+    const int unit = lane >> 2, wp = lane & 3;                     // lane l holds words 2 l, 2 l + 1 of the record
+    uint2 w = make_uint2(0u, 0u);
+    if (unit > 0 && fits && unit - 1 < nsteps) { w.x = (uint32_t)stepbuf[(unit - 1) * 8 + 2 * wp]; w.y = (uint32_t)stepbuf[(unit - 1) * 8 + 2 * wp + 1]; }
+    if (lane == 0) { w.x = seq; w.y = (uint32_t)(fits ? nsteps : -1); }
+    if (wp == 3) w.y = seq;
+    // (through the L2 to memory as well: a search launch that is already running may read the record before this launch ends)
+    __hip_atomic_store((unsigned long long *)(a.plan_rec + (size_t)blockIdx.x * (K1_PLAN_REC_WORDS / 2) + lane), ((unsigned long long)w.y << 32) | w.x,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- host side --------------------------------------------------------------------------------------
+int32_t cs_plan_drain(slamhip_cs *cs)
+{
+    if (cs->plan_stream) SH_HIP(hipStreamSynchronize(cs->plan_stream));
+    return SLAMHIP_OK;
+}
+
+void cs_plan_free(slamhip_cs *cs)
+{
+    if (cs->plan_stream) (void)hipStreamSynchronize(cs->plan_stream);
+    for (int i = 0; i < K1_PLAN_SLOTS; i++) {
+        (void)hipFree(cs->d_plan_px[i]); (void)hipFree(cs->d_plan_pst[i]); (void)hipFree(cs->d_plan_rec[i]);
+        cs->d_plan_px[i] = nullptr; cs->d_plan_pst[i] = nullptr; cs->d_plan_rec[i] = nullptr; cs->plan_slot_user[i] = 0;
+    }
+    cs->plan_cap_cand = cs->plan_cap_wgs = 0;
+}
+
 int32_t cs_alloc_candidates(slamhip_cs *cs, int count)
 {
     if (count <= cs->cap_cand) return SLAMHIP_OK;
+    SH_TRY(cs_plan_drain(cs));                                    // (a plan launch may still read the lists freed below)
     int cap = count + (count >> 2) + 256;
     if (cs->d_ev_off) (void)hipFree(cs->d_ev_off);
     if (cs->d_ev_idx) (void)hipFree(cs->d_ev_idx);
@@ -1899,17 +1987,79 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             SH_HIP(hipMemsetAsync((char *)cs->d_k1_gmin + 8, 0, 8, ctx->stream));
         }
         a.gmin = cs->d_k1_gmin; a.done = (unsigned *)((char *)cs->d_k1_gmin + 8); a.acc = cs->d_k1_acc;
+        static const int no_lat = env_int("SLAMHIP_K1_NO_LATTICE", 0);       // (a lattice list through the ordinary kernel: same results, for comparison)
+        const bool lat2 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 2 && group == K1_GROUP && cpl == 2;
+        const bool lat4 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 4 && group == K1_GROUP_BIG;
         g_cst.lap(1);
         SH_TRY(cs_side_join(cs));
+        // ---- the plan (k1_plan): one launch per search on a stream of its own, beside the search ---------------------------------
+        // Made for every search with jitter bounds (mode 1) whose inputs are known to be in memory: the plan launch is not ordered
+        // behind the operator's stream, so after a candidate gather or a scan upload in that stream (plan_inputs_after) it waits
+        // until a search launch behind them has STARTED (the started word).  A slot of the plan buffers is reused K1_PLAN_SLOTS
+        // plans later, when the search that read it has finished -- i.e. a later search launch has started; the host waits for
+        // that if it is that far ahead of the device (it then is in nobody's way).  SLAMHIP_K1_PLAN=0: never.
+        static const int plan_env = env_int("SLAMHIP_K1_PLAN", 1);
+        volatile uint32_t *h_started = (volatile uint32_t *)cs->h_key + 25;
+        a.started = (uint32_t *)cs->h_key + 25; a.launch_no = ++cs->k1_launches;
+        a.plan_px = nullptr; a.plan_pst = nullptr; a.plan_rec = nullptr; a.plan_seq = 0;
+        bool plan_on = plan_env && mode == 1 && a.grp_bounds != nullptr && !cs->k1_prelaunch && !lat2 && !lat4 && !ctx->mail_off;
+        if (plan_on && cs->plan_inputs_after != 0) {
+            if ((int32_t)(*h_started - cs->plan_inputs_after) >= 0) cs->plan_inputs_after = 0;
+            else { plan_on = false; cs->plan_stats[3]++; }
+        }
+        if (plan_on) {
+            if (!cs->plan_stream) SH_HIP(hipStreamCreateWithFlags(&cs->plan_stream, hipStreamNonBlocking));
+            if (count > cs->plan_cap_cand || n_wgs > cs->plan_cap_wgs) {
+                SH_HIP(hipStreamSynchronize(ctx->stream));          // (searches in flight read the buffers)
+                const int cc = std::max(cs->plan_cap_cand, count + count / 4 + 256), cw = std::max(cs->plan_cap_wgs, n_wgs + n_wgs / 4 + 64);
+                cs_plan_free(cs);
+                for (int i = 0; i < K1_PLAN_SLOTS; i++) {
+                    SH_HIP(hipMalloc(&cs->d_plan_px[i], sizeof(float4) * (size_t)cc));
+                    SH_HIP(hipMalloc(&cs->d_plan_pst[i], sizeof(uint32_t) * (size_t)(cc / 64 + 8)));
+                    SH_HIP(hipMalloc(&cs->d_plan_rec[i], sizeof(uint32_t) * K1_PLAN_REC_WORDS * (size_t)cw));
+                    SH_HIP(hipMemsetAsync(cs->d_plan_pst[i], 0, sizeof(uint32_t) * (size_t)(cc / 64 + 8), cs->plan_stream));
+                    SH_HIP(hipMemsetAsync(cs->d_plan_rec[i], 0, sizeof(uint32_t) * K1_PLAN_REC_WORDS * (size_t)cw, cs->plan_stream));
+                }
+                SH_HIP(hipStreamSynchronize(cs->plan_stream));
+                cs->plan_cap_cand = cc; cs->plan_cap_wgs = cw;
+            }
+            const unsigned slot = cs->plan_count % K1_PLAN_SLOTS;
+            const uint32_t user = cs->plan_slot_user[slot];
+            if (user != 0 && (int32_t)(*h_started - (user + 1)) < 0) {
+                // The host is K1_PLAN_SLOTS - 1 searches ahead of the device: it waits for the slot -- backpressure, the device has
+                // work queued -- but never longer than 20 ms or the context's wait bound; past that the search goes without a plan
+                // (nothing fails because of a plan).
+                cs->plan_stats[2]++;
+                const int64_t bound_us = 1000 * (ctx->wait_timeout_ms > 0 && ctx->wait_timeout_ms < 20 ? ctx->wait_timeout_ms : 20);
+                const double t0w = k1_now_us();
+                for (int spins = 0; (int32_t)(*h_started - (user + 1)) < 0; spins++) {
+                    __builtin_ia32_pause();
+                    if ((spins & 1023) == 1023 && k1_now_us() - t0w > (double)bound_us) break;
+                }
+                if ((int32_t)(*h_started - (user + 1)) < 0) { plan_on = false; cs->plan_stats[3]++; }
+            }
+        }
+        if (plan_on) {
+            const unsigned slot = cs->plan_count % K1_PLAN_SLOTS;
+            if (++cs->plan_seq == 0) cs->plan_seq = 1;
+            a.plan_px = cs->d_plan_px[slot]; a.plan_pst = cs->d_plan_pst[slot]; a.plan_rec = cs->d_plan_rec[slot]; a.plan_seq = cs->plan_seq;
+            const dim3 pgrid((unsigned)(n_wgs + sh_div_up(count, 256)));
+            if (group == K1_GROUP_BIG) hipLaunchKernelGGL((k1_plan<K1_GROUP_BIG, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
+            else if (group == K1_GROUP_SMALL) hipLaunchKernelGGL((k1_plan<K1_GROUP_SMALL, 1>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
+            else if (cpl == 4) hipLaunchKernelGGL((k1_plan<K1_GROUP, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
+            else if (cpl == 2) hipLaunchKernelGGL((k1_plan<K1_GROUP, 2>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
+            else hipLaunchKernelGGL((k1_plan<K1_GROUP, 1>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
+            SH_HIP(hipGetLastError());
+            cs->plan_slot_user[slot] = a.launch_no;
+            cs->plan_count++; cs->plan_stats[0]++;
+        }
+        if (!plan_on) cs->plan_stats[1]++;
         g_cst.lap(2);
         {
             sh_timer t(ctx, SLAMHIP_K_CS_DISTANCE);
 #define K1_LAUNCH(M, V, C, G) hipLaunchKernelGGL((k1_search_tiled<M, V, C, G>), dim3(n_wgs), dim3(G / C), lds, ctx->stream, a)
 #define K1_LAUNCH_LAT(C, G) hipLaunchKernelGGL((k1_search_tiled<1, false, C, G, true>), dim3(n_wgs), dim3(G / C), lds, ctx->stream, a)
 #define K1_LAUNCH_C(M, V) { if (group == K1_GROUP_BIG) K1_LAUNCH(M, V, 4, K1_GROUP_BIG); else if (group == K1_GROUP_SMALL) K1_LAUNCH(M, V, 1, K1_GROUP_SMALL); else if (cpl == 4) K1_LAUNCH(M, V, 4, K1_GROUP); else if (cpl == 2) K1_LAUNCH(M, V, 2, K1_GROUP); else K1_LAUNCH(M, V, 1, K1_GROUP); }
-            static const int no_lat = env_int("SLAMHIP_K1_NO_LATTICE", 0);       // (a lattice list through the ordinary kernel: same results, for comparison)
-            const bool lat2 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 2 && group == K1_GROUP && cpl == 2;
-            const bool lat4 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 4 && group == K1_GROUP_BIG;
             if (lat2) K1_LAUNCH_LAT(2, K1_GROUP);
             else if (lat4) K1_LAUNCH_LAT(4, K1_GROUP_BIG);
             else if (verify) { if (mode == 0) K1_LAUNCH_C(0, true) else if (mode == 1) K1_LAUNCH_C(1, true) else K1_LAUNCH_C(2, true) }

@@ -187,6 +187,50 @@ def test_search_full_size_vs_oracle(cs_mod, ctx, det, sim, size, R, K):
     dev.close()
 
 
+def ulp_diff32(a, b):
+    """distance in units in the last place between binary32 arrays (finite values of one sign or around zero)"""
+    ia = np.asarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.asarray(b, np.float32).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def test_generated_offsets_match_the_philox_specification(cs_mod, ctx, npo):
+    """The device generator that stands where FillRandomQueues stood (CoreSLAMProcessor.cs:599-612) against its specification:
+    (a) one Philox4x32-10 block computed ON THE DEVICE equals Random123's published known answers (the integer stream, bit for bit);
+    (b) a downloaded list equals the NumPy restatement of k_jitter (oracle/np_oracle.py: philox_jitters, binary64) to within the
+    accuracy of the device's logf / sincosf / normcdfinvf -- dtheta to a few units in the last place, dx and dy to ~1e-6 sigma (the
+    device's sincosf carries an absolute error of a few 1e-7) -- while a wrong word of the integer stream anywhere would move a
+    value by about one sigma; three (n, sigmas, seed, stream) with 64-bit seeds and streams."""
+    for ctr, key, want in npo.PHILOX4X32_10_KAT:
+        assert ctx.philox4x32_10(ctr, key) == want
+    assert ctx.philox4x32_10((5, 0, 3, 0), (42, 0)) == tuple(int(x) for x in npo.philox4x32_10(np.array([5, 0, 3, 0], np.uint64), (42, 0)))
+    dev = make_dev(cs_mod, ctx, 256)
+    worst_xy, worst_th = 0.0, 0
+    for n, sxy, sth, seed, stream in ((4000, 0.1, math.radians(10.0), 42, 1), (16383, 0.05, math.radians(3.0), 7, 3),
+                                      (70001, 0.2, math.radians(20.0), (1 << 40) + 5, (1 << 33) + 2)):
+        dev.generate_offsets(n, sxy, sth, seed=seed, stream=stream)
+        got = dev.offsets_download()
+        want = npo.philox_jitters(n, sxy, sth, seed=seed, stream=stream)
+        assert got.shape == want.shape
+        # dx, dy = sigma * rad * cos / sin(angle): the device's sincosf reduces its argument in binary32 -- an ABSOLUTE error of a few
+        # 1e-7 in cos / sin (measured on MI355X: 7e-7 at worst), so the bound is absolute, in units of sigma * rad (rad <= 5.8)
+        _, u = npo.philox_jitter_words(n, seed, stream)
+        rad = np.sqrt(-2.0 * np.log(u[:, 0]))                  # (0 where u is exactly 1.0)
+        for k in (0, 1):
+            e = np.abs(got[:, k].astype(np.float64) - want[:, k]) / (sxy * np.maximum(rad, 0.05))
+            worst_xy = max(worst_xy, float(e.max()))
+        # dtheta = sigma_theta * normcdfinvf(quantile): a few units in the last place (relative), 1e-9 sigma around zero
+        d = ulp_diff32(got[:, 2], want[:, 2].astype(np.float32))
+        near0 = np.abs(want[:, 2]) < 1e-3 * sth
+        assert (np.abs(got[near0, 2].astype(np.float64) - want[near0, 2]) < 1e-8 * sth).all()
+        worst_th = max(worst_th, int(d[~near0].max()))
+    print("generated list vs the binary64 restatement: worst |error| of dx, dy in units of sigma_xy * rad: %.2e; worst ulp distance of dtheta: %d" % (worst_xy, worst_th))
+    assert worst_xy < 2.5e-6 and worst_th <= 32, (worst_xy, worst_th)      # (a wrong Philox word anywhere moves a value by ~1 sigma)
+    dev.close()
+
+
 def test_search_changing_scans_one_candidate_list(cs_mod, ctx, det, sim):
     """The per-scan flow: one candidate list, a new scan before every search.  The search launch keeps the layout made for the
     previous scan while its counts of ray ranges are legal for the new scan's ray blocks, and makes the new one while the host
@@ -1176,8 +1220,10 @@ def test_search_and_update_host_trig(cs_mod, ctx, oc, sim, size, K):
 def test_blocking_wait_times_out_and_poisons_the_context(cs_mod, sim):
     """A blocking call whose completion word does not arrive within the context's bound (slamhip_ctx_set_wait_timeout) returns
     SLAMHIP_ERR_TIMEOUT and poisons the context: every later blocking call on it fails with the same code at once, nothing is
-    re-executed, and the handles are still destroyed cleanly.  (The 'kernel that never ends' is a queue of eighty one-million-
-    candidate searches in front of a blocking one, against a bound of 2 ms.)"""
+    re-executed, and the handles are still destroyed cleanly.  (The 'kernel that never ends' is a queue of one-million-candidate
+    searches in front of a blocking one, against a bound of 1 ms: the enqueue-only searches hold the host back to three launches
+    ahead of the device -- the plan slots' backpressure, slamhip_cs_plan_stats -- so the blocking call finds two or three searches
+    of ~0.4 ms each in front of its own.)"""
     import slam.net_amd.capi as capi
     ctx2 = cs_mod.Context(0)
     dev = cs_mod.CoreSlamDevice(ctx2, 40.0, 1024, 256)
@@ -1190,8 +1236,8 @@ def test_blocking_wait_times_out_and_poisons_the_context(cs_mod, sim):
         dev.generate_offsets((1 << 20) - 1, 0.1, 0.17, seed=3, stream=1)
         pose, dist, idx = dev.search(p)                              # (a sound call first: the bound is generous by default)
         assert not ctx2.poisoned
-        ctx2.set_wait_timeout(2)
-        for _ in range(80):
+        ctx2.set_wait_timeout(1)
+        for _ in range(40):
             dev.search_shard_enqueue(p, 0, 1 << 20)
         t0 = time.perf_counter()
         with pytest.raises(capi.SlamhipError) as e:

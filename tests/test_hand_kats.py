@@ -72,6 +72,25 @@ RAY_B = dict(args=(8, 8, 15, 18, 14, 16, 0, 128),
 RAY_C = dict(args=(9, 5, -2, 2, 1, 3, 0, 64),
              want={89: 40937, 88: 40937, 71: 40937, 70: 40937, 69: 40937, 52: 40937, 51: 35479, 50: 30021, 33: 24562, 32: 30021})
 
+# Ray D -- clipped by BOTH ClipRay calls (:365 on x with the quotient of y, then :366 with the axes swapped on the already clipped
+# end point), both quotients negative and truncated toward zero (floor would give one less each time); y-major, alpha = 128.
+#   Draw(x1=8, y1=8, x2=20, y2=22, xp=17, yp=18, value=0, alpha=128)
+#   :365 ClipRay(16, ref x2c=20, ref y2c=22, 8, 8): 20 >= 16, 20 != 8 ->
+#        y2c += (22-8)*(16-1-20)/(20-8) = 14*(-5)/12 = -70/12 = -5 (floor: -6) -> y2c=17, x2c=15
+#   :366 ClipRay(16, ref y2c=17, ref x2c=15, 8, 8): 17 >= 16, 17 != 8 ->
+#        x2c += (15-8)*(16-1-17)/(17-8) = 7*(-2)/9 = -14/9 = -1 (floor: -2) -> x2c=14, y2c=15:  the drawn ray ends at (14, 15)
+#   :368-374 dx=12 dy=14 dxc=|14-8|=6 dyc=|15-8|=7 incptrx=+1 incptry=+16 sincv=-1
+#   :377 dx>dy false -> dx=14, (dxc,dyc)=(7,6), (incptrx,incptry)=(16,1), derrorv=|yp-y2|=|18-22|=4
+#   :394-399 error=2*6-7=5 horiz=12 diago=2*(6-7)=-2 errorv=4/2=2 incv=-65500/4=-16375 incerrorv=-65500-4*(-16375)=0;  ptr=136
+#   hole: x > dx-2*derrorv = 6 and x <= dx-derrorv = 10: only x=7 is drawn of it -> pixval 65500-16375 = 49125; x=0..6 -> 65500
+#   walk (blend at ptr, then error>0 ? ptr+=1, error-=2 : error+=12; then ptr+=16):
+#     x=0 ptr=136 e=5 -> 137,e=3 -> 153 | x=1 ptr=153 e=3 -> 154,e=1 -> 170 | x=2 ptr=170 e=1 -> 171,e=-1 -> 187
+#     x=3 ptr=187 e=-1 -> e=11 -> 203   | x=4 ptr=203 e=11 -> 204,e=9 -> 220 | x=5 ptr=220 e=9 -> 221,e=7 -> 237
+#     x=6 ptr=237 e=7 -> 238,e=5 -> 254 | x=7 ptr=254 = 15*16+14: the twice-clipped end point (14,15)
+#   blend alpha 128 on 32750: 65500 -> 49125;  49125 -> (128*32750 + 128*49125) >> 8 = 10 480 000 >> 8 = 40937 (.5 dropped)
+RAY_D = dict(args=(8, 8, 20, 22, 17, 18, 0, 128),
+             want={136: 49125, 153: 49125, 170: 49125, 187: 49125, 203: 49125, 220: 49125, 237: 49125, 254: 40937})
+
 # Rays A then B on ONE map: pixel 136 (the robot's) is drawn twice, in ray order (:431 does not commute):
 #   after A: 49125; B blends 65500 onto it: (128*49125 + 128*65500) >> 8 = 14 672 000 >> 8 = 57312 (.5 dropped)
 A_THEN_B_136 = 57312
@@ -84,14 +103,14 @@ def _expect(want):
     return m
 
 
-@pytest.mark.parametrize("ray", [RAY_A, RAY_B, RAY_C], ids=["A", "B", "C"])
+@pytest.mark.parametrize("ray", [RAY_A, RAY_B, RAY_C, RAY_D], ids=["A", "B", "C", "D"])
 def test_hand_rays_c_oracle(oc, ray):
     pix = np.full(SIZE * SIZE, FRESH, np.uint16)
     oc.draw_ray_holemap(pix, SIZE, *ray["args"])
     assert (pix == _expect(ray["want"])).all(), np.flatnonzero(pix != _expect(ray["want"]))
 
 
-@pytest.mark.parametrize("ray", [RAY_A, RAY_B, RAY_C], ids=["A", "B", "C"])
+@pytest.mark.parametrize("ray", [RAY_A, RAY_B, RAY_C, RAY_D], ids=["A", "B", "C", "D"])
 def test_hand_rays_numpy_oracle(npo, ray):
     x1, y1, x2, y2, xp, yp, value, alpha = ray["args"]
     frags = npo.ray_fragments(SIZE, x1, y1, x2, y2, xp, yp, value)
@@ -105,6 +124,8 @@ def test_hand_clip_quotients(oc):
     # the two truncating divisions worked out above
     assert oc.clip_ray(16, 18, 15, 8, 8) == (True, 15, 13)            # ray B, second ClipRay: x2c 15 -> 13, y2c 18 -> 15
     assert oc.clip_ray(16, -2, 2, 9, 5) == (True, 0, 2)               # ray C, first ClipRay: (-6)/(-11) = 0
+    assert oc.clip_ray(16, 20, 22, 8, 8) == (True, 15, 17)            # ray D, first ClipRay: -70/12 = -5 (not -6)
+    assert oc.clip_ray(16, 17, 15, 8, 8) == (True, 15, 14)            # ray D, second ClipRay on the clipped point, axes swapped: -14/9 = -1 (not -2)
 
 
 def test_hand_ray_order_c_oracle(oc):
@@ -140,6 +161,39 @@ def test_hand_update_c_oracle(oc):
     n = oc.update_holemap(pix, SIZE, 2.0, UPDATE_XY, UPDATE_POSE, 2.0, 128)
     assert (pix == _update_want()).all()
     assert n == 7 + 8                                                  # steps 0..dxc of each ray blend one pixel each (:404)
+
+
+# Ray D through UpdateHoleMap (:496-534): same map and pose (Scale 2, px = py = 8.5, c = 2, s = 0), HoleWidth 5.0 m, Quality 128
+#   point (4.5, 5): x2p = 9, y2p = 10; xp = (int)17.5 = 17, yp = (int)18.5 = 18; dist = sqrt(81 + 100) = 13.4536;
+#                   add = 5.0*2/2/13.4536 = 0.37165 -> x2p = 12.3448, y2p = 13.7165 -> x2 = (int)20.84 = 20, y2 = (int)22.22 = 22   == ray D
+#   (every truncation is at least 0.16 away from an integer: no rounding detail of the float arithmetic can move it)
+UPDATE_XY_D = np.array([[4.5, 5.0]], np.float32)
+
+
+def test_hand_update_ray_d_c_oracle(oc):
+    pix = np.full(SIZE * SIZE, FRESH, np.uint16)
+    n = oc.update_holemap(pix, SIZE, 2.0, UPDATE_XY_D, UPDATE_POSE, 5.0, 128)
+    assert (pix == _expect(RAY_D["want"])).all() and n == 8
+
+
+def test_hand_update_ray_d_numpy_oracle(npo):
+    pix = np.full(SIZE * SIZE, FRESH, np.uint16)
+    pxcs = npo.poses_to_pxcs(UPDATE_POSE[None], 2.0)[0]
+    npo.update_holemap_pxcs(pix, SIZE, 2.0, UPDATE_XY_D, pxcs, 5.0, 128)
+    assert (pix == _expect(RAY_D["want"])).all()
+
+
+@pytest.mark.gpu
+def test_hand_update_ray_d_hip():
+    import slam.net_amd.coreslam as cs
+    ctx = cs.Context(0)
+    dev = cs.CoreSlamDevice(ctx, 8.0, SIZE, 16)
+    dev.set_scan(UPDATE_XY_D)
+    dev.update_holemap(UPDATE_POSE, 5.0, 128)
+    assert dev.last_holemap_pixels == 8
+    assert (dev.holemap_download() == _expect(RAY_D["want"])).all()
+    dev.close()
+    ctx.close()
 
 
 @pytest.mark.gpu

@@ -464,3 +464,38 @@ def test_hector_grid_hostile_points_c_vs_numpy(oc, npo, sim):
     finally:
         oc.set_trig_mode(oc.TRIG_LIBM)
 
+
+
+# ---- the device candidate generator's specification (what stands where FillRandomQueues stood, CoreSLAMProcessor.cs:599-612) -------
+def test_philox4x32_10_known_answers(npo):
+    """The NumPy restatement of the generator's integer stream against Random123's published kat_vectors (philox4x32, 10 rounds):
+    all-zero, all-ones and the digits-of-pi counter / key."""
+    for ctr, key, want in npo.PHILOX4X32_10_KAT:
+        got = npo.philox4x32_10(np.array(ctr, np.uint64), key)
+        assert tuple(int(x) for x in got) == want
+    # vectorised over counters == one at a time
+    ctrs = np.array([[i, 0, 5, 0] for i in range(7)], np.uint64)
+    many = npo.philox4x32_10(ctrs, (42, 0))
+    for i in range(7):
+        assert (many[i] == npo.philox4x32_10(ctrs[i], (42, 0))).all()
+
+
+def test_philox_jitters_structure(npo):
+    """philox_jitters (the binary64 restatement of k_jitter): jitter i depends on (seed, stream, i) only; dtheta is the i-th of n strata of
+    N(0, sigma_theta) -- ascending, each inside its stratum's quantile range; dx, dy are Box-Muller pairs of the block's first two words."""
+    from scipy.special import ndtr
+    n, sxy, sth = 4001, 0.1, math.radians(10.0)
+    j = npo.philox_jitters(n, sxy, sth, seed=42, stream=3)
+    assert j.shape == (n, 3) and np.isfinite(j).all()
+    assert (np.diff(j[:, 2]) > 0).all()
+    q = ndtr(j[:, 2] / np.float64(np.float32(sth)))
+    i = np.arange(n)
+    assert (q >= i / n - 1e-6).all() and (q <= (i + 1) / n + 1e-6).all()
+    w, u = npo.philox_jitter_words(n, 42, 3)
+    assert (w[5] == npo.philox4x32_10(np.array([5, 0, 3, 0], np.uint64), (42, 0))).all()
+    r2 = (j[:, 0] ** 2 + j[:, 1] ** 2) / np.float64(np.float32(sxy)) ** 2
+    assert np.allclose(r2, -2.0 * np.log(u[:, 0]), rtol=1e-6)
+    assert abs(j[:, 0].std() - sxy) < 0.005 and abs(j[:, 1].std() - sxy) < 0.005
+    # another stream / seed: another list
+    assert not np.allclose(j, npo.philox_jitters(n, sxy, sth, seed=42, stream=4))
+    assert not np.allclose(j, npo.philox_jitters(n, sxy, sth, seed=43, stream=3))
