@@ -3,21 +3,21 @@
 
 Workload (BASELINE.json `metric` / north_star): CoreSLAM Monte-Carlo search on a 2048^2 HoleMap with a
 1080-ray scan, --cands candidate poses per GPU per step (default 16384 = BASELINE.json configs[1]/[2]).
-One "step" = one full search over this rank's shard of the flat candidate list = ONE launch of K1
-(k1_search_tiled: candidate transform pose + jitter -> px,py,c,s with device trig, batched distance over
-all rays from LDS-staged HoleMap tiles, per-candidate accumulation and arg-min; at N = 1 the packed key of a step lands in a
-result word owned by the handle, slamhip_cs_search_shard_enqueue); with N > 1 GPUs the
-per-rank packed (distance << 32 | index) keys are min-all-reduced over RCCL (one 8-byte all-reduce per step).  All inputs (map, scan, jitter list) are resident in HBM
-before the timed region.  Weak scaling: per-GPU candidates are fixed as N grows.
+One "step" = one full search over this rank's shard of the flat candidate list = ONE launch of K1 (k1_search_tiled: batched
+distance over all rays from LDS-staged HoleMap tiles, per-candidate accumulation and arg-min; the packed key of a step lands in a
+result word owned by the handle, slamhip_cs_search_shard_enqueue) accompanied by ONE small launch on a stream of its own that
+makes the search's plan (k1_plan: the candidate transform pose + jitter -> px,py,c,s with deterministic trigonometry, once per
+candidate, and every workgroup's tile steps) -- both inside the timed region, every step.  With N > 1 GPUs the per-rank packed
+(distance << 32 | index) keys are min-all-reduced over RCCL, enqueued behind the search (the keys of 16 steps per collective).  All
+inputs (map, scan, jitter list) are resident in HBM before the timed region.  Weak scaling: per-GPU candidates are fixed as N grows.
 
-N > 1 reports the PER-SCAN form in `value`: every step is one blocking slamhip_cs_search_allreduce -- K1, the collective and the
-hand-over of the reduced key to the host, one behind the other, because the SLAM loop needs the winner of a scan before it can
-update the maps (CoreSLAMProcessor.cs:732 -> :750).  The overlapped form (the keys of 16 steps per collective on a second
-stream, nothing waits per step) and the latency of the bare collective are measured after the timed region and reported in
-`multi_gpu`.
+`value` is the SAME form at every N -- the enqueue-only search, nothing returns to the host per step -- so that a 1 -> N curve
+measures the exchange, not a change of form.  The BLOCKING per-scan form (K1, the collective, the reduced key on the host before
+the next step: what a SLAM loop pays, CoreSLAMProcessor.cs:732 -> :750) is measured after the timed region at every N, N = 1
+included, and reported beside it (`config.per_scan_blocking_us_per_step`, `multi_gpu.per_scan_blocking_us_per_step`).
 
-Timed region (N = 1): barrier + device synchronise, t0, K x one C call (the launch), one event record, ONE device synchronise,
-t1 -- event creation, the first event's record and every other synchronisation sit outside.
+Timed region: barrier + device synchronise, t0, K x (one C call: the search's two launches [+ the collective's call]), one event
+record, ONE device synchronise, t1 -- event creation, the first event's record and every other synchronisation sit outside.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -163,19 +163,27 @@ def main():
             ok = int(okt.item())
         if not ok and comm is not None:
             comm.close(); comm = None
+    # ONE form of a step at every N: the enqueue-only search -- nothing returns to the host per step.  N = 1: the ring search; N > 1:
+    # the same search launch + the key's min all-reduce enqueued behind it (library path: the keys of 16 steps per ncclAllReduce on the
+    # communicator's own stream; torch.distributed path: one all_reduce per step on the search's stream).  The BLOCKING per-scan form
+    # -- K1, the collective and the reduced key back on the host before the next step, what a SLAM loop pays per scan
+    # (CoreSLAMProcessor.cs:732 -> :750) -- is measured after the timed region at every N, N = 1 included (`per_scan_blocking_us_per_step`).
     if comm is not None:
-        step = comm.bind_search_allreduce(dev, base, first, count)   # per scan: blocking, returns the reduced key
-        step_overlapped = lib_step
-        collective = ("rccl ncclAllReduce(min, uint64, 1) issued by libslamhip (slamhip_cs_search_allreduce): per scan, on the operator's "
-                      "stream behind K1, reduced key handed to the host before the next step")
+        comm.set_batch(16)
+        step = lib_step
+        step_blocking = comm.bind_search_allreduce(dev, base, first, count)
+        collective = ("rccl ncclAllReduce(min, uint64, 16): the keys of 16 steps per collective, issued by libslamhip on the communicator's own stream "
+                      "behind one event (slamhip_cs_search_allreduce_async); nothing returns to the host per step")
     elif world > 1:
-        step = step_torch_per_scan
-        step_overlapped = step_torch
-        collective = "%s all_reduce(min, 8 B) per scan via torch.distributed, reduced key read by the host before the next step" % ("rccl" if backend == "nccl" else backend)
+        step = step_torch
+        step_blocking = step_torch_per_scan
+        collective = "%s all_reduce(min, 8 B) per step via torch.distributed on the search's stream, nothing read back per step" % ("rccl" if backend == "nccl" else backend)
         collective_ranks = dist.get_world_size()
     else:
         step = step_ring if os.environ.get("SLAMHIP_BENCH_N1_STEP", "ring") == "ring" else step_torch
-        step_overlapped = None
+
+        def step_blocking():
+            return dev.search_shard(base, first, count)
 
     def sync_all():
         ctx.synchronize()
@@ -219,7 +227,7 @@ def main():
     # depress `value`); the first is recorded BEFORE t0.  At N > 1 the timed region's stream also carries the collective and the
     # hand-over, so K1 is timed in the overlapped pass after the region (library path: the operator's stream carries K1 only)
     # or per launch in a short pass of its own (torch.distributed path).
-    two_events = world == 1 and not a.no_kernel_timing
+    two_events = (world == 1 or comm is not None) and not a.no_kernel_timing
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     if world > 1:
@@ -241,48 +249,92 @@ def main():
             final_key = step()
     if two_events:
         ev1.record(ext)
+    if comm is not None:
+        comm.synchronize()                  # (the keys of the last, partial batch are exchanged inside the region too)
     torch.cuda.synchronize()                # (the whole device: the library's streams included)
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    if comm is None:
+    if comm is not None:
+        final_key = comm.wait()                                    # (flushes the last batch of keys; the reduced key of the last step)
+    else:
         final_key = dev.key_read(ring_slot.value) if step is step_ring else int(key.item())
     k1_ms, k1_n = (0.0, 0)
     k1_how = "two HIP events on the operator's stream around the timed region"
     if two_events:
         k1_ms, k1_n = ev0.elapsed_time(ev1), a.steps
+    # ---- after the timed region: the blocking per-scan form, at every N ----------------------------------------------
+    n_ps = max(min(a.steps, 100), 20)
+    for _ in range(3):
+        step_blocking()
+    sync_all()
+    if world > 1:
+        dist.barrier()
+    gc.disable()
+    tb = time.perf_counter()
+    for _ in range(n_ps):
+        k_blocking = step_blocking()
+    dt_ps = time.perf_counter() - tb
+    gc.enable()
+    sync_all()
+    per_scan_us = dt_ps / n_ps * 1e6
+    blocking_key_ok = bool(int(k_blocking) == int(final_key))
+    # ---- ... and K1 as a per-scan flow sees it: a NEW scan in front of every search (what CoreSLAMProcessor.Update launches: no layout
+    # or cut made for this very scan -- the previous scan's are taken over when they are legal -- and a plan whose inputs changed).
+    # Eight scans from poses a few centimetres apart, 48 blocking searches, K1's duration from per-launch HIP event pairs (the
+    # library's own timers); beside it the same pairs around repeated searches of ONE scan (the headline's launch, same instrument).
+    first_search = None
+    if world == 1 and not a.no_kernel_timing:
+        try:
+            rng_f = sim.PCG32(777)
+            scans_f = []
+            for k in range(8):
+                p_f = (true_pose + np.array([0.02 * k, 0.01 * k, 0.002 * k], np.float32)).astype(np.float32)
+                scans_f.append(sim.make_scan(segs, p_f, a.rays, rng_f)[1])
+
+            def k1_events(new_scan_every_step, n):
+                for k in range(6):
+                    if new_scan_every_step:
+                        dev.set_scan(scans_f[k % 8])
+                    dev.search_shard(base, first, count)
+                ctx.timing_reset(); ctx.timing_enable(1 << capi.K_CS_DISTANCE)
+                for k in range(n):
+                    if new_scan_every_step:
+                        dev.set_scan(scans_f[k % 8])
+                    dev.search_shard(base, first, count)
+                ms_f, n_f = ctx.timing_get(capi.K_CS_DISTANCE)
+                ctx.timing_enable(0)
+                return ms_f / max(n_f, 1) * 1e3
+            us_new = k1_events(True, 48)
+            dev.set_scan(xy)
+            us_same = k1_events(False, 48)
+            first_search = {"first_search_of_new_scan_us": round(us_new, 3), "repeated_search_of_one_scan_us_same_instrument": round(us_same, 3),
+                            "how": "per-launch HIP event pairs around K1 (slamhip_ctx_timing_*), 48 blocking searches each; a new scan = slamhip_cs_set_scan of one of eight "
+                                   "scans cast a few centimetres apart in front of every search"}
+        except Exception as e:                                     # noqa: BLE001 -- an extra must never cost the line
+            first_search = {"error": repr(e)}
+        dev.set_scan(xy)
     multi = None
     if world > 1 or comm is not None:
-        # ---- after the timed region: the overlapped form, K1's launch time, the bare collective ----------------------
+        # ---- ... and, N > 1: this rank's search alone in the SAME form as the timed region (no collective: what N = 1 runs), K1's launch time where the
+        # region could not give it, the bare collective ----------------------
         n_ov = max(a.steps, 100)
-        if comm is not None:
-            comm.set_batch(16)
         for _ in range(5):
-            step_overlapped()
+            step_ring()
         sync_all()
         if world > 1:
             dist.barrier()
-        sync_all()
-        gc.disable()
-        ev_ok = comm is not None and not a.no_kernel_timing
-        if ev_ok:
-            ev0.record(ext)
         t1 = time.perf_counter()
         for _ in range(n_ov):
-            step_overlapped()
-        if ev_ok:
-            ev1.record(ext)
+            step_ring()
         sync_all()
+        dt_single = time.perf_counter() - t1
         if world > 1:
             dist.barrier()
-        dt_ov = time.perf_counter() - t1
         gc.enable()
-        if ev_ok:
-            k1_ms, k1_n = ev0.elapsed_time(ev1), n_ov
-            k1_how = "two HIP events on the operator's stream around the overlapped pass (that stream carries K1 launches only)"
-        elif not a.no_kernel_timing:
+        if not two_events and not a.no_kernel_timing:
             k1_how = "per-launch HIP event pairs, 50 launches after the timed region"
             ctx.timing_reset()
             ctx.timing_enable(1 << capi.K_CS_DISTANCE)
@@ -342,15 +394,16 @@ def main():
             except Exception as e:                                 # noqa: BLE001
                 fused = {"error": repr(e)}
         if world > 1:
-            t = torch.tensor([elapsed, dt_ov, ar_us if ar_us is not None else 0.0], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed, dt_single, ar_us if ar_us is not None else 0.0, per_scan_us], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, dt_ov, ar_max = float(t[0].item()), float(t[1].item()), float(t[2].item())
+            elapsed, dt_single, ar_max, per_scan_us = float(t[0].item()), float(t[1].item()), float(t[2].item()), float(t[3].item())
             ar_us = ar_max if ar_us is not None else None
-        multi = {"per_scan_us_per_step": elapsed / a.steps * 1e6,
-                 "overlapped_us_per_step": dt_ov / n_ov * 1e6, "overlapped_evals_per_s": float(K_total) * n_ov / dt_ov,
-                 "overlapped_steps": n_ov,
-                 "overlapped_form": ("keys of 16 steps per ncclAllReduce on the communicator's own stream behind one event" if comm is not None
-                                     else "search + all_reduce enqueued per step, nothing read back per step"),
+        multi = {"timed_form": "enqueue-only search + key all-reduce enqueued behind it (the form N = 1 times, plus the exchange)",
+                 "us_per_step": elapsed / a.steps * 1e6,
+                 "single_rank_same_form_us_per_step": dt_single / n_ov * 1e6,
+                 "efficiency_same_form": (dt_single / n_ov) / (elapsed / a.steps),
+                 "efficiency_same_form_is": "this rank's search alone, same enqueue-only form, same process (max over ranks) / the timed region's step: what the exchange costs a step -- NOT the driver's 1 -> N scaling efficiency",
+                 "per_scan_blocking_us_per_step": per_scan_us,
                  "allreduce_us": ar_us, "collective_ranks": collective_ranks, "replicas_equal": replicas,
                  "fused_scan_allreduce_and_update": fused}
 
@@ -371,6 +424,8 @@ def main():
                     "kernel": "k1_search_tiled", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(k1_n),
                     "bytes_per_launch": a.cands * bytes_per_eval,
                     "timing": k1_how, "valu": valu}
+            if first_search:
+                roof.update(first_search)
         out = {
             "metric": "candidate-pose distance evals/sec on 2048^2 map, 1080-ray scan, 1/2/4/8 GPU",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -380,8 +435,11 @@ def main():
                                    % (a.size, a.size, a.rays, a.cands),
                        "map": a.size, "rays": a.rays, "candidates_per_gpu": a.cands, "candidates_total": K_total,
                        "collective": collective, "collective_ranks": collective_ranks,
-                       "timed_region": ("%d steps, each one launch; one device synchronise inside" % a.steps) if world == 1 else
-                                       ("%d steps, each K1 + all-reduce + reduced key back on the host (per scan)" % a.steps),
+                       "timed_region": ("%d steps, each one search launch (+ its plan launch on a stream of its own); one device synchronise inside" % a.steps) if world == 1 else
+                                       ("%d steps, each one search launch + the key's all-reduce enqueued behind it -- the same enqueue-only form as N = 1; one device synchronise inside" % a.steps),
+                       "per_scan_blocking_us_per_step": per_scan_us,
+                       "per_scan_blocking_is": "the same search as a BLOCKING call per step (K1%s, the key on the host before the next step): %d steps after the timed region; its key equals the timed region's: %s"
+                                               % (" + the collective" if world > 1 or comm is not None else "", n_ps, blocking_key_ok),
                        "clock_warmup_steps": a.clock_warmup,
                        "cold_clocks": None if cold is None else {
                            "ms_per_step": cold * 1e3, "value": K_total / cold,
@@ -681,7 +739,7 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
                     us_cold = float(txt.split("from idle clocks:")[1].split(";")[0]) if "from idle clocks:" in txt else None
                     out["coreslam_processor_update_native_caller_2048_map_1080_rays_16385_candidates"] = {
                         "us_per_scan": us, "scans_per_s": 1e6 / us, "us_per_scan_first_300_scans_from_idle_clocks": us_cold,
-                        "caller": "tests/abi_harness.c --bench-proc (C, dlopen): a rectangular room; 300 scans timed after 1800 untimed ones (sustained clocks)"}
+                        "caller": "tests/abi_harness.c --bench-proc (C, dlopen): the simulator's field (the headline scan's scene), a moving robot; 300 scans timed after 1800 untimed ones (sustained clocks)"}
                 else:
                     out["coreslam_processor_update_native_caller_2048_map_1080_rays_16385_candidates"] = {"error": txt[-400:]}
                 # HectorSLAMProcessor.Update the same way (--bench-hsproc: 2048^2 x 3 levels, 1080 rays, every scan updating the grids)
@@ -691,7 +749,7 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
                     us = float(txt.split("hsproc_us_per_scan")[1].split()[0])
                     out["hector_processor_update_native_caller_2048_pyramid_3_levels_1080_rays"] = {
                         "us_per_scan": us, "scans_per_s": 1e6 / us,
-                        "caller": "tests/abi_harness.c --bench-hsproc (C, dlopen): the same room, every scan matched and the grids updated; 300 scans timed after 1800 untimed ones"}
+                        "caller": "tests/abi_harness.c --bench-hsproc (C, dlopen): the same field, every scan matched and the grids updated; 300 scans timed after 1800 untimed ones"}
                 else:
                     out["hector_processor_update_native_caller_2048_pyramid_3_levels_1080_rays"] = {"error": txt[-400:]}
     except Exception as e:                                         # noqa: BLE001
@@ -806,9 +864,11 @@ def pmc_traffic(a):
 def valu_ceiling(a, bytes_per_launch):
     """What actually binds the dominant kernel at this size: its VALU work.  Replayed from the committed SQ-counter profile of this
     command (profiles/rNN_k1_sq.json, newest round first; PMC counters cannot be read inside the timed run): busy_us = the time the
-    VALU pipes of a SIMD are busy per launch (SQ_ACTIVE_INST_VALU quad-cycles x 4 / 1024 SIMDs at 2.1 GHz), launch_us = the launch's
-    duration in the same profile, frac_of_hbm_roofline_if_valu_bound = the HBM-roofline fraction the launch would reach if it took
-    only busy_us -- the ceiling of this kernel at this candidate count, whatever its latencies.  None without a matching profile."""
+    VALU pipes of a SIMD are busy per launch = SQ_ACTIVE_INST_VALU quad-cycles x 4 / 1024 SIMDs / the shader clock MEASURED in the same
+    profile (GRBM_GUI_ACTIVE / launch duration, tools/prof_summary.py -- not an assumed clock), launch_us = the launch's duration in the
+    same profile, frac_of_hbm_roofline_if_valu_bound = the HBM-roofline fraction the launch would reach if it took only busy_us -- the
+    ceiling of this kernel at this candidate count, whatever its latencies.  None without a matching profile or when the profile's
+    figures are not self-consistent (busy_us must not exceed launch_us)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k1_sq.json")), reverse=True):
         try:
@@ -817,11 +877,17 @@ def valu_ceiling(a, bytes_per_launch):
             h = t["headline_16384_candidates"]
             if a.cands != 16384 or a.size != 2048 or a.rays != 1080:
                 return None
-            busy = float(h["derived"]["valu_busy_us_per_simd_if_evenly_spread"])
+            d = h["derived"]
+            if "shader_clock_ghz_measured" not in d:
+                continue                                           # (a profile of an earlier round: its busy estimate assumed a clock)
+            busy = float(d["valu_busy_us_per_simd_if_evenly_spread"])
             launch = float(h["avg_launch_ns_rocprof_stats"]) * 1e-3
+            if not busy <= launch:
+                return {"error": "profile not self-consistent: valu busy %.2f us > launch %.2f us" % (busy, launch), "source": os.path.relpath(path, ROOT)}
             return {"busy_us": round(busy, 2), "launch_us": round(launch, 2), "busy_frac_of_launch": round(busy / launch, 3),
+                    "shader_clock_ghz_measured": round(float(d["shader_clock_ghz_measured"]), 3),
                     "frac_of_hbm_roofline_if_valu_bound": round(bytes_per_launch / (busy * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
-                    "wave_cycles_waiting_frac": round(float(h["derived"].get("fraction_of_wave_cycles_waiting_waitcnt_or_barrier", 0.0)), 3),
+                    "wave_cycles_waiting_frac": round(float(d.get("fraction_of_wave_cycles_waiting_waitcnt_or_barrier", 0.0)), 3),
                     "source": "replayed from %s (separate rocprofv3 --pmc passes of this command, not this run)" % os.path.relpath(path, ROOT)}
         except Exception:
             pass
@@ -920,7 +986,9 @@ def cpu_baseline(a, dev, xy, base, offs, gpu_key, checks=(), pix=None):
             match[c["name"]] = bool(ok)
         except Exception as e:                                     # noqa: BLE001
             match[c["name"]] = repr(e)
-    return {"value": evals2 / secs2, "unit": "evals/s", "cores": T, "kind": "port",
+    return {"value": evals2 / secs2, "unit": "evals/s", "cores": T, "threads": T, "host_cores": os.cpu_count(),
+            "cores_is": "the threads the baseline ran (the reference's ParallelWorker is capped at 64 by WaitHandle.WaitAll); host_cores = the box's online cores",
+            "kind": "port",
             "sample": "%d scans x %d threads x (%d jitters + base) on the same map/scan/candidates, %.1f s"
                       % (scans, T, iters, secs2),
             "value_is": "mean over the sample (total evaluations / total seconds); median_scan and p95_scan are per-scan rates",

@@ -40,6 +40,22 @@ namespace HectorSLAM.Main
             PushIterations();
         }
 
+        /// <summary>The pyramid of a native HectorSLAMProcessor (slamhip_hsproc_hs): borrowed, the processor destroys it.</summary>
+        internal MapRepMultiMap(Device device, IntPtr borrowedPyramid, int numDepth)
+        {
+            Device = device;
+            ownsDevice = false;
+            Pyramid = new Handle(borrowedPyramid, _ => 0);
+            Maps = new OccGridMap[numDepth];
+            for (int i = 0; i < numDepth; i++)
+            {
+                Maps[i] = new OccGridMap(Device, Pyramid, i);
+                Maps[i].IterationsChanged = PushIterations;
+                Maps[i].FactorsChanged = () => { };
+            }
+            PushIterations();
+        }
+
         private unsafe void PushIterations()
         {
             int* it = stackalloc int[Maps.Length];
@@ -58,6 +74,12 @@ namespace HectorSLAM.Main
         {
             SetScan(scan);
             Native.Check(Native.slamhip_hs_update_by_scan(Pyramid.Ptr, pose));
+            foreach (OccGridMap m in Maps) m.mirrorStale = true;
+        }
+
+        /// <summary>The device maps changed behind this object's back (HectorSLAMProcessor.Update drives the native processor): host mirrors are stale.</summary>
+        internal void MarkStale()
+        {
             foreach (OccGridMap m in Maps) m.mirrorStale = true;
         }
 

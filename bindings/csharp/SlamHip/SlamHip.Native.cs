@@ -81,6 +81,15 @@ namespace SlamHip
         [DllImport(Lib)] internal static extern int slamhip_hs_match_level(IntPtr hs, int level, in Vector3 hint, int iterations, out Vector3 pose);
         [DllImport(Lib)] internal static extern int slamhip_hs_match_batch(IntPtr hs, Vector3* hints, int count, Vector3* poses);
         [DllImport(Lib)] internal static extern int slamhip_hs_update_by_scan(IntPtr hs, in Vector3 robotPoseWorld);
+        // HectorSLAM, processor level (HectorSLAMProcessor.cs:66-138): the Update state machine in the library -- match, the gate of :107-109 evaluated
+        // on the device, the grid update enqueued behind the match before the pose is back (one blocking wait per scan instead of two)
+        [DllImport(Lib)] internal static extern int slamhip_hsproc_create(IntPtr ctx, float mapResolution, int width, int height, in Vector3 startPose, int numDepth, out IntPtr proc);
+        [DllImport(Lib)] internal static extern int slamhip_hsproc_destroy(IntPtr proc);
+        [DllImport(Lib)] internal static extern int slamhip_hsproc_reset(IntPtr proc);
+        [DllImport(Lib)] internal static extern int slamhip_hsproc_update(IntPtr proc, Vector2* points, int nPoints, in Vector2 scanOrigin, in Vector3 poseHintWorld, int mapWithoutMatching, out int mapUpdated);
+        [DllImport(Lib)] internal static extern int slamhip_hsproc_get(IntPtr proc, out Vector3 matchPose, out Vector3 lastMapUpdatePose, out float matchTimingMs, out float updateTimingMs);
+        [DllImport(Lib)] internal static extern int slamhip_hsproc_set_thresholds(IntPtr proc, float minDistanceDiff, float minAngleDiff);
+        [DllImport(Lib)] internal static extern int slamhip_hsproc_hs(IntPtr proc, out IntPtr hs);
 
         // ---- one process, several GPUs -------------------------------------------------------------------------------
         [DllImport(Lib)] internal static extern int slamhip_group_create(int* deviceOrdinals, int n, float physicalMapSize, int holeMapSize, int obstacleMapSize, out IntPtr group);

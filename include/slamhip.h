@@ -82,7 +82,11 @@ void   *slamhip_ctx_stream(slamhip_ctx *ctx);                      /* hipStream_
  * <= 0: unbounded).  ParallelWorker.Work waits on its AutoResetEvents without a bound (BaseSLAM/ParallelWorker.cs:106-116): a worker
  * that never signals hangs the reference's caller for ever; here a completion word that does not arrive in time ends the call with
  * SLAMHIP_ERR_TIMEOUT and POISONS the context -- the device's state is unknown, nothing is restarted or re-executed in-process, and
- * every later blocking call or launch on the context fails with SLAMHIP_ERR_TIMEOUT at once.  The caller destroys its handles. */
+ * every later blocking call (every wait and every hand-over of a result to the host) on the context fails with SLAMHIP_ERR_TIMEOUT
+ * at once; enqueue-only calls are not checked.  The bound counts from the start of the wait, work queued in front of the awaited
+ * launch included: a caller that queues seconds of asynchronous work in front of a blocking call raises the bound first.  The caller
+ * destroys its handles -- slamhip_ctx_destroy of a poisoned context waits for the stream once more, for at most the bound, and then
+ * lets go of it (a kernel that never ends would otherwise move the hang into destroy); the process should then exit. */
 int32_t slamhip_ctx_set_wait_timeout(slamhip_ctx *ctx, int64_t timeout_ms);
 int32_t slamhip_ctx_poisoned(slamhip_ctx *ctx, int32_t *out_flag);
 /* Test hook (no device involved): the wait loop of a blocking call on a caller-owned word -- returns SLAMHIP_OK once *flag has

@@ -33,12 +33,10 @@ def extra_defs():
         d.append("-DK2_TIMES=1")
     if os.environ.get("SLAMHIP_K5_TIMES"):      # developer build: per-workgroup phase stamps in the Hector cell kernel
         d.append("-DK5_TIMES=1")
-    if os.environ.get("SLAMHIP_K1_EXP"):        # developer experiment (wrong results): parts of the search kernel left out, for its instruction budget
-        d.append("-DK1_EXP=%s" % os.environ["SLAMHIP_K1_EXP"])
     if os.environ.get("SLAMHIP_K1_DMA0"):       # developer A/B: 0 = the first tile through staging registers like the later ones
         d.append("-DK1_DMA0=%s" % os.environ["SLAMHIP_K1_DMA0"])
-    if os.environ.get("SLAMHIP_K2_EXP"):        # developer experiment (wrong results): which memory traffic bounds K2's step lanes
-        d.append("-DK2_EXP=%s" % os.environ["SLAMHIP_K2_EXP"])
+    # (the wrong-results experiment builds -DK1_EXP=n / -DK2_EXP=n are made as side variants only: tools/build_variant.py WORK <tag> -DK1_EXP=n,
+    # selected with SLAMHIP_LIB -- never as slam.net_amd/libslamhip.so)
     if os.environ.get("SLAMHIP_K2_LDS_RAYS"):   # developer experiment: rays of the K2 pixel kernel's LDS table
         d.append("-DK2_LDS_RAYS=%s" % os.environ["SLAMHIP_K2_LDS_RAYS"])
     return d

@@ -70,7 +70,18 @@ extern "C" int32_t slamhip_ctx_destroy(slamhip_ctx *c)
 {
     if (!c) return SLAMHIP_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (!c->poisoned) (void)hipStreamSynchronize(c->stream);
+    else {
+        // a wait on this context passed its bound: the stream may never drain -- give it the bound once more, then let go (the
+        // process should end: device state is unknown, see slamhip.h)
+        timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+        const int64_t bound = c->wait_timeout_ms > 0 ? c->wait_timeout_ms : 10000;
+        while (hipStreamQuery(c->stream) == hipErrorNotReady) {
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000L + (t1.tv_nsec - t0.tv_nsec) / 1000000L >= bound) break;
+            struct timespec nap = { 0, 200000 }; nanosleep(&nap, nullptr);
+        }
+    }
     for (int i = 0; i < c->n_pending; i++) { (void)hipEventDestroy(c->pending[i].a); (void)hipEventDestroy(c->pending[i].b); }
     for (int i = 0; i < c->n_pool; i++) (void)hipEventDestroy(c->pool[i]);
     free(c->pending); free(c->pool);

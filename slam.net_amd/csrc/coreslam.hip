@@ -207,7 +207,7 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
 {
     if (!cs) return SLAMHIP_OK;
     (void)hipSetDevice(cs->ctx->device);
-    (void)hipStreamSynchronize(cs->ctx->stream);
+    if (!cs->ctx->poisoned) (void)hipStreamSynchronize(cs->ctx->stream);     // (a poisoned context's stream may never drain: slamhip_ctx_destroy bounds that wait)
     cs_plan_free(cs);
     if (cs->plan_stream) (void)hipStreamDestroy(cs->plan_stream);
     (void)hipFree(cs->d_hole); (void)hipFree(cs->d_obst);
@@ -1722,6 +1722,14 @@ int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_
             const volatile uint64_t *hk = (const volatile uint64_t *)ctx->mailbox;
             const float *hp = (const float *)(ctx->mailbox + 2);
             const uint64_t key = hk[0];
+            if (key == ~0ull) {
+                // The search launch left without searching: it gave up waiting for this scan's tables (a host stalled for ~10 s between
+                // the launch and the answer above -- a debugger, a suspended process), its result word stayed at rest, and the map update
+                // behind it decoded that to the un-searched search pose.  The maps are no longer what the reference would hold: this is
+                // reported like any wait that passed its bound, and the context refuses further work.
+                ctx->poisoned = true;
+                SH_FAIL(SLAMHIP_ERR_TIMEOUT, "the search launched ahead of its scan's tables gave up waiting for them (host stalled); the maps were updated at the un-searched pose: the context is poisoned");
+            }
             if (out_pose) { out_pose[0] = hp[0]; out_pose[1] = hp[1]; out_pose[2] = hp[2]; }
             if (out_dist) *out_dist = (int32_t)(uint32_t)(key >> 32);
             if (out_index) *out_index = (int32_t)(uint32_t)key;

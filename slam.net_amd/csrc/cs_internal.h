@@ -86,6 +86,12 @@ struct slamhip_cs {
     // ray ranges of the uniform part cut by COST (rays + a weight per ray block touched) instead of by count (k1_balanced_cuts):
     // cuts by count of ranges (cuts[0 .. n], n <= the count asked for; empty: none), for scan generation k1_cut_gen at weight k1_cut_w
     std::vector<std::pair<int, std::vector<int>>> k1_cut_cache; uint32_t k1_cut_gen, k1_cut_layout_gen;
+    // ... and for the per-scan flow, where every launch sees a new scan: the uniform part's cut made for the PREVIOUS scan while the host
+    // waited for its pose (cs_layout_idle_refresh), used for the next scan's launch if it is legal for that scan's ray blocks (a cut
+    // only balances the launch: any legal one gives the same sums)
+    std::vector<int> k1_prev_cuts; int k1_prev_cuts_nc; uint32_t k1_prev_cuts_layout_gen; int k1_prev_cuts_points;
+    bool k1_launch_prev_cuts;                   // the search launch now in the stream took them (a prelaunched one: legality is tested when the tables exist)
+    float k1_last_pose[3]; int k1_last_group; bool k1_last_valid;   // the last tiled mode-1 launch: what the idle refresh makes the next cut for
     uint32_t k1_cut_seen_scan, k1_cut_seen_layout;   // the (scan, layout) of the last tiled launch: cuts are made from the second launch of a pair on
     uint32_t k1_layout_gen;                     // layouts made so far (k1_make_layout)
     std::vector<char> k1_cut_cand;              // per ray block: its tile may exceed the budget (worth the exact box test)

@@ -535,15 +535,24 @@ k1_search_tiled(const k1_args a)
         // launch starts (it starts behind the previous scan's map update): one load.  Bit 31: the host found that the launch's assumptions do not hold for this scan -- leave without a trace (the
         // result word stays rested: the map update that decodes it falls back to the search pose, holemap.hip; the host searches
         // again).  A host that never answers: the same after ~10 s, with the self-check counter raised.
+        // ONE wavefront watches the word and the verdict reaches the others through the LDS behind a barrier: a workgroup goes on or
+        // leaves as a whole (wavefronts that gave up one by one would leave a workgroup half gone -- accumulators not at rest), and
+        // the word is polled by an eighth of the wavefronts.
         uint32_t v = 0;
-        int spins = 0;
-        for (;;) {
-            v = __hip_atomic_load(a.scan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((v & 0x7fffffffu) == a.scan_seq) break;
-            if (++spins > (1 << 23)) { if (t == 0) atomicAdd(a.verify, 1u); v = 0x80000000u; break; }
-            __builtin_amdgcn_s_sleep(32);
+        if (wv == 0) {
+            int spins = 0;
+            for (;;) {
+                v = __hip_atomic_load(a.scan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((v & 0x7fffffffu) == a.scan_seq) break;
+                if (++spins > (1 << 23)) { if (t == 0) atomicAdd(a.verify, 1u); v = 0x80000000u; break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (blockIdx.x == 0 && t == 0) { ((uint32_t *)a.scan_flag)[8] = (uint32_t)spins; ((uint32_t *)a.scan_flag)[9] += (uint32_t)spins; }   // (developer aid: how long the first workgroup waited, SLAMHIP_FUSED_TIMES)
+            if (lane == 0) s_plan_ok = (int)v;
         }
-        if (blockIdx.x == 0 && t == 0) { ((uint32_t *)a.scan_flag)[8] = (uint32_t)spins; ((uint32_t *)a.scan_flag)[9] += (uint32_t)spins; }   // (developer aid: how long the first workgroup waited, SLAMHIP_FUSED_TIMES)
+        __syncthreads();
+        v = (uint32_t)s_plan_ok;
+        __syncthreads();                                           // (the word is used again below: the plan's verdict)
         if (__builtin_amdgcn_readfirstlane(v) & 0x80000000u) return;
     }
     // (the two block numbers are uniform, and the compiler would wait for them -- to move them into SGPRs -- before it issues
@@ -1712,15 +1721,101 @@ static bool k1_layout_legal(const slamhip_cs *cs)
     return true;
 }
 
-// The layout for the scan now set, made while the host has nothing else to do (it waits for a search's result): the launch that
-// just left used the previous scan's (cs_launch_distance).  Touches host state only.
-bool cs_k1_layout_legal(const slamhip_cs *cs) { return k1_layout_legal(cs); }
+// Is a cut -- ray ranges [cuts[c], cuts[c + 1]) -- legal for the scan now set: it covers the scan, and every range holds at most K1_MAXR
+// rays of at most K1_MAXP ray blocks?
+static bool k1_cuts_legal(const slamhip_cs *cs, const std::vector<int> &cuts)
+{
+    const int R = cs->n_points, n_rb = cs->n_rb;
+    const int *rb = cs->h_rb_start.data();
+    if (cuts.size() < 2 || cuts.front() != 0 || cuts.back() != R || n_rb < 1) return false;
+    int b = 0;
+    for (size_t c = 0; c + 1 < cuts.size(); c++) {
+        const int lo = cuts[c], hi = cuts[c + 1];
+        if (hi <= lo || hi - lo > K1_MAXR) return false;
+        while (b + 1 < n_rb && rb[b + 1] <= lo) b++;
+        int e = b;
+        while (e + 1 < n_rb && rb[e + 1] < hi) e++;
+        if (e - b + 1 > K1_MAXP) return false;
+    }
+    return true;
+}
 
+// The weight of a tile step in ray units for the cuts by cost (see cs_launch_distance): 26 where it was calibrated (2048^2 map = 51.2
+// pixels per metre, two candidates per lane), less on coarser maps and in proportion to what a ray costs the workgroup.
+static double k1_cut_wfix(const slamhip_cs *cs, int group)
+{
+    static const double cut_w20 = getenv("SLAMHIP_K1_CUT_WFIX") ? atof(getenv("SLAMHIP_K1_CUT_WFIX")) : 26.0;
+    const int cpl_group = group == K1_GROUP_BIG ? 4 : group == K1_GROUP_SMALL ? 1 : 2;
+    return cut_w20 * std::min(1.0, (double)cs->hscale / 51.2) * 2.0 / (double)cpl_group;
+}
+
+// One cut of the scan now set into nrc ranges by cost (k1_balanced_cuts with the block weights cs->k1_cut_wb, scaled down until the cut
+// keeps nearly all the ranges asked for; dropped if it puts more rays on banded tiles than the equal-count ranges do).  c: empty = none.
+static void k1_cuts_make(slamhip_cs *cs, int nrc, bool have_spread, const float pose3[3], int budget, std::vector<int> &c)
+{
+    static const int cut_keep = env_int("SLAMHIP_K1_CUT_KEEP", 90);   // per cent of the asked-for ranges a cut must keep
+    c.clear();
+    // The cut must keep (nearly) the asked-for count of ranges: where blocks are long in rays (coarse maps: a 64-ray block is
+    // one tile) heavy weights end in one block per range -- 17 ranges for 25 at 1024^2 -- and the workgroups that are not
+    // launched cost more than the steps that are saved (measured: 24 -> 33 us).  The weights are scaled down until it does.
+    std::vector<double> &wsc = cs->k1_cut_wsc;
+    double scale = 1.0;
+    for (int tries = 0; tries < 6; tries++, scale *= 0.6) {
+        wsc.resize(cs->k1_cut_wb.size());
+        for (size_t i = 0; i < wsc.size(); i++) wsc[i] = cs->k1_cut_wb[i] * scale;
+        const double tb0 = k1_now_us();
+        const int n = k1_balanced_cuts(cs, nrc, wsc, c);
+        g_cut_t[1] += k1_now_us() - tb0;
+        if (n < 1) { c.clear(); break; }
+        if (n * 100 >= nrc * cut_keep) break;
+        c.clear();
+    }
+    if (!c.empty() && nrc == cs->k1_uni_nc && have_spread) {
+        // a cut that puts more rays on banded tiles (for the uniform part's outer groups) than the equal-count ranges do is
+        // dropped: a banded piece costs its workgroup more than twice a plain one, the launch waits for it (1024^2 map:
+        // four workgroups at 19 us in a 21 us launch)
+        const double tc0 = k1_now_us();
+        const int banded = k1_cuts_banded_rays(cs, c, pose3, budget, cs->k1_cut_cand);
+        g_cut_t[2] += k1_now_us() - tc0;
+        if (banded > 0) {                                  // (seldom: the equal-count ranges are only looked at then)
+            std::vector<int> eq((size_t)nrc + 1);
+            for (int k = 0; k <= nrc; k++) eq[(size_t)k] = (int)(((long long)k * cs->n_points) / nrc);
+            if (banded > k1_cuts_banded_rays(cs, eq, pose3, budget, cs->k1_cut_cand)) c.clear();
+        }
+    }
+}
+
+// Are the layout's counts of ray ranges -- and the cut the launch now in the stream took over from the previous scan -- legal for the
+// scan now set?  (The search launched ahead of its scan's tables asks when the tables exist.)
+bool cs_k1_layout_legal(const slamhip_cs *cs)
+{
+    if (!k1_layout_legal(cs)) return false;
+    return !cs->k1_launch_prev_cuts || k1_cuts_legal(cs, cs->k1_prev_cuts);
+}
+
+// The layout for the scan now set, made while the host has nothing else to do (it waits for a search's result): the launch that
+// just left used the previous scan's (cs_launch_distance) -- and, for the next scan's launch, the uniform part's ray ranges cut by
+// cost (the per-scan flow sees every scan once: its launch takes the cut of the scan before, if legal).  Touches host state only.
 void cs_layout_idle_refresh(slamhip_cs *cs)
 {
-    if (!cs->k1_layout_stale || cs->k1_layout_dirty || cs->k1_scan_dirty || cs->n_points <= 0) return;
-    k1_make_layout(cs, cs->k1_layout_groups, cs->k1_layout_target, cs->k1_layout_budget, cs->k1_layout_spread, cs->k1_layout_band_parts);
-    cs->k1_layout_stale = false; cs->k1_layout_gen++;
+    if (cs->k1_layout_dirty || cs->k1_scan_dirty || cs->n_points <= 0) return;
+    if (cs->k1_layout_stale) {
+        k1_make_layout(cs, cs->k1_layout_groups, cs->k1_layout_target, cs->k1_layout_budget, cs->k1_layout_spread, cs->k1_layout_band_parts);
+        cs->k1_layout_stale = false; cs->k1_layout_gen++;
+    }
+    static const int idle_cuts = env_int("SLAMHIP_K1_IDLE_CUTS", 0);      // (off: measured a LOSS, see below)
+    if (!idle_cuts || !cs->k1_last_valid || cs->k1_uni_ng <= 0 || cs->n_points >= 65536 || !cs->h_scan_blob) return;
+    if (cs->k1_prev_cuts_layout_gen == cs->k1_layout_gen && cs->k1_prev_cuts_points == cs->n_points && cs->k1_prev_cuts_nc == cs->k1_uni_nc &&
+        cs->k1_cut_gen == cs->scan_gen && !cs->k1_prev_cuts.empty()) return;      // (made for this very scan and layout already)
+    static const double cut_wkb = getenv("SLAMHIP_K1_CUT_WKB") ? atof(getenv("SLAMHIP_K1_CUT_WKB")) : 0.0;
+    const double wfix = k1_cut_wfix(cs, cs->k1_last_group);
+    if (!(wfix > 0.0 || cut_wkb > 0.0)) return;
+    cs->k1_cut_cache.clear();
+    cs->k1_cut_gen = cs->scan_gen; cs->k1_cut_layout_gen = cs->k1_layout_gen;
+    k1_cut_weights(cs, cs->k1_layout_groups, cs->k1_layout_spread, wfix, cut_wkb, cs->k1_layout_budget, cs->k1_cut_wb);
+    k1_cuts_make(cs, cs->k1_uni_nc, cs->k1_layout_spread, cs->k1_last_pose, cs->k1_layout_budget, cs->k1_prev_cuts);
+    cs->k1_prev_cuts_nc = cs->k1_uni_nc; cs->k1_prev_cuts_layout_gen = cs->k1_layout_gen; cs->k1_prev_cuts_points = cs->n_points;
+    if (!cs->k1_prev_cuts.empty()) cs->k1_cut_cache.emplace_back(cs->k1_uni_nc, cs->k1_prev_cuts);    // (a second search of THIS scan finds it too)
 }
 
 // K1 over `count` candidates in evaluation order (d_ev_idx maps to flat indices).  mode 0: d_pxcs already holds
@@ -1744,6 +1839,9 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
     const bool sane = cs->pts_sane && cand_sane;
     const bool tiled = sane && (cs->hs % 8 == 0) && !force_global;
     if (cs->k1_prelaunch && !tiled) return CS_RC_NO_PRELAUNCH;      // (the fallback kernels read the scan's blocks on the host)
+#ifdef K1_TIMES
+    if (cs->k1_prelaunch) return CS_RC_NO_PRELAUNCH;               // (the developer build synchronises the stream inside this function: a prelaunched search would wait for a host that waits for it)
+#endif
     const int n_rb = cs->n_rb;
     int32_t *dist = want_dist ? cs->d_dist : nullptr;
     unsigned long long *key = (unsigned long long *)key_dst;
@@ -1852,18 +1950,17 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         // lane), less on coarser maps (smaller tiles, and the 64-ray cap makes blocks long in rays: 1024^2 wants about half, 256^2
         // none) and in proportion to what a ray costs the workgroup (four candidates per lane: a ray takes twice as long, the step
         // does not).  SLAMHIP_K1_CUT_WFIX = 0 and SLAMHIP_K1_CUT_WKB = 0: the equal-count formula everywhere.
-        static const double cut_w20 = getenv("SLAMHIP_K1_CUT_WFIX") ? atof(getenv("SLAMHIP_K1_CUT_WFIX")) : 26.0;
         static const double cut_wkb = getenv("SLAMHIP_K1_CUT_WKB") ? atof(getenv("SLAMHIP_K1_CUT_WKB")) : 0.0;
-        const int cpl_group = group == K1_GROUP_BIG ? 4 : group == K1_GROUP_SMALL ? 1 : 2;
-        const double cut_wfix = cut_w20 * std::min(1.0, (double)cs->hscale / 51.2) * 2.0 / (double)cpl_group;
-        static const int cut_keep = env_int("SLAMHIP_K1_CUT_KEEP", 90);   // per cent of the asked-for ranges a cut must keep
+        const double cut_wfix = k1_cut_wfix(cs, group);
         static const int cut_tab = env_int("SLAMHIP_K1_CUT_TAB", 0);      // (the listed groups too: measured slower)
         const int n_tab = (int)cs->k1_tab_group.size();
         const float pose3[3] = { bx, by, bth };
-        // The cuts cost the host ~7 us (mostly the exact box test of the pieces, k1_cuts_banded_rays) and buy a launch ~1 us: they are
-        // made when a scan is searched for the SECOND time under one layout -- a list searched from many poses, a benchmark loop --
-        // and never in the per-scan flow, where every launch sees a new scan and the host's time between two scans is what counts
-        // (measured there: CoreSLAMProcessor.Update 66 -> 77 us per scan with the cuts made for every scan).  SLAMHIP_K1_CUT_ALWAYS=1: always.
+        // The cuts cost the host ~7 us (mostly the exact box test of the pieces, k1_cuts_banded_rays) and buy a launch 1 - 2 us.  They
+        // are made (a) when a scan is searched for the SECOND time under one layout -- a list searched from many poses, a benchmark
+        // loop -- and (b), round 6, for every scan of the per-scan flow while the host waits for that scan's pose
+        // (cs_layout_idle_refresh: idle time), to be used by the NEXT scan's launch if they are legal for its ray blocks --
+        // consecutive scans look alike, and a cut only balances the launch.  Never on the host's critical path between two scans
+        // (measured there: CoreSLAMProcessor.Update 66 -> 77 us per scan).  SLAMHIP_K1_CUT_ALWAYS=1: always; SLAMHIP_K1_IDLE_CUTS=0: not (b).
         static const int cut_always = env_int("SLAMHIP_K1_CUT_ALWAYS", 0);
         const bool cut_repeat = cut_always || (cs->k1_cut_seen_scan == cs->scan_gen && cs->k1_cut_seen_layout == cs->k1_layout_gen);
         cs->k1_cut_seen_scan = cs->scan_gen; cs->k1_cut_seen_layout = cs->k1_layout_gen;
@@ -1881,34 +1978,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             for (auto &e : cs->k1_cut_cache) if (e.first == nrc) return e.second.empty() ? nullptr : &e.second;
             cs->k1_cut_cache.emplace_back(nrc, std::vector<int>());
             std::vector<int> &c = cs->k1_cut_cache.back().second;
-            // The cut must keep (nearly) the asked-for count of ranges: where blocks are long in rays (coarse maps: a 64-ray block is
-            // one tile) heavy weights end in one block per range -- 17 ranges for 25 at 1024^2 -- and the workgroups that are not
-            // launched cost more than the steps that are saved (measured: 24 -> 33 us).  The weights are scaled down until it does.
-            std::vector<double> &wsc = cs->k1_cut_wsc;
-            double scale = 1.0;
-            for (int tries = 0; tries < 6; tries++, scale *= 0.6) {
-                wsc.resize(cs->k1_cut_wb.size());
-                for (size_t i = 0; i < wsc.size(); i++) wsc[i] = cs->k1_cut_wb[i] * scale;
-                const double tb0 = k1_now_us();
-                const int n = k1_balanced_cuts(cs, nrc, wsc, c);
-                g_cut_t[1] += k1_now_us() - tb0;
-                if (n < 1) { c.clear(); break; }
-                if (n * 100 >= nrc * cut_keep) break;
-                c.clear();
-            }
-            if (!c.empty() && nrc == cs->k1_uni_nc && have_spread) {
-                // a cut that puts more rays on banded tiles (for the uniform part's outer groups) than the equal-count ranges do is
-                // dropped: a banded piece costs its workgroup more than twice a plain one, the launch waits for it (1024^2 map:
-                // four workgroups at 19 us in a 21 us launch)
-                const double tc0 = k1_now_us();
-                const int banded = k1_cuts_banded_rays(cs, c, pose3, budget, cs->k1_cut_cand);
-                g_cut_t[2] += k1_now_us() - tc0;
-                if (banded > 0) {                                  // (seldom: the equal-count ranges are only looked at then)
-                    std::vector<int> eq((size_t)nrc + 1);
-                    for (int k = 0; k <= nrc; k++) eq[(size_t)k] = (int)(((long long)k * cs->n_points) / nrc);
-                    if (banded > k1_cuts_banded_rays(cs, eq, pose3, budget, cs->k1_cut_cand)) c.clear();
-                }
-            }
+            k1_cuts_make(cs, nrc, have_spread, pose3, budget, c);
             return c.empty() ? nullptr : &c;
         };
         static const int cut_times = env_int("SLAMHIP_K1_CUT_TIMES", 0);     // developer aid: host time of the cuts, printed every 64 makes
@@ -1916,8 +1986,16 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         a.uni_cut = 0; a.tab_cut = 0;
         int n_cut = 0;                                                 // entries of a.cut in use
         a.uni_g0 = cs->k1_uni_g0; a.uni_ng = cs->k1_uni_ng > 0 ? cs->k1_uni_ng : 1; a.uni_nc = cs->k1_uni_nc;
+        cs->k1_launch_prev_cuts = false;
         if (cs->k1_uni_ng > 0) {
             const std::vector<int> *c = cuts_for(cs->k1_uni_nc);
+            if (!c && !cuts_on && mode == 1 && !cs->k1_prev_cuts.empty() && cs->k1_prev_cuts_nc == cs->k1_uni_nc && cs->k1_prev_cuts_layout_gen == cs->k1_layout_gen &&
+                cs->k1_prev_cuts_points == cs->n_points && (cs->k1_prelaunch || k1_cuts_legal(cs, cs->k1_prev_cuts))) {
+                // the cut made for the scan before (idle refresh): legal for this scan's blocks -- or, for a launch that precedes its
+                // scan's tables, tested when they exist (cs_k1_layout_legal: the launch is abandoned if it is not)
+                c = &cs->k1_prev_cuts;
+                cs->k1_launch_prev_cuts = true;
+            }
             if (c && (int)c->size() <= K1_MAXCUT) {
                 for (size_t i = 0; i < c->size(); i++) a.cut[i] = (unsigned short)(*c)[i];
                 n_cut = (int)c->size();
@@ -1987,6 +2065,7 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             SH_HIP(hipMemsetAsync((char *)cs->d_k1_gmin + 8, 0, 8, ctx->stream));
         }
         a.gmin = cs->d_k1_gmin; a.done = (unsigned *)((char *)cs->d_k1_gmin + 8); a.acc = cs->d_k1_acc;
+        if (mode == 1) { cs->k1_last_pose[0] = bx; cs->k1_last_pose[1] = by; cs->k1_last_pose[2] = bth; cs->k1_last_group = group; cs->k1_last_valid = true; }
         static const int no_lat = env_int("SLAMHIP_K1_NO_LATTICE", 0);       // (a lattice list through the ordinary kernel: same results, for comparison)
         const bool lat2 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 2 && group == K1_GROUP && cpl == 2;
         const bool lat4 = mode == 1 && !verify && !no_lat && cs->k1_lattice == 4 && group == K1_GROUP_BIG;
@@ -2002,7 +2081,10 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         volatile uint32_t *h_started = (volatile uint32_t *)cs->h_key + 25;
         a.started = (uint32_t *)cs->h_key + 25; a.launch_no = ++cs->k1_launches;
         a.plan_px = nullptr; a.plan_pst = nullptr; a.plan_rec = nullptr; a.plan_seq = 0;
-        bool plan_on = plan_env && mode == 1 && a.grp_bounds != nullptr && !cs->k1_prelaunch && !lat2 && !lat4 && !ctx->mail_off;
+        bool plan_on = plan_env && mode == 1 && a.grp_bounds != nullptr && !lat2 && !lat4 && !ctx->mail_off;
+        // (a search launched ahead of its scan's tables -- the per-scan flow -- gets the candidates' part of the plan only: the tile steps
+        // need the tables, which do not exist yet; its workgroups find no stamped record and plan for themselves)
+        const int n_plan_wgs = cs->k1_prelaunch ? 0 : n_wgs;
         if (plan_on && cs->plan_inputs_after != 0) {
             if ((int32_t)(*h_started - cs->plan_inputs_after) >= 0) cs->plan_inputs_after = 0;
             else { plan_on = false; cs->plan_stats[3]++; }
@@ -2043,12 +2125,12 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             const unsigned slot = cs->plan_count % K1_PLAN_SLOTS;
             if (++cs->plan_seq == 0) cs->plan_seq = 1;
             a.plan_px = cs->d_plan_px[slot]; a.plan_pst = cs->d_plan_pst[slot]; a.plan_rec = cs->d_plan_rec[slot]; a.plan_seq = cs->plan_seq;
-            const dim3 pgrid((unsigned)(n_wgs + sh_div_up(count, 256)));
-            if (group == K1_GROUP_BIG) hipLaunchKernelGGL((k1_plan<K1_GROUP_BIG, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
-            else if (group == K1_GROUP_SMALL) hipLaunchKernelGGL((k1_plan<K1_GROUP_SMALL, 1>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
-            else if (cpl == 4) hipLaunchKernelGGL((k1_plan<K1_GROUP, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
-            else if (cpl == 2) hipLaunchKernelGGL((k1_plan<K1_GROUP, 2>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
-            else hipLaunchKernelGGL((k1_plan<K1_GROUP, 1>), pgrid, dim3(64), 0, cs->plan_stream, a, n_wgs);
+            const dim3 pgrid((unsigned)(n_plan_wgs + sh_div_up(count, 256)));
+            if (group == K1_GROUP_BIG) hipLaunchKernelGGL((k1_plan<K1_GROUP_BIG, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);
+            else if (group == K1_GROUP_SMALL) hipLaunchKernelGGL((k1_plan<K1_GROUP_SMALL, 1>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);
+            else if (cpl == 4) hipLaunchKernelGGL((k1_plan<K1_GROUP, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);
+            else if (cpl == 2) hipLaunchKernelGGL((k1_plan<K1_GROUP, 2>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);
+            else hipLaunchKernelGGL((k1_plan<K1_GROUP, 1>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);
             SH_HIP(hipGetLastError());
             cs->plan_slot_user[slot] = a.launch_no;
             cs->plan_count++; cs->plan_stats[0]++;

@@ -172,11 +172,13 @@ extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_pos
             if (p->lattice) SH_TRY(slamhip_cs_generate_offsets_lattice(p->cs, nj, p->sigma_xy, p->sigma_theta, p->seed, p->scan_no));
             else SH_TRY(slamhip_cs_generate_offsets(p->cs, nj, p->sigma_xy, p->sigma_theta, p->seed, p->scan_no));
         }
-        p->scan_no++;
-        memcpy(p->last_odo, odo, sizeof(odo));                            // :745
         g_pt.lap(2);
         // set_scan (:723), search (:732), NormalizeAngle (:746) and both map updates (:750-751): the search launch first where it can
         SH_TRY(slamhip_cs_scan_search_and_update(p->cs, p->cloud.data(), n, search, p->hole_width, p->quality, p->max_hits, new_pose, nullptr, nullptr));
+        // (state moves only when the scan went through: a failed call leaves the odometry baseline and the list number where they
+        // were, as the reference's exception would -- the next Update searches from the same baseline)
+        p->scan_no++;
+        memcpy(p->last_odo, odo, sizeof(odo));                            // :745
         memcpy(p->pose, new_pose, sizeof(new_pose));                      // :747
         g_pt.lap(3); g_pt.done();
         return SLAMHIP_OK;

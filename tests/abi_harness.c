@@ -26,7 +26,7 @@
  *   abi_harness <libslamhip.so> --bench-hsproc <side> <levels> <rays> <scans>      HectorSLAMProcessor.Update, every scan updating the grids
  *     times slamhip_csproc_update (CoreSLAMProcessor.Update, CoreSLAMProcessor.cs:717-752) from a native caller: what a P/Invoke
  *     caller pays per scan, without an interpreter in the loop (bench.py's own figure goes through Python / ctypes).  The scans are
- *     a rectangular room seen from a slowly moving robot (ranges by ray / wall intersection, made here); prints one line
+ *     the simulator's field (Simulation/Field.cs:45-71) seen from a slowly moving robot (ranges by ray / wall intersection, made here); prints one line
  *     "proc_us_per_scan <x>".  Timing only: parity of this path is tests/test_gpu_coreslam.py's business.
  *
  * Replaces nothing in the reference: it stands where Simulation/MainWindow.xaml.cs:69-72,145-146 would stand if it were a C
@@ -357,13 +357,27 @@ static int32_t (*p_csproc_update)(slamhip_csproc *, const float *, const int32_t
 static int32_t (*p_csproc_get_pose)(slamhip_csproc *, float *);
 static int32_t (*p_ctx_synchronize)(slamhip_ctx *);
 
-/* range from (x, y) along angle a to the walls of the room [5,35] x [8,32] (metres; the robot stays inside) */
+/* range from (x, y) along angle a to the walls of the simulator's field -- the two closed polygons of Simulation/Field.cs:45-71 at
+ * scale 30 m, offset (5, 5) in the 40 m world (Simulation/MainWindow.xaml.cs:97): the scene bench.py's headline scan is cast in
+ * (SURVEY.md sec.8d), so that the search inside CoreSLAMProcessor.Update is comparable with the stand-alone one.  The robot stays
+ * inside the outer polygon and outside the inner one: every ray hits. */
+static const double FIELD_OUTER[12][2] = { {0.00, 0.0}, {1.00, 0.0}, {1.00, 0.2}, {0.80, 0.3}, {0.80, 0.5}, {1.00, 0.4},
+                                           {1.00, 1.0}, {0.6, 1.0}, {0.6, 0.8}, {0.5, 0.8}, {0.5, 1.0}, {0.0, 1.0} };
+static const double FIELD_INNER[4][2] = { {0.2, 0.3}, {0.3, 0.3}, {0.4, 0.7}, {0.3, 0.7} };
+static double seg_hit(double x, double y, double c, double s, const double p0[2], const double p1[2])
+{
+    const double ax = 5.0 + 30.0 * p0[0], ay = 5.0 + 30.0 * p0[1], bx = 5.0 + 30.0 * p1[0], by = 5.0 + 30.0 * p1[1];
+    const double ex = bx - ax, ey = by - ay, den = c * ey - s * ex;
+    if (fabs(den) < 1e-12) return 1e9;
+    const double t = ((ax - x) * ey - (ay - y) * ex) / den, u = ((ax - x) * s - (ay - y) * c) / den;
+    return (t > 1e-9 && u >= 0.0 && u <= 1.0) ? t : 1e9;
+}
 static float room_range(double x, double y, double a)
 {
     const double c = cos(a), s = sin(a);
     double t = 1e9;
-    if (c > 1e-12) t = fmin(t, (35.0 - x) / c); else if (c < -1e-12) t = fmin(t, (5.0 - x) / c);
-    if (s > 1e-12) t = fmin(t, (32.0 - y) / s); else if (s < -1e-12) t = fmin(t, (8.0 - y) / s);
+    for (int i = 0; i < 12; i++) t = fmin(t, seg_hit(x, y, c, s, FIELD_OUTER[i], FIELD_OUTER[(i + 1) % 12]));
+    for (int i = 0; i < 4; i++) t = fmin(t, seg_hit(x, y, c, s, FIELD_INNER[i], FIELD_INNER[(i + 1) % 4]));
     return (float)t;
 }
 

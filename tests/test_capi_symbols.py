@@ -124,5 +124,12 @@ def test_csharp_shim_binds_declared_symbols(capi):
     idle = sorted(f for f, names in families.items() if f not in ("version", "last", "device") and not (set(names) & used))
     assert not idle, idle
     for must in ("slamhip_group_search_and_update", "slamhip_group_generate_offsets", "slamhip_cs_update_maps_pxcs", "slamhip_cs_distance_pxcs",
-                 "slamhip_cs_offsets_download"):
+                 "slamhip_cs_offsets_download",
+                 # round 6: the drop-in HectorSLAMProcessor drives the library's processor (the gate on the device, one wait per scan),
+                 # not MatchData + UpdateByScan from managed code
+                 "slamhip_hsproc_create", "slamhip_hsproc_update", "slamhip_hsproc_get", "slamhip_hsproc_reset", "slamhip_hsproc_set_thresholds", "slamhip_hsproc_hs",
+                 # ... and CoreSLAMProcessor.Update the fused per-scan call that slamhip_csproc_update itself is built on
+                 "slamhip_cs_scan_search_and_update"):
         assert must in used, must
+    hp = open(os.path.join(shim, "HectorSLAM", "HectorSLAMProcessor.Hip.cs")).read()
+    assert "slamhip_hsproc_update" in hp and "MatchData(" not in hp and "UpdateByScan(" not in hp

@@ -1074,6 +1074,28 @@ def test_bench_two_ranks_share_one_gpu():
     assert j2["multi_gpu"]["replicas_equal"] is True                   # (both ranks built their HoleMap by the same updates)
     assert j2["config"]["winner_matches_oracle"] is True               # (N > 1: rank 0 checks the reduced key against one oracle search over the whole list)
     assert j1["roofline"]["launches"] == 20
+    # ONE form at every N: `value` is the enqueue-only search (+ the exchange) at N = 2 as at N = 1, and the blocking per-scan figure
+    # stands beside it at both
+    m = j2["multi_gpu"]
+    for k in ("us_per_step", "single_rank_same_form_us_per_step", "efficiency_same_form", "per_scan_blocking_us_per_step"):
+        assert m[k] > 0, k
+    assert abs(m["us_per_step"] - j2["ms_per_step"] * 1e3) < 1e-6
+    assert j2["config"]["per_scan_blocking_us_per_step"] > 0 and j1["config"]["per_scan_blocking_us_per_step"] > 0
+    assert "its key equals the timed region's: True" in j1["config"]["per_scan_blocking_is"]
+    assert "its key equals the timed region's: True" in j2["config"]["per_scan_blocking_is"]
+    assert "multi_gpu" not in j1
+    # the N = 1 line's value is reproduced by --gpus 1 under torch.distributed.run (the launcher the driver uses for N > 1)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port1 = so.getsockname()[1]
+    r1d = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port1), os.path.join(root, "bench.py"), "--gpus", "1", "--cands", "8192"] + common,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r1d.returncode == 0, r1d.stderr.decode(errors="replace")[-3000:]
+    j1d = json.loads([l for l in r1d.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert (j1d["config"]["best_index"], j1d["config"]["best_distance"]) == (j1["config"]["best_index"], j1["config"]["best_distance"])
+    assert j1d["n_gpus"] == 1 and "multi_gpu" not in j1d and j1d["config"]["timed_region"] == j1["config"]["timed_region"]
+    assert 0.5 < j1d["value"] / j1["value"] < 2.0                      # (the same form: the same figure, up to the noise of a 20-step region)
 
 
 def test_fuzz_parity_short():
@@ -1743,5 +1765,7 @@ def test_bench_library_collective_one_rank():
     assert "libslamhip" in j["config"]["collective"] and j["config"]["collective_ranks"] == 1
     m = j["multi_gpu"]
     assert m["replicas_equal"] is True and m["allreduce_us"] > 0
+    assert m["us_per_step"] > 0 and m["per_scan_blocking_us_per_step"] > m["us_per_step"] * 0.5 and 0 < m["efficiency_same_form"] < 2.0
+    assert "its key equals the timed region's: True" in j["config"]["per_scan_blocking_is"]
     f = m["fused_scan_allreduce_and_update"]
     assert f["first_scan_key_equals_search_key"] is True and f["replicas_equal_after"] is True and f["us_per_scan"] > 0, f

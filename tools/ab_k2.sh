@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 tags=${@:-$(ls $root/slam.net_amd/build/variants/*.so | xargs -n1 basename | sed 's/.so$//')}
 for rep in 1 2 3; do
   for t in $tags; do
-    out=/tmp/ab_$t_$rep; rm -rf $out
+    out=/tmp/ab_${t}_${rep}; rm -rf $out
     SLAMHIP_LIB=$root/slam.net_amd/build/variants/$t.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o s -- python3 $root/tools/${AB_SCRIPT:-prof_k2.py} > /dev/null 2>&1
     python3 - "$out" "$t" "$rep" <<'PY'
 import csv, glob, sys

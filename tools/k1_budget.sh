@@ -8,8 +8,11 @@ out=$root/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 bench="python3 $root/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras"
 : > $out/k1_budget.txt
+# (the EXP builds compute WRONG results: they are side variants selected with SLAMHIP_LIB -- tools/build_variant.py -- and never replace
+# slam.net_amd/libslamhip.so, so a killed run leaves the tree's library as it was)
 for e in 0 1 2 3 4; do
-  (cd $root && SLAMHIP_K1_EXP=$e python3 -m slam.net_amd.build --force > /dev/null 2>&1)
+  (cd $root && python3 tools/build_variant.py WORK k1exp$e -DK1_EXP=$e > /dev/null 2>&1)
+  export SLAMHIP_LIB=$root/slam.net_amd/build/variants/k1exp$e.so
   rm -rf /tmp/k1b_$e
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k1b_$e/st -o s -- $bench > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d /tmp/k1b_$e/pm -o p -- $bench > /dev/null 2>&1
@@ -32,5 +35,5 @@ for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
 print(line)
 PY
 done
-(cd $root && python3 -m slam.net_amd.build --force > /dev/null 2>&1)
+unset SLAMHIP_LIB
 cat $out/k1_budget.txt

@@ -25,6 +25,8 @@ run write     --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write 
 run tcc       --kernel-trace --pmc TCC_HIT TCC_MISS --output-format csv -d $out/tcc -o p -- $bench
 run sq1       --kernel-trace --pmc $SQ1 --output-format csv -d $out/sq1 -o p -- $bench
 run sq2       --kernel-trace --pmc $SQ2 --output-format csv -d $out/sq2 -o p -- $bench
+run grbm      --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/grbm -o p -- $bench
+run grbm_262k --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/grbm_262k -o p -- $bench --cands 262144 --steps 50
 run sq1_262k  --kernel-trace --pmc $SQ1 --output-format csv -d $out/sq1_262k -o p -- $bench --cands 262144 --steps 50
 run sq2_262k  --kernel-trace --pmc $SQ2 --output-format csv -d $out/sq2_262k -o p -- $bench --cands 262144 --steps 50
 k2="python3 $root/tools/prof_k2.py"

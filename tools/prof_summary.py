@@ -58,7 +58,7 @@ def bench_line(name):
 if "--collect" in sys.argv:
     out = {"stats": stats("stats"), "stats262k": stats("stats262k"), "k2stats": stats("k2stats"), "k5stats": stats("k5stats"), "k4stats": stats("k4stats"),
            "k4bstats": stats("k4bstats")}
-    for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2",
+    for sub in ("grbm", "grbm_262k", "fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2",
                 "k5fetch", "k5write", "k5sq1", "k5sq2", "k4fetch", "k4write", "k4sq1", "k4sq2"):
         out[sub] = pmc(sub)
     for name in ("timeline_c3.txt", "timeline_csproc.txt", "timeline_csproc_launch_ahead.txt", "timeline_hsproc.txt"):
@@ -123,7 +123,7 @@ if k1:
 
 
 # 4. SQ counters of K1: where the cycles of a launch go
-def sq_summary(s1, s2, kernel, avg_ns):
+def sq_summary(s1, s2, kernel, avg_ns, grbm=None):
     a, b = s1.get(kernel, {}), s2.get(kernel, {}) if s2 else {}
     if not a:
         return None
@@ -146,9 +146,28 @@ def sq_summary(s1, s2, kernel, avg_ns):
     if b and b.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_fraction_of_lds_cycles"] = b.get("SQ_LDS_BANK_CONFLICT", 0.0) / b["SQ_LDS_IDX_ACTIVE"]
     if avg_ns and a.get("SQ_INSTS_VALU"):
-        # 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU quad-cycles on average
-        d["valu_busy_us_per_simd_if_evenly_spread"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / 2.1e3
-        d["note"] = "quad-cycle counters (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*) count 4-cycle units (MI355X_MICROARCH.md); the busy estimate assumes 2.1 GHz"
+        # The shader clock of THIS profile (MI355X_MICROARCH.md: effective clock = GRBM_GUI_ACTIVE / kernel wall time; profiled passes
+        # clock lower than plain runs): GRBM_GUI_ACTIVE of the same kernel from its own pass (the counter is summed over the 8 XCDs
+        # when it comes out above the 2.4 GHz maximum: divided back), else SQ_BUSY_CYCLES / 32 shader engines.
+        gui = (grbm or {}).get(kernel, {}).get("GRBM_GUI_ACTIVE")
+        clk, how = None, None
+        if gui:
+            clk = gui / avg_ns
+            if clk > 2.6:
+                clk /= 8.0
+            how = "GRBM_GUI_ACTIVE / launch duration"
+        elif a.get("SQ_BUSY_CYCLES"):
+            clk = a["SQ_BUSY_CYCLES"] / 32.0 / avg_ns
+            how = "SQ_BUSY_CYCLES / 32 shader engines / launch duration"
+        if clk:
+            d["shader_clock_ghz_measured"] = clk
+            d["shader_clock_how"] = how
+            # 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU quad-cycles on average
+            busy = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / (clk * 1e3)
+            d["valu_busy_us_per_simd_if_evenly_spread"] = busy
+            d["valu_busy_consistent"] = bool(busy <= avg_ns * 1e-3)
+            assert busy <= avg_ns * 1e-3 * 1.02, "VALU busy time %.2f us exceeds the launch's %.2f us: the counter's unit or the clock is wrong" % (busy, avg_ns * 1e-3)
+        d["note"] = "quad-cycle counters (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*) count 4-cycle units (MI355X_MICROARCH.md); the busy estimate uses the clock measured in this profile"
     out["derived"] = d
     return out
 
@@ -157,8 +176,8 @@ k1s = k1_of(c["sq1"])
 if k1s:
     json.dump({
         "command": "tools/prof_bench.sh: rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes) -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras [--cands 262144 --steps 50]",
-        "headline_16384_candidates": sq_summary(c["sq1"], c["sq2"], k1s, float(k1row["AverageNs"]) if k1row else None),
-        "at_262144_candidates": sq_summary(c["sq1_262k"], c.get("sq2_262k") or None, k1_of(c["sq1_262k"]) or "", float(k1row262["AverageNs"]) if k1row262 else None),
+        "headline_16384_candidates": sq_summary(c["sq1"], c["sq2"], k1s, float(k1row["AverageNs"]) if k1row else None, c.get("grbm")),
+        "at_262144_candidates": sq_summary(c["sq1_262k"], c.get("sq2_262k") or None, k1_of(c["sq1_262k"]) or "", float(k1row262["AverageNs"]) if k1row262 else None, c.get("grbm_262k")),
     }, open(os.path.join(dst, tag + "_k1_sq.json"), "w"), indent=1)
 
 # 5. the HoleMap update: traffic and SQ counters of its kernel(s)
@@ -201,7 +220,7 @@ for name, outn in (("timeline_c3.txt", "_timeline_c3.txt"), ("timeline_csproc.tx
     if c.get(name):
         open(os.path.join(dst, tag + outn), "w").write(c[name])
 
-json.dump({k: c.get(k) for k in ("fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2",
+json.dump({k: c.get(k) for k in ("grbm", "grbm_262k", "fetch", "write", "tcc", "sq1", "sq2", "sq1_262k", "sq2_262k", "k2fetch", "k2write", "k2tcc", "k2sq1", "k2sq2",
                                  "k5fetch", "k5write", "k5sq1", "k5sq2", "k4fetch", "k4write", "k4sq1", "k4sq2")},
           open(os.path.join(dst, tag + "_bench_pmc_per_kernel.json"), "w"), indent=1)
 print("wrote profiles/%s_*; K1 rocprof avg %s ns (262144 candidates: %s ns)" % (tag, k1row["AverageNs"] if k1row else "?", k1row262["AverageNs"] if k1row262 else "?"))
