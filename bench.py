@@ -219,6 +219,11 @@ def main():
         for _ in range(a.clock_warmup):
             step()
         sync_all()
+        # (two milliseconds for the HIP runtime's own housekeeping: right behind thousands of launches its launch calls take 2 - 5 x as long
+        # for the next ~25 calls -- measured with the search's two launches per step: the first 20-step region behind the warm-up 19 - 24 us
+        # per step, every later one, or the first one behind this pause, 17.2 - 17.6; short enough for the clocks to stay up: tens of
+        # milliseconds let them fall)
+        time.sleep(0.002)
     for _ in range(max(a.warmup, 1)):
         final_key = step()
     sync_all()
@@ -236,14 +241,12 @@ def main():
     if two_events:
         ev0.record(ext)
     t0 = time.perf_counter()
-    if os.environ.get("SLAMHIP_BENCH_STEP_TIMES"):                 # developer aid: the host's time per step inside the timed region (stderr)
-        ts = [t0]
+    step_ts = None
+    if os.environ.get("SLAMHIP_BENCH_STEP_TIMES"):                 # developer aid: the host's time per step inside the timed region (printed after it)
+        step_ts = [t0]
         for _ in range(a.steps):
             final_key = step()
-            ts.append(time.perf_counter())
-        dts = np.diff(ts) * 1e6
-        print("bench.py host us per step: mean %.2f p50 %.2f p90 %.2f max %.2f; the ten longest: %s at %s" %
-              (dts.mean(), np.median(dts), np.percentile(dts, 90), dts.max(), np.round(np.sort(dts)[-10:], 1), np.argsort(dts)[-10:]), file=sys.stderr)
+            step_ts.append(time.perf_counter())
     else:
         for _ in range(a.steps):
             final_key = step()
@@ -257,6 +260,11 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if step_ts is not None:
+        dts = np.diff(step_ts) * 1e6
+        print("bench.py host us per step: mean %.2f p50 %.2f p90 %.2f max %.2f; enqueue done after %.1f us, the region's end (event, synchronise) took %.1f us; %s"
+              % (dts.mean(), np.median(dts), np.percentile(dts, 90), dts.max(), (step_ts[-1] - t0) * 1e6, (t0 + elapsed - step_ts[-1]) * 1e6,
+                 ("all steps: %s" % np.round(dts, 1)) if a.steps <= 40 else ("the ten longest: %s" % np.round(np.sort(dts)[-10:], 1))), file=sys.stderr)
     if comm is not None:
         final_key = comm.wait()                                    # (flushes the last batch of keys; the reduced key of the last step)
     else:

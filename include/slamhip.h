@@ -236,9 +236,9 @@ int32_t slamhip_cs_search_shard_async(slamhip_cs *cs, const float search_pose[3]
  * candidates min their keys straight into the word (the previous call's launch left it all ones), and the end of the launch is
  * the completion (the cross-thread arg-min of :695-705 as fire-and-forget atomics).  slamhip_cs_key_read waits for the handle's
  * stream and copies one such word to the host.
- * Backpressure (round 6): every search launch is accompanied by its plan (slamhip_cs_plan_stats), whose buffers exist four times, so
- * a caller that enqueues searches faster than the device runs them is held in this call until the search three launches back has
- * started (the device still has two searches queued: nothing idles) -- at most 20 ms or the context's wait bound, whichever is
+ * Backpressure (round 6): every such launch is accompanied by its plan (slamhip_cs_plan_stats), whose buffers exist eight times, so
+ * a caller that enqueues searches faster than the device runs them is held in this call until the search seven launches back has
+ * started (the device still has six searches queued: nothing idles) -- at most 20 ms or the context's wait bound, whichever is
  * shorter; past that the search is launched without a plan. */
 int32_t slamhip_cs_search_shard_enqueue(slamhip_cs *cs, const float search_pose[3], int32_t first, int32_t count,
                                         const uint64_t **d_key);
@@ -276,12 +276,13 @@ int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out_failures);
  * count, a new candidate list, SLAMHIP_PRELAUNCH=0 ...).  The results do not depend on the path taken. */
 int32_t slamhip_cs_prelaunch_stats(slamhip_cs *cs, uint64_t out[4]);
 
-/* Diagnostics of the search's PLAN (round 6; replaces nothing in the reference -- it is how CalculateDistanceSISD's candidate transform,
- * CoreSLAMProcessor.cs:232-235, is made once per candidate instead of once per candidate and ray range): every search launch of the
- * tiled kernel is accompanied by one small launch on a stream of its own that leaves each candidate's (px, py, c, s) and each
- * workgroup's tile steps in device memory, stamped; the search kernel uses what carries its stamp and works out the rest itself.
- * out[0] searches launched with a plan, out[1] without (explicit pose lists, lattice lists, prelaunched searches, SLAMHIP_K1_PLAN=0),
- * out[2] times the host waited for a free plan slot (it was four searches ahead of the device), out[3] plans not launched because a
+/* Diagnostics of the search's PLAN (round 6; replaces nothing in the reference -- it takes the per-workgroup planning of the batched
+ * CalculateDistanceSISD, CoreSLAMProcessor.cs:226-259, off the search launch's critical path): every search launch of the
+ * tiled kernel in its enqueue-only form is accompanied by one small launch on a stream of its own that leaves each workgroup's tile
+ * steps (bounds -> boxes -> steps: what its prologue would work out in front of its first tile) in device memory, stamped; a workgroup
+ * uses the record that carries its stamp and plans for itself otherwise.
+ * out[0] searches launched with a plan, out[1] without (blocking searches, explicit pose lists, lattice lists, prelaunched searches,
+ * SLAMHIP_K1_PLAN=0), out[2] times the host waited for a free plan slot (it was seven searches ahead of the device), out[3] plans not launched because a
  * launch that writes their inputs (candidate gather, scan upload) had not been seen to finish.  Results never depend on the path. */
 int32_t slamhip_cs_plan_stats(slamhip_cs *cs, uint64_t out[4]);
 

@@ -1597,8 +1597,8 @@ extern "C" int32_t slamhip_cs_selfcheck_failures(slamhip_cs *cs, uint32_t *out)
     SH_HIP(hipStreamSynchronize(cs->ctx->stream));
     *out = h[0];
     if (getenv("SLAMHIP_K1_STATS"))
-        fprintf(stderr, "[slamhip] K1 step kinds (ray x sub-batch units): group tile %u, sub-batch tiles %u, banded %u, global gathers %u; plan: workgroups with their record %u, without %u, wavefront slots with stamped candidates %u\n",
-                h[1], h[2], h[4], h[3], h[5], h[6], h[7]);
+        fprintf(stderr, "[slamhip] K1 step kinds (ray x sub-batch units): group tile %u, sub-batch tiles %u, banded %u, global gathers %u; plan: workgroups with their record %u, without %u\n",
+                h[1], h[2], h[4], h[3], h[5], h[6]);
     return SLAMHIP_OK;
 }
 

@@ -16,7 +16,7 @@
 #define K1_GROUP_BIG 2048              // ... or 512 lanes x 4 for large searches,
 #define K1_RING_SLOTS 4                // result words of the enqueue-only search (valid until K1_RING_SLOTS - 1 further ring launches)
 #define K1_GROUP_SMALL 512             // 512 lanes x 1 for small ones (slamhip_cs::k1_group, ensure_shard)
-#define K1_PLAN_SLOTS 4                // plans of searches in flight (distance.hip: a slot is reused when the search that read it has finished)
+#define K1_PLAN_SLOTS 8                // plans of searches in flight (distance.hip: a slot is reused when the search that read it has finished)
 
 
 // k1_make_layout (distance.hip): a ray block's terms of the cost estimate that do not depend on the candidate group
@@ -126,8 +126,8 @@ struct slamhip_cs {
     uint64_t *k1_ring_last;       // ... and this is the slot it used
     // the search's plan (distance.hip, k1_plan): K1_PLAN_SLOTS sets of buffers used in turn, filled on a stream of their own
     hipStream_t plan_stream;
-    float4 *d_plan_px[K1_PLAN_SLOTS]; uint32_t *d_plan_pst[K1_PLAN_SLOTS]; uint2 *d_plan_rec[K1_PLAN_SLOTS];
-    int plan_cap_cand, plan_cap_wgs;
+    uint2 *d_plan_rec[K1_PLAN_SLOTS];
+    int plan_cap_wgs;
     uint32_t plan_seq;            // stamps handed out (a stamp is never 0 and never reused while its slot holds it)
     uint32_t plan_count;          // plans launched (slot = plan_count % K1_PLAN_SLOTS)
     uint32_t k1_launches;         // tiled search launches so far: each stores its number into word 25 of h_key when it STARTS (k1_args::started)

@@ -235,16 +235,12 @@ struct k1_args {
     // starts -- the workgroups that finish candidates min their keys straight into it (no return, no count, no last finisher: the
     // END OF THE LAUNCH is the completion) -- and this launch leaves the NEXT slot all ones for the next one.  Null: key_out + the chain.
     unsigned long long *ring_slot, *ring_reset;
-    // The PLAN of a search (k1_plan, launched beside the search on a stream of its own, round 6): what a workgroup's prologue used to
-    // work out before its first tile -- every candidate's (px, py, c, s) (the deterministic trigonometry, once per candidate instead of
-    // once per candidate and ray range) and every workgroup's step records (bounds -> boxes -> tile steps) -- left in device memory and
-    // STAMPED with the plan's number: a workgroup that finds its record stamped plan_seq takes its steps from it, a wavefront that
-    // finds its 64 candidates' stamp takes their (px, py, c, s) from plan_px, anything else is worked out as before (a plan that is
-    // late, or was never made, costs time, never a result).  plan_px: (px, py, c, s) per candidate in evaluation order; plan_pst: one
-    // stamp per 64 candidates, stored after its candidates were written back -- and plan_px is only READ by a wavefront that has
-    // seen the stamp (no line of it can be in a cache from before); plan_rec: K1_PLAN_REC_WORDS words per workgroup, every 8-word
-    // unit carrying its own stamp (see k1_plan).  Null: no plan.
-    float4 *plan_px; uint32_t *plan_pst; uint2 *plan_rec; uint32_t plan_seq;
+    // The PLAN of a search (k1_plan, launched beside the search on a stream of its own, round 6): every workgroup's step records
+    // (bounds -> boxes -> tile steps: what its prologue used to work out before its first tile), left in device memory and STAMPED
+    // with the plan's number: a workgroup that finds its record stamped plan_seq takes its steps from it, any other plans for
+    // itself as before (a plan that is late, or was never made, costs time, never a result).  plan_rec: K1_PLAN_REC_WORDS words per
+    // workgroup, every 8-word unit carrying its own stamp (see k1_plan).  Null: no plan.
+    uint2 *plan_rec; uint32_t plan_seq;
     uint32_t *started; uint32_t launch_no;          // workgroup 0 stores launch_no here when the launch starts (pinned host word): everything before it in the stream has finished
     const uint32_t *scan_flag; uint32_t scan_seq;   // a launch that precedes its scan's tables (cs_search_and_update_prelaunched): wait here for scan_seq; bit 31 set: leave
     // launch layout: first the workgroups of the listed groups (expensive ones: more, smaller chunks), then the
@@ -380,7 +376,7 @@ template <bool MAX> __device__ static inline float k1_wave_redf(float x)      //
 
 // Which (candidate group, ray range) a workgroup of the search launch works on: the launch layout of k1_args (shared by the search
 // kernel and the plan kernel, which must agree).
-struct k1_wg_t { int g, nc, nbp, bp, rlo, rhi; };
+struct k1_wg_t { int g, nc, nbp, bp, rlo, rhi, chunk; };
 __device__ __forceinline__ k1_wg_t k1_wg_decode(const k1_args &a, const int bid)
 {
     int g, chunk, nc, nbp = 1;
@@ -421,7 +417,7 @@ __device__ __forceinline__ k1_wg_t k1_wg_decode(const k1_args &a, const int bid)
     if (a.n_rays <= 46340) {                                       // (rc < nrc <= n_rays: the products fit 32 bits; the 64-bit division is a hundred scalar instructions)
         rlo = (int)(((unsigned)rc * (unsigned)a.n_rays) / (unsigned)nrc); rhi = (int)(((unsigned)(rc + 1) * (unsigned)a.n_rays) / (unsigned)nrc);
     } else { rlo = (int)(((long long)rc * a.n_rays) / nrc); rhi = (int)(((long long)(rc + 1) * a.n_rays) / nrc); }
-    k1_wg_t W; W.g = g; W.nc = nc; W.nbp = nbp; W.bp = bp; W.rlo = rlo; W.rhi = rhi;
+    k1_wg_t W; W.g = g; W.nc = nc; W.nbp = nbp; W.bp = bp; W.rlo = rlo; W.rhi = rhi; W.chunk = chunk;
     return W;
 }
 
@@ -573,22 +569,10 @@ k1_search_tiled(const k1_args a)
 #pragma unroll
         for (int k = 0; k < 6; k++) gb[k] = a.grp_bounds[8 * (size_t)g + k];
     }
-    // The plan (k1_args): the workgroup's record -- wave 0, one 8-byte load per lane -- and the stamps of the lanes' candidates come
-    // with the first round trip; a wavefront whose stamp is the plan's reads (px, py, c, s) under the first tile's loads instead of
-    // making them, and needs no jitters.
+    // The plan (k1_args): the workgroup's record -- wave 0, one 8-byte load per lane -- comes with the first round trip.
     const bool planned = MODE == 1 && !LAT && pre && a.plan_rec != nullptr;
     uint2 prw = make_uint2(0u, 0u);
-    uint32_t pst[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; k++) pst[k] = 0u;
-    if (planned) {
-        if (wv == 0) prw = a.plan_rec[(size_t)blockIdx.x * (K1_PLAN_REC_WORDS / 2) + lane];
-#pragma unroll
-        for (int k = 0; k < CPL; k++) {
-            const int j = g * GROUP + k * LANES + t;
-            pst[k] = a.plan_pst[(j < count ? j : count - 1) >> 6];
-        }
-    }
+    if (planned && wv == 0) prw = a.plan_rec[(size_t)blockIdx.x * (K1_PLAN_REC_WORDS / 2) + lane];
     float4 q[CPL];
     float c3[CPL][3];
 #pragma unroll
@@ -596,7 +580,7 @@ k1_search_tiled(const k1_args a)
         const int j = g * GROUP + k * LANES + t;
         const int jc = j < count ? j : count - 1;
         if (MODE == 0) q[k] = a.pxcs[jc];
-        else if (!planned) { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
+        else { c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2]; }
     }
     int4 rinfo[RU];
     float2 rpt[RU];
@@ -773,33 +757,7 @@ k1_search_tiled(const k1_args a)
         K1_PREFETCH(0, true)
 #endif
         if (MODE != 0 && pre) {                                    // (the first tile's loads are in flight)
-            // With a plan, a wavefront whose candidates carry the plan's stamp (64 candidates of a slot share one: the choice is per
-            // wavefront, a scalar branch) reads (px, py, c, s); any other makes them as ever -- from jitters it loads now, a second
-            // round trip behind the tile's.  (ONE site for the trigonometry: a second, conditional copy of it cost the kernel 23
-            // vector registers.)
-            bool make = true;
-            if (planned) {
-                bool all_ok = true;
-#pragma unroll
-                for (int k = 0; k < CPL; k++) all_ok = all_ok && pst[k] == a.plan_seq;
-                if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {
-                    make = false;
-#pragma unroll
-                    for (int k = 0; k < CPL; k++) {
-                        const int j = g * GROUP + k * LANES + t;
-                        q[k] = a.plan_px[j < count ? j : count - 1];
-                    }
-                    if (VERIFY && lane == 0) atomicAdd(a.verify + 7, (unsigned)CPL);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < CPL; k++) {
-                        const int j = g * GROUP + k * LANES + t;
-                        const int jc = j < count ? j : count - 1;
-                        c3[k][0] = a.src3[3 * jc]; c3[k][1] = a.src3[3 * jc + 1]; c3[k][2] = a.src3[3 * jc + 2];
-                    }
-                }
-            }
-            if (make) {
+            {
 #pragma unroll
             for (int k = 0; k < CPL; k++) { if (K1_EXP == 1) q[k] = make_float4(a.bx * a.scale + c3[k][0], a.by * a.scale + c3[k][1], a.scale, c3[k][2]); else q[k] = k1_candidate<MODE == 0 ? 1 : MODE, true>(c3[k], a.bx, a.by, a.bth, a.scale); }
             }
@@ -1150,7 +1108,7 @@ k1_search_tiled(const k1_args a)
 
 // ---- the plan kernel --------------------------------------------------------------------------------------------
 // One launch per search, on a stream of its own beside the search launch (cs_launch_distance): what every workgroup of k1_search_tiled
-// would otherwise work out in front of its first tile, made ONCE and left in device memory (k1_args: plan_px, plan_pst, plan_rec).
+// would otherwise work out in front of its first tile, made ONCE and left in device memory (k1_args: plan_rec).
 //   blocks [0, n_wgs)       one wavefront per workgroup of the search launch: its ray range (k1_wg_decode -- the same layout), the group's
 //                           bounds from the jitter bounds, the boxes and step records of its pieces (k1_pieces.inc -- the same text), and
 //                           the record: 16 units of 8 words, [0] = {stamp, steps or -1, ...}, [1 + i] = step i, word 7 of every unit =
@@ -1167,26 +1125,7 @@ k1_plan(const k1_args a, const int n_wgs)
     constexpr int NW = 1, PF = 64;                                  // (k1_pieces.inc: PF * NW = the search workgroup's 64 staging vectors per lane and wave)
     const int lane = threadIdx.x, wv = 0;
     const uint32_t seq = a.plan_seq;
-    if ((int)blockIdx.x >= n_wgs) {
-        const int j0 = ((int)blockIdx.x - n_wgs) * 256 + lane;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = j0 + 64 * k;
-            if (j < a.count) {
-                const float c3[3] = { a.src3[3 * j], a.src3[3 * j + 1], a.src3[3 * j + 2] };
-                const float4 q = k1_candidate<1, true>(c3, a.bx, a.by, a.bth, a.scale);
-                // (agent-scope stores go THROUGH this XCD's L2 to memory; a release fence instead -- a write-back of the whole L2, once
-                // per block, under the running search whose accumulators live there -- cost the search launch beside it more than a microsecond)
-                unsigned long long *dst = (unsigned long long *)(a.plan_px + j);
-                __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(q.y) << 32) | __float_as_uint(q.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(q.w) << 32) | __float_as_uint(q.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every store above has been performed at the memory side
-        if (lane < 4 && j0 - lane + 64 * lane < a.count)
-            __hip_atomic_store(a.plan_pst + (((int)blockIdx.x - n_wgs) * 4 + lane), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
+    if ((int)blockIdx.x >= n_wgs) return;
     // (little LDS and few registers: these wavefronts share the compute units with the search launch before this one, which leaves
     // ~23 KB of LDS and 96 registers per lane free -- the rays are read from memory where the search kernel keeps a copy in LDS,
     // and only the records that fit a plan record are kept)
@@ -1239,10 +1178,10 @@ void cs_plan_free(slamhip_cs *cs)
 {
     if (cs->plan_stream) (void)hipStreamSynchronize(cs->plan_stream);
     for (int i = 0; i < K1_PLAN_SLOTS; i++) {
-        (void)hipFree(cs->d_plan_px[i]); (void)hipFree(cs->d_plan_pst[i]); (void)hipFree(cs->d_plan_rec[i]);
-        cs->d_plan_px[i] = nullptr; cs->d_plan_pst[i] = nullptr; cs->d_plan_rec[i] = nullptr; cs->plan_slot_user[i] = 0;
+        (void)hipFree(cs->d_plan_rec[i]);
+        cs->d_plan_rec[i] = nullptr; cs->plan_slot_user[i] = 0;
     }
-    cs->plan_cap_cand = cs->plan_cap_wgs = 0;
+    cs->plan_cap_wgs = 0;
 }
 
 int32_t cs_alloc_candidates(slamhip_cs *cs, int count)
@@ -2080,30 +2019,38 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         static const int plan_env = env_int("SLAMHIP_K1_PLAN", 1);
         volatile uint32_t *h_started = (volatile uint32_t *)cs->h_key + 25;
         a.started = (uint32_t *)cs->h_key + 25; a.launch_no = ++cs->k1_launches;
-        a.plan_px = nullptr; a.plan_pst = nullptr; a.plan_rec = nullptr; a.plan_seq = 0;
-        bool plan_on = plan_env && mode == 1 && a.grp_bounds != nullptr && !lat2 && !lat4 && !ctx->mail_off;
-        // (a search launched ahead of its scan's tables -- the per-scan flow -- gets the candidates' part of the plan only: the tile steps
-        // need the tables, which do not exist yet; its workgroups find no stamped record and plan for themselves)
-        const int n_plan_wgs = cs->k1_prelaunch ? 0 : n_wgs;
+        a.plan_rec = nullptr; a.plan_seq = 0;
+        // Which launches get one: the enqueue-only searches (result-ring form: the throughput form, fused scans, the all-reduce forms)
+        // -- their launch normally waits in the stream behind earlier work, so the plan has time to arrive.  Not a blocking search on
+        // its own (the launch starts at once: the plan would only arrive late and cost the host a launch; measured 27.8 -> 31.6 us
+        // per blocking call with it), and not a search launched ahead of its scan's tables -- the per-scan flow: the tile steps need
+        // the tables, which do not exist yet.  (Measured and dropped in round 6: the candidates' (px, py, c, s) made once per search --
+        // by the plan launch, or shared between a group's workgroups inside the search launch through memory -- instead of by every
+        // workgroup: reading them back costs a launch what the trigonometry does, 15.2 us with or without at the headline size.)
+        bool plan_on = plan_env && mode == 1 && ring && a.grp_bounds != nullptr && !cs->k1_prelaunch && !lat2 && !lat4 && !ctx->mail_off;
+        const int n_plan_wgs = n_wgs;
         if (plan_on && cs->plan_inputs_after != 0) {
             if ((int32_t)(*h_started - cs->plan_inputs_after) >= 0) cs->plan_inputs_after = 0;
             else { plan_on = false; cs->plan_stats[3]++; }
         }
         if (plan_on) {
-            if (!cs->plan_stream) SH_HIP(hipStreamCreateWithFlags(&cs->plan_stream, hipStreamNonBlocking));
-            if (count > cs->plan_cap_cand || n_wgs > cs->plan_cap_wgs) {
+            if (!cs->plan_stream) {
+                // (the highest priority the device offers: a plan is a few hundred short wavefronts that share the compute units with a
+                // search launch in full flight -- at equal priority they trickle in as that launch's workgroups retire, ~10 us)
+                int prio_lo = 0, prio_hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+                SH_HIP(hipStreamCreateWithPriority(&cs->plan_stream, hipStreamNonBlocking, prio_hi));
+            }
+            if (n_wgs > cs->plan_cap_wgs) {
                 SH_HIP(hipStreamSynchronize(ctx->stream));          // (searches in flight read the buffers)
-                const int cc = std::max(cs->plan_cap_cand, count + count / 4 + 256), cw = std::max(cs->plan_cap_wgs, n_wgs + n_wgs / 4 + 64);
+                const int cw = std::max(cs->plan_cap_wgs, n_wgs + n_wgs / 4 + 64);
                 cs_plan_free(cs);
                 for (int i = 0; i < K1_PLAN_SLOTS; i++) {
-                    SH_HIP(hipMalloc(&cs->d_plan_px[i], sizeof(float4) * (size_t)cc));
-                    SH_HIP(hipMalloc(&cs->d_plan_pst[i], sizeof(uint32_t) * (size_t)(cc / 64 + 8)));
                     SH_HIP(hipMalloc(&cs->d_plan_rec[i], sizeof(uint32_t) * K1_PLAN_REC_WORDS * (size_t)cw));
-                    SH_HIP(hipMemsetAsync(cs->d_plan_pst[i], 0, sizeof(uint32_t) * (size_t)(cc / 64 + 8), cs->plan_stream));
                     SH_HIP(hipMemsetAsync(cs->d_plan_rec[i], 0, sizeof(uint32_t) * K1_PLAN_REC_WORDS * (size_t)cw, cs->plan_stream));
                 }
                 SH_HIP(hipStreamSynchronize(cs->plan_stream));
-                cs->plan_cap_cand = cc; cs->plan_cap_wgs = cw;
+                cs->plan_cap_wgs = cw;
             }
             const unsigned slot = cs->plan_count % K1_PLAN_SLOTS;
             const uint32_t user = cs->plan_slot_user[slot];
@@ -2124,8 +2071,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         if (plan_on) {
             const unsigned slot = cs->plan_count % K1_PLAN_SLOTS;
             if (++cs->plan_seq == 0) cs->plan_seq = 1;
-            a.plan_px = cs->d_plan_px[slot]; a.plan_pst = cs->d_plan_pst[slot]; a.plan_rec = cs->d_plan_rec[slot]; a.plan_seq = cs->plan_seq;
-            const dim3 pgrid((unsigned)(n_plan_wgs + sh_div_up(count, 256)));
+            a.plan_rec = cs->d_plan_rec[slot]; a.plan_seq = cs->plan_seq;
+            const dim3 pgrid((unsigned)n_plan_wgs);
             if (group == K1_GROUP_BIG) hipLaunchKernelGGL((k1_plan<K1_GROUP_BIG, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);
             else if (group == K1_GROUP_SMALL) hipLaunchKernelGGL((k1_plan<K1_GROUP_SMALL, 1>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);
             else if (cpl == 4) hipLaunchKernelGGL((k1_plan<K1_GROUP, 4>), pgrid, dim3(64), 0, cs->plan_stream, a, n_plan_wgs);

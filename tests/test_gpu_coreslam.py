@@ -1243,8 +1243,8 @@ def test_blocking_wait_times_out_and_poisons_the_context(cs_mod, sim):
     """A blocking call whose completion word does not arrive within the context's bound (slamhip_ctx_set_wait_timeout) returns
     SLAMHIP_ERR_TIMEOUT and poisons the context: every later blocking call on it fails with the same code at once, nothing is
     re-executed, and the handles are still destroyed cleanly.  (The 'kernel that never ends' is a queue of one-million-candidate
-    searches in front of a blocking one, against a bound of 1 ms: the enqueue-only searches hold the host back to three launches
-    ahead of the device -- the plan slots' backpressure, slamhip_cs_plan_stats -- so the blocking call finds two or three searches
+    searches in front of a blocking one, against a bound of 1 ms: the enqueue-only searches hold the host back to seven launches
+    ahead of the device -- the plan slots' backpressure, slamhip_cs_plan_stats -- so the blocking call finds about six searches
     of ~0.4 ms each in front of its own.)"""
     import slam.net_amd.capi as capi
     ctx2 = cs_mod.Context(0)
