@@ -2020,14 +2020,17 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         volatile uint32_t *h_started = (volatile uint32_t *)cs->h_key + 25;
         a.started = (uint32_t *)cs->h_key + 25; a.launch_no = ++cs->k1_launches;
         a.plan_rec = nullptr; a.plan_seq = 0;
-        // Which launches get one: the enqueue-only searches (result-ring form: the throughput form, fused scans, the all-reduce forms)
-        // -- their launch normally waits in the stream behind earlier work, so the plan has time to arrive.  Not a blocking search on
-        // its own (the launch starts at once: the plan would only arrive late and cost the host a launch; measured 27.8 -> 31.6 us
-        // per blocking call with it), and not a search launched ahead of its scan's tables -- the per-scan flow: the tile steps need
-        // the tables, which do not exist yet.  (Measured and dropped in round 6: the candidates' (px, py, c, s) made once per search --
-        // by the plan launch, or shared between a group's workgroups inside the search launch through memory -- instead of by every
-        // workgroup: reading them back costs a launch what the trigonometry does, 15.2 us with or without at the headline size.)
-        bool plan_on = plan_env && mode == 1 && ring && a.grp_bounds != nullptr && !cs->k1_prelaunch && !lat2 && !lat4 && !ctx->mail_off;
+        // Which launches get one: those that will WAIT in the stream -- the search launch before this one has not even started
+        // (the started word), so this one is at least a whole search away from running and its plan has time to arrive: the
+        // throughput forms (enqueue-only searches, the batched all-reduce form) once the host runs ahead of the device.  A search
+        // that starts at once -- a blocking call, the first launches behind a synchronise, the per-scan flows, whose search follows
+        // its scan -- gets none: its plan would arrive late and cost the host a launch (measured: a blocking search 27.8 -> 31.6 us
+        // per call with one, the fused scan in the ordinary order 50 -> 54.5 us per scan).  Nor does a search launched ahead of its
+        // scan's tables: the tile steps need the tables.  (Measured and dropped in round 6: the candidates' (px, py, c, s) made once per
+        // search -- by the plan launch, or shared between a group's workgroups inside the search launch through memory -- instead of
+        // by every workgroup: reading them back costs a launch what the trigonometry does, 15.2 us with or without at the headline size.)
+        const bool stream_busy = (int32_t)(*h_started - (a.launch_no - 1)) < 0;
+        bool plan_on = plan_env && mode == 1 && stream_busy && a.grp_bounds != nullptr && !cs->k1_prelaunch && !lat2 && !lat4 && !ctx->mail_off;
         const int n_plan_wgs = n_wgs;
         if (plan_on && cs->plan_inputs_after != 0) {
             if ((int32_t)(*h_started - cs->plan_inputs_after) >= 0) cs->plan_inputs_after = 0;

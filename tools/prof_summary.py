@@ -149,24 +149,26 @@ def sq_summary(s1, s2, kernel, avg_ns, grbm=None):
         # The shader clock of THIS profile (MI355X_MICROARCH.md: effective clock = GRBM_GUI_ACTIVE / kernel wall time; profiled passes
         # clock lower than plain runs): GRBM_GUI_ACTIVE of the same kernel from its own pass (the counter is summed over the 8 XCDs
         # when it comes out above the 2.4 GHz maximum: divided back), else SQ_BUSY_CYCLES / 32 shader engines.
-        gui = (grbm or {}).get(kernel, {}).get("GRBM_GUI_ACTIVE")
+        # SQ_BUSY_CYCLES (same pass as the VALU counters) summed over the 32 shader engines of the 8 XCDs / the launch's duration: 2.2 GHz in
+        # the round-5 and round-6 profiles at both sizes.  (GRBM_GUI_ACTIVE per dispatch, tried in round 6, carries ~185 000 cycles of
+        # collection overhead per dispatch -- a 3 us copy kernel reads 181 456 -- and comes out above the 2.4 GHz maximum even after
+        # subtracting it: kept in the per-kernel file, not used.)
         clk, how = None, None
-        if gui:
-            clk = gui / avg_ns
-            if clk > 2.6:
-                clk /= 8.0
-            how = "GRBM_GUI_ACTIVE / launch duration"
-        elif a.get("SQ_BUSY_CYCLES"):
+        if a.get("SQ_BUSY_CYCLES"):
             clk = a["SQ_BUSY_CYCLES"] / 32.0 / avg_ns
             how = "SQ_BUSY_CYCLES / 32 shader engines / launch duration"
+        gui = (grbm or {}).get(kernel, {}).get("GRBM_GUI_ACTIVE")
+        if gui:
+            d["grbm_gui_active_per_dispatch_not_used"] = gui
         if clk:
             d["shader_clock_ghz_measured"] = clk
             d["shader_clock_how"] = how
-            # 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU quad-cycles on average
+            # 1024 SIMDs; a wave64 VALU instruction is counted as one quad-cycle unit of SQ_ACTIVE_INST_VALU: x 4 cycles is an UPPER bound of the
+            # SIMD's busy time (packed / transcendental mixes aside) -- where it exceeds the launch the estimate is marked inconsistent and
+            # bench.py does not replay it
             busy = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / (clk * 1e3)
             d["valu_busy_us_per_simd_if_evenly_spread"] = busy
             d["valu_busy_consistent"] = bool(busy <= avg_ns * 1e-3)
-            assert busy <= avg_ns * 1e-3 * 1.02, "VALU busy time %.2f us exceeds the launch's %.2f us: the counter's unit or the clock is wrong" % (busy, avg_ns * 1e-3)
         d["note"] = "quad-cycle counters (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*) count 4-cycle units (MI355X_MICROARCH.md); the busy estimate uses the clock measured in this profile"
     out["derived"] = d
     return out
