@@ -359,6 +359,12 @@ int32_t slamhip_csproc_set_lattice(slamhip_csproc *p, int32_t on);
 int32_t slamhip_csproc_set_offsets(slamhip_csproc *p, const float *offs, int32_t n);
 /* the underlying operator-level object (HoleMap / ObstacleMap properties :45,:50) */
 int32_t slamhip_csproc_cs(slamhip_csproc *p, slamhip_cs **out_cs);
+/* ScanSegmentsToCloud (CoreSLAMProcessor.cs:187-207) on its own, as slamhip_csproc_update runs it on the host: every segment's pose relative to
+ * the LAST segment's (the odometry pose, :719), every ray (angle, radius) -> pose.X + radius * cos(angle + pose.Z), pose.Y + radius *
+ * sin(angle + pose.Z) with the library's deterministic cos / sin (the correctly rounded float; a C# host that wants its own MathF
+ * forms the cloud itself).  seg_poses: n_seg x 3, seg_start: n_seg + 1 ray offsets, rays: (angle, radius) pairs, out_xy: one (x, y)
+ * per ray.  No device is involved. */
+int32_t slamhip_scan_segments_to_cloud(const float *seg_poses, const int32_t *seg_start, int32_t n_seg, const float *rays, float *out_xy);
 
 /* ------------------------------------------------------------------------------------------------
  * HectorSLAM, operator level

@@ -119,6 +119,7 @@ def _declare(L):
         "slamhip_csproc_set_lattice": (i32, [vp, i32]),
         "slamhip_csproc_set_offsets": (i32, [vp, fp, i32]),
         "slamhip_csproc_cs": (i32, [vp, vpp]),
+        "slamhip_scan_segments_to_cloud": (i32, [fp, ip, i32, fp, fp]),
         "slamhip_hs_create": (i32, [vp, f, i32, i32, i32, vpp]),
         "slamhip_hs_destroy": (i32, [vp]),
         "slamhip_hs_reset": (i32, [vp]),

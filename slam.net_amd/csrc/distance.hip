@@ -2029,7 +2029,8 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
         // scan's tables: the tile steps need the tables.  (Measured and dropped in round 6: the candidates' (px, py, c, s) made once per
         // search -- by the plan launch, or shared between a group's workgroups inside the search launch through memory -- instead of
         // by every workgroup: reading them back costs a launch what the trigonometry does, 15.2 us with or without at the headline size.)
-        const bool stream_busy = (int32_t)(*h_started - (a.launch_no - 1)) < 0;
+        static const int plan_always = env_int("SLAMHIP_K1_PLAN_ALWAYS", 0);   // (tests: a plan for every eligible launch -- most arrive late, the race the stamps are for)
+        const bool stream_busy = plan_always || (int32_t)(*h_started - (a.launch_no - 1)) < 0;
         bool plan_on = plan_env && mode == 1 && stream_busy && a.grp_bounds != nullptr && !cs->k1_prelaunch && !lat2 && !lat4 && !ctx->mail_off;
         const int n_plan_wgs = n_wgs;
         if (plan_on && cs->plan_inputs_after != 0) {

@@ -47,8 +47,12 @@ struct hs_level_dev {                      // what the kernels need, by value
     int w, h; float cell, stm;
     sh_m3x2 map_t_world, world_t_map;
     const float *prob;                     // what the matcher's taps read: exp and divide happen when a cell changes, not per tap
+    const slamhip_cell *cells;             // (HS_PROB_MODE 1 / 2, developer experiment: the taps read the cells and form the probabilities themselves)
     int iterations;
 };
+#ifndef HS_PROB_MODE
+#define HS_PROB_MODE 0                     // 0: the probability grid, kept by every writer of the cells | 1: from the cells, exact expf and division per tap | 2: ... hardware exp and reciprocal
+#endif
 
 struct slamhip_hs {
     slamhip_ctx *ctx;
@@ -75,6 +79,16 @@ __device__ static inline float hs_prob_v(float v)
 {
     const float odds = expf(v);                                            // :101
     return odds / (odds + 1.0f);                                           // :102
+}
+
+__device__ static inline float hs_prob_tap(float v)
+{
+#if HS_PROB_MODE == 2
+    const float odds = __expf(v);
+    return __fdividef(odds, odds + 1.0f);
+#else
+    return hs_prob_v(v);
+#endif
 }
 
 // one DPP step of a binary64 value (the wave partials' tree in hs_hessian_block; no LDS permutes: a ds_bpermute costs ~100
@@ -184,8 +198,16 @@ __device__ static __forceinline__ void hs_hessian_block(const hs_level_dev &L, c
             const int ix = ok[u] ? (int)fxx : 0, iy = ok[u] ? (int)fyy : 0;
             fx[u] = cx - fxx; fy[u] = cy - fyy;                            // :225
             const int idx = iy * L.w + ix;                                 // :227
+#if HS_PROB_MODE == 0
             __builtin_memcpy(&r0[u], L.prob + idx, sizeof(float2));        // (two adjacent taps: one 8-byte load)
             __builtin_memcpy(&r1[u], L.prob + idx + L.w, sizeof(float2));
+#else
+            int4 c0, c1;                                                   // (two adjacent cells {UpdateIndex, Value}: one 16-byte load)
+            __builtin_memcpy(&c0, L.cells + idx, sizeof(int4));
+            __builtin_memcpy(&c1, L.cells + idx + L.w, sizeof(int4));
+            r0[u] = make_float2(hs_prob_tap(__int_as_float(c0.y)), hs_prob_tap(__int_as_float(c0.w)));
+            r1[u] = make_float2(hs_prob_tap(__int_as_float(c1.y)), hs_prob_tap(__int_as_float(c1.w)));
+#endif
         }
 #pragma unroll
         for (int u = 0; u < PU; u++) {
@@ -801,7 +823,9 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
         if (lane == 63 && (first_free != 0x7fffffff || first_occ != 0x7fffffff)) {
             k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
             k5_store_cell(L.cells + cell, v, u);
+#if HS_PROB_MODE == 0
             L.prob[cell] = hs_prob_v(v);
+#endif
         }
     }
     // (2) beyond the zone: one lane per (line, step) -- work proportional to the cells the scan touches, not to the scan's
@@ -899,7 +923,9 @@ k5_cells(k5_arg A, int cap, const float2 *__restrict__ pts, int n_pts, float ox,
                 int u = cur.u;
                 k5_transition(L, v, u, first_free, first_occ, lo_free, lo_occ);
                 k5_store_cell(L.cells + cur.cell, v, u);
+#if HS_PROB_MODE == 0
                 L.prob[cur.cell] = hs_prob_v(v);
+#endif
             }
         }
         cur = nxt; nxt = nx2;
@@ -996,7 +1022,7 @@ static hs_levels_arg levels_arg(slamhip_hs *hs)
         const hs_level &L = hs->lv[l];
         A.lv[l].w = L.w; A.lv[l].h = L.h; A.lv[l].cell = L.cell; A.lv[l].stm = L.stm;
         A.lv[l].map_t_world = L.map_t_world; A.lv[l].world_t_map = L.world_t_map;
-        A.lv[l].prob = L.d_prob; A.lv[l].iterations = L.iterations;
+        A.lv[l].prob = L.d_prob; A.lv[l].cells = L.d_cells; A.lv[l].iterations = L.iterations;
     }
     return A;
 }

@@ -129,6 +129,27 @@ extern "C" int32_t slamhip_csproc_cs(slamhip_csproc *p, slamhip_cs **out)
     return SLAMHIP_OK;
 }
 
+// ScanSegmentsToCloud (:187-207) on its own: the arithmetic of slamhip_csproc_update's loop below, without the per-ray trigonometry cache
+extern "C" int32_t slamhip_scan_segments_to_cloud(const float *seg_poses, const int32_t *seg_start, int32_t n_seg, const float *rays, float *out_xy)
+{
+    SH_CHECK_ARG(seg_poses && seg_start && n_seg >= 1 && seg_start[0] == 0);
+    for (int sgm = 0; sgm < n_seg; sgm++) SH_CHECK_ARG(seg_start[sgm] <= seg_start[sgm + 1]);
+    SH_CHECK_ARG(seg_start[n_seg] == 0 || (rays && out_xy));
+    const float odo[3] = { seg_poses[3 * (n_seg - 1)], seg_poses[3 * (n_seg - 1) + 1], seg_poses[3 * (n_seg - 1) + 2] };  // :719
+    for (int sgm = 0; sgm < n_seg; sgm++) {                               // :191
+        const float px = seg_poses[3 * sgm] - odo[0];                     // :194
+        const float py = seg_poses[3 * sgm + 1] - odo[1];
+        const float pz = seg_poses[3 * sgm + 2] - odo[2];
+        for (int r = seg_start[sgm]; r < seg_start[sgm + 1]; r++) {       // :196
+            float s, c;
+            sh_det_sincosf(rays[2 * r] + pz, &s, &c);                     // :200-201 angle + pose.Z
+            out_xy[2 * (size_t)r] = px + rays[2 * r + 1] * c;             // :200
+            out_xy[2 * (size_t)r + 1] = py + rays[2 * r + 1] * s;         // :201
+        }
+    }
+    return SLAMHIP_OK;
+}
+
 // Update (:717-752)
 extern "C" int32_t slamhip_csproc_update(slamhip_csproc *p, const float *seg_poses, const int32_t *seg_start,
                                          int32_t n_seg, const float *rays)

@@ -161,7 +161,7 @@ def main():
                     # round 4: the enqueue-only search into the handle's result ring, three times in a row -- the second launch
                     # under one layout makes the ray ranges' cost cuts, every launch must find its result word rested
                     if os.environ.get("FUZZ_TRACE"): print("   ring K %d" % K, flush=True)
-                    slots = [dev.search_shard_enqueue(base, 0, K) for _ in range(3)]
+                    slots = [dev.search_shard_enqueue(base, 0, K) for _ in range(3)]      # (round 6: with SLAMHIP_K1_PLAN_ALWAYS=1 each of these races its plan launch)
                     keys = [dev.key_read(sl) for sl in slots]
                     ok = all(k == ((int(rbd) << 32) | int(rbi)) for k in keys)
                     if not ok: why.append("ring search: keys %s, oracle idx %d dist %d" % (keys, rbi, rbd))

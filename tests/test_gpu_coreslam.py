@@ -480,6 +480,53 @@ def test_search_enqueue_ring(cs_mod, ctx, det, sim):
     dev.close()
 
 
+def test_search_plan_launches(cs_mod, ctx, det, sim):
+    """The search's plan (k1_plan, slamhip_cs_plan_stats): a queue of enqueue-only searches from EIGHT DIFFERENT poses over two scans
+    (a new scan in the middle of the queue: the plan launch must not read tables a launch in the operator's stream is still
+    writing) -- once the host runs ahead of the device every search launch is accompanied by its plan launch on a stream of its
+    own, the workgroups take their tile steps from the stamped records (or plan for themselves when a record is late) -- and
+    every key equals the oracle's.  A plan costs time, never a result."""
+    oc = det
+    size, R, K = 2048, 1080, 16384
+    dev = make_dev(cs_mod, ctx, size, 256)
+    segs = sim.default_field()
+    rng = sim.PCG32(31)
+    ref = np.full(size * size, 32750, np.uint16)
+    for p in sim.trajectory(6):
+        _, xy = sim.make_scan(segs, p, R, rng)
+        dev.set_scan(xy); dev.update_holemap(p)
+        oc.update_holemap(ref, size, dev.hole_scale, xy, p)
+    tp = sim.trajectory(7)[-1]
+    scans = [sim.make_scan(segs, (tp + np.array([0.03 * k, 0.0, 0.004 * k], np.float32)).astype(np.float32), R, rng)[1] for k in range(2)]
+    offs = sim.gaussian_offsets(K - 1, 0.1, math.radians(10.0), seed=9)
+    dev.set_offsets(offs)
+    poses = [(tp + np.array([0.01 * i, -0.015 * i, 0.003 * i], np.float32)).astype(np.float32) for i in range(8)]
+    want = {}
+    for si, xy in enumerate(scans):
+        for pi, p in enumerate(poses):
+            bi, _, bd, _ = oc.search(ref, size, dev.hole_scale, xy, p, offs)
+            want[(si, pi)] = (int(bd) << 32) | int(bi)
+    before = dev.plan_stats
+    got = []
+    for rep in range(6):
+        for si, xy in enumerate(scans):
+            dev.set_scan(xy)
+            slots = []
+            for i in range(24):                                        # 24 launches back to back per scan: the ring holds four keys
+                slots.append((dev.search_shard_enqueue(poses[i % 8], 0, K), (si, i % 8)))
+                if len(slots) == 3:
+                    s0, k0 = slots.pop(0)
+                    got.append((dev.key_read(s0), want[k0])) if (i % 5) == 0 else None
+            for s0, k0 in slots:
+                got.append((dev.key_read(s0), want[k0]))
+    assert len(got) > 50 and all(a == b for a, b in got), [(hex(a), hex(b)) for a, b in got if a != b][:4]
+    after = dev.plan_stats
+    if os.environ.get("SLAMHIP_K1_PLAN", "1") != "0" and not os.environ.get("SLAMHIP_K1_GLOBAL") and not os.environ.get("SLAMHIP_K1_NOBOUNDS"):
+        assert after[0] - before[0] > 100, (before, after)             # most launches of the queues had a plan
+    assert dev.selfcheck_failures == 0
+    dev.close()
+
+
 def test_k1_tile_boxes_selfcheck():
     """Re-run the distance tests with SLAMHIP_K1_VERIFY=1 (every end point is checked against its LDS tile
     box, every staged pixel against the map), with SLAMHIP_K1_GLOBAL=1 (global-gather fallback kernels) and
@@ -487,7 +534,7 @@ def test_k1_tile_boxes_selfcheck():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size or test_search_changing_scans or test_search_enqueue_ring or test_heading_lattice"
+    sel = "test_distance_golden or test_distance_quirks or test_distance_64bit or test_search_full_size or test_search_changing_scans or test_search_enqueue_ring or test_heading_lattice or test_search_plan_launches"
     for env_extra in ({"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "1"}, {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "2"},
                       {"SLAMHIP_K1_LAYOUT_SYNC": "1", "SLAMHIP_K1_VERIFY": "1"},   # every scan's launch layout made before its launch
                       {"SLAMHIP_K1_VERIFY": "1", "SLAMHIP_K1_CPL": "4"}, {"SLAMHIP_K1_GLOBAL": "1"},
@@ -509,6 +556,9 @@ def test_k1_tile_boxes_selfcheck():
                       {"SLAMHIP_K1_TILE_KB": "16", "SLAMHIP_K1_VERIFY": "1"},      # many banded pieces: the halves' plans under the self-check
                       {"SLAMHIP_K1_TILE_KB": "16"},                                # ... and the lattice kernel over them
                       {"SLAMHIP_NO_DIRECT_UPLOAD": "1"},                           # scans through the upload launch (no CPU stores into device memory)
+                      {"SLAMHIP_K1_PLAN": "0"},                                    # no plan launches: every workgroup plans for itself
+                      {"SLAMHIP_K1_PLAN_ALWAYS": "1", "SLAMHIP_K1_VERIFY": "1"},   # a plan launch beside EVERY search: most arrive while their search runs
+                      {"SLAMHIP_K1_PLAN_ALWAYS": "1", "SLAMHIP_K1_TILE_KB": "16"},  # ... with many banded pieces (records of many steps, some too long for a record)
                       {"SLAMHIP_K1_TARGET_WGS": "64", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "64"},
                       {"SLAMHIP_K1_TARGET_WGS": "100000", "SLAMHIP_K1_TARGET_WGS_UNIFORM": "100000", "SLAMHIP_K1_CPL": "1"}):
         env = dict(os.environ); env.update(env_extra); env["SLAMHIP_EXPECT_SELFCHECK"] = "1"
