@@ -503,6 +503,7 @@ def main():
         dist.destroy_process_group()
 
 
+
 def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
     """Secondary figures, same process, after the headline's timed region: the headline search at larger candidate counts
     (the launch is latency-bound at 16 384 candidates: these show the kernel's throughput), and BASELINE.json's other
@@ -684,12 +685,21 @@ def other_workloads(a, ctx, dev, segs, xy, base, bytes_per_eval, checks):
         proc.Update([cs.ScanSegment(pscans[i], zero)])
     ctx.synchronize()
     t0 = time.perf_counter()
+    per_scan = []
     for i in range(200):
+        ts = time.perf_counter()
         proc.Update([cs.ScanSegment(pscans[10 + i % 60], zero)])
+        per_scan.append(time.perf_counter() - ts)
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / 200
+    if os.environ.get("SLAMHIP_BENCH_STEP_TIMES"):
+        sp = sorted(per_scan)
+        print("[bench] Update through the mirror: median %.1f p90 %.1f max %.1f us; over 3x median: %s" % (
+            sp[100] * 1e6, sp[180] * 1e6, sp[-1] * 1e6, [(i, round(t * 1e6)) for i, t in enumerate(per_scan) if t > 3 * sp[100]][:20]), file=sys.stderr)
     out["coreslam_processor_update_2048_map_1080_rays_16384_candidates"] = {"us_per_scan": dt * 1e6, "scans_per_s": 1.0 / dt,
-                                                                            "caller": "Python mirror of the C# class over ctypes (the interpreter's part of a scan is ~8 us)"}
+                                                                            "caller": "Python mirror of the C# class over ctypes (the interpreter's part of a scan is ~8 us)",
+                                                                            "searches_launched_ahead_abandoned_layout_remade_refused": list(proc.device.prelaunch_stats),
+                                                                            "prepared_lists_served_prepared": list(proc.device.prepared_lists())}
     # the same loop with the host mirror of the HoleMap kept up to date: one asynchronous request per scan behind the Update
     # (what the C# shim's default MirrorMaps does) -- a MOVING robot, so what changes per scan is what a real run changes
     pm = np.zeros(2048 * 2048, np.uint16)

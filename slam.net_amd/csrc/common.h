@@ -22,6 +22,14 @@ void slamhip_set_error(const char *fmt, ...);
 struct slamhip_ctx {
     int device;
     hipStream_t stream;
+    // The helper streams of every operator object of the context, made -- and USED once, which is when the runtime binds a stream to a
+    // hardware queue -- at context creation, straight after the operator's stream: plan (the search's plan launches, highest priority),
+    // side (the next scan's candidate list), mirror (host-mirror pushes).  Queues are dealt to the compute pipes in creation order,
+    // and two queues of one pipe do not run side by side: a side stream made late in a process that had made other streams landed on
+    // the operator's pipe, its launch waited until the operator's queue went idle, and a scan of the launch-ahead flow took 76 us
+    // instead of 46 (round 6, bench.py's CoreSLAMProcessor section).  Four streams made back to back take four different pipes.
+    hipStream_t plan_stream, side_stream, mirror_stream;
+    void *d_touch;            // 256 B the creation-time launches write
     int num_cus;
     // timing
     uint32_t timing;          // bit mask of timed kernel classes

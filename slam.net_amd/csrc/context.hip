@@ -41,11 +41,33 @@ extern "C" int32_t slamhip_ctx_create(int32_t device, slamhip_ctx **out)
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // (the highest priority the device offers for the plan stream: a plan is a few hundred short wavefronts that share the compute
+        // units with a search launch in full flight -- at equal priority they trickle in as that launch's workgroups retire, ~10 us)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        e = hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, prio_hi);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->mirror_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&c->d_touch, 256);
+    if (e == hipSuccess) {
+        // first use = hardware queue: in this order, see common.h
+        hipStream_t order[4] = { c->stream, c->plan_stream, c->side_stream, c->mirror_stream };
+        for (int i = 0; i < 4 && e == hipSuccess; i++) {
+            e = hipMemsetAsync((char *)c->d_touch + 64 * i, 0, 64, order[i]);
+            if (e == hipSuccess) e = hipStreamSynchronize(order[i]);
+        }
+    }
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) {
+        if (c->d_touch) (void)hipFree(c->d_touch);
+        if (c->mirror_stream) (void)hipStreamDestroy(c->mirror_stream);
+        if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+        if (c->plan_stream) (void)hipStreamDestroy(c->plan_stream);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         free(c);
-        SH_FAIL(SLAMHIP_ERR_HIP, "context creation failed (stream / pinned mailbox): %s", hipGetErrorString(e));
+        SH_FAIL(SLAMHIP_ERR_HIP, "context creation failed (streams / pinned mailbox): %s", hipGetErrorString(e));
     }
     memset(c->mailbox, 0, 64);
     {
@@ -85,7 +107,10 @@ extern "C" int32_t slamhip_ctx_destroy(slamhip_ctx *c)
     for (int i = 0; i < c->n_pending; i++) { (void)hipEventDestroy(c->pending[i].a); (void)hipEventDestroy(c->pending[i].b); }
     for (int i = 0; i < c->n_pool; i++) (void)hipEventDestroy(c->pool[i]);
     free(c->pending); free(c->pool);
+    if (!c->poisoned) { (void)hipStreamSynchronize(c->plan_stream); (void)hipStreamSynchronize(c->side_stream); (void)hipStreamSynchronize(c->mirror_stream); }
+    (void)hipStreamDestroy(c->mirror_stream); (void)hipStreamDestroy(c->side_stream); (void)hipStreamDestroy(c->plan_stream);
     (void)hipStreamDestroy(c->stream);
+    (void)hipFree(c->d_touch);
     if (c->mailbox) (void)hipHostFree(c->mailbox);
     pthread_mutex_destroy(&c->mail_lock);
     free(c);

@@ -209,7 +209,6 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipSetDevice(cs->ctx->device);
     if (!cs->ctx->poisoned) (void)hipStreamSynchronize(cs->ctx->stream);     // (a poisoned context's stream may never drain: slamhip_ctx_destroy bounds that wait)
     cs_plan_free(cs);
-    if (cs->plan_stream) (void)hipStreamDestroy(cs->plan_stream);
     (void)hipFree(cs->d_hole); (void)hipFree(cs->d_obst);
     (void)hipFree(cs->d_scan_blob); if (cs->h_scan_blob) (void)hipHostFree(cs->h_scan_blob);
     (void)hipFree(cs->d_scan_flag);
@@ -219,8 +218,8 @@ extern "C" int32_t slamhip_cs_destroy(slamhip_cs *cs)
     (void)hipFree(cs->d_key); (void)hipFree(cs->d_grp_bounds); (void)hipFree(cs->d_verify);
     (void)hipFree(cs->d_k1_gmin); (void)hipFree(cs->d_k1_acc); (void)hipFree(cs->d_k1_ring);
     if (cs->h_key) (void)hipHostFree(cs->h_key);
-    if (cs->mirror_stream) { (void)hipStreamSynchronize(cs->mirror_stream); (void)hipStreamDestroy(cs->mirror_stream); }
-    if (cs->side_stream) { (void)hipStreamSynchronize(cs->side_stream); (void)hipStreamDestroy(cs->side_stream); }
+    // (the helper streams are the context's: what this object put into them is waited for, the streams stay)
+    if (!cs->ctx->poisoned) { (void)hipStreamSynchronize(cs->mirror_stream); (void)hipStreamSynchronize(cs->side_stream); }
     (void)hipFree(cs->d_side_arrive);
     (void)hipFree(cs->spec_offs_flat); (void)hipFree(cs->spec_ev_off); (void)hipFree(cs->spec_ev_idx); (void)hipFree(cs->spec_grp_bounds);
     (void)hipFree(cs->cool_offs_flat); (void)hipFree(cs->cool_ev_off); (void)hipFree(cs->cool_ev_idx); (void)hipFree(cs->cool_grp_bounds);
@@ -246,6 +245,7 @@ extern "C" int32_t slamhip_cs_create(slamhip_ctx *ctx, float physical, int32_t h
     SH_HIP(hipSetDevice(ctx->device));
     slamhip_cs *cs = new slamhip_cs();
     cs->ctx = ctx;
+    cs->plan_stream = ctx->plan_stream; cs->side_stream = ctx->side_stream; cs->mirror_stream = ctx->mirror_stream;   // (the context's: common.h)
     cs->physical = physical;
     cs->hs = hole_size; cs->hscale = (float)hole_size / physical;          // HoleMap.cs:19-20
     cs->os = obst_size; cs->oscale = (float)obst_size / physical;          // ObstacleMap.cs:19-20
@@ -527,7 +527,6 @@ static int32_t mirror_resources(slamhip_cs *cs)
     SH_HIP(hipMalloc(&cs->d_mirror_rows, sizeof(int2) * (size_t)cs->hs));
     SH_HIP(hipHostMalloc(&cs->h_mirror_rows, sizeof(int2) * (size_t)cs->hs));
     SH_HIP(hipHostMalloc(&cs->h_mirror_sum, sizeof(int) * 8));
-    SH_HIP(hipStreamCreateWithFlags(&cs->mirror_stream, hipStreamNonBlocking));
     SH_HIP(hipEventCreateWithFlags(&cs->ev_snap, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&cs->ev_push, hipEventDisableTiming));
     return SLAMHIP_OK;
@@ -1132,8 +1131,7 @@ static int32_t cs_speculate_next(slamhip_cs *cs)
     cs->spec_valid = false;
     if (off || !cs->spec_base_ok || !cs->offs_on_device_sorted || cs->gen_pending || n <= 0 || cs->shard_first != 0 || cs->shard_count != n + 1 ||
         ctx->timing != 0 || ctx->mail_off) return SLAMHIP_OK;
-    if (!cs->side_stream) {
-        SH_HIP(hipStreamCreateWithFlags(&cs->side_stream, hipStreamNonBlocking));
+    if (!cs->d_side_arrive) {
         SH_HIP(hipMalloc(&cs->d_side_arrive, 64));
         SH_HIP(hipMemset(cs->d_side_arrive, 0, 64));
     }

@@ -190,13 +190,19 @@ int32_t cs_search_and_update_prelaunched(slamhip_cs *cs, const float *xy, int32_
                                          int32_t max_hits, float out_pose[3], int32_t *out_dist, int32_t *out_index, bool *took);   // coreslam.hip; *took = false: nothing done, the caller takes the ordinary order
 // developer switch SLAMHIP_FUSED_TIMES=1: host clock between the stages of the per-scan calls (mean over 64 calls, stderr)
 struct cs_stage_times {
-    bool on; double acc[12]; int n; timespec t; const char *what;
-    explicit cs_stage_times(const char *w) : on(getenv("SLAMHIP_FUSED_TIMES") != nullptr), n(0), what(w) { for (double &a : acc) a = 0; }
+    bool on; double acc[12], cur[12]; int n; timespec t; const char *what;
+    explicit cs_stage_times(const char *w) : on(getenv("SLAMHIP_FUSED_TIMES") != nullptr), n(0), what(w) { for (double &a : acc) a = 0; for (double &a : cur) a = 0; }
     void start() { if (on) clock_gettime(CLOCK_MONOTONIC, &t); }
-    void lap(int k) { if (!on) return; timespec u; clock_gettime(CLOCK_MONOTONIC, &u); acc[k] += (u.tv_sec - t.tv_sec) * 1e6 + (u.tv_nsec - t.tv_nsec) * 1e-3; t = u; }
+    void lap(int k) { if (!on) return; timespec u; clock_gettime(CLOCK_MONOTONIC, &u); const double d = (u.tv_sec - t.tv_sec) * 1e6 + (u.tv_nsec - t.tv_nsec) * 1e-3; acc[k] += d; cur[k] += d; t = u; }
     void done()
     {
-        if (!on || ++n < 64) return;
+        if (!on) return;
+        {   // (a call that took over half a millisecond: its own stages, at once)
+            double sum = 0; for (double a : cur) sum += a;
+            if (sum > 500.0) { fprintf(stderr, "[slamhip] SLOW call (%.0f us), %s:", sum, what); for (double a : cur) fprintf(stderr, " %.1f", a); fprintf(stderr, "\n"); }
+            for (double &a : cur) a = 0;
+        }
+        if (++n < 64) return;
         fprintf(stderr, "[slamhip] host stages (us), %s:", what);
         for (int k = 0; k < 12; k++) fprintf(stderr, " %.2f", acc[k] / n);
         fprintf(stderr, "\n");

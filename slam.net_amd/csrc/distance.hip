@@ -2038,13 +2038,6 @@ int32_t cs_launch_distance(slamhip_cs *cs, int mode, const float pose[3], int co
             else { plan_on = false; cs->plan_stats[3]++; }
         }
         if (plan_on) {
-            if (!cs->plan_stream) {
-                // (the highest priority the device offers: a plan is a few hundred short wavefronts that share the compute units with a
-                // search launch in full flight -- at equal priority they trickle in as that launch's workgroups retire, ~10 us)
-                int prio_lo = 0, prio_hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-                SH_HIP(hipStreamCreateWithPriority(&cs->plan_stream, hipStreamNonBlocking, prio_hi));
-            }
             if (n_wgs > cs->plan_cap_wgs) {
                 SH_HIP(hipStreamSynchronize(ctx->stream));          // (searches in flight read the buffers)
                 const int cw = std::max(cs->plan_cap_wgs, n_wgs + n_wgs / 4 + 64);

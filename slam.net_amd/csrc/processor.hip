@@ -12,14 +12,18 @@
 
 // developer aid (SLAMHIP_PROC_TIMES=1): average host time of the stages of Update, printed every 64 searching scans
 struct proc_times {
-    bool on; double acc[6]; int n;
+    bool on; double acc[6], cur[6]; int n;
     std::chrono::steady_clock::time_point t;
-    proc_times() : on(getenv("SLAMHIP_PROC_TIMES") != nullptr), n(0) { for (double &a : acc) a = 0; }
+    proc_times() : on(getenv("SLAMHIP_PROC_TIMES") != nullptr), n(0) { for (double &a : acc) a = 0; for (double &a : cur) a = 0; }
     void start() { if (on) t = std::chrono::steady_clock::now(); }
-    void lap(int k) { if (!on) return; auto u = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::micro>(u - t).count(); t = u; }
+    void lap(int k) { if (!on) return; auto u = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double, std::micro>(u - t).count(); acc[k] += d; cur[k] += d; t = u; }
     void done()
     {
-        if (!on || ++n < 64) return;
+        if (!on) return;
+        if (cur[0] + cur[1] + cur[2] + cur[3] > 500.0)     // (a slow call: its own stages, at once)
+            fprintf(stderr, "[slamhip] SLOW Update: cloud %.1f | set_scan %.1f | candidates %.1f | search+update %.1f us\n", cur[0], cur[1], cur[2], cur[3]);
+        for (double &a : cur) a = 0;
+        if (++n < 64) return;
         fprintf(stderr, "[slamhip] Update host stages (us): cloud %.1f | set_scan %.1f | candidates %.1f | search+update (enqueue, wait, read back) %.1f\n",
                 acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
         for (double &a : acc) a = 0;
