@@ -299,11 +299,46 @@ template <int BDIM>
 __global__ void __launch_bounds__(BDIM)
 k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__restrict__ hints, float3 hint1,
          float *__restrict__ out, int only_level, int iters_override, uint32_t *mail, uint32_t mail_seq,
-         const float2 *up_src, float2 *up_dst, uint32_t *up_flag, uint32_t up_seq)
+         const float2 *up_src, float2 *up_dst, uint32_t *up_flag, uint32_t up_seq, int n_helpers_from)
 {
     __shared__ double red[2 * hs_shape<BDIM>::RED];
     __shared__ float2 pts_s[HS_LDS_PTS];
     const int b = blockIdx.x;
+    if (n_helpers_from > 0 && b >= n_helpers_from) {
+        // Round 6 -- the single match's HELPER workgroups.  In the per-scan flow the grid update has just rewritten the cached
+        // probabilities from every XCD, and the first iteration on each level finds none of its taps in the L2 (the points' phase:
+        // 14.0 us per match against 8.9 on a resting pyramid).  Requesting the finer levels' taps early from the matching
+        // workgroup itself was measured a loss in round 5 (its own taps queue behind them).  Workgroups are dealt to the XCDs round
+        // robin, so workgroup 8 of the launch shares its L2 with workgroup 0: it requests the lines of the FINER levels' taps at the
+        // hint pose -- the match moves the pose by a cell or two, a line holds 32 -- while workgroup 0 iterates on the coarse level,
+        // and leaves.  Workgroups 1 .. 7 (other XCDs) leave at once.  Nothing is written: a prefetch, never a result.
+#ifndef K4_HELP_ALL
+#define K4_HELP_ALL 0
+#endif
+        if ((!K4_HELP_ALL && (b & 7) != 0) || n <= 0 || only_level >= 0) return;
+        const float2 *src = up_src ? up_src : pts;
+        float acc = 0.f;
+        for (int l = A.n - (K4_HELP_ALL == 2 ? 1 : 2); l >= 0; l--) {
+            const hs_level_dev &L = A.lv[l];
+            float est[3];
+            sh_v2_transform(hint1.x, hint1.y, L.map_t_world, &est[0], &est[1]);
+            est[2] = hint1.z;
+            float s, c;
+            sh_det_sincosf(est[2], &s, &c);
+            const sh_m3x2 t = sh_m3x2_mul(sh_m3x2_mul(hs_rotation_sc(est[2], s, c), sh_m3x2_translation(est[0] * L.cell, est[1] * L.cell)), sh_m3x2_scale(L.stm));
+            const float limx = (float)L.w - 2.0f, limy = (float)L.h - 2.0f;
+            for (int i = threadIdx.x; i < n; i += BDIM) {
+                const float2 p = src[i];
+                float cx, cy;
+                sh_v2_transform(p.x, p.y, t, &cx, &cy);
+                const bool ok = !(!(cx == cx) || !(cy == cy) || cx < 0.0f || cx > limx || cy < 0.0f || cy > limy);
+                const int idx = ok ? (int)floorf(cy) * L.w + (int)floorf(cx) : 0;
+                acc += L.prob[idx] + L.prob[idx + L.w];
+            }
+        }
+        asm volatile("" :: "v"(acc));                                       // (the loads are kept; their values are not)
+        return;
+    }
     float est_w[3] = { hint1.x, hint1.y, hint1.z };                         // :43 (a single hint travels in the launch arguments)
     if (hints) { est_w[0] = hints[3 * b]; est_w[1] = hints[3 * b + 1]; est_w[2] = hints[3 * b + 2]; }
 #ifdef K4_TIMES
@@ -1350,8 +1385,11 @@ static int32_t run_match(slamhip_hs *hs, const float *hints, int B, float *out, 
         uint32_t *mb = mail1 ? ctx->mailbox : (uint32_t *)nullptr;
         if (mail1) mail_seq = sh_mail_seq_next(ctx);
         const int lanes = B <= 8 ? lanes1 : 256;
-#define K4_LAUNCH(BD) hipLaunchKernelGGL(k4_match<BD>, dim3(B), dim3(BD), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points, d_hints, h1, d_out, \
-                                         only_level, iters, mb, mail_seq, up_src, up_dst, up_flag, up_seq)
+        // (a single full match in the per-scan flow brings helper workgroups: k4_match)
+        static const int helpers_env = getenv("SLAMHIP_K4_HELPERS") ? atoi(getenv("SLAMHIP_K4_HELPERS")) : 1;
+        const int helpers = B == 1 && only_level < 0 && hs->n_levels > 1 && hs->n_points > 0 && helpers_env > 0 ? 8 * helpers_env : 0;
+#define K4_LAUNCH(BD) hipLaunchKernelGGL(k4_match<BD>, dim3(B + helpers), dim3(BD), 0, ctx->stream, levels_arg(hs), hs->d_pts, hs->n_points, d_hints, h1, d_out, \
+                                         only_level, iters, mb, mail_seq, up_src, up_dst, up_flag, up_seq, helpers ? B : 0)
         if (lanes == 1024) K4_LAUNCH(1024);
         else if (lanes == 512) K4_LAUNCH(512);
         else K4_LAUNCH(256);

@@ -518,3 +518,73 @@ def test_hand_estimate_step_hip():
     assert (got == STEP_WANT).all(), got
     rep.close()
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One EstimateTransformationLogLh step whose H has OFF-DIAGONAL entries, so that Matrix4x4.Invert's cofactors -- not only its
+# diagonal -- decide the step (ScanMatcher.cs:93-125), with the clamp of :107-111 and the float rounding of NormalizeAngle
+# (:76, MathEx.cs:116-138) behind it.  Same grid as above (32 x 32, CellLength 1: map = world), EstimateIterations = 1, hint
+# (10, 20, 0): sinRot = 0, cosRot = 1 (:145-146), rotDeriv = -y * gx + x * gy (:169-170).
+#   B = (0, 3.5): as above -- dTr.Y += 0.125, H22 += 0.25, gx = -0, rotDeriv = 0
+#   P1 = (0, 0) -> map (10, 20), factors (0, 0); cell (11, 20) holds 50: intensities [0.5, 1.0, 0.5, 0.5]
+#       gx = -((0.5 - 1.0)*1 + 0*0) = 0.5; gy = -(0*1 + 0.5*0) = -0; P = 0.5, funVal 0.5; rotDeriv = -0*0.5 + 0*(-0) = -0
+#       dTr.X += 0.25; H11 += 0.25 (nothing else: every other product has a zero factor)
+#   P2 = (4, 1) -> map (14, 21), factors (0, 0); cells (14, 21) and (14, 22) hold 50: intensities [1.0, 0.5, 1.0, 0.5]
+#       gx = -((1.0 - 0.5)*1 + (1.0 - 0.5)*0) = -0.5; gy = -((1.0 - 1.0)*1 + (0.5 - 0.5)*0) = -0; P = 1.0, funVal = 0
+#       rotDeriv = (-1)*(-0.5) + 4*(-0) = 0.5;  dTr += 0;  H11 += 0.25, H33 += 0.25, H13 += (-0.5)(0.5) = -0.25
+#   H = [[0.5, 0, -0.25], [0, 0.25, 0], [-0.25, 0, 0.25]] (M44 = 1, :202), dTr = (0.25, 0.125, 0); M11, M22 != 0 (:97)
+#   Matrix4x4.Invert (cofactor expansion; a..p row by row: a=0.5 c=-0.25 f=0.25 i=-0.25 k=0.25 p=1, the rest 0):
+#       kp_lo = k*p - l*o = 0.25, ip_lm = i*p - l*m = -0.25, the other 2 x 2 minors of rows 3, 4 are (+-)0
+#       a11 = f*kp_lo = 0.0625;  a13 = -(f*ip_lm) = 0.0625;  a12 = a14 = (+-)0
+#       det = a*a11 + c*a13 = 0.03125 - 0.015625 = 0.015625 = 2^-6  (every product and sum exact in binary32);  invDet = 64
+#       M11 = a11*64 = 4;  M31 = a13*64 = 4;  M22 = (a*kp_lo - c*ip_lm)*64 = (0.125 - 0.0625)*64 = 4
+#       M13 = (b*(g*p - h*o) - c*(f*p - h*n) + d*(f*o - g*n))*64 = (0 + 0.25*0.25 + 0)*64 = 4;  M33 = (a*(f*p - h*n))*64 = 0.125*64 = 8
+#       M12, M21, M23, M32 = (+-)0
+#   iH = [[4, 0, 4], [0, 4, 0], [4, 0, 8]] -- a diagonal-only inverse (1/H11, 1/H22, 1/H33) = diag(2, 4, 4) would give the step (0.5, 0.5, 0)
+#   searchDir = Vector3.Transform(dTr, iH) (:105): X = 0.25*4 + 0.125*0 + 0*4 = 1.0;  Y = 0.125*4 = 0.5;  Z = 0.25*4 + 0 + 0*8 = 1.0
+#   :107-111 Z > 0.2 -> Z = 0.2f;  estimate = (11, 20.5, 0.2f) (:119)
+#   :76 NormalizeAngle(0.2f), pi2 = 3.14159274f * 2 = 6.28318548f = K * 2^-21 (binade [4, 8): ulp 2^-21):
+#       fmodf(0.2f, pi2) = 0.2f = 419430.40625 * 2^-21;  0.2f + pi2 rounds to (K + 419430) * 2^-21;  fmodf(that, pi2) = 419430 * 2^-21
+#       = 0.19999980926513671875 = 0x3E4CCCC0 (not > pi): the pose's angle -- 13 ulp below 0.2f
+OFFD_XY = np.array([[0.0, 3.5], [0.0, 0.0], [4.0, 1.0]], np.float32)
+OFFD_HINT = np.array([10.0, 20.0, 0.0], np.float32)
+OFFD_CELLS_50 = [24 * 32 + 10, 24 * 32 + 11, 20 * 32 + 11, 21 * 32 + 14, 22 * 32 + 14]
+OFFD_H = np.array([[0.5, 0.0, -0.25], [0.0, 0.25, 0.0], [-0.25, 0.0, 0.25]], np.float32)
+OFFD_DTR = np.array([0.25, 0.125, 0.0], np.float32)
+OFFD_WANT = np.array([11.0, 20.5, np.array([0x3E4CCCC0], np.uint32).view(np.float32)[0]], np.float32)
+
+
+def test_hand_offdiagonal_step_c_oracle(oc):
+    g = oc.Grid(1.0, 32, 32)
+    g.cells["value"][OFFD_CELLS_50] = 50.0
+    H, d = g.hessian(OFFD_XY, OFFD_HINT, 1)
+    assert (H == OFFD_H).all() and (d == OFFD_DTR).all(), (H, d)
+    got = g.match(OFFD_XY, OFFD_HINT, iterations=1)
+    assert (got.view(np.uint32) == OFFD_WANT.view(np.uint32)).all(), got
+    g.close()
+
+
+def test_hand_offdiagonal_hessian_numpy_oracle(npo):
+    ng = npo.NpGrid(1.0, 32, 32)
+    ng.value[OFFD_CELLS_50] = 50.0
+    H, d = ng.hessian(OFFD_XY, OFFD_HINT, 1)
+    assert (H == OFFD_H).all() and (d == OFFD_DTR).all(), (H, d)
+
+
+@pytest.mark.gpu
+def test_hand_offdiagonal_step_hip():
+    import slam.net_amd.coreslam as cs
+    import slam.net_amd.hector as hs
+    ctx = cs.Context(0)
+    rep = hs.MapRepMultiMap(1.0, (32, 32), 1, ctx=ctx)
+    cells = rep.Maps[0].GetCells().copy()
+    cells["value"][OFFD_CELLS_50] = 50.0
+    rep.Maps[0].SetCells(cells)
+    rep.set_scan(hs.ScanCloud(OFFD_XY))
+    H, d = rep.Maps[0].Hessian(OFFD_HINT)
+    assert (H == OFFD_H).all() and (d == OFFD_DTR).all(), (H, d)
+    rep.Maps[0].EstimateIterations = 1
+    got = hs.ScanMatcher(1).MatchData(rep.Maps[0], hs.ScanCloud(OFFD_XY), OFFD_HINT)
+    assert (np.asarray(got, np.float32).view(np.uint32) == OFFD_WANT.view(np.uint32)).all(), got
+    rep.close()
+    ctx.close()
