@@ -72,7 +72,10 @@ const char *slamhip_last_error(void);
 int32_t slamhip_device_count(int32_t *out_count);
 
 /* Replaces `new ParallelWorker(numThreads)` (BaseSLAM/ParallelWorker.cs:34-56): the execution resource
- * the hot path runs on.  One context = one GPU ordinal + one non-blocking HIP stream. */
+ * the hot path runs on.  One context = one GPU ordinal + one non-blocking HIP stream, the OPERATOR's stream: everything a caller
+ * can observe is ordered on it.  (The context also owns three helper streams -- plan launches, the next scan's candidate list,
+ * host-mirror pushes -- created and bound to hardware queues together with it: create contexts early and keep them; a
+ * process should not need more than one per GPU.) */
 int32_t slamhip_ctx_create(int32_t device_ordinal, slamhip_ctx **out);
 int32_t slamhip_ctx_destroy(slamhip_ctx *ctx);                     /* ParallelWorker.Dispose :122-139 */
 int32_t slamhip_ctx_synchronize(slamhip_ctx *ctx);
