@@ -316,7 +316,11 @@ k4_match(hs_levels_arg A, const float2 *__restrict__ pts, int n, const float *__
 #define K4_HELP_ALL 0
 #endif
         if ((!K4_HELP_ALL && (b & 7) != 0) || n <= 0 || only_level >= 0) return;
-        const float2 *src = up_src ? up_src : pts;
+        // (The points are read from the DEVICE copy, never from the staging block: the host may refill -- or free and reallocate -- that
+        // block as soon as workgroup 0 has read it, long before this workgroup runs; round 6's soak, seed 6105, a memory access fault.
+        // On a freshly set scan the device copy still holds the previous scan, or a mixture while workgroup 0 stores the new one: end
+        // points of consecutive scans fall on the same lines, and whatever floats are found there are range-tested like any point.)
+        const float2 *src = pts;
         float acc = 0.f;
         for (int l = A.n - (K4_HELP_ALL == 2 ? 1 : 2); l >= 0; l--) {
             const hs_level_dev &L = A.lv[l];

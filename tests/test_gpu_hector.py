@@ -331,8 +331,9 @@ def test_hector_processor_wait_update_mode():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "test_hector_processor_gating or test_hector_processor_long_run"
-    for env_extra in ({"SLAMHIP_HS_WAIT_UPDATE": "1"}, {"SLAMHIP_NO_HOSTWAIT": "1"}):
+    sel = "test_hector_processor_gating or test_hector_processor_long_run or test_match"
+    # (round 6: ... and without the single match's helper workgroup -- a prefetch, never a result -- or with two of them)
+    for env_extra in ({"SLAMHIP_HS_WAIT_UPDATE": "1"}, {"SLAMHIP_NO_HOSTWAIT": "1"}, {"SLAMHIP_K4_HELPERS": "0"}, {"SLAMHIP_K4_HELPERS": "2"}):
         env = dict(os.environ); env.update(env_extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_hector.py"), "-m", "gpu", "-x", "-q",
                             "-k", sel], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
