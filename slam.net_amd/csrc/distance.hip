@@ -665,7 +665,9 @@ k1_search_tiled(const k1_args a)
     // cost the search kernel 24 more vector registers and, at four candidates per lane, spills)
 #define K1_PIECE_STAMP K1_STAMP(4)
 #define K1_STEP_SLOT(i) (i)
+#define K1_PIECE_RAY(i) (i)
 #include "k1_pieces.inc"
+#undef K1_PIECE_RAY
 #undef K1_STEP_SLOT
 #undef K1_PIECE_STAMP
     __syncthreads();
@@ -1143,7 +1145,11 @@ k1_plan(const k1_args a, const int n_wgs)
     if (lane == 0) s_nsteps = 0;
     for (int i = lane; i < nrays; i += 64) {
         const int4 ri = a.ray_blk[rlo + i];
-        if (i == 0 || ri.x == rlo + i) pieces[ri.z - blk_first] = make_int2(i, (ri.y < rhi ? ri.y : rhi) - (rlo + i));
+        // (A plan launch that was kept waiting -- its queue behind another on the same compute pipe -- can run after its search has
+        // finished, while the host stores the NEXT scan's tables into this very block: what it reads may be torn.  Its record will
+        // carry a stamp nobody waits for; what it must not do is follow a torn index out of its arrays.)
+        const int pidx = ri.z - blk_first;
+        if ((i == 0 || ri.x == rlo + i) && (unsigned)pidx < (unsigned)K1_MAXP) pieces[pidx] = make_int2(i, (ri.y < rhi ? ri.y : rhi) - (rlo + i));
     }
     const float2 *cpts = a.pts + rlo;
     k1_bounds_from_jitter(a, gb, bnd, lane);
@@ -1151,7 +1157,9 @@ k1_plan(const k1_args a, const int n_wgs)
     const int npieces = min(blk_last - blk_first + 1, K1_MAXP);   // (a plan that lags so far behind that its scan's block is being rewritten must still end)
 #define K1_PIECE_STAMP
 #define K1_STEP_SLOT(i) k1_plan_slot(i)                        /* (a function: the argument is an atomicAdd) */
+#define K1_PIECE_RAY(i) min(max((i), 0), nrays - 1)            /* (see above: torn tables) */
 #include "k1_pieces.inc"
+#undef K1_PIECE_RAY
 #undef K1_STEP_SLOT
 #undef K1_PIECE_STAMP
     __syncthreads();
