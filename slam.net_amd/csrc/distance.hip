@@ -1747,6 +1747,10 @@ void cs_layout_idle_refresh(slamhip_cs *cs)
 {
     if (cs->k1_layout_dirty || cs->k1_scan_dirty || cs->n_points <= 0) return;
     if (cs->k1_layout_stale) {
+        // (the layout follows the search heading: a launch-ahead search keeps the last layout only while its heading is within 0.1 rad
+        // of the layout's -- cs_launch_distance -- and a robot that turns half a degree per scan used to lose the launch-ahead flow,
+        // and 15 us, every dozen scans: 11 of 205 in bench.py's trajectory)
+        if (cs->k1_last_valid && cs->k1_layout_spread) cs->k1_layout_theta = cs->k1_last_pose[2];
         k1_make_layout(cs, cs->k1_layout_groups, cs->k1_layout_target, cs->k1_layout_budget, cs->k1_layout_spread, cs->k1_layout_band_parts);
         cs->k1_layout_stale = false; cs->k1_layout_gen++;
     }
