@@ -197,9 +197,10 @@ struct cs_stage_times {
     void done()
     {
         if (!on) return;
-        {   // (a call that took over half a millisecond: its own stages, at once)
+        {   // (a call that took over half a millisecond -- or SLAMHIP_SLOW_US -- : its own stages, at once)
             double sum = 0; for (double a : cur) sum += a;
-            if (sum > 500.0) { fprintf(stderr, "[slamhip] SLOW call (%.0f us), %s:", sum, what); for (double a : cur) fprintf(stderr, " %.1f", a); fprintf(stderr, "\n"); }
+            static const double slow_us = getenv("SLAMHIP_SLOW_US") ? atof(getenv("SLAMHIP_SLOW_US")) : 500.0;
+            if (sum > slow_us) { fprintf(stderr, "[slamhip] SLOW call (%.0f us), %s:", sum, what); for (double a : cur) fprintf(stderr, " %.1f", a); fprintf(stderr, "\n"); }
             for (double &a : cur) a = 0;
         }
         if (++n < 64) return;
